@@ -1,0 +1,197 @@
+/*
+ * lkm.h -- C ABI of liblkm.so, the MI355X-native replacement for the `lk_moe` engine that
+ * LvLLM (guqiong96/Lvllm) delegates its routed-expert MoE hot path to.
+ *
+ * Plain C: pointers, sizes and a config struct; no torch / HIP types in the signatures.
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference tree).  The Python module `lk_moe` (repo root) binds these with ctypes and
+ * re-creates the reference's class surface (MOEConfigV2, MOE_BF16, ... .cpu_decode(),
+ * .cpu_prefill(), .gpu_prefill()) so `vllm/model_executor/layers/fused_moe/routed_experts.py`
+ * runs unchanged -- see INTEGRATION.md.
+ *
+ * All functions return 0 on success and a negative LKM_E_* code on failure;
+ * lkm_last_error() returns a thread-local human-readable message.  Nothing here ever
+ * falls back to a CPU path: if no gfx950 device is usable the call fails.
+ */
+#ifndef LKM_H
+#define LKM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LKM_ABI_VERSION 1
+
+/* error codes */
+#define LKM_OK 0
+#define LKM_E_INVALID (-1)     /* bad argument / unsupported configuration */
+#define LKM_E_HIP (-2)         /* HIP runtime error (message has the hipError string) */
+#define LKM_E_NOMEM (-3)
+#define LKM_E_UNSUPPORTED (-4) /* format known but not built yet (NVFP4 / MXFP4) */
+
+/* activation (hidden-state) dtypes: suffix of the lk_moe class name
+ * (MOE_BF16 vs MOE_FP16 ..., routed_experts.py:1514-1533) */
+#define LKM_DT_F32 0
+#define LKM_DT_BF16 1
+#define LKM_DT_F16 2
+
+/* expert weight formats = the lk_moe class family (routed_experts.py:1363-1397) */
+#define LKM_W_BF16 0     /* MOE_BF16          : w13 [E,2I,H] bf16, w2 [E,H,I] bf16            */
+#define LKM_W_F16 1      /* MOE_FP16          : same in fp16                                   */
+#define LKM_W_FP8_E4M3 2 /* MOE_FP8[_FP16]    : e4m3fn + fp32 block scales [E,N/gN,K/gK]       */
+#define LKM_W_INT4_B8 3  /* MOE_WNA16[_FP16]  : uint4b8 bytes [E,N,K/2] + act-dtype scales     */
+#define LKM_W_NVFP4 4    /* MOE_NVFP4[_FP16]  : SURVEY 8(f3), not built -> LKM_E_UNSUPPORTED   */
+#define LKM_W_MXFP4 5    /* MOE_MXFP4[_FP16]  : SURVEY 8(f3), not built -> LKM_E_UNSUPPORTED   */
+
+/* MOEConfigV2.activation_type (routed_experts.py:160-164) */
+#define LKM_ACT_SILU 0
+#define LKM_ACT_SWIGLUOAI 1
+#define LKM_ACT_RELU2 2
+
+/* fp8 compute mode */
+#define LKM_FP8_W8A16 0 /* lk_moe semantics: weight-only fp8, activations stay bf16/fp16      */
+#define LKM_FP8_W8A8 1  /* in-tree operator semantics: dynamic 1 x groupK activation quant     */
+
+/*
+ * Mirrors lk_moe.MOEConfigV2 field for field (routed_experts.py:1490-1511), plus the three
+ * things the reference encodes in the class name / pointer set (weight format, activation
+ * dtype, fp8 mode).
+ */
+typedef struct LkmConfig {
+    int32_t abi_version;      /* = LKM_ABI_VERSION */
+    int32_t num_processes;    /* TP or EP world size            (:1435-1438) */
+    int32_t process_id;       /* rank in that group                          */
+    int32_t gpu_id;           /* HIP device ordinal                          */
+    int32_t has_gate_proj;    /* 0 => non-gated (relu2) experts              */
+    int32_t expert_num;       /* LOCAL experts                               */
+    int32_t top_k;
+    int32_t hidden_size;
+    int32_t intermediate_size; /* per TP partition                           */
+    int32_t max_batch_size;   /* max_num_batched_tokens                      */
+    int32_t max_num_seqs;     /* decode batch bound (x (1+spec tokens))      */
+    int32_t stride;           /* CPU tiling hint of the original engine: accepted, unused */
+    int32_t group_min_len;    /* idem                                        */
+    int32_t group_max_len;    /* prefill chunk length (:1323-1330)           */
+    int32_t groupN;           /* quant block shape (rows)                    */
+    int32_t groupK;           /* quant block shape (K)                       */
+    int32_t activation_type;  /* LKM_ACT_*                                   */
+    float swiglu_alpha;
+    float swiglu_limit;
+    int32_t use_gpu_prefill;
+    int32_t weight_format;    /* LKM_W_*                                     */
+    int32_t act_dtype;        /* LKM_DT_BF16 | LKM_DT_F16                    */
+    int32_t fp8_mode;         /* LKM_FP8_*                                   */
+    int32_t reserved[8];
+} LkmConfig;
+
+typedef struct LkmEngine* LkmHandle;
+
+/* -------------------------------------------------------------------------------------------
+ * Engine life cycle.
+ * Replaces lk_moe.MOE_*(cfg, w13_ptr, w2_ptr, w13_scale_ptr, w2_scale_ptr,
+ *                        w13_global_scale_ptr, w2_global_scale_ptr)
+ * (routed_experts.py:1514-1533, 1596-1616, 1648-1668).  Pointers may be host OR device
+ * memory (detected); contiguous, layouts of SURVEY 8(a5).  The engine COPIES the weights
+ * (pre-shuffled into its MFMA-native HBM layout) -- the caller frees its tensors right
+ * after (routed_experts.py:1420-1432).  NULL = absent.
+ */
+int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2, const void* w13_scale,
+               const void* w2_scale, const void* w13_global_scale, const void* w2_global_scale,
+               LkmHandle* out);
+void lkm_destroy(LkmHandle h);
+
+/*
+ * Replaces lk_moe.MOE_*.cpu_decode(stream, num_tokens, top_k, hidden_ptr, topk_ids_ptr,
+ *                                  topk_weights_ptr, out_f32_ptr)   (routed_experts.py:1840-1855)
+ * All DEVICE pointers; asynchronous on `stream` (a hipStream_t, 0 = default stream);
+ * capturable in a hipGraph (no allocation, no synchronisation).  hidden [num_tokens,H] in the
+ * activation dtype; ids int32 [num_tokens,top_k], local ids, <0 = skip; weights fp32;
+ * out fp32 [num_tokens,H], every row written.
+ */
+int lkm_decode(LkmHandle h, void* stream, int32_t num_tokens, int32_t top_k, const void* hidden,
+               const int32_t* topk_ids, const float* topk_weights, float* out_f32);
+
+/*
+ * Replaces lk_moe.MOE_*.cpu_prefill(num_tokens, top_k, ids_ptr, weights_ptr, hidden_ptr,
+ *                                   out_f32_ptr)                  (routed_experts.py:1858-1882)
+ * All HOST pointers; blocking.  (The data crosses PCIe both ways; kept for API parity.)
+ */
+int lkm_prefill_host(LkmHandle h, int32_t num_tokens, int32_t top_k, const int32_t* topk_ids,
+                     const float* topk_weights, const void* hidden, float* out_f32);
+
+/*
+ * Replaces lk_moe.MOE_*.gpu_prefill(hidden_ptr, out_ptr, topk_ids_ptr, topk_weights_ptr,
+ *                                   num_tokens, top_k, stream)    (routed_experts.py:1884-1899)
+ * DEVICE pointers; out has the activation dtype; asynchronous on `stream`.
+ */
+int lkm_prefill_device(LkmHandle h, const void* hidden, void* out, const int32_t* topk_ids,
+                       const float* topk_weights, int32_t num_tokens, int32_t top_k, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Routing (runs just before the engine call, moe_runner.py:577-600).
+ *
+ * Replaces torch.ops._moe_C.topk_softmax / topk_sigmoid
+ * (vllm/_custom_ops.py:2228-2290 -> csrc/libtorch_stable/moe/topk_softmax_kernels.cu:822-860).
+ * logits [M,E] in `logits_dtype` (LKM_DT_*); bias fp32 [E] or NULL; scoring 0=softmax 1=sigmoid.
+ * Outputs: weights fp32 [M,K], ids int32 [M,K].  DEVICE pointers, async on stream.
+ */
+int lkm_topk_softmax(void* stream, const void* logits, int32_t logits_dtype, const float* bias,
+                     int32_t M, int32_t E, int32_t K, int32_t scoring, int32_t renormalize,
+                     float routed_scaling, float* out_weights, int32_t* out_ids);
+
+/*
+ * Replaces grouped_topk / torch.ops._moe_C.grouped_topk
+ * (vllm/model_executor/layers/fused_moe/router/grouped_topk_router.py:80-161).
+ */
+int lkm_grouped_topk(void* stream, const void* logits, int32_t logits_dtype, const float* bias,
+                     int32_t M, int32_t E, int32_t K, int32_t n_group, int32_t topk_group,
+                     int32_t scoring, int32_t renormalize, float routed_scaling,
+                     float* out_weights, int32_t* out_ids);
+
+/*
+ * Replaces RoutedExperts.global_to_local_expert_ids (routed_experts.py:1332-1342):
+ * out[i] = ids[i] < 0 ? -1 : expert_map[clamp(ids[i], 0, E-1)].  DEVICE pointers.
+ */
+int lkm_map_expert_ids(void* stream, const int32_t* ids, int64_t n, const int32_t* expert_map,
+                       int32_t E, int32_t* out);
+
+/*
+ * Token->expert scatter metadata, exposed for tests and for the expert-parallel host code.
+ * Stable counting sort of the n_slots = M*K assignments by expert
+ * (csrc/cpu/cpu_fused_moe.cpp:200-227; moe_permute's stable sort, moe_permute_unpermute_kernel.cu:45-60).
+ * counts [E], offsets [E+1], sorted_slot [n_slots] (tail = -1), pos_of_slot [n_slots] (-1 = skipped).
+ */
+int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots, int32_t E, int32_t* counts,
+                   int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot);
+
+/* -------------------------------------------------------------------------------------------
+ * Introspection / measurement.
+ */
+const char* lkm_last_error(void);
+int lkm_abi_version(void);
+/* number of visible HIP devices and the gfx arch name of device 0 (buf >= 32 bytes) */
+int lkm_device_info(int32_t* n_devices, char* arch_buf, int32_t buf_len);
+
+/* When enabled the engine brackets every kernel of the next decode/prefill_device call with
+ * hipEvents on the call's stream (NOT graph-capturable while on). */
+int lkm_set_profiling(LkmHandle h, int32_t enable);
+#define LKM_PROF_SORT 0
+#define LKM_PROF_GEMM1 1
+#define LKM_PROF_GEMM2 2
+#define LKM_PROF_COMBINE 3
+#define LKM_PROF_N 4
+/* Synchronises the profiled stream and returns per-kernel milliseconds of the last call. */
+int lkm_get_profile(LkmHandle h, float* ms /* [LKM_PROF_N] */);
+/* HBM bytes held by this engine (weights + scales), and its launch geometry as text. */
+int64_t lkm_weight_bytes(LkmHandle h);
+int lkm_describe(LkmHandle h, char* buf, int32_t buf_len);
+/* tuning knobs (bench / tests): key in {"nt1","nt2","kw1","sk2","tbmax"}; value <= 0 = auto */
+int lkm_set_tuning(LkmHandle h, const char* key, int32_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LKM_H */

@@ -1,0 +1,83 @@
+"""Builds liblkm.so (the gfx950 HIP kernels + C ABI) in-tree with hipcc.
+
+No torch in the build: the library is plain HIP behind a C ABI (include/lkm.h).  Each .hip
+translation unit is compiled in parallel, objects are cached by source hash under
+lvllm_amd/csrc/_obj/, and the link produces lvllm_amd/liblkm.so (git-ignored; it travels to
+the GPU box with the tree).  hipcc cross-compiles for gfx950 without a GPU present.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+OBJ = CSRC / "_obj"
+LIB = PKG / "liblkm.so"
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: liblkm.so cannot be built (ROCm toolchain required)")
+    return exe
+
+
+def _digest(src: Path, headers: list[Path]) -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for p in [src, *headers]:
+        h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def _compile(src: Path, headers: list[Path], verbose: bool) -> Path:
+    tag = _digest(src, headers)
+    obj = OBJ / f"{src.stem}.{tag}.o"
+    if obj.exists():
+        return obj
+    for old in OBJ.glob(f"{src.stem}.*.o"):
+        old.unlink()
+    cmd = [_hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    if verbose:
+        print("[lkm build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile (if stale) and link liblkm.so; returns its path."""
+    OBJ.mkdir(parents=True, exist_ok=True)
+    srcs = sorted(CSRC.glob("*.hip"))
+    headers = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "lkm.h"]
+    if force:
+        for o in OBJ.glob("*.o"):
+            o.unlink()
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, headers, verbose), srcs))
+    stamp = OBJ / "link.stamp"
+    want = " ".join(o.name for o in objs)
+    if LIB.exists() and stamp.exists() and stamp.read_text() == want and not force:
+        return LIB
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+    if verbose:
+        print("[lkm build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link of liblkm.so failed:\n{r.stdout}\n{r.stderr}")
+    stamp.write_text(want)
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose=True)
+    print(p)

@@ -1,0 +1,222 @@
+// dispatch.hip -- token->expert scatter metadata (stable counting sort) and the top-k combine.
+//
+// Reference semantics (paths relative to the reference tree):
+//   sort     csrc/cpu/cpu_fused_moe.cpp:200-227 (count / exclusive prefix / scatter in ascending
+//            slot order) == the stable radix sort of moe_permute
+//            (csrc/libtorch_stable/moe/moe_permute_unpermute_kernel.cu:45-60).  Unlike
+//            moe_align_block_size (moe_align_sum_kernels.cu:316, atomicAdd ranks) the order inside
+//            an expert is deterministic here: ascending flat slot index m*K+k.
+//   combine  finalizeMoeRoutingKernel (permute_unpermute_kernels/moe_permute_unpermute_kernel.inl:
+//            91-143) / moe_sum: out[m] = sum_k w[m,k] * y[pos(m,k)], fp32, ascending k.
+#include "lkm_kernels.h"
+
+namespace lkm {
+
+constexpr int kSortThreads = 1024;
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kMaxLocalExperts = 512;
+
+// meta[0] = number of active experts, meta[1] = total routed rows, meta[2] = max rows of one expert
+__global__ __launch_bounds__(kSortThreads) void sort_slots_kernel(
+    const int32_t* __restrict__ ids, int n_slots, int E, int32_t* __restrict__ counts,
+    int32_t* __restrict__ offsets, int32_t* __restrict__ sorted_slot,
+    int32_t* __restrict__ pos_of_slot, int32_t* __restrict__ active, int32_t* __restrict__ meta) {
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    int32_t* cnt = smem;                 // [E]
+    int32_t* off = cnt + E;              // [E]
+    int32_t* run = off + E;              // [E]
+    int32_t* wsum = run + E;             // [kSortWaves] scan carries (64-bit packed as 2 ints)
+    int32_t* wcnt = wsum + 4 * kSortWaves;  // [kSortWaves][E]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    for (int e = tid; e < E; e += kSortThreads) {
+        cnt[e] = 0;
+        run[e] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < n_slots; i += kSortThreads) {
+        int id = ids[i];
+        if (id >= 0 && id < E) atomicAdd(&cnt[id], 1);
+    }
+    __syncthreads();
+
+    // exclusive scan of cnt[] and of the (cnt>0) flags, 1024 experts per pass
+    int carry_cnt = 0, carry_act = 0, maxc = 0;
+    for (int base = 0; base < E; base += kSortThreads) {
+        int e = base + tid;
+        int c = (e < E) ? cnt[e] : 0;
+        int a = c > 0 ? 1 : 0;
+        int sc = c, sa = a;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int tc = __shfl_up(sc, d, 64), ta = __shfl_up(sa, d, 64);
+            if (lane >= d) {
+                sc += tc;
+                sa += ta;
+            }
+        }
+        if (lane == 63) {
+            wsum[wv] = sc;
+            wsum[kSortWaves + wv] = sa;
+        }
+        __syncthreads();
+        int pc = 0, pa = 0;
+        for (int w = 0; w < wv; ++w) {
+            pc += wsum[w];
+            pa += wsum[kSortWaves + w];
+        }
+        int tot_c = 0, tot_a = 0;
+        for (int w = 0; w < kSortWaves; ++w) {
+            tot_c += wsum[w];
+            tot_a += wsum[kSortWaves + w];
+        }
+        int ex_c = carry_cnt + pc + sc - c;
+        int ex_a = carry_act + pa + sa - a;
+        if (e < E) {
+            off[e] = ex_c;
+            counts[e] = c;
+            offsets[e] = ex_c;
+            if (a) active[ex_a] = e;
+        }
+        maxc = max(maxc, c);
+        carry_cnt += tot_c;
+        carry_act += tot_a;
+        __syncthreads();
+    }
+    // block max of maxc
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) maxc = max(maxc, __shfl_xor(maxc, m, 64));
+    if (lane == 0) wsum[2 * kSortWaves + wv] = maxc;
+    __syncthreads();
+    if (tid == 0) {
+        int mm = 0;
+        for (int w = 0; w < kSortWaves; ++w) mm = max(mm, wsum[2 * kSortWaves + w]);
+        offsets[E] = carry_cnt;
+        meta[0] = carry_act;
+        meta[1] = carry_cnt;
+        meta[2] = mm;
+    }
+    const int total = carry_cnt;
+
+    // stable scatter, 1024 slots per pass
+    for (int base = 0; base < n_slots; base += kSortThreads) {
+        for (int j = tid; j < kSortWaves * E; j += kSortThreads) wcnt[j] = 0;
+        __syncthreads();
+        const int i = base + tid;
+        int id = -1;
+        if (i < n_slots) {
+            id = ids[i];
+            if (id < 0 || id >= E) id = -1;
+        }
+        // rank among equal ids inside this wave (lower lanes first)
+        int rank = 0, wc = 0;
+        bool done = id < 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        while (true) {
+            unsigned long long rem = __ballot(!done);
+            if (rem == 0ull) break;
+            int leader = __ffsll((long long)rem) - 1;
+            int v = __shfl(id, leader, 64);
+            unsigned long long m = __ballot(!done && id == v);
+            if (!done && id == v) {
+                rank = __popcll(m & lt);
+                wc = __popcll(m);
+                done = true;
+                if (rank == 0) wcnt[wv * E + v] = wc;
+            }
+        }
+        __syncthreads();
+        int p = -1;
+        if (id >= 0) {
+            int before = 0;
+            for (int w = 0; w < wv; ++w) before += wcnt[w * E + id];
+            p = off[id] + run[id] + before + rank;
+        }
+        __syncthreads();
+        if (id >= 0 && rank == 0) atomicAdd(&run[id], wc);
+        if (i < n_slots) {
+            pos_of_slot[i] = p;
+            if (p >= 0) sorted_slot[p] = i;
+        }
+        __syncthreads();
+    }
+    for (int p = total + tid; p < n_slots; p += kSortThreads) sorted_slot[p] = -1;
+}
+
+// out[m][h] = sum_k w[m,k] * sum_s y[s][pos(m,k)][h]   (fp32; s ascending, then k ascending)
+template <typename OutT>
+__device__ __forceinline__ void store4(OutT* p, f32x4 v);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, f32x4 v) {
+    *(f32x4*)p = v;
+}
+struct bf16_out { unsigned short v; };
+struct f16_out { unsigned short v; };
+template <>
+__device__ __forceinline__ void store4<bf16_out>(bf16_out* p, f32x4 v) {
+    u32x2 o;
+    o.x = ActT<LKM_DT_BF16>::pack2(v.x, v.y);
+    o.y = ActT<LKM_DT_BF16>::pack2(v.z, v.w);
+    *(u32x2*)p = o;
+}
+template <>
+__device__ __forceinline__ void store4<f16_out>(f16_out* p, f32x4 v) {
+    u32x2 o;
+    o.x = ActT<LKM_DT_F16>::pack2(v.x, v.y);
+    o.y = ActT<LKM_DT_F16>::pack2(v.z, v.w);
+    *(u32x2*)p = o;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ y, int SK,
+                                                      size_t sk_stride,
+                                                      const int32_t* __restrict__ pos_of_slot,
+                                                      const float* __restrict__ tw, int M, int K,
+                                                      int H, OutT* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int m = blockIdx.y;
+    const int h = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (h >= H) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+        int p = pos_of_slot[m * K + k];
+        if (p < 0) continue;
+        float w = tw[m * K + k];
+        const float* yp = y + (size_t)p * H + h;
+        f32x4 v = *(const f32x4*)yp;
+        for (int s = 1; s < SK; ++s) v += *(const f32x4*)(yp + s * sk_stride);
+        acc += w * v;
+    }
+    store4<OutT>(out + (size_t)m * H + h, acc);
+}
+
+int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
+                int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
+                int32_t* meta) {
+    LKM_REQUIRE(E > 0 && E <= kMaxLocalExperts, "sort: local experts E=%d out of range (1..%d)", E, kMaxLocalExperts);
+    size_t lds = sizeof(int32_t) * ((size_t)3 * E + 4 * kSortWaves + (size_t)kSortWaves * E);
+    hipLaunchKernelGGL(sort_slots_kernel, dim3(1), dim3(kSortThreads), lds, st, ids, n_slots, E,
+                       counts, offsets, sorted_slot, pos_of_slot, active, meta);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
+                   const int32_t* pos_of_slot, const float* tw, int M, int K, int H, void* out,
+                   int out_dt) {
+    if (M == 0) return LKM_OK;
+    dim3 grid(ceil_div(H, 1024), M), block(256);
+    if (out_dt == LKM_DT_F32)
+        hipLaunchKernelGGL(combine_kernel<float>, grid, block, 0, st, y, SK, sk_stride, pos_of_slot,
+                           tw, M, K, H, (float*)out);
+    else if (out_dt == LKM_DT_BF16)
+        hipLaunchKernelGGL(combine_kernel<bf16_out>, grid, block, 0, st, y, SK, sk_stride,
+                           pos_of_slot, tw, M, K, H, (bf16_out*)out);
+    else
+        hipLaunchKernelGGL(combine_kernel<f16_out>, grid, block, 0, st, y, SK, sk_stride,
+                           pos_of_slot, tw, M, K, H, (f16_out*)out);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+}  // namespace lkm

@@ -1,0 +1,467 @@
+// gemm_skinny.hip -- per-expert grouped GEMMs for the decode regime (few rows per expert).
+//
+// Computes what the reference's routed-expert operator computes between the router and the final
+// sum:   act = ACT(x_e . W13[e]^T)   and   y = act . W2[e]^T
+//   math spec : vllm/model_executor/layers/fused_moe/fused_moe.py:298-610 (fp32 accumulate),
+//               :64-295 (int4: b = T((nib-8)*scale)), csrc/cpu/cpu_fused_moe.cpp:229-522,
+//               activation: csrc/libtorch_stable/activation_kernels.cu:57-75,401-408,
+//               vllm/model_executor/layers/fused_moe/activation.py:208-210 (relu2).
+//
+// MI355X design (this is NOT how the reference does it):
+//   * decode is HBM-bound (8 FLOP/B for Mixtral M=32): the kernel is a weight STREAMER.  Weights
+//     are the MFMA *A* operand (16 weight rows x 32 k per mfma_f32_16x16x32), tokens are the *B*
+//     operand (32 k x 16 tokens), so one 1-KiB wave-wide nontemporal global_load_dwordx4 of the
+//     pre-shuffled layout (lkm_common.h) IS an A fragment: no LDS round trip, no shuffles, every
+//     weight byte crosses HBM->VGPR exactly once and feeds TB MFMAs (TB = 16-token blocks).
+//   * one wavefront owns NT 16-row tiles (x2 for gate+up) over a K range; loads are double-buffered
+//     in registers one "unit" (64 or 128 k) ahead, so each wave keeps >= NT*2*LOADS KiB in flight;
+//     thousands of waves => >= 32 KiB in flight per CU, the streaming regime of MI355X_MICROARCH.
+//   * quantised formats are decoded in registers right before the MFMA (int4: nibble -> f32 ->
+//     fma(q, s, -8s) (exact) -> RNE to the act dtype == the reference's T((q-8)*s); fp8: hardware
+//     v_cvt_pk_f32_fp8 (exact in bf16/f16), block scale applied to the fp32 partial sums).
+//   * GEMM1 fuses the activation (SiLU-mul / swigluoai / relu2) into the epilogue and writes the
+//     act-dtype intermediate in expert-sorted row order; GEMM2 writes fp32 split-K partials that the
+//     combine kernel (dispatch.hip) reduces together with the top-k weighting.
+#pragma once
+#include "lkm_kernels.h"
+
+namespace lkm {
+
+// ------------------------------------------------------------------ in-register weight decoders
+template <int WF, int ADT>
+struct Dec;
+
+template <int ADT>
+struct DecPlain {
+    static constexpr int UNITK = 64, LOADS = 2, KSTEPS = 2;
+    static constexpr bool UNIT_SCALE = false;
+    struct Aux {};
+    static __device__ __forceinline__ void load_aux(Aux&, const void*, size_t, int, int) {}
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux&, int ks) {
+        return raw[ks];
+    }
+};
+template <>
+struct Dec<LKM_W_BF16, LKM_DT_BF16> : DecPlain<LKM_DT_BF16> {};
+template <>
+struct Dec<LKM_W_F16, LKM_DT_F16> : DecPlain<LKM_DT_F16> {};
+
+template <int ADT>
+struct Dec<LKM_W_INT4_B8, ADT> {
+    static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
+    static constexpr bool UNIT_SCALE = false;
+    struct Aux {
+        float s[4];
+    };
+    // scales: [tile][unit][16 rows][spu] act dtype; tu = tile*U + unit
+    static __device__ __forceinline__ void load_aux(Aux& a, const void* sbase, size_t tu, int lane,
+                                                    int spu) {
+        const unsigned short* p = (const unsigned short*)sbase + (tu * 16 + (lane & 15)) * spu;
+        if (spu == 1) {
+            float s = ActT<ADT>::to_f32(p[0]);
+            a.s[0] = a.s[1] = a.s[2] = a.s[3] = s;
+        } else if (spu == 2) {
+            unsigned v = *(const unsigned*)p;
+            a.s[0] = a.s[1] = ActT<ADT>::to_f32((unsigned short)(v & 0xffffu));
+            a.s[2] = a.s[3] = ActT<ADT>::to_f32((unsigned short)(v >> 16));
+        } else {
+            u32x2 v = *(const u32x2*)p;
+            a.s[0] = ActT<ADT>::to_f32((unsigned short)(v.x & 0xffffu));
+            a.s[1] = ActT<ADT>::to_f32((unsigned short)(v.x >> 16));
+            a.s[2] = ActT<ADT>::to_f32((unsigned short)(v.y & 0xffffu));
+            a.s[3] = ActT<ADT>::to_f32((unsigned short)(v.y >> 16));
+        }
+    }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux& a, int ks) {
+        const unsigned w = raw[0][ks];
+        const float s = a.s[ks];
+        const float m8 = -8.0f * s;
+        const unsigned lo = w & 0x0f0f0f0fu, hi = (w >> 4) & 0x0f0f0f0fu;
+        u32x4 o;
+        // byte b of the dword holds k=2b (low nibble) and k=2b+1 (high nibble)
+        o.x = ActT<ADT>::pack2(__builtin_fmaf((float)(lo & 0xffu), s, m8),
+                               __builtin_fmaf((float)(hi & 0xffu), s, m8));
+        o.y = ActT<ADT>::pack2(__builtin_fmaf((float)((lo >> 8) & 0xffu), s, m8),
+                               __builtin_fmaf((float)((hi >> 8) & 0xffu), s, m8));
+        o.z = ActT<ADT>::pack2(__builtin_fmaf((float)((lo >> 16) & 0xffu), s, m8),
+                               __builtin_fmaf((float)((hi >> 16) & 0xffu), s, m8));
+        o.w = ActT<ADT>::pack2(__builtin_fmaf((float)(lo >> 24), s, m8),
+                               __builtin_fmaf((float)(hi >> 24), s, m8));
+        return o;
+    }
+};
+
+template <int ADT>
+struct Dec<LKM_W_FP8_E4M3, ADT> {
+    static constexpr int UNITK = 128, LOADS = 2, KSTEPS = 4;
+    static constexpr bool UNIT_SCALE = true;
+    struct Aux {
+        f32x4 s;  // block scale of this lane's 4 output rows (g*4 + r)
+    };
+    // scales: [tile][unit][16 rows] fp32
+    static __device__ __forceinline__ void load_aux(Aux& a, const void* sbase, size_t tu, int lane,
+                                                    int) {
+        a.s = *(const f32x4*)((const float*)sbase + tu * 16 + (lane >> 4) * 4);
+    }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux&, int ks) {
+        const unsigned d0 = raw[ks >> 1][(ks & 1) * 2], d1 = raw[ks >> 1][(ks & 1) * 2 + 1];
+        f32x2 p0 = __builtin_amdgcn_cvt_pk_f32_fp8(d0, false);
+        f32x2 p1 = __builtin_amdgcn_cvt_pk_f32_fp8(d0, true);
+        f32x2 p2 = __builtin_amdgcn_cvt_pk_f32_fp8(d1, false);
+        f32x2 p3 = __builtin_amdgcn_cvt_pk_f32_fp8(d1, true);
+        u32x4 o;
+        o.x = ActT<ADT>::pack2(p0.x, p0.y);
+        o.y = ActT<ADT>::pack2(p1.x, p1.y);
+        o.z = ActT<ADT>::pack2(p2.x, p2.y);
+        o.w = ActT<ADT>::pack2(p3.x, p3.y);
+        return o;
+    }
+};
+
+template <int LOADS, int KSTEPS, int NTT, int TB, typename Aux>
+struct Stage {
+    u32x4 w[NTT][LOADS];
+    u32x4 x[TB][KSTEPS];
+    Aux aux[NTT];
+};
+
+// Streams units [u0,u1) of NTT tiles against TB token blocks into acc[NTT][TB].
+template <int WF, int ADT, int NTT, int TB>
+struct Streamer {
+    typedef Dec<WF, ADT> D;
+    typedef Stage<D::LOADS, D::KSTEPS, NTT, TB, typename D::Aux> St;
+
+    static __device__ __forceinline__ void load(St& st, const u32x4* const (&wp)[NTT],
+                                                const void* sbase, const size_t (&stu)[NTT], int spu,
+                                                const unsigned short* const (&xp)[TB],
+                                                const bool (&xok)[TB], int u, int Kreal, int g8,
+                                                int lane, int ntb) {
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) {
+#pragma unroll
+            for (int l = 0; l < D::LOADS; ++l)
+                st.w[t][l] = __builtin_nontemporal_load(wp[t] + ((size_t)u * D::LOADS + l) * 64);
+            D::load_aux(st.aux[t], sbase, stu[t] + u, lane, spu);
+        }
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            if (b < ntb) {
+#pragma unroll
+                for (int ks = 0; ks < D::KSTEPS; ++ks) {
+                    const int k = u * D::UNITK + ks * 32 + g8;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (xok[b] && k + 8 <= Kreal) v = *(const u32x4*)(xp[b] + k);
+                    st.x[b][ks] = v;
+                }
+            }
+        }
+    }
+
+    static __device__ __forceinline__ void compute(const St& st, f32x4 (&acc)[NTT][TB], int ntb) {
+        if constexpr (D::UNIT_SCALE) {
+            f32x4 part[NTT][TB];
+#pragma unroll
+            for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                for (int b = 0; b < TB; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < D::KSTEPS; ++ks)
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    const u32x4 a = D::frag(st.w[t], st.aux[t], ks);
+#pragma unroll
+                    for (int b = 0; b < TB; ++b)
+                        if (b < ntb) part[t][b] = ActT<ADT>::mfma(a, st.x[b][ks], part[t][b]);
+                }
+#pragma unroll
+            for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                for (int b = 0; b < TB; ++b)
+                    if (b < ntb) acc[t][b] += st.aux[t].s * part[t][b];
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < D::KSTEPS; ++ks)
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    const u32x4 a = D::frag(st.w[t], st.aux[t], ks);
+#pragma unroll
+                    for (int b = 0; b < TB; ++b)
+                        if (b < ntb) acc[t][b] = ActT<ADT>::mfma(a, st.x[b][ks], acc[t][b]);
+                }
+        }
+    }
+
+    static __device__ __forceinline__ void run(f32x4 (&acc)[NTT][TB], const u32x4* const (&wp)[NTT],
+                                               const void* sbase, const size_t (&stu)[NTT], int spu,
+                                               const unsigned short* const (&xp)[TB],
+                                               const bool (&xok)[TB], int u0, int u1, int Kreal,
+                                               int lane, int ntb) {
+        const int g8 = (lane >> 4) * 8;
+        St st[2];
+        if (u0 < u1) load(st[0], wp, sbase, stu, spu, xp, xok, u0, Kreal, g8, lane, ntb);
+        for (int u = u0; u < u1; u += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int uu = u + h;
+                if (uu < u1) {
+                    if (uu + 1 < u1)
+                        load(st[h ^ 1], wp, sbase, stu, spu, xp, xok, uu + 1, Kreal, g8, lane, ntb);
+                    compute(st[h], acc, ntb);
+                }
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ float act_silu(float g) { return g / (1.0f + lkm_expf(-g)); }
+
+// ------------------------------------------------------------------ GEMM1 + activation
+// grid = (groups, max_active_experts); block = 64*KW threads: the KW waves of a workgroup split K
+// and reduce through LDS (needed when an expert has too few tiles to fill the chip, e.g. M=1).
+template <int WF, int ADT, int NT, int TB, bool GATED>
+__global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
+    typedef Dec<WF, ADT> D;
+    constexpr int NTT = GATED ? 2 * NT : NT;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NTT*TB][64] f32x4
+    const int ai = blockIdx.y;
+    if (ai >= p.meta[0]) return;
+    const int e = p.active[ai];
+    const int m_e = p.counts[e], off_e = p.offsets[e];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, KW = blockDim.x >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int tile0 = blockIdx.x * NT;
+    const int T_all = p.T_half * p.halves;
+
+    const u32x4* wp[NTT];
+    size_t stu[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+        const int tile = (GATED && t >= NT) ? p.T_half + tile0 + (t - NT) : tile0 + t;
+        const size_t tl = (size_t)e * T_all + tile;
+        wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
+        stu[t] = tl * p.U;
+    }
+    const int u0 = (int)((long long)wave * p.U / KW), u1 = (int)((long long)(wave + 1) * p.U / KW);
+
+    for (int sb = 0; sb < m_e; sb += 16 * TB) {
+        const int rows = min(m_e - sb, 16 * TB);
+        const int ntb = (rows + 15) >> 4;
+        const unsigned short* xp[TB];
+        bool xok[TB];
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const int r = sb + b * 16 + j;
+            xok[b] = r < m_e;
+            const int slot = p.sorted_slot[off_e + (xok[b] ? r : 0)];
+            const int tok = slot / p.top_k;
+            xp[b] = (const unsigned short*)p.x + (size_t)tok * p.ldx;
+        }
+        f32x4 acc[NTT][TB];
+#pragma unroll
+        for (int t = 0; t < NTT; ++t)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        Streamer<WF, ADT, NTT, TB>::run(acc, wp, p.s, stu, p.spu, xp, xok, u0, u1, p.Kreal, lane, ntb);
+
+        if (KW > 1) {
+            // fixed-order cross-wave sum: wave KW-1 stores, KW-2 .. 1 add, wave 0 takes the total
+            for (int w = KW - 1; w >= 1; --w) {
+                if (wave == w) {
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                        for (int b = 0; b < TB; ++b) {
+                            f32x4* q = (f32x4*)red + (t * TB + b) * 64 + lane;
+                            if (w == KW - 1)
+                                *q = acc[t][b];
+                            else
+                                *q = *q + acc[t][b];
+                        }
+                }
+                __syncthreads();
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                    for (int b = 0; b < TB; ++b)
+                        acc[t][b] = *((f32x4*)red + (t * TB + b) * 64 + lane) + acc[t][b];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            // D layout: lane (g,j): rows tile*16 + g*4 + r (r=0..3), token column j
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const int r_tok = sb + b * 16 + j;
+                if (b < ntb && r_tok < m_e) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int n = (tile0 + t) * 16 + g * 4;
+                        if (n < p.n_real) {
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float a = acc[t][b][r];
+                                if (GATED) {
+                                    const float up = acc[NT + t][b][r];
+                                    if (p.act_type == LKM_ACT_SWIGLUOAI) {
+                                        const float gg = fminf(a, p.limit);
+                                        const float uu = fmaxf(fminf(up, p.limit), -p.limit);
+                                        v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
+                                    } else {
+                                        v[r] = act_silu(a) * up;
+                                    }
+                                } else {
+                                    const float tt = a > 0.0f ? a : 0.0f;
+                                    v[r] = tt * tt;
+                                }
+                            }
+                            unsigned short* o = (unsigned short*)p.out + (size_t)(off_e + r_tok) * p.ldo + n;
+                            if (n + 4 <= p.n_real) {
+                                u32x2 pk;
+                                pk.x = ActT<ADT>::pack2(v[0], v[1]);
+                                pk.y = ActT<ADT>::pack2(v[2], v[3]);
+                                *(u32x2*)o = pk;
+                            } else {
+                                for (int r = 0; r < 4 && n + r < p.n_real; ++r) o[r] = ActT<ADT>::from_f32(v[r]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ GEMM2 (split-K partials)
+// grid = (ceil(groups*SK / 4), max_active_experts); block = 256 = 4 independent waves.
+template <int WF, int ADT, int NT, int TB>
+__global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
+    typedef Dec<WF, ADT> D;
+    const int ai = blockIdx.y;
+    if (ai >= p.meta[0]) return;
+    const int e = p.active[ai];
+    const int m_e = p.counts[e], off_e = p.offsets[e];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int uid = blockIdx.x * 4 + wave;
+    if (uid >= p.groups * p.SK) return;
+    const int grp = uid / p.SK, sk = uid % p.SK;
+    const int tile0 = grp * NT;
+
+    const u32x4* wp[NT];
+    size_t stu[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const size_t tl = (size_t)e * p.T_half + tile0 + t;
+        wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
+        stu[t] = tl * p.U;
+    }
+    const int u0 = (int)((long long)sk * p.U / p.SK), u1 = (int)((long long)(sk + 1) * p.U / p.SK);
+
+    for (int sb = 0; sb < m_e; sb += 16 * TB) {
+        const int rows = min(m_e - sb, 16 * TB);
+        const int ntb = (rows + 15) >> 4;
+        const unsigned short* xp[TB];
+        bool xok[TB];
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const int r = sb + b * 16 + j;
+            xok[b] = r < m_e;
+            xp[b] = (const unsigned short*)p.x + (size_t)(off_e + (xok[b] ? r : 0)) * p.ldx;
+        }
+        f32x4 acc[NT][TB];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        Streamer<WF, ADT, NT, TB>::run(acc, wp, p.s, stu, p.spu, xp, xok, u0, u1, p.Kreal, lane, ntb);
+
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const int r_tok = sb + b * 16 + j;
+            if (b < ntb && r_tok < m_e) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int n = (tile0 + t) * 16 + g * 4;
+                    float* o = (float*)p.out + (size_t)sk * p.sk_stride + (size_t)(off_e + r_tok) * p.ldo + n;
+                    if (n + 4 <= p.n_real) {
+                        *(f32x4*)o = acc[t][b];
+                    } else {
+                        for (int r = 0; r < 4 && n + r < p.n_real; ++r) o[r] = acc[t][b][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ launchers (per format TU)
+template <int WF, int ADT, int NT, int TB>
+static int launch_g1_t(hipStream_t st, const GemmParams& p, bool gated, int kw, int max_active) {
+    dim3 grid(p.groups, max_active), block(64 * kw);
+    const int ntt = gated ? 2 * NT : NT;
+    const size_t lds = kw > 1 ? (size_t)ntt * TB * 64 * sizeof(f32x4) : 0;
+    // only register-resident variants are built (see -Rpass-analysis=kernel-resource-usage)
+    if (gated) {
+        if constexpr (NT <= 2 && NT * TB <= 4) {
+            hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, true>), grid, block, lds, st, p);
+        } else {
+            set_error("gemm1: gated variant nt=%d tb=%d is not built (register budget)", NT, TB);
+            return LKM_E_INVALID;
+        }
+    } else {
+        if constexpr (NT * TB <= 8) {
+            hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, false>), grid, block, lds, st, p);
+        } else {
+            set_error("gemm1: variant nt=%d tb=%d is not built (register budget)", NT, TB);
+            return LKM_E_INVALID;
+        }
+    }
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+template <int WF, int ADT, int NT, int TB>
+static int launch_g2_t(hipStream_t st, const GemmParams& p, int max_active) {
+    dim3 grid(ceil_div(p.groups * p.SK, 4), max_active), block(256);
+    if constexpr (NT * TB <= 8) {
+        hipLaunchKernelGGL((gemm2_kernel<WF, ADT, NT, TB>), grid, block, 0, st, p);
+    } else {
+        set_error("gemm2: variant nt=%d tb=%d is not built (register budget)", NT, TB);
+        return LKM_E_INVALID;
+    }
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+#define LKM_DISPATCH_TB(FN, WF, ADT, NT, ...)                                    \
+    switch (cfg.tb) {                                                            \
+    case 1: return FN<WF, ADT, NT, 1>(__VA_ARGS__);                              \
+    case 2: return FN<WF, ADT, NT, 2>(__VA_ARGS__);                              \
+    case 4: return FN<WF, ADT, NT, 4>(__VA_ARGS__);                              \
+    default: set_error("gemm: unsupported tb=%d", cfg.tb); return LKM_E_INVALID; \
+    }
+#define LKM_DISPATCH_NT(FN, WF, ADT, ...)                                        \
+    switch (cfg.nt) {                                                            \
+    case 1: LKM_DISPATCH_TB(FN, WF, ADT, 1, __VA_ARGS__)                         \
+    case 2: LKM_DISPATCH_TB(FN, WF, ADT, 2, __VA_ARGS__)                         \
+    case 4: LKM_DISPATCH_TB(FN, WF, ADT, 4, __VA_ARGS__)                         \
+    default: set_error("gemm: unsupported nt=%d", cfg.nt); return LKM_E_INVALID; \
+    }
+
+// Each gemm_<fmt>.hip instantiates one (weight format, activation dtype) pair:
+#define LKM_DEFINE_GEMM_LAUNCHERS(SUFFIX, WF, ADT)                                              \
+    int launch_gemm1_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
+                              bool gated, int max_active) {                                     \
+        LKM_DISPATCH_NT(launch_g1_t, WF, ADT, st, p, gated, cfg.kw, max_active)                 \
+    }                                                                                           \
+    int launch_gemm2_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
+                              int max_active) {                                                 \
+        LKM_DISPATCH_NT(launch_g2_t, WF, ADT, st, p, max_active)                                \
+    }
+
+}  // namespace lkm

@@ -1,0 +1,652 @@
+// lkm_api.hip -- host side of liblkm.so: the C ABI declared in include/lkm.h.
+//
+// One LkmEngine == one lk_moe.MOE_* instance of the reference == the routed experts of one MoE
+// layer on one GPU (routed_experts.py:1399-1418).  The engine owns the pre-shuffled weights in
+// HBM; scratch (sort metadata, intermediate, split-K partials) is a per-device arena shared by all
+// engines because the layers of a model execute one after another on the worker's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "lkm_kernels.h"
+
+namespace lkm {
+
+// ------------------------------------------------------------------ error string
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------ per-device scratch arena
+// Grow-only: blocks that were handed out stay valid until process exit, so hipGraphs captured with
+// an older (smaller) arena keep working after a later engine asked for more.
+struct Arena {
+    int device = -1;
+    size_t cap_slots = 0, act_elems = 0, y_elems = 0;
+    int E_cap = 0;
+    int32_t *counts = nullptr, *offsets = nullptr, *active = nullptr, *meta = nullptr;
+    int32_t *sorted_slot = nullptr, *pos_of_slot = nullptr;
+    void* act = nullptr;  // [cap_slots][ld_act] 16-bit
+    float* y = nullptr;   // split-K partials
+    std::vector<void*> retired;
+};
+static std::mutex g_arena_mu;
+static Arena g_arenas[64];
+
+template <typename T>
+static int grow(T*& ptr, size_t& have, size_t want, std::vector<void*>& retired) {
+    if (want <= have && ptr) return LKM_OK;
+    void* np = nullptr;
+    hipError_t err = hipMalloc(&np, want * sizeof(T));
+    if (err != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(err));
+        return LKM_E_NOMEM;
+    }
+    if (ptr) retired.push_back((void*)ptr);
+    ptr = (T*)np;
+    have = want;
+    return LKM_OK;
+}
+
+static int arena_reserve(int device, int E, size_t slots, size_t act_elems, size_t y_elems, Arena** out) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    LKM_REQUIRE(device >= 0 && device < 64, "device ordinal %d out of range", device);
+    Arena& a = g_arenas[device];
+    a.device = device;
+    int rc;
+    if (E > a.E_cap) {
+        size_t h = 0;
+        int32_t* p = nullptr;
+        // counts[E] offsets[E+1] active[E] meta[8] in one block
+        size_t n = (size_t)3 * E + 1 + 8;
+        if ((rc = grow(p, h, n, a.retired)) != LKM_OK) return rc;
+        if (a.counts) a.retired.push_back(a.counts);
+        a.counts = p;
+        a.offsets = p + E;
+        a.active = a.offsets + E + 1;
+        a.meta = a.active + E;
+        a.E_cap = E;
+    }
+    if (slots > a.cap_slots) {
+        size_t h1 = 0, h2 = 0;
+        int32_t *s1 = nullptr, *s2 = nullptr;
+        if ((rc = grow(s1, h1, slots, a.retired)) != LKM_OK) return rc;
+        if ((rc = grow(s2, h2, slots, a.retired)) != LKM_OK) return rc;
+        if (a.sorted_slot) a.retired.push_back(a.sorted_slot);
+        if (a.pos_of_slot) a.retired.push_back(a.pos_of_slot);
+        a.sorted_slot = s1;
+        a.pos_of_slot = s2;
+        a.cap_slots = slots;
+    }
+    {
+        unsigned short* p = (unsigned short*)a.act;
+        if ((rc = grow(p, a.act_elems, act_elems, a.retired)) != LKM_OK) return rc;
+        a.act = p;
+    }
+    if ((rc = grow(a.y, a.y_elems, y_elems, a.retired)) != LKM_OK) return rc;
+    *out = &a;
+    return LKM_OK;
+}
+
+}  // namespace lkm
+
+using namespace lkm;
+
+// ------------------------------------------------------------------ engine
+struct LkmEngine {
+    LkmConfig cfg;
+    int device;
+    int E, H, I, K;            // local experts, hidden, intermediate, top_k
+    bool gated, interleaved;
+    int wf, adt;
+    // geometry
+    int unitk;
+    int T1_half, U1;           // w13: tiles per half, units along H
+    int T2, U2;                // w2 : tiles (rows = H), units along I
+    int ld_act;                // row stride of the intermediate
+    int spu;                   // int4 scales per unit
+    // HBM
+    void *w13 = nullptr, *w2 = nullptr, *s13 = nullptr, *s2 = nullptr;
+    int64_t weight_bytes = 0;
+    // scratch
+    Arena* arena = nullptr;
+    size_t cap_tokens = 0;
+    // host-IO staging for prefill_host
+    void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
+    size_t io_tokens = 0;
+    // tuning overrides (<=0 = auto)
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0;
+    // profiling
+    bool prof = false;
+    hipEvent_t ev[LKM_PROF_N + 1] = {};
+    hipStream_t prof_stream = nullptr;
+    bool prof_valid = false;
+    char last_desc[512] = "";
+};
+
+static bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear sticky error for unregistered host memory
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// copy-or-alias: returns a device pointer holding `bytes` of src; *tmp is set if it must be freed
+static int to_device(const void* src, size_t bytes, const void** dev, void** tmp) {
+    *tmp = nullptr;
+    if (is_device_ptr(src)) {
+        *dev = src;
+        return LKM_OK;
+    }
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) for weight staging failed: %s", bytes, hipGetErrorString(e));
+        return LKM_E_NOMEM;
+    }
+    e = hipMemcpy(d, src, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        set_error("hipMemcpy H2D of weights failed: %s", hipGetErrorString(e));
+        return LKM_E_HIP;
+    }
+    *dev = d;
+    *tmp = d;
+    return LKM_OK;
+}
+
+static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+static size_t wbytes_per_elem_x2(int wf) {  // bytes per 2 elements
+    switch (wf) {
+    case LKM_W_BF16:
+    case LKM_W_F16: return 4;
+    case LKM_W_FP8_E4M3: return 2;
+    default: return 1;
+    }
+}
+
+extern "C" int lkm_abi_version(void) { return LKM_ABI_VERSION; }
+extern "C" const char* lkm_last_error(void) { return g_err; }
+
+extern "C" int lkm_device_info(int32_t* n_devices, char* arch_buf, int32_t buf_len) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    if (n_devices) *n_devices = n;
+    if (arch_buf && buf_len > 0) {
+        arch_buf[0] = 0;
+        if (n > 0) {
+            hipDeviceProp_t prop;
+            LKM_HIP_CHECK(hipGetDeviceProperties(&prop, 0));
+            snprintf(arch_buf, buf_len, "%s", prop.gcnArchName);
+        }
+    }
+    return LKM_OK;
+}
+
+extern "C" void lkm_destroy(LkmHandle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->w13) (void)hipFree(h->w13);
+    if (h->w2) (void)hipFree(h->w2);
+    if (h->s13) (void)hipFree(h->s13);
+    if (h->s2) (void)hipFree(h->s2);
+    if (h->io_x) (void)hipFree(h->io_x);
+    if (h->io_ids) (void)hipFree(h->io_ids);
+    if (h->io_w) (void)hipFree(h->io_w);
+    if (h->io_out) (void)hipFree(h->io_out);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete h;
+}
+
+extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
+                          const void* w13_scale, const void* w2_scale, const void* w13_gs,
+                          const void* w2_gs, LkmHandle* out) {
+    LKM_REQUIRE(cfg && out, "lkm_create: null argument");
+    *out = nullptr;
+    LKM_REQUIRE(cfg->abi_version == LKM_ABI_VERSION, "lkm_create: ABI version %d != %d", cfg->abi_version, LKM_ABI_VERSION);
+    (void)w13_gs;
+    (void)w2_gs;
+    if (cfg->weight_format == LKM_W_NVFP4 || cfg->weight_format == LKM_W_MXFP4) {
+        set_error("lkm_create: NVFP4/MXFP4 expert formats are not built yet (SURVEY 8 f3)");
+        return LKM_E_UNSUPPORTED;
+    }
+    const int wf = cfg->weight_format, adt = cfg->act_dtype;
+    LKM_REQUIRE(wf >= LKM_W_BF16 && wf <= LKM_W_INT4_B8, "lkm_create: bad weight_format %d", wf);
+    LKM_REQUIRE(adt == LKM_DT_BF16 || adt == LKM_DT_F16, "lkm_create: act_dtype must be bf16 or fp16");
+    LKM_REQUIRE(!(wf == LKM_W_BF16 && adt != LKM_DT_BF16) && !(wf == LKM_W_F16 && adt != LKM_DT_F16),
+                "lkm_create: unquantised weights must have the activation dtype");
+    LKM_REQUIRE(w13 && w2, "lkm_create: null weight pointer");
+    LKM_REQUIRE(cfg->expert_num > 0 && cfg->expert_num <= 512, "lkm_create: expert_num=%d out of range (1..512)", cfg->expert_num);
+    LKM_REQUIRE(cfg->hidden_size > 0 && cfg->hidden_size % 8 == 0, "lkm_create: hidden_size=%d must be a positive multiple of 8", cfg->hidden_size);
+    LKM_REQUIRE(cfg->intermediate_size > 0 && cfg->intermediate_size % 8 == 0, "lkm_create: intermediate_size=%d must be a positive multiple of 8", cfg->intermediate_size);
+    LKM_REQUIRE(cfg->top_k > 0, "lkm_create: top_k must be > 0");
+    LKM_REQUIRE(cfg->activation_type >= LKM_ACT_SILU && cfg->activation_type <= LKM_ACT_RELU2, "lkm_create: bad activation_type %d", cfg->activation_type);
+    const bool gated = cfg->has_gate_proj != 0;
+    LKM_REQUIRE(!(gated && cfg->activation_type == LKM_ACT_RELU2), "lkm_create: relu2 experts are non-gated (has_gate_proj must be 0)");
+    LKM_REQUIRE(!(!gated && cfg->activation_type != LKM_ACT_RELU2), "lkm_create: non-gated experts support activation_type 2 (relu2) only");
+    if (wf == LKM_W_FP8_E4M3) {
+        LKM_REQUIRE(cfg->fp8_mode == LKM_FP8_W8A16, "lkm_create: fp8 W8A8 mode is not built yet; use LKM_FP8_W8A16");
+        LKM_REQUIRE(w13_scale && w2_scale, "lkm_create: fp8 weights need scales");
+        LKM_REQUIRE(cfg->groupN > 0 && cfg->groupK > 0 && cfg->groupK % 128 == 0, "lkm_create: fp8 needs groupN>0 and groupK a multiple of 128 (got %d,%d)", cfg->groupN, cfg->groupK);
+    }
+    if (wf == LKM_W_INT4_B8) {
+        LKM_REQUIRE(w13_scale && w2_scale, "lkm_create: int4 weights need scales");
+        LKM_REQUIRE(cfg->groupN == 1, "lkm_create: int4 expects groupN == 1 (got %d)", cfg->groupN);
+        const int g = cfg->groupK;
+        LKM_REQUIRE(g >= 32 && (g <= 128 ? 128 % g == 0 : g % 128 == 0), "lkm_create: int4 groupK=%d unsupported (32, 64, 128 or a multiple of 128)", g);
+        LKM_REQUIRE(cfg->hidden_size % g == 0 && cfg->intermediate_size % g == 0, "lkm_create: groupK=%d must divide hidden and intermediate sizes", g);
+    }
+    int ndev = 0;
+    LKM_HIP_CHECK(hipGetDeviceCount(&ndev));
+    LKM_REQUIRE(cfg->gpu_id >= 0 && cfg->gpu_id < ndev, "lkm_create: gpu_id=%d but %d HIP devices visible", cfg->gpu_id, ndev);
+    LKM_HIP_CHECK(hipSetDevice(cfg->gpu_id));
+    {
+        hipDeviceProp_t prop;
+        LKM_HIP_CHECK(hipGetDeviceProperties(&prop, cfg->gpu_id));
+        LKM_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "lkm_create: device %d is %s; this engine is built for gfx950 (MI355X) only", cfg->gpu_id, prop.gcnArchName);
+    }
+
+    LkmEngine* h = new LkmEngine();
+    h->cfg = *cfg;
+    h->device = cfg->gpu_id;
+    h->E = cfg->expert_num;
+    h->H = cfg->hidden_size;
+    h->I = cfg->intermediate_size;
+    h->K = cfg->top_k;
+    h->gated = gated;
+    h->interleaved = gated && cfg->activation_type == LKM_ACT_SWIGLUOAI;
+    h->wf = wf;
+    h->adt = adt;
+    h->unitk = wf_unitk(wf);
+    h->T1_half = round_up(ceil_div(h->I, 16), 4);
+    h->U1 = ceil_div(h->H, h->unitk);
+    h->T2 = round_up(ceil_div(h->H, 16), 4);
+    h->U2 = ceil_div(h->I, h->unitk);
+    h->ld_act = h->I;
+    h->spu = (wf == LKM_W_INT4_B8) ? (cfg->groupK >= 128 ? 1 : 128 / cfg->groupK) : 0;
+
+    const int loads = wf_loads(wf);
+    const int halves = gated ? 2 : 1;
+    const size_t w13_vec = (size_t)h->E * halves * h->T1_half * h->U1 * loads * 64;
+    const size_t w2_vec = (size_t)h->E * h->T2 * h->U2 * loads * 64;
+    int rc = LKM_OK;
+    auto fail = [&](int code) {
+        lkm_destroy(h);
+        return code;
+    };
+#define LKM_TRY(expr)                        \
+    do {                                     \
+        rc = (expr);                         \
+        if (rc != LKM_OK) return fail(rc);   \
+    } while (0)
+#define LKM_TRY_HIP(expr)                                                                   \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            set_error("%s failed: %s", #expr, hipGetErrorString(_e));                       \
+            return fail(_e == hipErrorOutOfMemory ? LKM_E_NOMEM : LKM_E_HIP);               \
+        }                                                                                   \
+    } while (0)
+
+    LKM_TRY_HIP(hipMalloc(&h->w13, w13_vec * 16));
+    LKM_TRY_HIP(hipMalloc(&h->w2, w2_vec * 16));
+    h->weight_bytes = (int64_t)(w13_vec + w2_vec) * 16;
+
+    RepackDims d13{h->E, h->I, halves, h->interleaved ? 1 : 0, h->H, h->T1_half, h->U1};
+    RepackDims d2{h->E, h->H, 1, 0, h->I, h->T2, h->U2};
+    {
+        const size_t n13 = (size_t)h->E * halves * h->I, n2 = (size_t)h->E * h->H;
+        const size_t b13 = n13 * h->H / 2 * wbytes_per_elem_x2(wf);
+        const size_t b2 = n2 * h->I / 2 * wbytes_per_elem_x2(wf);
+        const void* dsrc;
+        void* tmp;
+        LKM_TRY(to_device(w13, b13, &dsrc, &tmp));
+        rc = launch_repack_w(nullptr, wf, dsrc, h->w13, d13);
+        hipError_t se = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (rc != LKM_OK) return fail(rc);
+        LKM_TRY_HIP(se);
+        LKM_TRY(to_device(w2, b2, &dsrc, &tmp));
+        rc = launch_repack_w(nullptr, wf, dsrc, h->w2, d2);
+        se = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (rc != LKM_OK) return fail(rc);
+        LKM_TRY_HIP(se);
+    }
+    if (wf == LKM_W_INT4_B8) {
+        const int g = cfg->groupK;
+        const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16 * h->spu;
+        const size_t n2 = (size_t)h->E * h->T2 * h->U2 * 16 * h->spu;
+        LKM_TRY_HIP(hipMalloc(&h->s13, n13 * 2));
+        LKM_TRY_HIP(hipMalloc(&h->s2, n2 * 2));
+        h->weight_bytes += (int64_t)(n13 + n2) * 2;
+        const void* dsrc;
+        void* tmp;
+        LKM_TRY(to_device(w13_scale, (size_t)h->E * halves * h->I * (h->H / g) * 2, &dsrc, &tmp));
+        rc = launch_repack_s_int4(nullptr, dsrc, h->s13, d13, g, h->spu);
+        hipError_t se = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (rc != LKM_OK) return fail(rc);
+        LKM_TRY_HIP(se);
+        LKM_TRY(to_device(w2_scale, (size_t)h->E * h->H * (h->I / g) * 2, &dsrc, &tmp));
+        rc = launch_repack_s_int4(nullptr, dsrc, h->s2, d2, g, h->spu);
+        se = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (rc != LKM_OK) return fail(rc);
+        LKM_TRY_HIP(se);
+    } else if (wf == LKM_W_FP8_E4M3) {
+        const int gN = cfg->groupN, gK = cfg->groupK;
+        const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16;
+        const size_t n2 = (size_t)h->E * h->T2 * h->U2 * 16;
+        LKM_TRY_HIP(hipMalloc(&h->s13, n13 * 4));
+        LKM_TRY_HIP(hipMalloc(&h->s2, n2 * 4));
+        h->weight_bytes += (int64_t)(n13 + n2) * 4;
+        const void* dsrc;
+        void* tmp;
+        const size_t src13 = (size_t)h->E * ceil_div(halves * h->I, gN) * ceil_div(h->H, gK) * 4;
+        const size_t src2 = (size_t)h->E * ceil_div(h->H, gN) * ceil_div(h->I, gK) * 4;
+        LKM_TRY(to_device(w13_scale, src13, &dsrc, &tmp));
+        rc = launch_repack_s_fp8(nullptr, dsrc, h->s13, d13, gN, gK);
+        hipError_t se = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (rc != LKM_OK) return fail(rc);
+        LKM_TRY_HIP(se);
+        LKM_TRY(to_device(w2_scale, src2, &dsrc, &tmp));
+        rc = launch_repack_s_fp8(nullptr, dsrc, h->s2, d2, gN, gK);
+        se = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (rc != LKM_OK) return fail(rc);
+        LKM_TRY_HIP(se);
+    }
+
+    // scratch: sized for the larger of the decode batch and one prefill chunk
+    size_t chunk = cfg->group_max_len > 0 ? (size_t)cfg->group_max_len : 4224;
+    if (cfg->max_batch_size > 0 && (size_t)cfg->max_batch_size < chunk) chunk = cfg->max_batch_size;
+    size_t cap = cfg->max_num_seqs > 0 ? (size_t)cfg->max_num_seqs : 1;
+    if (chunk > cap) cap = chunk;
+    h->cap_tokens = cap;
+    const size_t slots = cap * h->K;
+    const size_t y_rows = slots > 8 * (slots < 2048 ? slots : 2048) ? slots : 8 * (slots < 2048 ? slots : 2048);
+    LKM_TRY(arena_reserve(h->device, h->E, slots, slots * h->ld_act, y_rows * h->H, &h->arena));
+    for (auto& e : h->ev) LKM_TRY_HIP(hipEventCreate(&e));
+    *out = h;
+    return LKM_OK;
+#undef LKM_TRY
+#undef LKM_TRY_HIP
+}
+
+// ------------------------------------------------------------------ launch geometry heuristics
+static int pow2_floor(int v) {
+    int p = 1;
+    while (p * 2 <= v) p *= 2;
+    return p;
+}
+
+static void pick_cfg(const LkmEngine* h, int M, LaunchCfg* c1, LaunchCfg* c2, size_t n_slots) {
+    const int kTargetWaves = 3072;
+    const int n_act = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
+    int tb = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    if (h->t_tb > 0) tb = h->t_tb;
+    // GEMM1
+    int nt1 = 1;
+    for (int c : {4, 2}) {
+        if (h->gated && c == 4 && tb >= 2) continue;  // register budget
+        if ((long long)n_act * (h->T1_half / c) >= kTargetWaves) {
+            nt1 = c;
+            break;
+        }
+    }
+    if (h->t_nt1 > 0) nt1 = h->t_nt1;
+    int kw = 1;
+    {
+        long long waves = (long long)n_act * (h->T1_half / nt1);
+        while (kw < 8 && waves * kw < kTargetWaves / 2 && h->U1 / (kw * 2) >= 2) kw *= 2;
+    }
+    if (h->t_kw1 > 0) kw = h->t_kw1;
+    *c1 = LaunchCfg{nt1, tb, kw, 1};
+    // GEMM2
+    int nt2 = 2;
+    if ((long long)n_act * (h->T2 / 2) < kTargetWaves / 8) nt2 = 1;
+    if (h->t_nt2 > 0) nt2 = h->t_nt2;
+    int sk = 1;
+    {
+        long long waves = (long long)n_act * (h->T2 / nt2);
+        while (sk < 8 && waves * sk < kTargetWaves && h->U2 / (sk * 2) >= 2) sk *= 2;
+    }
+    if (h->t_sk2 > 0) sk = h->t_sk2;
+    // split-K slabs must fit the partial buffer
+    const size_t y_rows = h->arena->y_elems / h->H;
+    while (sk > 1 && (size_t)sk * n_slots > y_rows) sk /= 2;
+    *c2 = LaunchCfg{nt2, tb, 1, sk};
+    (void)pow2_floor;
+}
+
+// one chunk: rows [0,M) of the given pointers
+static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, const int32_t* ids,
+                     const float* tw, void* out, int out_dt) {
+    Arena* a = h->arena;
+    const size_t n_slots = (size_t)M * K;
+    LaunchCfg c1, c2;
+    pick_cfg(h, M, &c1, &c2, n_slots);
+    const bool prof = h->prof;
+    if (prof) {
+        h->prof_stream = st;
+        LKM_HIP_CHECK(hipEventRecord(h->ev[0], st));
+    }
+    int rc = launch_sort(st, ids, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot,
+                         a->pos_of_slot, a->active, a->meta);
+    if (rc != LKM_OK) return rc;
+    if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[1], st));
+    const int max_active = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
+
+    GemmParams p1{};
+    p1.w = h->w13;
+    p1.s = h->s13;
+    p1.spu = h->spu;
+    p1.T_half = h->T1_half;
+    p1.halves = h->gated ? 2 : 1;
+    p1.U = h->U1;
+    p1.Kreal = h->H;
+    p1.n_real = h->I;
+    p1.x = x;
+    p1.ldx = h->H;
+    p1.top_k = K;
+    p1.counts = a->counts;
+    p1.offsets = a->offsets;
+    p1.active = a->active;
+    p1.meta = a->meta;
+    p1.sorted_slot = a->sorted_slot;
+    p1.out = a->act;
+    p1.ldo = h->ld_act;
+    p1.sk_stride = 0;
+    p1.SK = 1;
+    p1.groups = h->T1_half / c1.nt;
+    p1.act_type = h->cfg.activation_type;
+    p1.alpha = h->cfg.swiglu_alpha;
+    p1.limit = h->cfg.swiglu_limit;
+    rc = launch_gemm1(st, h->wf, h->adt, c1, p1, h->gated, max_active);
+    if (rc != LKM_OK) return rc;
+    if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[2], st));
+
+    GemmParams p2{};
+    p2.w = h->w2;
+    p2.s = h->s2;
+    p2.spu = h->spu;
+    p2.T_half = h->T2;
+    p2.halves = 1;
+    p2.U = h->U2;
+    p2.Kreal = h->I;
+    p2.n_real = h->H;
+    p2.x = a->act;
+    p2.ldx = h->ld_act;
+    p2.top_k = K;
+    p2.counts = a->counts;
+    p2.offsets = a->offsets;
+    p2.active = a->active;
+    p2.meta = a->meta;
+    p2.sorted_slot = a->sorted_slot;
+    p2.out = a->y;
+    p2.ldo = h->H;
+    p2.sk_stride = n_slots * (size_t)h->H;
+    p2.SK = c2.sk;
+    p2.groups = h->T2 / c2.nt;
+    rc = launch_gemm2(st, h->wf, h->adt, c2, p2, max_active);
+    if (rc != LKM_OK) return rc;
+    if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
+
+    rc = launch_combine(st, a->y, c2.sk, p2.sk_stride, a->pos_of_slot, tw, M, K, h->H, out, out_dt);
+    if (rc != LKM_OK) return rc;
+    if (prof) {
+        LKM_HIP_CHECK(hipEventRecord(h->ev[4], st));
+        h->prof_valid = true;
+    }
+    snprintf(h->last_desc, sizeof(h->last_desc),
+             "M=%d K=%d | gemm1 nt=%d tb=%d kw=%d grid=(%d,%d) | gemm2 nt=%d tb=%d sk=%d grid=(%d,%d)",
+             M, K, c1.nt, c1.tb, c1.kw, p1.groups, max_active, c2.nt, c2.tb, c2.sk,
+             ceil_div(p2.groups * c2.sk, 4), max_active);
+    return LKM_OK;
+}
+
+static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, const int32_t* ids,
+                      const float* tw, void* out, int out_dt) {
+    LKM_REQUIRE(h, "null engine handle");
+    LKM_REQUIRE(M >= 0, "num_tokens=%d < 0", M);
+    LKM_REQUIRE(K > 0 && K <= 64, "top_k=%d out of range", K);
+    if (M == 0) return LKM_OK;
+    LKM_REQUIRE(x && ids && tw && out, "null device pointer");
+    LKM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, "hidden/out pointers must be 16-byte aligned");
+    LKM_HIP_CHECK(hipSetDevice(h->device));
+    // the arena was sized with cfg.top_k; a different K only changes how many tokens fit a chunk
+    size_t chunk = h->arena->cap_slots / (size_t)K;
+    if (h->arena->act_elems / ((size_t)K * h->ld_act) < chunk) chunk = h->arena->act_elems / ((size_t)K * h->ld_act);
+    if (h->arena->y_elems / ((size_t)K * h->H) < chunk) chunk = h->arena->y_elems / ((size_t)K * h->H);
+    LKM_REQUIRE(chunk > 0, "scratch arena too small for top_k=%d", K);
+    const size_t xrow = (size_t)h->H * 2, orow = (size_t)h->H * (out_dt == LKM_DT_F32 ? 4 : 2);
+    for (size_t m0 = 0; m0 < (size_t)M; m0 += chunk) {
+        const int mc = (int)((size_t)M - m0 < chunk ? (size_t)M - m0 : chunk);
+        int rc = run_chunk(h, st, mc, K, (const char*)x + m0 * xrow, ids + m0 * K, tw + m0 * K,
+                           (char*)out + m0 * orow, out_dt);
+        if (rc != LKM_OK) return rc;
+    }
+    return LKM_OK;
+}
+
+extern "C" int lkm_decode(LkmHandle h, void* stream, int32_t num_tokens, int32_t top_k,
+                          const void* hidden, const int32_t* topk_ids, const float* topk_weights,
+                          float* out_f32) {
+    return run_device(h, (hipStream_t)stream, num_tokens, top_k, hidden, topk_ids, topk_weights,
+                      out_f32, LKM_DT_F32);
+}
+
+extern "C" int lkm_prefill_device(LkmHandle h, const void* hidden, void* out,
+                                  const int32_t* topk_ids, const float* topk_weights,
+                                  int32_t num_tokens, int32_t top_k, void* stream) {
+    LKM_REQUIRE(h, "null engine handle");
+    return run_device(h, (hipStream_t)stream, num_tokens, top_k, hidden, topk_ids, topk_weights, out,
+                      h->adt);
+}
+
+extern "C" int lkm_prefill_host(LkmHandle h, int32_t num_tokens, int32_t top_k,
+                                const int32_t* topk_ids, const float* topk_weights,
+                                const void* hidden, float* out_f32) {
+    LKM_REQUIRE(h, "null engine handle");
+    LKM_REQUIRE(num_tokens >= 0 && top_k > 0, "bad sizes");
+    if (num_tokens == 0) return LKM_OK;
+    LKM_REQUIRE(topk_ids && topk_weights && hidden && out_f32, "null host pointer");
+    LKM_HIP_CHECK(hipSetDevice(h->device));
+    const size_t M = num_tokens;
+    if (M > h->io_tokens || !h->io_x) {
+        if (h->io_x) (void)hipFree(h->io_x);
+        if (h->io_ids) (void)hipFree(h->io_ids);
+        if (h->io_w) (void)hipFree(h->io_w);
+        if (h->io_out) (void)hipFree(h->io_out);
+        h->io_x = h->io_ids = h->io_w = h->io_out = nullptr;
+        h->io_tokens = 0;
+        LKM_HIP_CHECK(hipMalloc(&h->io_x, M * h->H * 2));
+        LKM_HIP_CHECK(hipMalloc(&h->io_ids, M * 64 * 4));
+        LKM_HIP_CHECK(hipMalloc(&h->io_w, M * 64 * 4));
+        LKM_HIP_CHECK(hipMalloc(&h->io_out, M * h->H * 4));
+        h->io_tokens = M;
+    }
+    LKM_REQUIRE(top_k <= 64, "top_k=%d out of range", top_k);
+    LKM_HIP_CHECK(hipMemcpy(h->io_x, hidden, M * h->H * 2, hipMemcpyHostToDevice));
+    LKM_HIP_CHECK(hipMemcpy(h->io_ids, topk_ids, M * top_k * 4, hipMemcpyHostToDevice));
+    LKM_HIP_CHECK(hipMemcpy(h->io_w, topk_weights, M * top_k * 4, hipMemcpyHostToDevice));
+    int rc = run_device(h, nullptr, num_tokens, top_k, h->io_x, (const int32_t*)h->io_ids,
+                        (const float*)h->io_w, h->io_out, LKM_DT_F32);
+    if (rc != LKM_OK) return rc;
+    LKM_HIP_CHECK(hipMemcpy(out_f32, h->io_out, M * h->H * 4, hipMemcpyDeviceToHost));
+    return LKM_OK;
+}
+
+extern "C" int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots, int32_t E,
+                              int32_t* counts, int32_t* offsets, int32_t* sorted_slot,
+                              int32_t* pos_of_slot) {
+    LKM_REQUIRE(n_slots >= 0 && E > 0, "sort_slots: bad sizes");
+    // active/meta scratch: borrow the tail of a temporary allocation
+    int32_t* tmp = nullptr;
+    LKM_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(int32_t) * ((size_t)E + 8)));
+    int rc = launch_sort((hipStream_t)stream, ids, n_slots, E, counts, offsets, sorted_slot,
+                         pos_of_slot, tmp, tmp + E);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(tmp);
+    if (rc != LKM_OK) return rc;
+    LKM_HIP_CHECK(e);
+    return LKM_OK;
+}
+
+extern "C" int lkm_set_profiling(LkmHandle h, int32_t enable) {
+    LKM_REQUIRE(h, "null engine handle");
+    h->prof = enable != 0;
+    h->prof_valid = false;
+    return LKM_OK;
+}
+
+extern "C" int lkm_get_profile(LkmHandle h, float* ms) {
+    LKM_REQUIRE(h && ms, "null argument");
+    LKM_REQUIRE(h->prof_valid, "no profiled call recorded (lkm_set_profiling + a decode/prefill call first)");
+    LKM_HIP_CHECK(hipEventSynchronize(h->ev[LKM_PROF_N]));
+    for (int i = 0; i < LKM_PROF_N; ++i) LKM_HIP_CHECK(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    return LKM_OK;
+}
+
+extern "C" int64_t lkm_weight_bytes(LkmHandle h) { return h ? h->weight_bytes : 0; }
+
+extern "C" int lkm_describe(LkmHandle h, char* buf, int32_t buf_len) {
+    LKM_REQUIRE(h && buf && buf_len > 0, "null argument");
+    snprintf(buf, buf_len, "E=%d H=%d I=%d wf=%d adt=%d gated=%d T1_half=%d U1=%d T2=%d U2=%d | %s",
+             h->E, h->H, h->I, h->wf, h->adt, (int)h->gated, h->T1_half, h->U1, h->T2, h->U2,
+             h->last_desc);
+    return LKM_OK;
+}
+
+extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
+    LKM_REQUIRE(h && key, "null argument");
+    if (!strcmp(key, "nt1")) h->t_nt1 = value;
+    else if (!strcmp(key, "nt2")) h->t_nt2 = value;
+    else if (!strcmp(key, "kw1")) h->t_kw1 = value;
+    else if (!strcmp(key, "sk2")) h->t_sk2 = value;
+    else if (!strcmp(key, "tbmax")) h->t_tb = value;
+    else {
+        set_error("lkm_set_tuning: unknown key '%s'", key);
+        return LKM_E_INVALID;
+    }
+    return LKM_OK;
+}

@@ -1,0 +1,148 @@
+// lkm_common.h -- shared types / device helpers for the gfx950 MoE expert path.
+// Written for MI355X (gfx950, wave64) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lkm.h"
+
+namespace lkm {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------ host-side error plumbing
+void set_error(const char* fmt, ...);
+#define LKM_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ::lkm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                             __FILE__, __LINE__);                                        \
+            return LKM_E_HIP;                                                            \
+        }                                                                                \
+    } while (0)
+#define LKM_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::lkm::set_error(__VA_ARGS__);     \
+            return LKM_E_INVALID;              \
+        }                                      \
+    } while (0)
+
+// ------------------------------------------------------------------ device math
+// Deterministic expf: the operation sequence is shared bit-for-bit with
+// oracle/lkm_oracle.c: lkm_or_expf (explicit fma, contraction off), so routing scores and
+// therefore routing ids/weights are reproducible between the GPU and the CPU oracle.
+// Stands in for the reference's expf (topk_softmax_kernels.cu:428, activation_kernels.cu).
+__device__ __forceinline__ float lkm_expf(float x) {
+#pragma clang fp contract(off)
+    if (!(x == x)) return x;
+    if (x > 88.72283f) return __builtin_inff();
+    if (x < -103.97f) return 0.0f;
+    const float LOG2E = 1.44269504088896341f;
+    const float LN2_HI = 0.693145751953125f;
+    const float LN2_LO = 1.42860682030941723e-6f;
+    float n = __builtin_rintf(x * LOG2E);
+    float r = __builtin_fmaf(-n, LN2_HI, x);
+    r = __builtin_fmaf(-n, LN2_LO, r);
+    float p = 1.9841270e-4f;
+    p = __builtin_fmaf(p, r, 1.3888889e-3f);
+    p = __builtin_fmaf(p, r, 8.3333338e-3f);
+    p = __builtin_fmaf(p, r, 4.1666668e-2f);
+    p = __builtin_fmaf(p, r, 1.6666667e-1f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    int ni = (int)n;
+    int n1 = ni / 2, n2 = ni - n1;
+    float s1 = __builtin_bit_cast(float, (unsigned)(n1 + 127) << 23);
+    float s2 = __builtin_bit_cast(float, (unsigned)(n2 + 127) << 23);
+    return (p * s1) * s2;
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
+    return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    return __builtin_bit_cast(unsigned short, (__bf16)f);  // v_cvt_pk_bf16_f32: RNE
+}
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short h) {
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+__device__ __forceinline__ unsigned short f32_to_f16_bits(float f) {
+    return __builtin_bit_cast(unsigned short, (_Float16)f);
+}
+
+// Activation-dtype traits: the MFMA flavour and the scalar conversions.
+template <int DT>
+struct ActT;
+template <>
+struct ActT<LKM_DT_BF16> {
+    typedef bf16x8 vec8;
+    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                       __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(unsigned short h) { return bf16_bits_to_f32(h); }
+    static __device__ __forceinline__ unsigned short from_f32(float f) { return f32_to_bf16_bits(f); }
+    // pack two f32 -> two act elements in one dword (lo = a)
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
+    }
+};
+template <>
+struct ActT<LKM_DT_F16> {
+    typedef f16x8 vec8;
+    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                      __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(unsigned short h) { return f16_bits_to_f32(h); }
+    static __device__ __forceinline__ unsigned short from_f32(float f) { return f32_to_f16_bits(f); }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        return (unsigned)f32_to_f16_bits(a) | ((unsigned)f32_to_f16_bits(b) << 16);
+    }
+};
+
+__host__ __device__ constexpr inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ constexpr inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------ pre-shuffled weight geometry
+// A weight matrix [N rows][K] (K contiguous, "B^T" form) is stored per expert as
+//   [tile = n/16][unit = k/UNITK][load][lane 0..63][16 bytes]
+// so that one wave-wide global_load_dwordx4 fetches 1 KiB of contiguous HBM that is already the
+// MFMA A-operand fragment(s) of mfma_f32_16x16x32: lane l = g*16 + i holds row tile*16+i,
+// k = unit*UNITK + kstep*32 + g*8 + (0..7).
+//   bf16/f16 : UNITK = 64,  LOADS = 2 (load = kstep),          one dwordx4 = 8 elements
+//   fp8 e4m3 : UNITK = 128, LOADS = 2 (load l: .xy = kstep 2l, .zw = kstep 2l+1; 2 x 8 bytes)
+//   uint4b8  : UNITK = 128, LOADS = 1 (dword s = kstep s),     one dwordx4 = 4 x 8 nibbles
+template <int WF>
+struct WGeom;
+template <>
+struct WGeom<LKM_W_BF16> {
+    static constexpr int UNITK = 64, LOADS = 2, KSTEPS = 2;
+};
+template <>
+struct WGeom<LKM_W_F16> {
+    static constexpr int UNITK = 64, LOADS = 2, KSTEPS = 2;
+};
+template <>
+struct WGeom<LKM_W_FP8_E4M3> {
+    static constexpr int UNITK = 128, LOADS = 2, KSTEPS = 4;
+};
+template <>
+struct WGeom<LKM_W_INT4_B8> {
+    static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
+};
+
+inline int wf_unitk(int wf) { return (wf == LKM_W_BF16 || wf == LKM_W_F16) ? 64 : 128; }
+inline int wf_loads(int wf) { return wf == LKM_W_INT4_B8 ? 1 : 2; }
+
+}  // namespace lkm

@@ -1,0 +1,67 @@
+// lkm_kernels.h -- parameter blocks and host launchers shared between the translation units of
+// liblkm.so (kernels live in routing.hip / dispatch.hip / repack.hip / gemm_skinny.hip).
+#pragma once
+#include "lkm_common.h"
+
+namespace lkm {
+
+// ---- repack.hip
+struct RepackDims {
+    int E, n_half, halves, interleaved;  // source rows N = n_half*halves
+    int K;                               // source K (elements)
+    int T_half, U;                       // dest tiles per half, units
+};
+int launch_repack_w(hipStream_t st, int wf, const void* src, void* dst, const RepackDims& d);
+int launch_repack_s_int4(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group,
+                         int spu);
+int launch_repack_s_fp8(hipStream_t st, const void* src, void* dst, const RepackDims& d, int gN,
+                        int gK);
+
+// ---- dispatch.hip
+int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
+                int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
+                int32_t* meta);
+int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
+                   const int32_t* pos_of_slot, const float* tw, int M, int K, int H, void* out,
+                   int out_dt);
+
+// ---- gemm_skinny.hip
+struct GemmParams {
+    // weights (pre-shuffled), scales (pre-shuffled or null)
+    const void* w;
+    const void* s;
+    int spu;     // int4: scales per 128-k unit (1,2,4)
+    int T_half;  // tiles per half (gate / up); w2: tiles total
+    int halves;  // 2 gated w13, 1 otherwise
+    int U;       // K units
+    int Kreal;   // real K (elements) for the token-operand bounds check
+    int n_real;  // real rows per half (I for GEMM1, H for GEMM2)
+    // token operand
+    const void* x;  // GEMM1: hidden [M][H] ; GEMM2: act [rows][ldx]
+    int ldx;        // row stride of x in elements
+    int top_k;      // GEMM1: slot -> token = slot / top_k
+    // routing metadata (device)
+    const int32_t* counts;
+    const int32_t* offsets;
+    const int32_t* active;
+    const int32_t* meta;
+    const int32_t* sorted_slot;
+    // outputs
+    void* out;  // GEMM1: act [rows][ldo] act dtype ; GEMM2: y [SK][sk_stride] fp32
+    int ldo;
+    size_t sk_stride;  // GEMM2: elements between split-K slabs
+    int SK;            // GEMM2: number of K splits
+    int groups;        // tile groups per expert = T_half / NT
+    // activation
+    int act_type;
+    float alpha, limit;
+};
+struct LaunchCfg {
+    int nt, tb, kw, sk;
+};
+int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
+                 bool gated, int max_active);
+int launch_gemm2(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
+                 int max_active);
+
+}  // namespace lkm

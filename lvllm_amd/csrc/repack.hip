@@ -1,0 +1,184 @@
+// repack.hip -- one-time conversion of the reference's expert weight layouts (SURVEY 8(a5),
+// routed_experts.py:1440-1616) into the engine's MFMA-native HBM layout (lkm_common.h: WGeom).
+//
+// The lk_moe contract says the constructor must copy the weights (the caller frees its tensors
+// right after, routed_experts.py:1420-1432), so the pre-shuffle costs nothing extra: every 16-byte
+// vector of the destination is produced by one thread from <= 2 contiguous source segments.
+//
+// Destination (per expert):  [tile][unit][load][lane 64][16 B]
+//   rows: "halves" (gate rows then up rows for w13; one half for w2), each half padded to a
+//         multiple of 16*kTilePad rows with zero tiles; interleaved gate/up (swigluoai,
+//         activation_kernels.cu:401-440) is de-interleaved here.
+//   K   : padded with zeros to a multiple of UNITK.
+#include "lkm_kernels.h"
+
+namespace lkm {
+
+// element (row n, k0..k0+cnt) byte address helpers per format
+// PLAIN16: 2 bytes/elem; FP8: 1 byte/elem; INT4: 1/2 byte/elem
+template <int WF>
+__global__ __launch_bounds__(256) void repack_w_kernel(const uint8_t* __restrict__ src,
+                                                       u32x4* __restrict__ dst, RepackDims d) {
+    typedef WGeom<WF> G;
+    const size_t nvec = (size_t)d.E * d.halves * d.T_half * d.U * G::LOADS * 64;
+    size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    const int lane = (int)(v & 63);
+    size_t t = v >> 6;
+    const int ld = (int)(t % G::LOADS);
+    t /= G::LOADS;
+    const int u = (int)(t % d.U);
+    t /= d.U;
+    const int tile = (int)(t % (d.halves * d.T_half));
+    const int e = (int)(t / (d.halves * d.T_half));
+    const int i = lane & 15, g = lane >> 4;
+    const int half = tile / d.T_half;
+    const int idx = (tile % d.T_half) * 16 + i;
+    const bool row_ok = idx < d.n_half;
+    const int N = d.n_half * d.halves;
+    const int n = d.interleaved ? idx * d.halves + half : half * d.n_half + idx;
+
+    unsigned out[4] = {0u, 0u, 0u, 0u};
+    if (row_ok) {
+        if (WF == LKM_W_BF16 || WF == LKM_W_F16) {
+            const int k0 = u * 64 + ld * 32 + g * 8;
+            const unsigned short* p = (const unsigned short*)src + ((size_t)e * N + n) * d.K;
+            unsigned short h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (k0 + j < d.K) ? p[k0 + j] : (unsigned short)0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = (unsigned)h[2 * j] | ((unsigned)h[2 * j + 1] << 16);
+        } else if (WF == LKM_W_FP8_E4M3) {
+            const uint8_t* p = src + ((size_t)e * N + n) * d.K;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {  // kstep = 2*ld + q
+                const int k0 = u * 128 + (2 * ld + q) * 32 + g * 8;
+                unsigned lo = 0, hi = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lo |= (unsigned)((k0 + j < d.K) ? p[k0 + j] : 0) << (8 * j);
+                    hi |= (unsigned)((k0 + 4 + j < d.K) ? p[k0 + 4 + j] : 0) << (8 * j);
+                }
+                out[2 * q] = lo;
+                out[2 * q + 1] = hi;
+            }
+        } else {  // INT4: bytes [E][N][K/2]; zero padding must decode to 0 => stored nibble 8
+            const uint8_t* p = src + ((size_t)e * N + n) * (d.K / 2);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k0 = u * 128 + s * 32 + g * 8;
+                unsigned w = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned b = (k0 + 2 * j < d.K) ? p[(k0 >> 1) + j] : 0x88u;
+                    w |= b << (8 * j);
+                }
+                out[s] = w;
+            }
+        }
+    } else if (WF == LKM_W_INT4_B8) {
+        out[0] = out[1] = out[2] = out[3] = 0x88888888u;
+    }
+    u32x4 o;
+    o.x = out[0];
+    o.y = out[1];
+    o.z = out[2];
+    o.w = out[3];
+    dst[v] = o;
+}
+
+// int4 group scales: src act-dtype [E][N][K/g]  ->  dst [E][tile][unit][16 rows][SPU] (same dtype)
+__global__ __launch_bounds__(256) void repack_s_int4_kernel(const unsigned short* __restrict__ src,
+                                                            unsigned short* __restrict__ dst,
+                                                            RepackDims d, int group, int spu) {
+    const size_t n_out = (size_t)d.E * d.halves * d.T_half * d.U * 16 * spu;
+    size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_out) return;
+    const int j = (int)(v % spu);
+    size_t t = v / spu;
+    const int i = (int)(t & 15);
+    t >>= 4;
+    const int u = (int)(t % d.U);
+    t /= d.U;
+    const int tile = (int)(t % (d.halves * d.T_half));
+    const int e = (int)(t / (d.halves * d.T_half));
+    const int half = tile / d.T_half;
+    const int idx = (tile % d.T_half) * 16 + i;
+    const int N = d.n_half * d.halves;
+    const int n = d.interleaved ? idx * d.halves + half : half * d.n_half + idx;
+    const int k = u * 128 + j * (128 / spu);
+    unsigned short s = 0;
+    if (idx < d.n_half && k < d.K) s = src[((size_t)e * N + n) * (d.K / group) + k / group];
+    dst[v] = s;
+}
+
+// fp8 block scales: src fp32 [E][ceil(N/gN)][ceil(K/gK)] -> dst fp32 [E][tile][unit][16 rows]
+__global__ __launch_bounds__(256) void repack_s_fp8_kernel(const float* __restrict__ src,
+                                                           float* __restrict__ dst, RepackDims d,
+                                                           int gN, int gK) {
+    const size_t n_out = (size_t)d.E * d.halves * d.T_half * d.U * 16;
+    size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_out) return;
+    size_t t = v;
+    const int i = (int)(t & 15);
+    t >>= 4;
+    const int u = (int)(t % d.U);
+    t /= d.U;
+    const int tile = (int)(t % (d.halves * d.T_half));
+    const int e = (int)(t / (d.halves * d.T_half));
+    const int half = tile / d.T_half;
+    const int idx = (tile % d.T_half) * 16 + i;
+    const int N = d.n_half * d.halves;
+    const int n = d.interleaved ? idx * d.halves + half : half * d.n_half + idx;
+    const int k = u * 128;
+    const int NB = ceil_div(N, gN), KB = ceil_div(d.K, gK);
+    float s = 0.0f;
+    if (idx < d.n_half && k < d.K) s = src[((size_t)e * NB + n / gN) * KB + k / gK];
+    dst[v] = s;
+}
+
+int launch_repack_w(hipStream_t st, int wf, const void* src, void* dst, const RepackDims& d) {
+    const int loads = wf_loads(wf);
+    const size_t nvec = (size_t)d.E * d.halves * d.T_half * d.U * loads * 64;
+    dim3 grid((unsigned)ceil_div64((int64_t)nvec, 256)), block(256);
+    switch (wf) {
+    case LKM_W_BF16:
+        hipLaunchKernelGGL(repack_w_kernel<LKM_W_BF16>, grid, block, 0, st, (const uint8_t*)src, (u32x4*)dst, d);
+        break;
+    case LKM_W_F16:
+        hipLaunchKernelGGL(repack_w_kernel<LKM_W_F16>, grid, block, 0, st, (const uint8_t*)src, (u32x4*)dst, d);
+        break;
+    case LKM_W_FP8_E4M3:
+        hipLaunchKernelGGL(repack_w_kernel<LKM_W_FP8_E4M3>, grid, block, 0, st, (const uint8_t*)src, (u32x4*)dst, d);
+        break;
+    case LKM_W_INT4_B8:
+        hipLaunchKernelGGL(repack_w_kernel<LKM_W_INT4_B8>, grid, block, 0, st, (const uint8_t*)src, (u32x4*)dst, d);
+        break;
+    default:
+        set_error("repack: unsupported weight format %d", wf);
+        return LKM_E_UNSUPPORTED;
+    }
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+int launch_repack_s_int4(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group,
+                         int spu) {
+    const size_t n_out = (size_t)d.E * d.halves * d.T_half * d.U * 16 * spu;
+    hipLaunchKernelGGL(repack_s_int4_kernel, dim3((unsigned)ceil_div64((int64_t)n_out, 256)),
+                       dim3(256), 0, st, (const unsigned short*)src, (unsigned short*)dst, d, group,
+                       spu);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+int launch_repack_s_fp8(hipStream_t st, const void* src, void* dst, const RepackDims& d, int gN,
+                        int gK) {
+    const size_t n_out = (size_t)d.E * d.halves * d.T_half * d.U * 16;
+    hipLaunchKernelGGL(repack_s_fp8_kernel, dim3((unsigned)ceil_div64((int64_t)n_out, 256)),
+                       dim3(256), 0, st, (const float*)src, (float*)dst, d, gN, gK);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+}  // namespace lkm

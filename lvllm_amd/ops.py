@@ -1,0 +1,235 @@
+"""Torch-tensor front-ends of the router / scatter kernels and of the expert engine.
+
+These mirror the reference's *operator* signatures (same names, argument meaning, error
+behaviour) so the parity tests read like the reference's own tests; torch is used only for
+device memory and the current stream.  Everything executes in liblkm.so -- no eager fallback.
+
+Reference interfaces mirrored (relative to the reference tree):
+  fused_topk        vllm/model_executor/layers/fused_moe/router/fused_topk_router.py:81-125
+  fused_topk_bias   vllm/model_executor/layers/fused_moe/router/fused_topk_bias_router.py
+  grouped_topk      vllm/model_executor/layers/fused_moe/router/grouped_topk_router.py:80-161
+  global_to_local_expert_ids   vllm/model_executor/layers/fused_moe/routed_experts.py:1332-1342
+  determine_expert_map         vllm/model_executor/layers/fused_moe/expert_map_manager.py:22-92
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _clib
+from .lk_moe_api import (MOE_BF16, MOE_FP16, MOE_FP8, MOE_FP8_FP16, MOE_WNA16, MOE_WNA16_FP16,
+                         MOEConfigV2)
+
+_DT = {torch.float32: _clib.DT_F32, torch.bfloat16: _clib.DT_BF16, torch.float16: _clib.DT_F16}
+_SCORING = {"softmax": 0, "sigmoid": 1}
+
+
+def _stream(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream or None)
+
+
+def _ptr(t: torch.Tensor | None) -> C.c_void_p:
+    return C.c_void_p(None if t is None else t.data_ptr())
+
+
+def _need_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("lvllm_amd ops run on the GPU only (got a CPU tensor); there is no CPU path")
+
+
+def topk_softmax(gating_output: torch.Tensor, topk: int, renormalize: bool,
+                 e_score_correction_bias: torch.Tensor | None = None,
+                 scoring_func: str = "softmax", routed_scaling_factor: float = 1.0):
+    """-> (topk_weights fp32 [M,K], topk_ids int32 [M,K])"""
+    _need_cuda(gating_output, e_score_correction_bias)
+    if scoring_func not in _SCORING:
+        raise ValueError(f"Unsupported scoring function: {scoring_func}")
+    if gating_output.dtype not in _DT:
+        raise ValueError(f"unsupported gating dtype {gating_output.dtype}")
+    g = gating_output.contiguous()
+    M, E = g.shape
+    bias = None
+    if e_score_correction_bias is not None:
+        bias = e_score_correction_bias.to(torch.float32).contiguous()
+    w = torch.empty((M, topk), dtype=torch.float32, device=g.device)
+    ids = torch.empty((M, topk), dtype=torch.int32, device=g.device)
+    _clib.check(_clib.lib().lkm_topk_softmax(_stream(g), _ptr(g), _DT[g.dtype], _ptr(bias), M, E, topk,
+                                             _SCORING[scoring_func], int(renormalize),
+                                             float(routed_scaling_factor), _ptr(w), _ptr(ids)))
+    return w, ids
+
+
+def fused_topk(hidden_states: torch.Tensor, gating_output: torch.Tensor, topk: int, renormalize: bool,
+               indices_type: torch.dtype | None = None, scoring_func: str = "softmax"):
+    """fused_topk_router.py:81-125 -> (topk_weights, topk_ids, token_expert_indices)"""
+    assert hidden_states.size(0) == gating_output.size(0), "Number of tokens mismatch"
+    w, ids = topk_softmax(gating_output, topk, renormalize, None, scoring_func)
+    M = gating_output.size(0)
+    # source_rows[m,k] = k*M + m  (topk_softmax_kernels.cu:568)
+    dev = gating_output.device
+    tei = (torch.arange(topk, device=dev, dtype=torch.int32)[None, :] * M
+           + torch.arange(M, device=dev, dtype=torch.int32)[:, None])
+    if indices_type is not None and indices_type != torch.int32:
+        ids = ids.to(indices_type)
+    return w, ids, tei
+
+
+def fused_topk_bias(hidden_states: torch.Tensor, gating_output: torch.Tensor,
+                    e_score_correction_bias: torch.Tensor, topk: int, renormalize: bool,
+                    scoring_func: str = "softmax", routed_scaling_factor: float = 1.0):
+    assert hidden_states.size(0) == gating_output.size(0), "Number of tokens mismatch"
+    return topk_softmax(gating_output, topk, renormalize, e_score_correction_bias, scoring_func,
+                        routed_scaling_factor)
+
+
+def grouped_topk(hidden_states: torch.Tensor, gating_output: torch.Tensor, topk: int,
+                 renormalize: bool, num_expert_group: int = 0, topk_group: int = 0,
+                 scoring_func: str = "softmax", routed_scaling_factor: float = 1.0,
+                 e_score_correction_bias: torch.Tensor | None = None):
+    """grouped_topk_router.py:80-161 -> (topk_weights fp32, topk_ids int32)."""
+    assert hidden_states.size(0) == gating_output.size(0), "Number of tokens mismatch"
+    _need_cuda(gating_output, e_score_correction_bias)
+    if scoring_func not in _SCORING:
+        raise ValueError(f"Unsupported scoring function: {scoring_func}")
+    g = gating_output.contiguous()
+    M, E = g.shape
+    bias = None
+    if e_score_correction_bias is not None:
+        bias = e_score_correction_bias.to(torch.float32).contiguous()
+    w = torch.empty((M, topk), dtype=torch.float32, device=g.device)
+    ids = torch.empty((M, topk), dtype=torch.int32, device=g.device)
+    _clib.check(_clib.lib().lkm_grouped_topk(_stream(g), _ptr(g), _DT[g.dtype], _ptr(bias), M, E, topk,
+                                             num_expert_group, topk_group, _SCORING[scoring_func],
+                                             int(renormalize), float(routed_scaling_factor),
+                                             _ptr(w), _ptr(ids)))
+    return w, ids
+
+
+def determine_expert_map(ep_size: int, ep_rank: int, global_num_experts: int,
+                         expert_placement_strategy: str = "linear"):
+    """expert_map_manager.py:22-92 -> (local_num_experts, expert_map int32 [E] | None).  Host logic."""
+    assert ep_size > 0
+    if ep_size == 1:
+        return global_num_experts, None
+    base, rem = divmod(global_num_experts, ep_size)
+    local = base + 1 if ep_rank < rem else base
+    emap = torch.full((global_num_experts,), -1, dtype=torch.int32)
+    if expert_placement_strategy == "linear":
+        start = ep_rank * base + min(ep_rank, rem)
+        emap[start:start + local] = torch.arange(local, dtype=torch.int32)
+    elif expert_placement_strategy == "round_robin":
+        emap[torch.arange(ep_rank, global_num_experts, ep_size)] = torch.arange(local, dtype=torch.int32)
+    else:
+        raise ValueError(f"Unsupported expert placement strategy '{expert_placement_strategy}', "
+                         "expected one of ('linear', 'round_robin')")
+    return local, emap
+
+
+def global_to_local_expert_ids(topk_ids: torch.Tensor, expert_map: torch.Tensor) -> torch.Tensor:
+    """routed_experts.py:1332-1342: non-local / negative ids -> -1."""
+    _need_cuda(topk_ids)
+    ids = topk_ids.to(torch.int32).contiguous()
+    emap = expert_map.to(device=ids.device, dtype=torch.int32).contiguous()
+    out = torch.empty_like(ids)
+    _clib.check(_clib.lib().lkm_map_expert_ids(_stream(ids), _ptr(ids), ids.numel(), _ptr(emap),
+                                               emap.numel(), _ptr(out)))
+    return out
+
+
+def sort_slots(topk_ids: torch.Tensor, num_experts: int):
+    """Stable counting sort of the M*K slots by expert.
+    -> counts [E], offsets [E+1], sorted_slot [M*K] (tail -1), pos_of_slot [M*K] (-1 = skipped)."""
+    _need_cuda(topk_ids)
+    ids = topk_ids.to(torch.int32).contiguous().view(-1)
+    n = ids.numel()
+    dev = ids.device
+    counts = torch.empty(num_experts, dtype=torch.int32, device=dev)
+    offsets = torch.empty(num_experts + 1, dtype=torch.int32, device=dev)
+    sorted_slot = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    _clib.check(_clib.lib().lkm_sort_slots(_stream(ids), _ptr(ids), n, num_experts, _ptr(counts),
+                                           _ptr(offsets), _ptr(sorted_slot), _ptr(pos)))
+    return counts, offsets, sorted_slot[:n], pos[:n]
+
+
+_CLS = {("bf16", torch.bfloat16): MOE_BF16, ("bf16", torch.float16): MOE_FP16,
+        ("fp16", torch.float16): MOE_FP16,
+        ("fp8", torch.bfloat16): MOE_FP8, ("fp8", torch.float16): MOE_FP8_FP16,
+        ("int4", torch.bfloat16): MOE_WNA16, ("int4", torch.float16): MOE_WNA16_FP16}
+
+
+class RoutedExpertsEngine:
+    """Torch-level convenience over the lk_moe classes: builds the MOEConfigV2 from tensors exactly
+    the way RoutedExperts._process_{bf6_fp16,wna16,fp8} do (routed_experts.py:1440-1668) and exposes
+    the three forward paths on tensors (cf. _cpu_decode/_cpu_prefill/_gpu_prefill, :1840-1899)."""
+
+    def __init__(self, w13: torch.Tensor, w2: torch.Tensor, *, top_k: int, act_dtype: torch.dtype,
+                 fmt: str = "bf16", w13_scale: torch.Tensor | None = None,
+                 w2_scale: torch.Tensor | None = None, group_n: int = 0, group_k: int = 0,
+                 has_gate_proj: bool = True, activation_type: int = 0, swiglu_alpha: float = 1.702,
+                 swiglu_limit: float = 7.0, max_num_seqs: int = 256, max_batch_size: int = 8192,
+                 group_max_len: int = 0, num_processes: int = 1, process_id: int = 0,
+                 gpu_id: int | None = None):
+        E = w13.shape[0]
+        H = w2.shape[1]
+        inter = w13.shape[1] // (2 if has_gate_proj else 1)
+        cfg = MOEConfigV2()
+        cfg.num_processes, cfg.process_id = num_processes, process_id
+        cfg.gpu_id = torch.cuda.current_device() if gpu_id is None else gpu_id
+        cfg.has_gate_proj = has_gate_proj
+        cfg.expert_num, cfg.top_k = E, top_k
+        cfg.hidden_size, cfg.intermediate_size = H, inter
+        cfg.max_batch_size, cfg.max_num_seqs = max_batch_size, max_num_seqs
+        cfg.group_max_len = group_max_len or (min(4096, max_batch_size) + 128)
+        cfg.groupN, cfg.groupK = group_n, group_k
+        cfg.activation_type = activation_type
+        cfg.swiglu_alpha, cfg.swiglu_limit = swiglu_alpha, swiglu_limit
+        self.cfg = cfg
+        self.H, self.K, self.act_dtype = H, top_k, act_dtype
+        cls = _CLS[(fmt, act_dtype)]
+        w13c, w2c = w13.contiguous(), w2.contiguous()
+        s13 = None if w13_scale is None else w13_scale.contiguous()
+        s2 = None if w2_scale is None else w2_scale.contiguous()
+        self.engine = cls(cfg, w13c.data_ptr(), w2c.data_ptr(), 0 if s13 is None else s13.data_ptr(),
+                          0 if s2 is None else s2.data_ptr(), 0, 0)
+        if w13c.is_cuda:
+            torch.cuda.synchronize()
+
+    def decode(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor,
+               out: torch.Tensor | None = None) -> torch.Tensor:
+        """fp32 [M,H]   (cf. RoutedExperts._cpu_decode)"""
+        _need_cuda(hidden, topk_weights, topk_ids)
+        M = hidden.size(0)
+        if out is None:
+            out = torch.empty((M, self.H), dtype=torch.float32, device=hidden.device)
+        assert hidden.dtype == self.act_dtype and hidden.is_contiguous()
+        assert topk_ids.dtype == torch.int32 and topk_weights.dtype == torch.float32
+        assert topk_ids.is_contiguous() and topk_weights.is_contiguous()
+        self.engine.cpu_decode(torch.cuda.current_stream(hidden.device).cuda_stream, M, topk_ids.size(1),
+                               hidden.data_ptr(), topk_ids.data_ptr(), topk_weights.data_ptr(),
+                               out.data_ptr())
+        return out
+
+    def prefill(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
+        """activation dtype [M,H]   (cf. RoutedExperts._gpu_prefill)"""
+        _need_cuda(hidden, topk_weights, topk_ids)
+        assert hidden.dtype == self.act_dtype and hidden.is_contiguous()
+        assert topk_ids.dtype == torch.int32 and topk_weights.dtype == torch.float32
+        out = torch.empty_like(hidden)
+        self.engine.gpu_prefill(hidden.data_ptr(), out.data_ptr(), topk_ids.data_ptr(),
+                                topk_weights.data_ptr(), hidden.size(0), topk_ids.size(1),
+                                torch.cuda.current_stream(hidden.device).cuda_stream)
+        return out
+
+    def prefill_host(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
+        """CPU tensors in, fp32 CPU tensor out   (cf. RoutedExperts._cpu_prefill)"""
+        assert not hidden.is_cuda
+        hidden = hidden.contiguous()
+        ids = topk_ids.to(torch.int32).contiguous()
+        tw = topk_weights.to(torch.float32).contiguous()
+        out = torch.empty((hidden.size(0), self.H), dtype=torch.float32)
+        self.engine.cpu_prefill(hidden.size(0), ids.size(1), ids.data_ptr(), tw.data_ptr(),
+                                hidden.data_ptr(), out.data_ptr())
+        return out

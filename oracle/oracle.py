@@ -1,0 +1,232 @@
+"""ctypes front-end of the CPU oracle (oracle/lkm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke() -- never by lvllm_amd/ or lk_moe/ (tests/test_boundary.py checks).
+Parity status: see the header of lkm_oracle.c ("lk_moe boundary unpinned"; in-tree operator
+pinned by tests/golden/).
+
+Arrays are numpy; bf16/fp16 tensors travel as uint16 bit patterns.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "liblkm_oracle.so"
+
+F32, BF16, F16 = 0, 1, 2
+W_BF16, W_F16, W_FP8, W_INT4 = 0, 1, 2, 3
+ACT_SILU, ACT_SWIGLUOAI, ACT_RELU2 = 0, 1, 2
+
+
+def build(force: bool = False) -> Path:
+    src = HERE / "lkm_oracle.c"
+    if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+        r = subprocess.run(["make", "-C", str(HERE), "-B" if force else "-s", "liblkm_oracle.so"],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"oracle build failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(str(LIB_PATH))
+        _lib.lkm_or_expf.restype = C.c_float
+        _lib.lkm_or_expf.argtypes = [C.c_float]
+        _lib.lkm_or_expert_map.restype = C.c_int
+        _lib.lkm_or_moe.restype = C.c_int
+        _lib.lkm_or_num_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt=None):
+    a = np.ascontiguousarray(a)
+    return a if dt is None or a.dtype == dt else a.astype(dt)
+
+
+def dtype_code(a: np.ndarray, hint: int | None = None) -> int:
+    if a.dtype == np.float32:
+        return F32
+    if a.dtype == np.uint16:
+        if hint is None:
+            raise ValueError("uint16 array needs an explicit dtype hint (BF16 or F16)")
+        return hint
+    if a.dtype == np.float16:
+        return F16
+    raise ValueError(f"unsupported dtype {a.dtype}")
+
+
+def expf(x: float) -> float:
+    return float(lib().lkm_or_expf(C.c_float(x)))
+
+
+def f32_to_bits(a: np.ndarray, dt: int) -> np.ndarray:
+    a = _c(a, np.float32)
+    out = np.empty(a.shape, np.uint16)
+    lib().lkm_or_cvt_f32_to(_p(a), C.c_int(dt), C.c_int64(a.size), _p(out))
+    return out
+
+
+def bits_to_f32(a: np.ndarray, dt: int) -> np.ndarray:
+    a = _c(a)
+    out = np.empty(a.shape, np.float32)
+    lib().lkm_or_cvt_to_f32(_p(a), C.c_int(dt), C.c_int64(a.size), _p(out))
+    return out
+
+
+def fp8_to_f32(a: np.ndarray) -> np.ndarray:
+    a = _c(a, np.uint8)
+    out = np.empty(a.shape, np.float32)
+    lib().lkm_or_fp8_to_f32(_p(a), C.c_int64(a.size), _p(out))
+    return out
+
+
+def f32_to_fp8(a: np.ndarray) -> np.ndarray:
+    a = _c(a, np.float32)
+    out = np.empty(a.shape, np.uint8)
+    lib().lkm_or_f32_to_fp8(_p(a), C.c_int64(a.size), _p(out))
+    return out
+
+
+def topk_softmax(logits: np.ndarray, K: int, *, dt: int | None = None, bias=None, scoring: int = 0,
+                 renormalize: bool = True, routed_scaling: float = 1.0):
+    logits = _c(logits)
+    code = dtype_code(logits, dt)
+    if logits.dtype == np.float16:
+        logits = logits.view(np.uint16)
+    M, E = logits.shape
+    bias = None if bias is None else _c(bias, np.float32)
+    w = np.empty((M, K), np.float32)
+    ids = np.empty((M, K), np.int32)
+    lib().lkm_or_topk_softmax(_p(logits), C.c_int(code), _p(bias), C.c_int(M), C.c_int(E), C.c_int(K),
+                              C.c_int(scoring), C.c_int(int(renormalize)), C.c_float(routed_scaling),
+                              _p(w), _p(ids))
+    return w, ids
+
+
+def grouped_topk(logits: np.ndarray, K: int, n_group: int, topk_group: int, *, dt: int | None = None,
+                 bias=None, scoring: int = 1, renormalize: bool = True, routed_scaling: float = 1.0):
+    logits = _c(logits)
+    code = dtype_code(logits, dt)
+    if logits.dtype == np.float16:
+        logits = logits.view(np.uint16)
+    M, E = logits.shape
+    bias = None if bias is None else _c(bias, np.float32)
+    w = np.empty((M, K), np.float32)
+    ids = np.empty((M, K), np.int32)
+    lib().lkm_or_grouped_topk(_p(logits), C.c_int(code), _p(bias), C.c_int(M), C.c_int(E), C.c_int(K),
+                              C.c_int(n_group), C.c_int(topk_group), C.c_int(scoring),
+                              C.c_int(int(renormalize)), C.c_float(routed_scaling), _p(w), _p(ids))
+    return w, ids
+
+
+def expert_map(ep_size: int, ep_rank: int, E: int, strategy: int = 0):
+    m = np.empty(E, np.int32)
+    n = lib().lkm_or_expert_map(C.c_int(ep_size), C.c_int(ep_rank), C.c_int(E), C.c_int(strategy), _p(m))
+    return int(n), m
+
+
+def map_ids(ids: np.ndarray, emap: np.ndarray) -> np.ndarray:
+    ids = _c(ids, np.int32)
+    emap = _c(emap, np.int32)
+    out = np.empty(ids.shape, np.int32)
+    lib().lkm_or_map_ids(_p(ids), C.c_int64(ids.size), _p(emap), C.c_int(emap.size), _p(out))
+    return out
+
+
+def sort_slots(ids: np.ndarray, E: int):
+    flat = _c(ids, np.int32).reshape(-1)
+    n = flat.size
+    counts = np.empty(E, np.int32)
+    offsets = np.empty(E + 1, np.int32)
+    sorted_slot = np.empty(max(n, 1), np.int32)
+    pos = np.empty(max(n, 1), np.int32)
+    lib().lkm_or_sort(_p(flat), C.c_int(n), C.c_int(E), _p(counts), _p(offsets), _p(sorted_slot), _p(pos))
+    return counts, offsets, sorted_slot[:n], pos[:n]
+
+
+class _Desc(C.Structure):
+    _fields_ = [("E", C.c_int32), ("H", C.c_int32), ("I", C.c_int32), ("has_gate", C.c_int32),
+                ("activation", C.c_int32), ("swiglu_alpha", C.c_float), ("swiglu_limit", C.c_float),
+                ("act_dtype", C.c_int32), ("wfmt", C.c_int32), ("groupN", C.c_int32),
+                ("groupK", C.c_int32), ("round_gemm1", C.c_int32), ("w8a8", C.c_int32)]
+
+
+@dataclass
+class MoeDesc:
+    E: int
+    H: int
+    I: int
+    has_gate: bool = True
+    activation: int = ACT_SILU
+    swiglu_alpha: float = 1.702
+    swiglu_limit: float = 7.0
+    act_dtype: int = BF16
+    wfmt: int = W_BF16
+    groupN: int = 0
+    groupK: int = 0
+    round_gemm1: bool = False
+    w8a8: bool = False
+
+
+def moe(d: MoeDesc, w13, w2, x, ids, tw, s13=None, s2=None) -> np.ndarray:
+    """Routed experts; returns fp32 [M,H].  Arrays: see lkm_or_moe."""
+    x = _c(x)
+    ids = _c(ids, np.int32)
+    tw = _c(tw, np.float32)
+    M, K = ids.shape
+    assert x.shape == (M, d.H), (x.shape, M, d.H)
+    w13, w2 = _c(w13), _c(w2)
+    s13 = None if s13 is None else _c(s13)
+    s2 = None if s2 is None else _c(s2)
+    cd = _Desc(d.E, d.H, d.I, int(d.has_gate), d.activation, d.swiglu_alpha, d.swiglu_limit,
+               d.act_dtype, d.wfmt, d.groupN, d.groupK, int(d.round_gemm1), int(d.w8a8))
+    out = np.empty((M, d.H), np.float32)
+    rc = lib().lkm_or_moe(C.byref(cd), _p(w13), _p(w2), _p(s13), _p(s2), _p(x), _p(ids), _p(tw),
+                          C.c_int(M), C.c_int(K), _p(out))
+    assert rc == 0
+    return out
+
+
+def quant_int4(w_bits: np.ndarray, dt: int, g: int):
+    """w_bits: uint16 [..., N, K] in dtype dt -> (packed uint8 [..., N, K/2], scales uint16 [..., N, K/g])"""
+    w_bits = _c(w_bits, np.uint16)
+    *lead, N, K = w_bits.shape
+    flat = w_bits.reshape(-1, K)
+    packed = np.zeros((flat.shape[0], K // 2), np.uint8)
+    scales = np.empty((flat.shape[0], K // g), np.uint16)
+    lib().lkm_or_quant_int4(_p(flat), C.c_int(dt), C.c_int64(flat.shape[0]), C.c_int64(K), C.c_int(g),
+                            _p(packed), _p(scales))
+    return packed.reshape(*lead, N, K // 2), scales.reshape(*lead, N, K // g)
+
+
+def quant_fp8_block(w: np.ndarray, gN: int, gK: int):
+    """w: f32 [E, N, K] -> (q uint8 [E,N,K], scales f32 [E, ceil(N/gN), ceil(K/gK)])"""
+    w = _c(w, np.float32)
+    E, N, K = w.shape
+    nb, kb = -(-N // gN), -(-K // gK)
+    q = np.empty((E, N, K), np.uint8)
+    s = np.empty((E, nb, kb), np.float32)
+    for e in range(E):
+        lib().lkm_or_quant_fp8_block(_p(w[e]), C.c_int64(N), C.c_int64(K), C.c_int(gN), C.c_int(gK),
+                                     _p(q[e]), _p(s[e]))
+    return q, s
+
+
+def num_threads() -> int:
+    return int(lib().lkm_or_num_threads())

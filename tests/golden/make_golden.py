@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by RUNNING the reference's own oracle functions.
+
+The reference package cannot be imported in this container (missing zmq, msgspec, ... -- SURVEY.md
+8c), so this script parses the reference source files under /root/reference with `ast`, pulls out
+the pure-torch oracle FUNCTIONS the reference's tests use for this path, and exec()s them as they
+are, with tiny stand-ins only for the names they look up (enum members, the native SiluAndMul).
+Nothing of the reference is copied into the repo: only the numeric input/output vectors are saved.
+
+Functions executed (paths relative to /root/reference):
+  torch_topk                        tests/kernels/moe/test_fused_topk.py:18-44
+  grouped_topk                      vllm/model_executor/layers/fused_moe/router/grouped_topk_router.py:80-161
+  determine_expert_map              vllm/model_executor/layers/fused_moe/expert_map_manager.py:22-113
+  ref_fused_moe                     tests/kernels/moe/test_cpu_fused_moe.py:46-107
+  _swigluoai_forward_native         vllm/model_executor/layers/fused_moe/cpu_fused_moe.py:30-46
+  SiluAndMul.forward_native         vllm/model_executor/layers/activation.py:140-143
+  torch_experts / torch_moe         tests/kernels/utils.py:855-1021
+  quantize_weights                  vllm/model_executor/layers/quantization/utils/quant_utils.py:642-738
+  scalar_types.uint4b8              vllm/scalar_type.py
+  native_per_token_group_quant_fp8  tests/kernels/quant_utils.py:157-180
+  native_w8a8_block_matmul          tests/kernels/quant_utils.py:91-154
+  torch_w8a8_block_fp8_moe          tests/kernels/moe/test_block_fp8.py:107-137
+
+Run here (needs /root/reference):   python tests/golden/make_golden.py
+The GPU box never runs this; it only reads the committed .npz files.
+"""
+from __future__ import annotations
+
+import ast
+import enum
+import importlib.util
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+
+
+def extract(path: str, names: list[str], ns: dict, cls: str | None = None, strip_decorators=True):
+    """exec the named top-level functions (or methods of `cls`) of a reference file into ns."""
+    src = (REF / path).read_text()
+    tree = ast.parse(src)
+    body = tree.body
+    if cls is not None:
+        body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls).body
+    found = []
+    for node in body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            if strip_decorators:
+                node.decorator_list = []
+            mod = ast.Module(body=[node], type_ignores=[])
+            code = compile(ast.fix_missing_locations(mod), str(REF / path), "exec")
+            exec(code, ns)
+            found.append(node.name)
+    missing = set(names) - set(found)
+    if missing:
+        raise RuntimeError(f"{path}: functions not found: {missing}")
+    return ns
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    """bf16/fp16 tensor -> uint16 bit patterns; fp8 -> uint8; others unchanged."""
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+    if t.dtype == torch.float8_e4m3fn:
+        return t.contiguous().view(torch.uint8).numpy()
+    return t.contiguous().numpy()
+
+
+# ----------------------------------------------------------------------------- stand-ins
+class MoEActivation(enum.Enum):
+    SILU = "silu"
+    SWIGLUOAI = "swigluoai"
+
+    @property
+    def custom_op_name(self):
+        return {"silu": "silu_and_mul", "swigluoai": "swigluoai_and_mul"}[self.value]
+
+
+def base_ns() -> dict:
+    ns = {"torch": torch, "F": F, "np": np, "MoEActivation": MoEActivation}
+    # the reference's own native SiluAndMul
+    extract("vllm/model_executor/layers/activation.py", ["forward_native"], ns, cls="SiluAndMul")
+    silu_native = ns.pop("forward_native")
+
+    class SiluAndMul:  # shape of vllm.model_executor.layers.activation.SiluAndMul
+        forward_native = staticmethod(silu_native)
+
+        def __call__(self, x):
+            return silu_native(x)
+
+    ns["SiluAndMul"] = SiluAndMul
+    extract("vllm/model_executor/layers/fused_moe/cpu_fused_moe.py", ["_swigluoai_forward_native"], ns)
+    ns["_CPU_MOE_ACT_FN"] = {MoEActivation.SILU: silu_native,
+                             MoEActivation.SWIGLUOAI: ns["_swigluoai_forward_native"]}
+    ns["op_registry"] = {"silu_and_mul": SiluAndMul}
+    return ns
+
+
+# ----------------------------------------------------------------------------- generators
+def gen_topk(ns):
+    extract("tests/kernels/moe/test_fused_topk.py", ["torch_topk"], ns)
+    torch_topk = ns["torch_topk"]
+    cases = {}
+    idx = 0
+    # the reference's own grid (test_fused_topk.py:47-56) + the model shapes of SURVEY 8
+    grid = [(m, e, k) for m in (1, 33, 56) for e in (6, 16) for k in (3, 4)]
+    grid += [(32, 8, 2), (5, 128, 8), (7, 256, 8), (3, 384, 8)]
+    for (m, e, k) in grid:
+        for renorm in (True, False):
+            for scoring in ("softmax", "sigmoid"):
+                for dtype in (torch.float32, torch.bfloat16, torch.float16):
+                    for with_bias in (False, True):
+                        if with_bias and (idx % 3):
+                            idx += 1
+                            continue
+                        torch.manual_seed(0)
+                        _hidden = torch.randn((m, 64), dtype=dtype)
+                        gating = torch.randn((m, e), dtype=dtype)
+                        bias = torch.randn((e,), dtype=torch.float32) if with_bias else None
+                        w, ids = torch_topk(gating_output=gating, topk=k, renormalize=renorm,
+                                            e_score_correction_bias=bias, scoring_func=scoring)
+                        key = f"c{idx}"
+                        cases[key + "_logits"] = bits(gating)
+                        cases[key + "_meta"] = np.array(
+                            [m, e, k, int(renorm), 0 if scoring == "softmax" else 1,
+                             {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype],
+                             int(with_bias)], np.int32)
+                        if with_bias:
+                            cases[key + "_bias"] = bias.numpy()
+                        cases[key + "_w"] = w.float().numpy()
+                        cases[key + "_ids"] = ids.to(torch.int32).numpy()
+                        idx += 1
+    cases["n"] = np.array(idx, np.int32)
+    np.savez_compressed(OUT / "topk.npz", **cases)
+    print("topk.npz:", idx, "cases")
+
+
+def gen_grouped(ns):
+    envs = types.SimpleNamespace(VLLM_USE_FUSED_MOE_GROUPED_TOPK=False, VLLM_BATCH_INVARIANT=False)
+    plat = types.SimpleNamespace(is_cuda=lambda: False)
+    ns2 = dict(ns, envs=envs, current_platform=plat)
+    extract("vllm/model_executor/layers/fused_moe/router/grouped_topk_router.py", ["grouped_topk"], ns2)
+    grouped_topk = ns2["grouped_topk"]
+    cases = {}
+    idx = 0
+    # shapes of tests/kernels/moe/test_grouped_topk.py:77-86
+    for m in (1, 33):
+        for (e, k, ng, tg) in ((16, 2, 8, 2), (128, 2, 8, 2), (256, 8, 8, 4), (384, 8, 1, 1), (128, 8, 1, 1)):
+            for renorm in (True, False):
+                for scoring in ("softmax", "sigmoid"):
+                    for rsf in (1.0, 2.5):
+                        for with_bias in (True, False):
+                            torch.manual_seed(idx)
+                            logits = torch.randn((m, e), dtype=torch.float32)
+                            bias = torch.randn((e,), dtype=torch.float32) if with_bias else None
+                            w, ids = grouped_topk(torch.empty((m, 0)), logits, k, renorm, ng, tg,
+                                                  scoring, rsf, bias)
+                            key = f"c{idx}"
+                            cases[key + "_logits"] = logits.numpy()
+                            cases[key + "_meta"] = np.array(
+                                [m, e, k, ng, tg, int(renorm), 0 if scoring == "softmax" else 1,
+                                 int(with_bias)], np.int32)
+                            cases[key + "_rsf"] = np.array(rsf, np.float32)
+                            if with_bias:
+                                cases[key + "_bias"] = bias.numpy()
+                            cases[key + "_w"] = w.numpy()
+                            cases[key + "_ids"] = ids.numpy()
+                            idx += 1
+    cases["n"] = np.array(idx, np.int32)
+    np.savez_compressed(OUT / "grouped_topk.npz", **cases)
+    print("grouped_topk.npz:", idx, "cases")
+
+
+def gen_expert_map(ns):
+    ns2 = dict(ns, ExpertPlacementStrategy=str)
+    extract("vllm/model_executor/layers/fused_moe/expert_map_manager.py", ["determine_expert_map"], ns2)
+    f = ns2["determine_expert_map"]
+    cases = {}
+    idx = 0
+    for E in (8, 10, 128, 256, 7):
+        for ep in (1, 2, 3, 4, 8):
+            for strat in ("linear", "round_robin"):
+                for r in range(ep):
+                    n, emap, _ = f(ep, r, E, strat)
+                    cases[f"c{idx}_meta"] = np.array([ep, r, E, 0 if strat == "linear" else 1, n], np.int32)
+                    cases[f"c{idx}_map"] = (emap.numpy() if emap is not None
+                                            else np.arange(E, dtype=np.int32))
+                    idx += 1
+    cases["n"] = np.array(idx, np.int32)
+    np.savez_compressed(OUT / "expert_map.npz", **cases)
+    print("expert_map.npz:", idx, "cases")
+
+
+def _route(score: torch.Tensor, k: int):
+    p = torch.softmax(score.float(), dim=-1)
+    w, ids = torch.topk(p, k)
+    w = w / w.sum(dim=-1, keepdim=True)
+    return w.float(), ids.to(torch.int32)
+
+
+def gen_moe_bf16(ns):
+    extract("tests/kernels/moe/test_cpu_fused_moe.py", ["ref_fused_moe"], ns)
+    ns2 = dict(ns, moe_kernel_quantize_input=lambda a, s, qd, pt, bs=None: (a, None),
+               native_w8a8_block_matmul=None)
+    extract("tests/kernels/utils.py", ["torch_experts"], ns2)
+    ref_fused_moe, torch_experts = ns["ref_fused_moe"], ns2["torch_experts"]
+    cases = {}
+    idx = 0
+    # (M, I, H, E, K): small members of test_moe.py:292-303 / test_cpu_fused_moe.py grids
+    for (m, n, k, e, topk, act) in ((1, 128, 128, 8, 2, "silu"), (33, 256, 128, 4, 2, "silu"),
+                                    (17, 64, 256, 16, 6, "silu"), (33, 128, 128, 4, 2, "swigluoai"),
+                                    (64, 128, 256, 4, 1, "silu")):
+        for dtype in (torch.bfloat16, torch.float16):
+            if dtype == torch.float16 and (m, n) not in ((1, 128), (33, 256)):
+                continue
+            torch.manual_seed(7)
+            a = torch.randn((m, k), dtype=dtype) / 10
+            w1 = torch.randn((e, 2 * n, k), dtype=dtype) / 10
+            w2 = torch.randn((e, k, n), dtype=dtype) / 10
+            score = torch.randn((m, e), dtype=dtype)
+            tw, ids = _route(score, topk)
+            activation = MoEActivation.SILU if act == "silu" else MoEActivation.SWIGLUOAI
+            out_cpu = ref_fused_moe(a, w1, w2, None, None, tw, ids.long(), activation)
+            key = f"c{idx}"
+            cases[key + "_meta"] = np.array([m, n, k, e, topk, 1 if dtype == torch.bfloat16 else 2,
+                                             0 if act == "silu" else 1], np.int32)
+            cases[key + "_a"] = bits(a)
+            cases[key + "_w1"] = bits(w1)
+            cases[key + "_w2"] = bits(w2)
+            cases[key + "_tw"] = tw.numpy()
+            cases[key + "_ids"] = ids.numpy()
+            cases[key + "_out_cpu"] = bits(out_cpu)           # test_cpu_fused_moe oracle
+            if act == "silu":
+                out_gpu = torch_experts(a, w1, w2, tw, ids.long())
+                cases[key + "_out_gpu"] = bits(out_gpu)       # in-tree GPU-operator oracle
+            idx += 1
+    cases["n"] = np.array(idx, np.int32)
+    np.savez_compressed(OUT / "moe_dense.npz", **cases)
+    print("moe_dense.npz:", idx, "cases")
+
+
+def gen_moe_int4(ns):
+    spec = importlib.util.spec_from_file_location("ref_scalar_type", REF / "vllm/scalar_type.py")
+    st = importlib.util.module_from_spec(spec)
+    sys.modules["ref_scalar_type"] = st
+    spec.loader.exec_module(st)
+    ns2 = dict(ns, ScalarType=st.ScalarType, scalar_types=st.scalar_types)
+    extract("vllm/model_executor/layers/quantization/utils/quant_utils.py", ["quantize_weights"], ns2)
+    extract("tests/kernels/moe/test_cpu_fused_moe.py", ["ref_fused_moe"], ns2)
+    quantize_weights, ref_fused_moe = ns2["quantize_weights"], ns2["ref_fused_moe"]
+    cases = {}
+    idx = 0
+    for (m, n, k, e, topk, g) in ((1, 128, 128, 4, 2, 128), (33, 256, 128, 4, 2, 64),
+                                  (20, 128, 256, 4, 2, 32), (33, 128, 256, 4, 2, 128)):
+        for dtype in (torch.bfloat16, torch.float16):
+            if dtype == torch.float16 and g != 64:
+                continue
+            torch.manual_seed(7)
+            a = torch.randn((m, k), dtype=dtype) / 10
+            w1 = torch.randn((e, 2 * n, k), dtype=dtype) / 10
+            w2 = torch.randn((e, k, n), dtype=dtype) / 10
+            score = torch.randn((m, e), dtype=dtype)
+            tw, ids = _route(score, topk)
+            packs, scales, refs = [], [], []
+            for w in (w1, w2):
+                qw, sc, rf = [], [], []
+                for i in range(e):
+                    # test_moe.py:634-641
+                    weight, qweight, s, _ = quantize_weights(w[i].T, st.scalar_types.uint4b8, g, False, False)
+                    weight = weight.T
+                    qweight = qweight.T.contiguous().to(torch.uint8)
+                    qweight = qweight[:, 1::2] * 16 + qweight[:, ::2]
+                    qw.append(qweight)
+                    sc.append(s.T.contiguous())
+                    rf.append(weight.contiguous())
+                packs.append(torch.stack(qw))
+                scales.append(torch.stack(sc))
+                refs.append(torch.stack(rf))
+            out = ref_fused_moe(a, refs[0], refs[1], None, None, tw, ids.long(), MoEActivation.SILU)
+            key = f"c{idx}"
+            cases[key + "_meta"] = np.array([m, n, k, e, topk, g, 1 if dtype == torch.bfloat16 else 2], np.int32)
+            cases[key + "_a"] = bits(a)
+            cases[key + "_w1"] = bits(w1)
+            cases[key + "_w2"] = bits(w2)
+            cases[key + "_q1"] = packs[0].numpy()
+            cases[key + "_q2"] = packs[1].numpy()
+            cases[key + "_s1"] = bits(scales[0])
+            cases[key + "_s2"] = bits(scales[1])
+            if idx == 0:   # dequantised reference weights: one case is enough to pin the dequant
+                cases[key + "_ref1"] = bits(refs[0])
+                cases[key + "_ref2"] = bits(refs[1])
+            cases[key + "_tw"] = tw.numpy()
+            cases[key + "_ids"] = ids.numpy()
+            cases[key + "_out"] = bits(out)
+            idx += 1
+    cases["n"] = np.array(idx, np.int32)
+    np.savez_compressed(OUT / "moe_int4.npz", **cases)
+    print("moe_int4.npz:", idx, "cases")
+
+
+def gen_moe_fp8(ns):
+    ns2 = dict(ns, is_deep_gemm_e8m0_used=lambda: False, _ceil_to_ue8m0=None,
+               FP8_DTYPE=torch.float8_e4m3fn)
+    extract("tests/kernels/quant_utils.py",
+            ["native_per_token_group_quant_fp8", "native_w8a8_block_matmul"], ns2)
+    extract("tests/kernels/moe/test_block_fp8.py", ["torch_w8a8_block_fp8_moe"], ns2)
+    f = ns2["torch_w8a8_block_fp8_moe"]
+    cases = {}
+    idx = 0
+    for (m, n, k, e, topk) in ((1, 128, 128, 2, 1), (33, 256, 128, 8, 2), (16, 128, 256, 8, 6)):
+        dtype = torch.bfloat16
+        torch.manual_seed(0)
+        a = torch.randn((m, k), dtype=dtype) / 10
+        score = torch.randn((m, e), dtype=dtype)
+        w1f = torch.randn((e, 2 * n, k), dtype=torch.float32) / 10
+        w2f = torch.randn((e, k, n), dtype=torch.float32) / 10
+        blk = [128, 128]
+
+        def blockq(w):
+            E_, N_, K_ = w.shape
+            nb, kb = -(-N_ // 128), -(-K_ // 128)
+            q = torch.empty_like(w, dtype=torch.float8_e4m3fn)
+            s = torch.empty((E_, nb, kb), dtype=torch.float32)
+            for e_ in range(E_):
+                for i in range(nb):
+                    for j in range(kb):
+                        t = w[e_, i * 128:(i + 1) * 128, j * 128:(j + 1) * 128]
+                        sc = t.abs().max().clamp(min=1e-4) / 448.0
+                        s[e_, i, j] = sc
+                        q[e_, i * 128:(i + 1) * 128, j * 128:(j + 1) * 128] = (t / sc).to(torch.float8_e4m3fn)
+            return q, s
+
+        w1, w1s = blockq(w1f)
+        w2, w2s = blockq(w2f)
+        p = torch.softmax(score.float(), dim=-1)
+        tw, ids = torch.topk(p, topk)      # fused_topk(..., renormalize=False), test_block_fp8.py:176
+        out = f(a, w1, w2, w1s, w2s, tw, ids, blk)
+        key = f"c{idx}"
+        cases[key + "_meta"] = np.array([m, n, k, e, topk], np.int32)
+        cases[key + "_a"] = bits(a)
+        cases[key + "_w1"] = bits(w1)
+        cases[key + "_w2"] = bits(w2)
+        cases[key + "_w1s"] = w1s.numpy()
+        cases[key + "_w2s"] = w2s.numpy()
+        cases[key + "_tw"] = tw.float().numpy()
+        cases[key + "_ids"] = ids.to(torch.int32).numpy()
+        cases[key + "_out"] = bits(out)
+        idx += 1
+    cases["n"] = np.array(idx, np.int32)
+    np.savez_compressed(OUT / "moe_fp8_block.npz", **cases)
+    print("moe_fp8_block.npz:", idx, "cases")
+
+
+def main():
+    if not REF.exists():
+        sys.exit("needs /root/reference (run in the build container, not on the GPU box)")
+    torch.set_num_threads(8)
+    ns = base_ns()
+    gen_topk(dict(ns))
+    gen_grouped(dict(ns))
+    gen_expert_map(dict(ns))
+    gen_moe_bf16(dict(ns))
+    gen_moe_int4(dict(ns))
+    gen_moe_fp8(dict(ns))
+
+
+if __name__ == "__main__":
+    main()

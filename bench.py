@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py -- MoE-layer decode throughput of the MI355X-native routed-expert path.
+
+Metric (BASELINE.json): MoE-layer decode tokens/s + grouped-GEMM % of roofline, Mixtral-8x7B.
+Workload at N=1: BASELINE.json configs[1] -- Mixtral-8x7B bf16 experts (E=8, top-2, H=4096,
+I=14336), decode batch 32, synthetic hidden states / router logits / random-init weights, all
+resident in HBM before the timed region.  One "step" = one pass of the hot path over the batch:
+router top-k (a1) -> scatter (sort) -> grouped GEMM1 + SiLU-mul -> grouped GEMM2 -> top-k combine.
+
+N>1 (launched by torch.distributed.run, one rank per GPU, RCCL): experts are sharded E/N per
+rank (linear placement), every rank keeps its own 32-token batch, routed rows travel by
+all-to-all (lvllm_amd/ep.py) -- weak scaling; value = all ranks' tokens / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
+GEMM1, algorithmic weight bytes / its mean duration from HIP events on the launch stream) and
+`cpu_baseline` (the CPU oracle = a port of the reference algorithm, timed on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WORKLOADS = {
+    # name: (E, K, H, I, M, fmt)
+    "mixtral8x7b_bf16_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="bf16"),
+    "mixtral8x7b_int4g128_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="int4", g=128),
+    "qwen3_30b_a3b_bf16_decode_m1": dict(E=128, K=8, H=2048, I=768, M=1, fmt="bf16"),
+}
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def make_weights(E_local, first_expert, H, I, dev, fmt, g=128):
+    """random-init experts, per-expert seeds so that any EP sharding sees the same model."""
+    w13 = torch.empty((E_local, 2 * I, H), dtype=torch.bfloat16, device=dev)
+    w2 = torch.empty((E_local, H, I), dtype=torch.bfloat16, device=dev)
+    for e in range(E_local):
+        gen = torch.Generator(device=dev).manual_seed(7000 + first_expert + e)
+        w13[e] = (torch.randn((2 * I, H), generator=gen, device=dev, dtype=torch.float32) / 10).to(torch.bfloat16)
+        w2[e] = (torch.randn((H, I), generator=gen, device=dev, dtype=torch.float32) / 10).to(torch.bfloat16)
+    return w13, w2
+
+
+def quantize_int4(w: torch.Tensor, g: int):
+    """uint4b8 symmetric group quantisation on the GPU (same recipe as quantize_weights,
+    quant_utils.py:642-738; the parity tests check the oracle's version bit-exactly)."""
+    E, N, K = w.shape
+    wg = w.view(E, N, K // g, g)
+    mx, mn = wg.max(dim=-1).values, wg.min(dim=-1).values
+    s = torch.maximum((mx / 7).abs(), (mn / -8).abs())
+    q = torch.round(wg / s[..., None]).clamp(-8, 7).to(torch.int32) + 8
+    q = q.view(E, N, K)
+    packed = (q[..., 1::2] * 16 + q[..., ::2]).to(torch.uint8)
+    return packed.contiguous(), s.contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="mixtral8x7b_bf16_decode_m32", choices=list(WORKLOADS))
+    ap.add_argument("--ep-mode", default="a2a", choices=["a2a", "ar"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--tune", default="", help="comma list key=value for lkm_set_tuning (nt1,nt2,kw1,sk2,tbmax)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from lvllm_amd import ops
+    from lvllm_amd.ep import ExpertParallelExperts
+
+    wl = WORKLOADS[args.workload]
+    E, K, H, I, M, fmt = wl["E"], wl["K"], wl["H"], wl["I"], wl["M"], wl["fmt"]
+    assert E % world == 0 or world == 1, "experts must shard evenly for the bench"
+    E_local = E // world
+    first = rank * E_local
+    w13, w2 = make_weights(E_local, first, H, I, dev, fmt)
+    if fmt == "int4":
+        g = wl["g"]
+        q13, s13 = quantize_int4(w13, g)
+        q2, s2 = quantize_int4(w2, g)
+        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="int4",
+                                      w13_scale=s13, w2_scale=s2, group_n=1, group_k=g,
+                                      max_num_seqs=max(256, M * world), num_processes=world, process_id=rank)
+    else:
+        eng = ops.RoutedExpertsEngine(w13, w2, top_k=K, act_dtype=torch.bfloat16, fmt="bf16",
+                                      max_num_seqs=max(256, M * world), num_processes=world, process_id=rank)
+    if args.tune:
+        eng.engine.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
+
+    # synthetic inputs (seed 7): x = randn/10, router logits = randn
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    x = (torch.randn((M, H), generator=gen, device=dev) / 10).to(torch.bfloat16)
+    logits = torch.randn((M, E), generator=gen, device=dev, dtype=torch.float32)
+    out = torch.empty((M, H), dtype=torch.float32, device=dev)
+
+    if world == 1:
+        def step():
+            tw, ids = ops.topk_softmax(logits, K, True)
+            eng.decode(x, tw, ids, out=out)
+    else:
+        def local_compute(rows, lids, ws):
+            return eng.decode(rows, ws.contiguous(), lids.contiguous())
+        ep = ExpertParallelExperts(local_compute, E, H, mode=args.ep_mode)
+
+        def step():
+            tw, ids = ops.topk_softmax(logits, K, True)
+            out.copy_(ep.forward(x, tw, ids))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (also the un-captured reference result)
+    for _ in range(max(1, args.warmup)):
+        step()
+    barrier()
+    launch = "eager"
+    graph = None
+    if world == 1 and not args.no_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                step()
+            graph.replay()
+            torch.cuda.synchronize()
+            launch = "hipgraph"
+        except Exception as e:  # capture is an optimisation of the launch path only
+            print(f"[bench] graph capture unavailable ({e}); timing eager launches", file=sys.stderr)
+            graph = None
+    run = (lambda: graph.replay()) if graph is not None else step
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    tokens_per_s = M * world / (dt / args.steps)
+
+    # ---- dominant-kernel roofline: GEMM1 duration from HIP events on the launch stream
+    roofline = None
+    prof_ms = None
+    if rank == 0:
+        tw, ids = ops.topk_softmax(logits, K, True)
+        if world > 1:
+            ids = torch.where((ids >= first) & (ids < first + E_local), ids - first, torch.full_like(ids, -1))
+        eng.engine.set_profiling(True)
+        acc = {"sort": 0.0, "gemm1": 0.0, "gemm2": 0.0, "combine": 0.0}
+        reps = 50
+        for _ in range(5):
+            eng.decode(x, tw, ids, out=out)
+        for _ in range(reps):
+            eng.decode(x, tw, ids, out=out)
+            p = eng.engine.get_profile()
+            for k_ in acc:
+                acc[k_] += p[k_]
+        eng.engine.set_profiling(False)
+        prof_ms = {k_: v / reps for k_, v in acc.items()}
+        e_act = int(torch.unique(ids[ids >= 0]).numel())
+        bpe = {"bf16": 2.0, "int4": 0.5}[fmt]
+        scale_bytes = 0.0 if fmt == "bf16" else 2.0 / wl["g"]
+        g1_bytes = e_act * 2 * I * H * (bpe + scale_bytes)          # algorithmic weight bytes of GEMM1
+        achieved = g1_bytes / (prof_ms["gemm1"] * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get(args.workload, {}).get("gemm1_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "gemm1_act_kernel", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "algorithmic_bytes": g1_bytes,
+                    "kernel_ms": {k_: round(v, 4) for k_, v in prof_ms.items()}}
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        tw, ids = ops.topk_softmax(logits, K, True)
+        twn, idn = tw.cpu().numpy(), ids.cpu().numpy()
+        xb = x.cpu().view(torch.int16).numpy().view(np.uint16)
+        if fmt == "bf16":
+            d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+            a13 = w13.cpu().view(torch.int16).numpy().view(np.uint16)
+            a2 = w2.cpu().view(torch.int16).numpy().view(np.uint16)
+            cargs = dict(w13=a13, w2=a2)
+        else:
+            d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_INT4, groupN=1, groupK=wl["g"])
+            cargs = dict(w13=q13.cpu().numpy(), w2=q2.cpu().numpy(),
+                         s13=s13.cpu().view(torch.int16).numpy().view(np.uint16),
+                         s2=s2.cpu().view(torch.int16).numpy().view(np.uint16))
+        ref = orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)            # untimed first pass (page-in)
+        n, t_cpu = 0, 0.0
+        while n < 2 or (t_cpu < args.cpu_seconds and n < 50):
+            c0 = time.perf_counter()
+            ref = orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)
+            t_cpu += time.perf_counter() - c0
+            n += 1
+        gpu_out = eng.decode(x, tw, ids).cpu().numpy()
+        err = float(np.abs(gpu_out - ref).max() / max(1e-9, np.abs(ref).max()))
+        cpu = {"value": round(M / (t_cpu / n), 2), "unit": "tokens/s", "cores": orc.num_threads(),
+               "kind": "port",
+               "sample": f"{n} full {args.workload} layer passes (M={M}) through oracle/lkm_oracle.c, "
+                         f"{t_cpu:.1f} s of CPU work; lk_moe itself is a closed binary absent from the reference tree",
+               "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err}
+
+    if rank == 0:
+        line = {
+            "metric": "moe_layer_decode_tokens_per_s", "value": round(tokens_per_s, 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if fmt == "bf16" else "int4-w/bf16-act", "data": "synthetic",
+            "config": {"workload": args.workload, "experts": E, "top_k": K, "hidden": H,
+                       "intermediate": I, "batch_per_gpu": M,
+                       "parallelism": "single" if world == 1 else f"ep{world}-{args.ep_mode}",
+                       "launch": launch, "geometry": eng.engine.describe()},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,242 @@
+"""GPU parity: the routed-expert engine (lk_moe surface -> C ABI -> HIP kernels) vs the CPU oracle,
+vs the reference's golden vectors, and through size-independent properties at full Mixtral size.
+
+Tolerances (stated here, used below):
+  vs oracle (same rounding points, fp32 accumulation order differs):  atol 2e-3, rtol 1e-2
+  vs reference golden:  bf16/int4 atol 2e-2 rtol 0 (test_moe.py:233-234); cpu oracle default
+                        atol 1e-3 rtol 1.6e-2 bf16 / 1e-3 fp16 (allclose_default.py:8-9)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.helpers import bits_to_torch, dt_of, load_golden, make_routing, torch_to_bits
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ATOL, RTOL = 2e-3, 1e-2
+
+
+def _eng(*a, **k):
+    from lvllm_amd.ops import RoutedExpertsEngine
+    return RoutedExpertsEngine(*a, **k)
+
+
+def _run_decode(eng, a, tw, ids):
+    return eng.decode(a.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)).cpu().numpy()
+
+
+def test_library_loaded_and_device():
+    from lvllm_amd import _clib
+    n, arch = _clib.device_info()
+    assert n >= 1 and arch.startswith("gfx950"), (n, arch)
+
+
+def test_dense_golden_cases():
+    for i, c in load_golden("moe_dense.npz"):
+        m, n, k, e, topk, dt, act = [int(v) for v in c["meta"]]
+        tdt = torch.bfloat16 if dt == orc.BF16 else torch.float16
+        w1, w2, a = bits_to_torch(c["w1"], dt), bits_to_torch(c["w2"], dt), bits_to_torch(c["a"], dt)
+        eng = _eng(w1, w2, top_k=topk, act_dtype=tdt, fmt="bf16",
+                   activation_type=0 if act == 0 else 1)             # host pointers: engine copies
+        out = _run_decode(eng, a, c["tw"], c["ids"])
+        d = orc.MoeDesc(E=e, H=k, I=n, activation=act, act_dtype=dt,
+                        wfmt=orc.W_BF16 if dt == orc.BF16 else orc.W_F16)
+        ref = orc.moe(d, c["w1"], c["w2"], c["a"], c["ids"], c["tw"])
+        np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=f"case {i} vs oracle")
+        gold = orc.bits_to_f32(c["out_cpu"], dt)
+        np.testing.assert_allclose(orc.bits_to_f32(orc.f32_to_bits(out, dt), dt), gold, atol=1e-3,
+                                   rtol=1.6e-2 if dt == orc.BF16 else 2e-3, err_msg=f"case {i} vs ref_fused_moe")
+        if "out_gpu" in c:
+            np.testing.assert_allclose(out, orc.bits_to_f32(c["out_gpu"], dt), atol=2e-2, rtol=0,
+                                       err_msg=f"case {i} vs torch_experts")
+        # gpu_prefill: activation-dtype output of the same math
+        pre = eng.prefill(a.to(DEV), torch.from_numpy(c["tw"]).to(DEV), torch.from_numpy(c["ids"]).to(DEV))
+        np.testing.assert_array_equal(torch_to_bits(pre), orc.f32_to_bits(out, dt))
+
+
+def test_int4_golden_cases():
+    for i, c in load_golden("moe_int4.npz"):
+        m, n, k, e, topk, g, dt = [int(v) for v in c["meta"]]
+        tdt = torch.bfloat16 if dt == orc.BF16 else torch.float16
+        eng = _eng(torch.from_numpy(c["q1"]), torch.from_numpy(c["q2"]), top_k=topk, act_dtype=tdt,
+                   fmt="int4", w13_scale=bits_to_torch(c["s1"], dt), w2_scale=bits_to_torch(c["s2"], dt),
+                   group_n=1, group_k=g)
+        out = _run_decode(eng, bits_to_torch(c["a"], dt), c["tw"], c["ids"])
+        d = orc.MoeDesc(E=e, H=k, I=n, act_dtype=dt, wfmt=orc.W_INT4, groupN=1, groupK=g)
+        ref = orc.moe(d, c["q1"], c["q2"], c["a"], c["ids"], c["tw"], s13=c["s1"], s2=c["s2"])
+        np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=f"case {i} vs oracle")
+        np.testing.assert_allclose(out, orc.bits_to_f32(c["out"], dt), atol=2e-2, rtol=0,
+                                   err_msg=f"case {i} vs reference (dequantised-weight oracle)")
+
+
+def test_fp8_w8a16_golden_inputs():
+    for i, c in load_golden("moe_fp8_block.npz"):
+        m, n, k, e, topk = [int(v) for v in c["meta"]]
+        eng = _eng(torch.from_numpy(c["w1"]), torch.from_numpy(c["w2"]), top_k=topk,
+                   act_dtype=torch.bfloat16, fmt="fp8", w13_scale=torch.from_numpy(c["w1s"]),
+                   w2_scale=torch.from_numpy(c["w2s"]), group_n=128, group_k=128)
+        out = _run_decode(eng, bits_to_torch(c["a"], orc.BF16), c["tw"], c["ids"])
+        d = orc.MoeDesc(E=e, H=k, I=n, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128)
+        ref = orc.moe(d, c["w1"], c["w2"], c["a"], c["ids"], c["tw"], s13=c["w1s"], s2=c["w2s"])
+        np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=f"case {i} vs oracle")
+        # the pinned W8A8 oracle of the reference, at its own tolerance
+        np.testing.assert_allclose(out, orc.bits_to_f32(c["out"], orc.BF16), atol=0.035, rtol=0.035)
+
+
+def _rand_case(M, E, K, H, I, dtype, seed, gated=True, drop=0.0, skew=0.0):
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn((M, H), generator=g) / 10).to(dtype)
+    w13 = (torch.randn((E, (2 if gated else 1) * I, H), generator=g) / 10).to(dtype)
+    w2 = (torch.randn((E, H, I), generator=g) / 10).to(dtype)
+    tw, ids = make_routing(M, E, K, seed, skew=skew, drop=drop)
+    return a, w13, w2, tw, ids
+
+
+@pytest.mark.parametrize("M,E,K,H,I", [
+    (1, 8, 2, 128, 128), (3, 4, 4, 256, 64), (16, 8, 2, 512, 256), (17, 8, 2, 136, 72),
+    (33, 16, 4, 384, 200), (70, 4, 2, 128, 128), (150, 2, 2, 256, 128), (200, 64, 6, 128, 64),
+    (5, 128, 8, 2048, 768),
+])
+def test_dense_random_shapes_ragged(M, E, K, H, I):
+    """ragged / empty experts, -1 (non-local) ids, sizes that are not multiples of the tile."""
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=M * 7 + E, drop=0.15, skew=1.0)
+    eng = _eng(w13.to(DEV), w2.to(DEV), top_k=K, act_dtype=torch.bfloat16)      # device pointers
+    out = _run_decode(eng, a, tw, ids)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+    np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL)
+    # rows whose slots are all skipped must be exactly zero
+    dead = (ids < 0).all(axis=1)
+    assert (out[dead] == 0).all()
+
+
+def test_relu2_non_gated():
+    M, E, K, H, I = 19, 8, 2, 256, 128
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=5, gated=False)
+    eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16, has_gate_proj=False, activation_type=2)
+    out = _run_decode(eng, a, tw, ids)
+    d = orc.MoeDesc(E=E, H=H, I=I, has_gate=False, activation=orc.ACT_RELU2, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+    np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL)
+
+
+def test_all_launch_geometries_agree():
+    """every (nt, tb, kw, sk) variant computes the same function (fp32 reorder tolerance)."""
+    M, E, K, H, I = 40, 8, 2, 512, 256
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=11)
+    eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+    base = _run_decode(eng, a, tw, ids)
+    for nt1, tb, kw in ((1, 1, 1), (1, 2, 2), (1, 4, 4), (2, 1, 8), (2, 2, 1)):
+        for nt2, sk in ((1, 1), (2, 4), (4, 2)):
+            if nt2 * tb > 8:
+                continue
+            eng.engine.set_tuning(nt1=nt1, tbmax=tb, kw1=kw, nt2=nt2, sk2=sk)
+            out = _run_decode(eng, a, tw, ids)
+            np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())
+
+
+def test_prefill_host_and_chunking():
+    M, E, K, H, I = 300, 8, 2, 128, 128
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=3)
+    eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16, max_num_seqs=8, max_batch_size=64,
+               group_max_len=64)                                   # forces 64-token chunks
+    out_dev = _run_decode(eng, a, tw, ids)
+    out_host = eng.prefill_host(a, torch.from_numpy(tw), torch.from_numpy(ids)).numpy()
+    np.testing.assert_array_equal(out_dev, out_host)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+    np.testing.assert_allclose(out_dev, ref, atol=ATOL, rtol=RTOL)
+
+
+def test_decode_is_hip_graph_capturable():
+    """cpu_decode is called under graph capture in the reference (moe_runner.py:609-614)."""
+    M, E, K, H, I = 32, 8, 2, 256, 128
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=9)
+    eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+    ad, twd, idd = a.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)
+    out = torch.zeros((M, H), dtype=torch.float32, device=DEV)
+    eager = eng.decode(ad, twd, idd).clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        eng.decode(ad, twd, idd, out=out)          # warm-up on the side stream
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        eng.decode(ad, twd, idd, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    # new routing in the same buffers, replayed
+    tw2, ids2 = make_routing(M, E, K, seed=123)
+    twd.copy_(torch.from_numpy(tw2)); idd.copy_(torch.from_numpy(ids2))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eng.decode(ad, twd, idd))
+
+
+def test_errors_are_loud():
+    from lvllm_amd._clib import LkmError
+    w13 = torch.zeros((2, 64, 36), dtype=torch.bfloat16)     # hidden 36 not a multiple of 8
+    w2 = torch.zeros((2, 36, 32), dtype=torch.bfloat16)
+    with pytest.raises(LkmError):
+        _eng(w13, w2, top_k=1, act_dtype=torch.bfloat16)
+    import lk_moe
+    cfg = lk_moe.MOEConfigV2()
+    cfg.expert_num, cfg.top_k, cfg.hidden_size, cfg.intermediate_size = 2, 1, 64, 64
+    with pytest.raises(LkmError):
+        lk_moe.MOE_NVFP4(cfg, 1, 1, 1, 1, 1, 1)               # not built -> raises
+
+
+@pytest.fixture(scope="module")
+def mixtral():
+    """Mixtral-8x7B expert shapes (BASELINE.json configs[1]): E=8 K=2 H=4096 I=14336, bf16."""
+    E, K, H, I = 8, 2, 4096, 14336
+    torch.manual_seed(7)
+    w13 = torch.randn((E, 2 * I, H), dtype=torch.bfloat16, device=DEV) / 10
+    w2 = torch.randn((E, H, I), dtype=torch.bfloat16, device=DEV) / 10
+    eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+    return eng, w13, w2
+
+
+def test_mixtral_full_size_properties(mixtral):
+    eng, w13, w2 = mixtral
+    M, E, K, H = 32, 8, 2, 4096
+    torch.manual_seed(1)
+    a = (torch.randn((M, H), device=DEV) / 10).to(torch.bfloat16)
+    tw, ids = make_routing(M, E, K, seed=2)
+    twd, idd = torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)
+    y = eng.decode(a, twd, idd).clone()
+    assert torch.isfinite(y).all() and y.abs().max() > 0
+    # linearity in the routing weights: x2 is exact in fp32
+    assert torch.equal(eng.decode(a, twd * 2, idd), y * 2)
+    # idempotence / determinism
+    assert torch.equal(eng.decode(a, twd, idd), y)
+    # token-permutation equivariance (bit-exact: a token's result does not depend on its row)
+    perm = torch.randperm(M, device=DEV)
+    yp = eng.decode(a[perm].contiguous(), twd[perm].contiguous(), idd[perm].contiguous())
+    assert torch.equal(yp, y[perm])
+    # top-k decomposition: sum over single-slot runs == full run (fp32 sum of 2 terms, same order)
+    parts = torch.zeros_like(y)
+    for k in range(K):
+        idk = torch.full_like(idd, -1)
+        idk[:, k] = idd[:, k]
+        parts += eng.decode(a, twd, idk)
+    torch.testing.assert_close(parts, y, atol=1e-6, rtol=1e-6)
+    # dropping every slot gives exact zeros
+    assert (eng.decode(a, twd, torch.full_like(idd, -1)) == 0).all()
+
+
+def test_mixtral_full_size_vs_oracle(mixtral):
+    eng, w13, w2 = mixtral
+    M, E, K, H, I = 6, 8, 2, 4096, 14336
+    torch.manual_seed(3)
+    a = (torch.randn((M, H)) / 10).to(torch.bfloat16)
+    tw, ids = make_routing(M, E, K, seed=4)
+    out = _run_decode(eng, a, tw, ids)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+    scale = float(np.abs(ref).max())
+    np.testing.assert_allclose(out, ref, atol=2e-3 * scale, rtol=1e-2)

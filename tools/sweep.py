@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Kernel-geometry sweep on the GPU box: per-kernel HIP-event timings for every launch geometry of
+the decode path (lkm_set_tuning), printed as a table + JSON lines.  Development tool."""
+from __future__ import annotations
+
+import argparse
+import itertools
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from bench import WORKLOADS, make_weights, quantize_int4  # noqa: E402
+from lvllm_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="mixtral8x7b_bf16_decode_m32")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--g1", default="1:1:1,1:2:1,2:1:1,2:2:1,1:2:2,1:4:1,4:1:1", help="nt1:tb:kw list")
+    ap.add_argument("--g2", default="1:1,1:2,1:4,2:1,2:2,2:4,2:8,4:2,4:4", help="nt2:sk list")
+    ap.add_argument("--M", type=int, default=0)
+    args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    if args.M:
+        wl["M"] = args.M
+    E, K, H, I, M, fmt = wl["E"], wl["K"], wl["H"], wl["I"], wl["M"], wl["fmt"]
+    dev = torch.device("cuda", 0)
+    w13, w2 = make_weights(E, 0, H, I, dev, fmt)
+    if fmt == "int4":
+        q13, s13 = quantize_int4(w13, wl["g"]); q2, s2 = quantize_int4(w2, wl["g"])
+        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="int4", w13_scale=s13,
+                                      w2_scale=s2, group_n=1, group_k=wl["g"])
+        bpe = 0.5 + 2.0 / wl["g"]
+    else:
+        eng = ops.RoutedExpertsEngine(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+        bpe = 2.0
+    del w13, w2
+    gen = torch.Generator(device=dev).manual_seed(7)
+    x = (torch.randn((M, H), generator=gen, device=dev) / 10).to(torch.bfloat16)
+    logits = torch.randn((M, E), generator=gen, device=dev)
+    tw, ids = ops.topk_softmax(logits, K, True)
+    e_act = int(torch.unique(ids).numel())
+    g1_bytes, g2_bytes = e_act * 2 * I * H * bpe, e_act * H * I * bpe
+    out = torch.empty((M, H), dtype=torch.float32, device=dev)
+    eng.engine.set_profiling(True)
+
+    def measure():
+        acc = {"sort": 0.0, "gemm1": 0.0, "gemm2": 0.0, "combine": 0.0}
+        for _ in range(3):
+            eng.decode(x, tw, ids, out=out)
+        for _ in range(args.reps):
+            eng.decode(x, tw, ids, out=out)
+            p = eng.engine.get_profile()
+            for k in acc:
+                acc[k] += p[k] / args.reps
+        return acc
+
+    print(f"# {args.workload} M={M} e_act={e_act} g1={g1_bytes/1e9:.3f} GB g2={g2_bytes/1e9:.3f} GB")
+    base = None
+    for spec in args.g1.split(","):
+        nt1, tb, kw = map(int, spec.split(":"))
+        try:
+            eng.engine.set_tuning(nt1=nt1, tbmax=tb, kw1=kw, nt2=0, sk2=0)
+            p = measure()
+        except Exception as e:
+            print(f"g1 nt={nt1} tb={tb} kw={kw}: FAILED {e}")
+            continue
+        gbs = g1_bytes / (p["gemm1"] * 1e-3) / 1e9
+        print(f"g1 nt={nt1} tb={tb} kw={kw}: gemm1 {p['gemm1']*1e3:8.1f} us  {gbs:7.1f} GB/s  ({gbs/80:.1f}% of 8 TB/s)  sort {p['sort']*1e3:.1f} us")
+        print(json.dumps({"k": "gemm1", "nt": nt1, "tb": tb, "kw": kw, "us": p["gemm1"] * 1e3, "GBs": gbs}))
+    tb2 = 2 if M <= 32 else 4
+    for spec in args.g2.split(","):
+        nt2, sk = map(int, spec.split(":"))
+        for tb in sorted({1 if M <= 16 else tb2, tb2}):
+            if nt2 * tb > 8:
+                continue
+            try:
+                eng.engine.set_tuning(nt1=0, tbmax=tb, kw1=0, nt2=nt2, sk2=sk)
+                p = measure()
+            except Exception as e:
+                print(f"g2 nt={nt2} tb={tb} sk={sk}: FAILED {e}")
+                continue
+            gbs = g2_bytes / (p["gemm2"] * 1e-3) / 1e9
+            print(f"g2 nt={nt2} tb={tb} sk={sk}: gemm2 {p['gemm2']*1e3:8.1f} us  {gbs:7.1f} GB/s  ({gbs/80:.1f}%)  combine {p['combine']*1e3:.1f} us")
+            print(json.dumps({"k": "gemm2", "nt": nt2, "tb": tb, "sk": sk, "us": p["gemm2"] * 1e3, "GBs": gbs, "combine_us": p["combine"] * 1e3}))
+    eng.engine.set_tuning(nt1=0, tbmax=0, kw1=0, nt2=0, sk2=0)
+    p = measure()
+    tot = sum(p.values())
+    print(f"auto: {eng.engine.describe()}")
+    print(f"auto: sort {p['sort']*1e3:.1f} gemm1 {p['gemm1']*1e3:.1f} gemm2 {p['gemm2']*1e3:.1f} combine {p['combine']*1e3:.1f} total {tot*1e3:.1f} us "
+          f"-> {(g1_bytes+g2_bytes)/(tot*1e-3)/1e9:.0f} GB/s layer, {M/(tot*1e-3):.0f} tok/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,41 @@ EXPORTS = tuple(_SIGS)
 _lib = None
 
 
+def _bind_hip_runtime() -> str:
+    """liblkm.so is linked WITHOUT a DT_NEEDED on libamdhip64 (hipcc -no-hip-rt) so that a process
+    holds exactly one HIP runtime: the one already mapped (PyTorch-ROCm bundles its own under
+    torch/lib), else torch's bundled one if torch is installed (a later `import torch` then
+    shares it), else the system ROCm one.  It is promoted to RTLD_GLOBAL so liblkm.so binds to it."""
+    import importlib.util
+    import os
+    path = None
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+    except OSError:
+        pass
+    if path is None:
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                path = cand
+    if path is None:
+        for cand in ("/opt/rocm/lib/libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"):
+            if cand.startswith("/") and not os.path.exists(cand):
+                continue
+            path = cand
+            break
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return path
+
+
+HIP_RUNTIME_PATH = None
+
+
 def lib() -> C.CDLL:
     """Loads liblkm.so once; raises (never falls back) if it is not there."""
     global _lib
@@ -80,6 +115,8 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run "
                 "`python -m lvllm_amd.build` (needs hipcc). There is no CPU fallback.")
+        global HIP_RUNTIME_PATH
+        HIP_RUNTIME_PATH = _bind_hip_runtime()
         cdll = C.CDLL(str(LIB_PATH))
         for name, (res, args) in _SIGS.items():
             fn = getattr(cdll, name)   # AttributeError if the symbol is missing: fail loudly

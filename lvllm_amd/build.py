@@ -65,10 +65,12 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         objs = list(ex.map(lambda s: _compile(s, headers, verbose), srcs))
     stamp = OBJ / "link.stamp"
-    want = " ".join(o.name for o in objs)
+    want = "no-hip-rt " + " ".join(o.name for o in objs)
     if LIB.exists() and stamp.exists() and stamp.read_text() == want and not force:
         return LIB
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+    # -no-hip-rt: no DT_NEEDED on libamdhip64; the loader (_clib._bind_hip_runtime) binds the library to
+    # the ONE HIP runtime of the process (torch's bundled one when PyTorch-ROCm is loaded).
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-no-hip-rt", "-o", str(LIB), *map(str, objs)]
     if verbose:
         print("[lkm build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -393,49 +393,39 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
 }
 
 // ------------------------------------------------------------------ launch geometry heuristics
-static int pow2_floor(int v) {
-    int p = 1;
-    while (p * 2 <= v) p *= 2;
-    return p;
-}
-
 static void pick_cfg(const LkmEngine* h, int M, LaunchCfg* c1, LaunchCfg* c2, size_t n_slots) {
-    const int kTargetWaves = 3072;
+    // Measured on MI355X (profiles/sweep_r01_*.log): one 16-row tile per wave streams best
+    // (7168 waves x 64 threads for Mixtral GEMM1: 6.7 TB/s vs 6.4 TB/s at two tiles); wider tiles
+    // only pay when the token operand traffic (TB blocks) starts to matter.
+    const int kMinWaves = 2048;
     const int n_act = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
     int tb = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     if (h->t_tb > 0) tb = h->t_tb;
-    // GEMM1
+    // GEMM1 (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4; else nt*tb<=8)
     int nt1 = 1;
-    for (int c : {4, 2}) {
-        if (h->gated && c == 4 && tb >= 2) continue;  // register budget
-        if ((long long)n_act * (h->T1_half / c) >= kTargetWaves) {
-            nt1 = c;
-            break;
-        }
-    }
+    if (tb >= 4 && !h->gated && (long long)n_act * (h->T1_half / 2) >= 2 * kMinWaves) nt1 = 2;
     if (h->t_nt1 > 0) nt1 = h->t_nt1;
     int kw = 1;
     {
         long long waves = (long long)n_act * (h->T1_half / nt1);
-        while (kw < 8 && waves * kw < kTargetWaves / 2 && h->U1 / (kw * 2) >= 2) kw *= 2;
+        while (kw < 8 && waves * kw < kMinWaves && h->U1 / (kw * 2) >= 2) kw *= 2;
     }
     if (h->t_kw1 > 0) kw = h->t_kw1;
     *c1 = LaunchCfg{nt1, tb, kw, 1};
     // GEMM2
-    int nt2 = 2;
-    if ((long long)n_act * (h->T2 / 2) < kTargetWaves / 8) nt2 = 1;
+    int nt2 = 1;
+    if (tb >= 4 && (long long)n_act * (h->T2 / 2) >= 2 * kMinWaves) nt2 = 2;
     if (h->t_nt2 > 0) nt2 = h->t_nt2;
     int sk = 1;
     {
         long long waves = (long long)n_act * (h->T2 / nt2);
-        while (sk < 8 && waves * sk < kTargetWaves && h->U2 / (sk * 2) >= 2) sk *= 2;
+        while (sk < 8 && waves * sk < kMinWaves && h->U2 / (sk * 2) >= 2) sk *= 2;
     }
     if (h->t_sk2 > 0) sk = h->t_sk2;
     // split-K slabs must fit the partial buffer
     const size_t y_rows = h->arena->y_elems / h->H;
     while (sk > 1 && (size_t)sk * n_slots > y_rows) sk /= 2;
     *c2 = LaunchCfg{nt2, tb, 1, sk};
-    (void)pow2_floor;
 }
 
 // one chunk: rows [0,M) of the given pointers

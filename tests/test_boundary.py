@@ -19,12 +19,13 @@ def _declared():
 def test_library_builds_and_exports_every_declared_symbol():
     from lvllm_amd import build
     lib_path = build.build()
-    lib = ctypes.CDLL(str(lib_path))
+    assert lib_path.exists()
+    from lvllm_amd import _clib
+    lib = _clib.lib()          # binds the process's single HIP runtime, then dlopens liblkm.so
     names = _declared()
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/lkm.h but not exported by liblkm.so"
-    from lvllm_amd import _clib
     assert sorted(_clib.EXPORTS) == names, "ctypes binding and header disagree"
     assert _clib.lib().lkm_abi_version() == _clib.LKM_ABI_VERSION
 

@@ -188,7 +188,8 @@ int lkm_get_profile(LkmHandle h, float* ms /* [LKM_PROF_N] */);
 /* HBM bytes held by this engine (weights + scales), and its launch geometry as text. */
 int64_t lkm_weight_bytes(LkmHandle h);
 int lkm_describe(LkmHandle h, char* buf, int32_t buf_len);
-/* tuning knobs (bench / tests): key in {"nt1","nt2","kw1","sk2","tbmax"}; value <= 0 = auto */
+/* tuning knobs (bench / tests): key in {"nt1","nt2","kw1","sk2","tbmax","tiled","waves"};
+ * value 0 = auto ("tiled": -1 forces the skinny streamer, 64 / 128 force a token-tile size) */
 int lkm_set_tuning(LkmHandle h, const char* key, int32_t value);
 
 #ifdef __cplusplus

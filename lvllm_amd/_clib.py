@@ -8,8 +8,11 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os
+
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "liblkm.so"
+# LKM_LIB_PATH: development override to A/B an experimental build of the same library
+LIB_PATH = Path(os.environ.get("LKM_LIB_PATH", PKG / "liblkm.so"))
 
 LKM_ABI_VERSION = 1
 OK, E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED = 0, -1, -2, -3, -4

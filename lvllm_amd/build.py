@@ -54,8 +54,16 @@ def _compile(src: Path, headers: list[Path], verbose: bool) -> Path:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile (if stale) and link liblkm.so; returns its path."""
+def build(force: bool = False, verbose: bool = False, extra_flags: tuple[str, ...] = (),
+          out: Path | None = None) -> Path:
+    """Compile (if stale) and link liblkm.so; returns its path.  extra_flags/out build an
+    experimental variant next to the default library (development only)."""
+    global FLAGS, OBJ, LIB
+    if extra_flags or out:
+        FLAGS = [*FLAGS, *extra_flags]
+        tag = hashlib.sha256(" ".join(extra_flags).encode()).hexdigest()[:8]
+        OBJ = CSRC / f"_obj_{tag}"
+        LIB = out or PKG / f"liblkm_{tag}.so"
     OBJ.mkdir(parents=True, exist_ok=True)
     srcs = sorted(CSRC.glob("*.hip"))
     headers = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "lkm.h"]
@@ -81,5 +89,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    p = build(force="--force" in sys.argv, verbose=True)
+    extra = tuple(a[len("--flag="):] for a in sys.argv if a.startswith("--flag="))
+    outs = [a[len("--out="):] for a in sys.argv if a.startswith("--out=")]
+    p = build(force="--force" in sys.argv, verbose="-q" not in sys.argv, extra_flags=extra,
+              out=Path(outs[0]).resolve() if outs else None)
     print(p)

@@ -12,95 +12,110 @@
 
 namespace lkm {
 
-constexpr int kSortThreads = 1024;
-constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kMaxLocalExperts = 512;
 
-// meta[0] = number of active experts, meta[1] = total routed rows, meta[2] = max rows of one expert
-__global__ __launch_bounds__(kSortThreads) void sort_slots_kernel(
+// meta[0] = number of active experts, meta[1] = total routed rows, meta[2] = max rows of one expert,
+// meta[3] = number of (expert, token-tile) work items when tile_rows > 0.
+// One workgroup of THREADS threads (64 / 256 / 1024 by problem size: the decode case M*K <= 64 runs as
+// a single wavefront, where barriers are free).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void sort_slots_kernel(
     const int32_t* __restrict__ ids, int n_slots, int E, int32_t* __restrict__ counts,
     int32_t* __restrict__ offsets, int32_t* __restrict__ sorted_slot,
-    int32_t* __restrict__ pos_of_slot, int32_t* __restrict__ active, int32_t* __restrict__ meta) {
+    int32_t* __restrict__ pos_of_slot, int32_t* __restrict__ active, int32_t* __restrict__ meta,
+    int tile_rows, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0) {
+    constexpr int WAVES = THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     int32_t* cnt = smem;                 // [E]
     int32_t* off = cnt + E;              // [E]
     int32_t* run = off + E;              // [E]
-    int32_t* wsum = run + E;             // [kSortWaves] scan carries (64-bit packed as 2 ints)
-    int32_t* wcnt = wsum + 4 * kSortWaves;  // [kSortWaves][E]
+    int32_t* wsum = run + E;             // [4][WAVES] scan carries
+    int32_t* wcnt = wsum + 4 * WAVES;    // [WAVES][E]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    for (int e = tid; e < E; e += kSortThreads) {
+    for (int e = tid; e < E; e += THREADS) {
         cnt[e] = 0;
         run[e] = 0;
     }
     __syncthreads();
-    for (int i = tid; i < n_slots; i += kSortThreads) {
+    for (int i = tid; i < n_slots; i += THREADS) {
         int id = ids[i];
         if (id >= 0 && id < E) atomicAdd(&cnt[id], 1);
     }
     __syncthreads();
 
-    // exclusive scan of cnt[] and of the (cnt>0) flags, 1024 experts per pass
-    int carry_cnt = 0, carry_act = 0, maxc = 0;
-    for (int base = 0; base < E; base += kSortThreads) {
+    // exclusive scans of cnt[], of the (cnt>0) flags and of the per-expert tile counts
+    int carry_cnt = 0, carry_act = 0, carry_til = 0, maxc = 0;
+    for (int base = 0; base < E; base += THREADS) {
         int e = base + tid;
         int c = (e < E) ? cnt[e] : 0;
         int a = c > 0 ? 1 : 0;
-        int sc = c, sa = a;
+        int t = tile_rows > 0 ? (c + tile_rows - 1) / tile_rows : 0;
+        int sc = c, sa = a, stl = t;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            int tc = __shfl_up(sc, d, 64), ta = __shfl_up(sa, d, 64);
+            int tc = __shfl_up(sc, d, 64), ta = __shfl_up(sa, d, 64), tt = __shfl_up(stl, d, 64);
             if (lane >= d) {
                 sc += tc;
                 sa += ta;
+                stl += tt;
             }
         }
         if (lane == 63) {
             wsum[wv] = sc;
-            wsum[kSortWaves + wv] = sa;
+            wsum[WAVES + wv] = sa;
+            wsum[2 * WAVES + wv] = stl;
         }
         __syncthreads();
-        int pc = 0, pa = 0;
-        for (int w = 0; w < wv; ++w) {
-            pc += wsum[w];
-            pa += wsum[kSortWaves + w];
-        }
-        int tot_c = 0, tot_a = 0;
-        for (int w = 0; w < kSortWaves; ++w) {
-            tot_c += wsum[w];
-            tot_a += wsum[kSortWaves + w];
+        int pc = 0, pa = 0, pt = 0, tot_c = 0, tot_a = 0, tot_t = 0;
+        for (int w = 0; w < WAVES; ++w) {
+            int xc = wsum[w], xa = wsum[WAVES + w], xt = wsum[2 * WAVES + w];
+            if (w < wv) {
+                pc += xc;
+                pa += xa;
+                pt += xt;
+            }
+            tot_c += xc;
+            tot_a += xa;
+            tot_t += xt;
         }
         int ex_c = carry_cnt + pc + sc - c;
         int ex_a = carry_act + pa + sa - a;
+        int ex_t = carry_til + pt + stl - t;
         if (e < E) {
             off[e] = ex_c;
             counts[e] = c;
             offsets[e] = ex_c;
             if (a) active[ex_a] = e;
+            for (int i = 0; i < t; ++i) {
+                tile_e[ex_t + i] = e;
+                tile_r0[ex_t + i] = i * tile_rows;
+            }
         }
         maxc = max(maxc, c);
         carry_cnt += tot_c;
         carry_act += tot_a;
+        carry_til += tot_t;
         __syncthreads();
     }
-    // block max of maxc
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) maxc = max(maxc, __shfl_xor(maxc, m, 64));
-    if (lane == 0) wsum[2 * kSortWaves + wv] = maxc;
+    if (lane == 0) wsum[3 * WAVES + wv] = maxc;
     __syncthreads();
     if (tid == 0) {
         int mm = 0;
-        for (int w = 0; w < kSortWaves; ++w) mm = max(mm, wsum[2 * kSortWaves + w]);
+        for (int w = 0; w < WAVES; ++w) mm = max(mm, wsum[3 * WAVES + w]);
         offsets[E] = carry_cnt;
         meta[0] = carry_act;
         meta[1] = carry_cnt;
         meta[2] = mm;
+        meta[3] = carry_til;
     }
     const int total = carry_cnt;
 
-    // stable scatter, 1024 slots per pass
-    for (int base = 0; base < n_slots; base += kSortThreads) {
-        for (int j = tid; j < kSortWaves * E; j += kSortThreads) wcnt[j] = 0;
+    // stable scatter, THREADS slots per pass
+    for (int base = 0; base < n_slots; base += THREADS) {
+        for (int j = tid; j < WAVES * E; j += THREADS) wcnt[j] = 0;
         __syncthreads();
         const int i = base + tid;
         int id = -1;
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_slots_kernel(
         }
         __syncthreads();
     }
-    for (int p = total + tid; p < n_slots; p += kSortThreads) sorted_slot[p] = -1;
+    for (int p = total + tid; p < n_slots; p += THREADS) sorted_slot[p] = -1;
 }
 
 // out[m][h] = sum_k w[m,k] * sum_s y[s][pos(m,k)][h]   (fp32; s ascending, then k ascending)
@@ -190,13 +205,29 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
     store4<OutT>(out + (size_t)m * H + h, acc);
 }
 
+template <int THREADS>
+static void launch_sort_t(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
+                          int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot,
+                          int32_t* active, int32_t* meta, int tile_rows, int32_t* tile_e,
+                          int32_t* tile_r0) {
+    constexpr int WAVES = THREADS / 64;
+    size_t lds = sizeof(int32_t) * ((size_t)3 * E + 4 * WAVES + (size_t)WAVES * E);
+    hipLaunchKernelGGL(sort_slots_kernel<THREADS>, dim3(1), dim3(THREADS), lds, st, ids, n_slots, E,
+                       counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_e,
+                       tile_r0);
+}
+
 int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
                 int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
-                int32_t* meta) {
+                int32_t* meta, int tile_rows, int32_t* tile_e, int32_t* tile_r0) {
     LKM_REQUIRE(E > 0 && E <= kMaxLocalExperts, "sort: local experts E=%d out of range (1..%d)", E, kMaxLocalExperts);
-    size_t lds = sizeof(int32_t) * ((size_t)3 * E + 4 * kSortWaves + (size_t)kSortWaves * E);
-    hipLaunchKernelGGL(sort_slots_kernel, dim3(1), dim3(kSortThreads), lds, st, ids, n_slots, E,
-                       counts, offsets, sorted_slot, pos_of_slot, active, meta);
+    LKM_REQUIRE(tile_rows == 0 || (tile_e && tile_r0), "sort: tile list requested without buffers");
+    if (n_slots <= 64 && E <= 64)
+        launch_sort_t<64>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_e, tile_r0);
+    else if (n_slots <= 512 && E <= 256)
+        launch_sort_t<256>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_e, tile_r0);
+    else
+        launch_sort_t<1024>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_e, tile_r0);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

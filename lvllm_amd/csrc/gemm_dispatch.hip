@@ -1,9 +1,11 @@
 // gemm_dispatch.hip -- routes (weight format, activation dtype) to the per-format launchers.
 #include "lkm_kernels.h"
 namespace lkm {
-#define LKM_DECL(SUFFIX)                                                                      \
-    int launch_gemm1_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);   \
-    int launch_gemm2_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, int);
+#define LKM_DECL(SUFFIX)                                                                            \
+    int launch_gemm1_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);         \
+    int launch_gemm2_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, int);               \
+    int launch_gemm1_tiled_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);   \
+    int launch_gemm2_tiled_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 LKM_DECL(bf16) LKM_DECL(f16) LKM_DECL(int4_bf16) LKM_DECL(int4_f16) LKM_DECL(fp8_bf16) LKM_DECL(fp8_f16)
 #undef LKM_DECL
 
@@ -30,6 +32,32 @@ int launch_gemm2(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const Ge
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm2_fp8_bf16(st, cfg, p, max_active);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm2_fp8_f16(st, cfg, p, max_active);
     set_error("gemm2: unsupported weight format %d with activation dtype %d", wf, adt);
+    return LKM_E_UNSUPPORTED;
+}
+
+int launch_gemm1_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
+                       bool gated, int max_tiles) {
+    if (max_tiles <= 0) return LKM_OK;
+    if (wf == LKM_W_BF16 && adt == LKM_DT_BF16) return launch_gemm1_tiled_bf16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_F16 && adt == LKM_DT_F16) return launch_gemm1_tiled_f16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_gemm1_tiled_int4_bf16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm1_tiled_int4_f16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm1_tiled_fp8_bf16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm1_tiled_fp8_f16(st, cfg, p, gated, max_tiles);
+    set_error("gemm1 tiled: unsupported weight format %d with activation dtype %d", wf, adt);
+    return LKM_E_UNSUPPORTED;
+}
+
+int launch_gemm2_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
+                       int max_tiles) {
+    if (max_tiles <= 0) return LKM_OK;
+    if (wf == LKM_W_BF16 && adt == LKM_DT_BF16) return launch_gemm2_tiled_bf16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_F16 && adt == LKM_DT_F16) return launch_gemm2_tiled_f16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_gemm2_tiled_int4_bf16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm2_tiled_int4_f16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm2_tiled_fp8_bf16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm2_tiled_fp8_f16(st, cfg, p, max_tiles);
+    set_error("gemm2 tiled: unsupported weight format %d with activation dtype %d", wf, adt);
     return LKM_E_UNSUPPORTED;
 }
 }  // namespace lkm

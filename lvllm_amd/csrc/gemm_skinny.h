@@ -37,7 +37,7 @@ struct DecPlain {
     static constexpr bool UNIT_SCALE = false;
     struct Aux {};
     static __device__ __forceinline__ void load_aux(Aux&, const void*, size_t, int, int) {}
-    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux&, int ks) {
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux&, int ks, int) {
         return raw[ks];
     }
 };
@@ -51,32 +51,29 @@ struct Dec<LKM_W_INT4_B8, ADT> {
     static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
     static constexpr bool UNIT_SCALE = false;
     struct Aux {
-        float s[4];
+        u32x2 raw;   // up to four act-dtype scales of this lane's weight row for the 128-k unit
     };
-    // scales: [tile][unit][16 rows][spu] act dtype; tu = tile*U + unit
+    typedef u32x2 __attribute__((aligned(2))) u32x2_unaligned;
+    // scales: [tile][unit][16 rows][spu] act dtype; tu = tile*U + unit.  Branch-free: always fetch 8
+    // bytes (the buffer is padded) and pick entry (kstep*spu)/4 when the fragment is decoded, so the
+    // load has no dependent ALU work and stays in flight with the weight loads.
     static __device__ __forceinline__ void load_aux(Aux& a, const void* sbase, size_t tu, int lane,
                                                     int spu) {
         const unsigned short* p = (const unsigned short*)sbase + (tu * 16 + (lane & 15)) * spu;
-        if (spu == 1) {
-            float s = ActT<ADT>::to_f32(p[0]);
-            a.s[0] = a.s[1] = a.s[2] = a.s[3] = s;
-        } else if (spu == 2) {
-            unsigned v = *(const unsigned*)p;
-            a.s[0] = a.s[1] = ActT<ADT>::to_f32((unsigned short)(v & 0xffffu));
-            a.s[2] = a.s[3] = ActT<ADT>::to_f32((unsigned short)(v >> 16));
-        } else {
-            u32x2 v = *(const u32x2*)p;
-            a.s[0] = ActT<ADT>::to_f32((unsigned short)(v.x & 0xffffu));
-            a.s[1] = ActT<ADT>::to_f32((unsigned short)(v.x >> 16));
-            a.s[2] = ActT<ADT>::to_f32((unsigned short)(v.y & 0xffffu));
-            a.s[3] = ActT<ADT>::to_f32((unsigned short)(v.y >> 16));
-        }
+        a.raw = *(const u32x2_unaligned*)p;
     }
-    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux& a, int ks) {
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux& a, int ks,
+                                                 int spu) {
         const unsigned w = raw[0][ks];
-        const float s = a.s[ks];
+        const int idx = (ks * spu) >> 2;   // 0 for g>=128, ks/2 for g=64, ks for g=32
+        const unsigned long long bits =
+            ((unsigned long long)a.raw.y << 32 | a.raw.x) >> (16 * idx);
+        const float s = ActT<ADT>::to_f32((unsigned short)(bits & 0xffffu));
         const float m8 = -8.0f * s;
-        const unsigned lo = w & 0x0f0f0f0fu, hi = (w >> 4) & 0x0f0f0f0fu;
+        unsigned lo = w & 0x0f0f0f0fu, hi = (w >> 4) & 0x0f0f0f0fu;
+        // keep lo/hi opaque: the byte extracts below then select v_cvt_f32_ubyte0..3 directly
+        // (23 VALU per 8 weights instead of ~31 with per-nibble v_bfe_u32)
+        asm volatile("" : "+v"(lo), "+v"(hi));
         u32x4 o;
         // byte b of the dword holds k=2b (low nibble) and k=2b+1 (high nibble)
         o.x = ActT<ADT>::pack2(__builtin_fmaf((float)(lo & 0xffu), s, m8),
@@ -103,7 +100,7 @@ struct Dec<LKM_W_FP8_E4M3, ADT> {
                                                     int) {
         a.s = *(const f32x4*)((const float*)sbase + tu * 16 + (lane >> 4) * 4);
     }
-    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux&, int ks) {
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux&, int ks, int) {
         const unsigned d0 = raw[ks >> 1][(ks & 1) * 2], d1 = raw[ks >> 1][(ks & 1) * 2 + 1];
         f32x2 p0 = __builtin_amdgcn_cvt_pk_f32_fp8(d0, false);
         f32x2 p1 = __builtin_amdgcn_cvt_pk_f32_fp8(d0, true);
@@ -143,21 +140,29 @@ struct Streamer {
                 st.w[t][l] = __builtin_nontemporal_load(wp[t] + ((size_t)u * D::LOADS + l) * 64);
             D::load_aux(st.aux[t], sbase, stu[t] + u, lane, spu);
         }
+        // Token rows beyond the expert's count point at a valid row (their D columns are never
+        // stored, and a B column cannot contaminate another), so the loads are unconditional:
+        // no exec-mask branches in the streaming loop.  Only a ragged K tail needs zero fill.
+        const bool tail = (u + 1) * D::UNITK > Kreal;   // wave-uniform, false for every model shape
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
             if (b < ntb) {
 #pragma unroll
                 for (int ks = 0; ks < D::KSTEPS; ++ks) {
                     const int k = u * D::UNITK + ks * 32 + g8;
-                    u32x4 v = {0u, 0u, 0u, 0u};
-                    if (xok[b] && k + 8 <= Kreal) v = *(const u32x4*)(xp[b] + k);
-                    st.x[b][ks] = v;
+                    if (!tail) {
+                        st.x[b][ks] = *(const u32x4*)(xp[b] + k);
+                    } else {
+                        u32x4 v = {0u, 0u, 0u, 0u};
+                        if (k + 8 <= Kreal) v = *(const u32x4*)(xp[b] + k);
+                        st.x[b][ks] = v;
+                    }
                 }
             }
         }
     }
 
-    static __device__ __forceinline__ void compute(const St& st, f32x4 (&acc)[NTT][TB], int ntb) {
+    static __device__ __forceinline__ void compute(const St& st, f32x4 (&acc)[NTT][TB], int ntb, int spu) {
         if constexpr (D::UNIT_SCALE) {
             f32x4 part[NTT][TB];
 #pragma unroll
@@ -168,7 +173,7 @@ struct Streamer {
             for (int ks = 0; ks < D::KSTEPS; ++ks)
 #pragma unroll
                 for (int t = 0; t < NTT; ++t) {
-                    const u32x4 a = D::frag(st.w[t], st.aux[t], ks);
+                    const u32x4 a = D::frag(st.w[t], st.aux[t], ks, spu);
 #pragma unroll
                     for (int b = 0; b < TB; ++b)
                         if (b < ntb) part[t][b] = ActT<ADT>::mfma(a, st.x[b][ks], part[t][b]);
@@ -183,7 +188,7 @@ struct Streamer {
             for (int ks = 0; ks < D::KSTEPS; ++ks)
 #pragma unroll
                 for (int t = 0; t < NTT; ++t) {
-                    const u32x4 a = D::frag(st.w[t], st.aux[t], ks);
+                    const u32x4 a = D::frag(st.w[t], st.aux[t], ks, spu);
 #pragma unroll
                     for (int b = 0; b < TB; ++b)
                         if (b < ntb) acc[t][b] = ActT<ADT>::mfma(a, st.x[b][ks], acc[t][b]);
@@ -206,7 +211,7 @@ struct Streamer {
                 if (uu < u1) {
                     if (uu + 1 < u1)
                         load(st[h ^ 1], wp, sbase, stu, spu, xp, xok, uu + 1, Kreal, g8, lane, ntb);
-                    compute(st[h], acc, ntb);
+                    compute(st[h], acc, ntb, spu);
                 }
             }
         }

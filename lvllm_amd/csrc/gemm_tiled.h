@@ -1,0 +1,299 @@
+// gemm_tiled.h -- per-expert grouped GEMMs for 32 < rows-per-expert (decode at large batch,
+// prefill): same math as gemm_skinny.h, different data movement.
+//
+//   * a workgroup = WAVES wavefronts = one (expert, token tile of TM = 16*TBW rows) work item x one
+//     group of WAVES*NT 16-row weight tiles.  The TOKEN operand (MFMA B) is staged through LDS once
+//     per K unit and shared by all waves (XOR-swizzled rows -> conflict-free ds_read_b128), so its
+//     L2 traffic is amortised over WAVES*NT*(1|2) weight tiles instead of being re-read per tile;
+//   * the WEIGHT operand (MFMA A) still goes HBM/L2 -> VGPR directly in the pre-shuffled layout:
+//     every wave owns different rows, so there is nothing to share and no LDS round trip;
+//   * accumulators NTT x TBW x f32x4 per lane; one s_barrier per K unit, LDS double-buffered, the
+//     next unit's token rows and weight fragments are in flight (registers) across the barrier.
+// Work items come from the device-side list the sort kernel emits (tile_e / tile_r0, meta[3]).
+#pragma once
+#include "gemm_skinny.h"
+
+namespace lkm {
+
+template <int ROWB>
+__device__ __forceinline__ int x_swizzle(int row) {
+    // 16-byte slot permutation inside a token row so that 16 lanes reading the same logical slot of
+    // 16 different rows hit 16 different 16-B bank groups of the 256-B LDS bank row.
+    return ROWB == 128 ? ((row >> 1) & 7) : (row & 15);
+}
+
+template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1>
+__global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
+    typedef Dec<WF, ADT> D;
+    constexpr int NTT = (IS_G1 && GATED) ? 2 * NT : NT;
+    constexpr int TM = TBW * 16;
+    constexpr int THREADS = WAVES * 64;
+    constexpr int ROWB = D::UNITK * 2;   // bytes of one token row per K unit
+    constexpr int SLOTS = ROWB / 16;
+    constexpr int PIECES = TM * SLOTS / THREADS;
+    static_assert(PIECES >= 1 && TM * SLOTS % THREADS == 0, "staging split");
+    extern __shared__ __attribute__((aligned(16))) char xlds[];   // [2][TM][ROWB]
+
+    const int ti = blockIdx.y;
+    if (ti >= p.meta[3]) return;
+    const int e = p.tile_e[ti], r0 = p.tile_r0[ti];
+    const int m_e = p.counts[e], off_e = p.offsets[e];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int tile0 = (blockIdx.x * WAVES + wave) * NT;
+    const bool wave_on = tile0 < p.T_half;            // tail group of a padded tile count
+    const int T_all = p.T_half * p.halves;
+
+    const u32x4* wp[NTT];
+    size_t stu[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+        const int tile = (IS_G1 && GATED && t >= NT) ? p.T_half + tile0 + (t - NT) : tile0 + t;
+        const size_t tl = (size_t)e * T_all + (wave_on ? tile : 0);
+        wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
+        stu[t] = tl * p.U;
+    }
+
+    // staging assignment of this thread: PIECES 16-byte pieces per unit
+    const unsigned short* xrow[PIECES];
+    int xsrc_off[PIECES];   // element offset of the piece inside the unit (logical slot * 8)
+    int xdst[PIECES];       // byte offset inside one LDS buffer
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const int pc = q * THREADS + tid;
+        const int row = pc / SLOTS, pslot = pc % SLOTS;
+        const int lslot = pslot ^ x_swizzle<ROWB>(row);
+        const int r = r0 + row;
+        const int rr = r < m_e ? r : r0;
+        if (IS_G1) {
+            const int slot = p.sorted_slot[off_e + rr];
+            xrow[q] = (const unsigned short*)p.x + (size_t)(slot / p.top_k) * p.ldx;
+        } else {
+            xrow[q] = (const unsigned short*)p.x + (size_t)(off_e + rr) * p.ldx;
+        }
+        xsrc_off[q] = lslot * 8;
+        xdst[q] = row * ROWB + pslot * 16;
+    }
+
+    f32x4 acc[NTT][TBW];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+        for (int b = 0; b < TBW; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct WStage {
+        u32x4 w[NTT][D::LOADS];
+        typename D::Aux aux[NTT];
+    };
+    WStage ws[2];
+    u32x4 xs[PIECES];
+
+    // rows beyond the expert's count read a valid row (their D columns are never stored): the loads
+    // are unconditional; only a ragged K tail (never for the model shapes) is zero-filled.
+    auto load_x = [&](int u) {
+        const bool tail = (u + 1) * D::UNITK > p.Kreal;   // workgroup-uniform
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            const int k = u * D::UNITK + xsrc_off[q];
+            if (!tail) {
+                xs[q] = *(const u32x4*)(xrow[q] + k);
+            } else {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (k + 8 <= p.Kreal) v = *(const u32x4*)(xrow[q] + k);
+                xs[q] = v;
+            }
+        }
+    };
+    auto load_w = [&](WStage& s, int u) {
+        if (wave_on) {
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) {
+#pragma unroll
+                for (int l = 0; l < D::LOADS; ++l) {
+                    const u32x4* a = wp[t] + ((size_t)u * D::LOADS + l) * 64;
+                    s.w[t][l] = p.stream_nt ? __builtin_nontemporal_load(a) : *a;
+                }
+                D::load_aux(s.aux[t], p.s, stu[t] + u, lane, p.spu);
+            }
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) *(u32x4*)(xlds + buf * (TM * ROWB) + xdst[q]) = xs[q];
+    };
+    auto compute = [&](const WStage& s, int buf) {
+        if (!wave_on) return;
+        const char* xb = xlds + buf * (TM * ROWB);
+        if constexpr (D::UNIT_SCALE) {
+            f32x4 part[NTT][TBW];
+#pragma unroll
+            for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                for (int b = 0; b < TBW; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < D::KSTEPS; ++ks) {
+                u32x4 bf[TBW];
+#pragma unroll
+                for (int b = 0; b < TBW; ++b) {
+                    const int row = b * 16 + j;
+                    bf[b] = *(const u32x4*)(xb + row * ROWB + (((ks * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
+                }
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    const u32x4 a = D::frag(s.w[t], s.aux[t], ks, p.spu);
+#pragma unroll
+                    for (int b = 0; b < TBW; ++b) part[t][b] = ActT<ADT>::mfma(a, bf[b], part[t][b]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                for (int b = 0; b < TBW; ++b) acc[t][b] += s.aux[t].s * part[t][b];
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < D::KSTEPS; ++ks) {
+                u32x4 bf[TBW];
+#pragma unroll
+                for (int b = 0; b < TBW; ++b) {
+                    const int row = b * 16 + j;
+                    bf[b] = *(const u32x4*)(xb + row * ROWB + (((ks * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
+                }
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    const u32x4 a = D::frag(s.w[t], s.aux[t], ks, p.spu);
+#pragma unroll
+                    for (int b = 0; b < TBW; ++b) acc[t][b] = ActT<ADT>::mfma(a, bf[b], acc[t][b]);
+                }
+            }
+        }
+    };
+
+    const int U = p.U;
+    load_x(0);
+    load_w(ws[0], 0);
+    store_x(0);
+    __syncthreads();
+    if (p.dbg & 2) {
+        __builtin_amdgcn_s_sleep(100);
+        __syncthreads();
+    }
+    for (int u = 0; u < U; u += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int uu = u + h;
+            if (uu < U) {
+                const bool more = uu + 1 < U;
+                if (more) {
+                    load_x(uu + 1);            // token rows first: their wait leaves the weights in flight
+                    load_w(ws[h ^ 1], uu + 1);
+                }
+                compute(ws[h], h);
+                if (p.dbg & 1) __syncthreads();
+                if (more) store_x(h ^ 1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // epilogue: D layout lane (g,j): rows tile*16 + g*4 + r, token column j of block b
+    if (!wave_on) return;
+#pragma unroll
+    for (int b = 0; b < TBW; ++b) {
+        const int r_tok = r0 + b * 16 + j;
+        if (r_tok < m_e) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = (tile0 + t) * 16 + g * 4;
+                if (n >= p.n_real) continue;
+                if (IS_G1) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = acc[t][b][r];
+                        if (GATED) {
+                            const float up = acc[NTT - NT + t][b][r];
+                            if (p.act_type == LKM_ACT_SWIGLUOAI) {
+                                const float gg = fminf(a, p.limit);
+                                const float uu = fmaxf(fminf(up, p.limit), -p.limit);
+                                v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
+                            } else {
+                                v[r] = act_silu(a) * up;
+                            }
+                        } else {
+                            const float tt = a > 0.0f ? a : 0.0f;
+                            v[r] = tt * tt;
+                        }
+                    }
+                    unsigned short* o = (unsigned short*)p.out + (size_t)(off_e + r_tok) * p.ldo + n;
+                    if (n + 4 <= p.n_real) {
+                        u32x2 pk;
+                        pk.x = ActT<ADT>::pack2(v[0], v[1]);
+                        pk.y = ActT<ADT>::pack2(v[2], v[3]);
+                        *(u32x2*)o = pk;
+                    } else {
+                        for (int r = 0; r < 4 && n + r < p.n_real; ++r) o[r] = ActT<ADT>::from_f32(v[r]);
+                    }
+                } else {
+                    float* o = (float*)p.out + (size_t)(off_e + r_tok) * p.ldo + n;
+                    if (n + 4 <= p.n_real) {
+                        *(f32x4*)o = acc[t][b];
+                    } else {
+                        for (int r = 0; r < 4 && n + r < p.n_real; ++r) o[r] = acc[t][b][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1>
+static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
+    constexpr int ROWB = Dec<WF, ADT>::UNITK * 2;
+    constexpr size_t lds = (size_t)2 * TBW * 16 * ROWB;
+    dim3 grid(ceil_div(p.T_half, WAVES * NT), max_tiles), block(WAVES * 64);
+    auto kern = gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1>;
+    if (lds > 64 * 1024) {
+        LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, p);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+// tiled variants built per format: (TM, WAVES, NT) = (64,4,1) (64,8,1) (128,8,1) (128,8,2 non-gated)
+#define LKM_TILED_CASE(TBW, WAVES, NT, G, IS1)                                             \
+    if (cfg.tiled == TBW * 16 && cfg.waves == WAVES && cfg.nt == NT)                      \
+        return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1>(st, p, max_tiles);
+
+#define LKM_DEFINE_TILED_LAUNCHERS(SUFFIX, WF, ADT)                                                   \
+    int launch_gemm1_tiled_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
+                                    bool gated, int max_tiles) {                                      \
+        constexpr int WF_ = WF, ADT_ = ADT;                                                           \
+        if (gated) {                                                                                  \
+            LKM_TILED_CASE(4, 4, 1, true, true)                                                       \
+            LKM_TILED_CASE(4, 8, 1, true, true)                                                       \
+            LKM_TILED_CASE(8, 8, 1, true, true)                                                       \
+        } else {                                                                                      \
+            LKM_TILED_CASE(4, 4, 1, false, true)                                                      \
+            LKM_TILED_CASE(4, 8, 1, false, true)                                                      \
+            LKM_TILED_CASE(8, 8, 1, false, true)                                                      \
+            LKM_TILED_CASE(8, 8, 2, false, true)                                                      \
+        }                                                                                             \
+        set_error("gemm1 tiled: variant tm=%d waves=%d nt=%d gated=%d not built", cfg.tiled,          \
+                  cfg.waves, cfg.nt, (int)gated);                                                     \
+        return LKM_E_INVALID;                                                                         \
+    }                                                                                                 \
+    int launch_gemm2_tiled_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
+                                    int max_tiles) {                                                  \
+        constexpr int WF_ = WF, ADT_ = ADT;                                                           \
+        LKM_TILED_CASE(4, 4, 1, false, false)                                                         \
+        LKM_TILED_CASE(4, 8, 1, false, false)                                                         \
+        LKM_TILED_CASE(4, 4, 2, false, false)                                                         \
+        LKM_TILED_CASE(8, 8, 1, false, false)                                                         \
+        LKM_TILED_CASE(8, 8, 2, false, false)                                                         \
+        set_error("gemm2 tiled: variant tm=%d waves=%d nt=%d not built", cfg.tiled, cfg.waves,        \
+                  cfg.nt);                                                                            \
+        return LKM_E_INVALID;                                                                         \
+    }
+
+}  // namespace lkm

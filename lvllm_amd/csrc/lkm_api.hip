@@ -34,6 +34,8 @@ struct Arena {
     int E_cap = 0;
     int32_t *counts = nullptr, *offsets = nullptr, *active = nullptr, *meta = nullptr;
     int32_t *sorted_slot = nullptr, *pos_of_slot = nullptr;
+    int32_t *tile_e = nullptr, *tile_r0 = nullptr;   // [cap_slots/64 + E_cap + 8] each
+    size_t tile_cap = 0;
     void* act = nullptr;  // [cap_slots][ld_act] 16-bit
     float* y = nullptr;   // split-K partials
     std::vector<void*> retired;
@@ -87,6 +89,20 @@ static int arena_reserve(int device, int E, size_t slots, size_t act_elems, size
         a.cap_slots = slots;
     }
     {
+        const size_t want = a.cap_slots / 64 + (size_t)a.E_cap + 8;
+        if (want > a.tile_cap) {
+            size_t h1 = 0, h2 = 0;
+            int32_t *t1 = nullptr, *t2 = nullptr;
+            if ((rc = grow(t1, h1, want, a.retired)) != LKM_OK) return rc;
+            if ((rc = grow(t2, h2, want, a.retired)) != LKM_OK) return rc;
+            if (a.tile_e) a.retired.push_back(a.tile_e);
+            if (a.tile_r0) a.retired.push_back(a.tile_r0);
+            a.tile_e = t1;
+            a.tile_r0 = t2;
+            a.tile_cap = want;
+        }
+    }
+    {
         unsigned short* p = (unsigned short*)a.act;
         if ((rc = grow(p, a.act_elems, act_elems, a.retired)) != LKM_OK) return rc;
         a.act = p;
@@ -123,7 +139,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_tmask = 3, t_dbg = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -334,8 +350,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
         const int g = cfg->groupK;
         const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16 * h->spu;
         const size_t n2 = (size_t)h->E * h->T2 * h->U2 * 16 * h->spu;
-        LKM_TRY_HIP(hipMalloc(&h->s13, n13 * 2));
-        LKM_TRY_HIP(hipMalloc(&h->s2, n2 * 2));
+        LKM_TRY_HIP(hipMalloc(&h->s13, n13 * 2 + 16));   // +16: the kernels fetch 8 bytes per lane
+        LKM_TRY_HIP(hipMalloc(&h->s2, n2 * 2 + 16));
         h->weight_bytes += (int64_t)(n13 + n2) * 2;
         const void* dsrc;
         void* tmp;
@@ -399,6 +415,26 @@ static void pick_cfg(const LkmEngine* h, int M, LaunchCfg* c1, LaunchCfg* c2, si
     // only pay when the token operand traffic (TB blocks) starts to matter.
     const int kMinWaves = 2048;
     const int n_act = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
+    // More than two 16-token blocks per expert possible -> stage the token operand through LDS
+    // (gemm_tiled.h); measured: at M=128 the skinny streamer drops to 4.6 TB/s (bf16) / 1.3 TB/s (int4)
+    // because every wave re-reads the token rows from L2.
+    int tiled = 0;
+    const size_t avg_rows = n_slots / (size_t)(n_act > 0 ? n_act : 1);
+    // measured (profiles/r01_sweep_*): Mixtral bf16 M=64 (16 rows/expert) skinny 537 us vs tiled 570 us;
+    // M=128 (32 rows/expert) skinny 714 us vs tiled64 585 us; 64-row tiles beat 128-row tiles up to
+    // M=512 (875 vs 1023 us), 4 waves beat 8.
+    if (M > 32 && avg_rows > 24) tiled = 64;
+    if (h->t_tiled > 0) tiled = h->t_tiled;
+    if (h->t_tiled < 0) tiled = 0;
+    if (tiled) {
+        const int waves = h->t_waves > 0 ? h->t_waves : (tiled == 128 ? 8 : 4);
+        int nt1 = h->t_nt1 > 0 ? h->t_nt1 : 1;
+        int nt2 = h->t_nt2 > 0 ? h->t_nt2 : 1;
+        *c1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves};
+        *c2 = LaunchCfg{nt2, tiled / 16, 1, 1, tiled, waves};
+        if (h->t_tmask == 3) return;
+    }
+    const LaunchCfg t1 = *c1, t2 = *c2;
     int tb = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     if (h->t_tb > 0) tb = h->t_tb;
     // GEMM1 (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4; else nt*tb<=8)
@@ -411,9 +447,11 @@ static void pick_cfg(const LkmEngine* h, int M, LaunchCfg* c1, LaunchCfg* c2, si
         while (kw < 8 && waves * kw < kMinWaves && h->U1 / (kw * 2) >= 2) kw *= 2;
     }
     if (h->t_kw1 > 0) kw = h->t_kw1;
-    *c1 = LaunchCfg{nt1, tb, kw, 1};
+    *c1 = LaunchCfg{nt1, tb, kw, 1, 0, 0};
     // GEMM2
-    int nt2 = 1;
+    // sub-16-bit weights: two tiles per wave halve the token-operand loads per weight byte
+    // (int4 M=32: gemm2 120 us -> 85 us)
+    int nt2 = (h->wf == LKM_W_INT4_B8 || h->wf == LKM_W_FP8_E4M3) && tb >= 2 ? 2 : 1;
     if (tb >= 4 && (long long)n_act * (h->T2 / 2) >= 2 * kMinWaves) nt2 = 2;
     if (h->t_nt2 > 0) nt2 = h->t_nt2;
     int sk = 1;
@@ -425,7 +463,12 @@ static void pick_cfg(const LkmEngine* h, int M, LaunchCfg* c1, LaunchCfg* c2, si
     // split-K slabs must fit the partial buffer
     const size_t y_rows = h->arena->y_elems / h->H;
     while (sk > 1 && (size_t)sk * n_slots > y_rows) sk /= 2;
-    *c2 = LaunchCfg{nt2, tb, 1, sk};
+    *c2 = LaunchCfg{nt2, tb, 1, sk, 0, 0};
+    if (tiled) {   // debug: tiled on one GEMM only (the sort still emits the tile list)
+        if (h->t_tmask & 1) *c1 = t1; else c1->tiled = 0;
+        if (h->t_tmask & 2) *c2 = t2; else c2->tiled = 0;
+        if (!(h->t_tmask & 1)) c1->waves = -tiled;   // carries the tile size for the sort
+    }
 }
 
 // one chunk: rows [0,M) of the given pointers
@@ -441,10 +484,15 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         LKM_HIP_CHECK(hipEventRecord(h->ev[0], st));
     }
     int rc = launch_sort(st, ids, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot,
-                         a->pos_of_slot, a->active, a->meta);
+                         a->pos_of_slot, a->active, a->meta,
+                         c1.tiled ? c1.tiled : (c2.tiled ? c2.tiled : 0), a->tile_e, a->tile_r0);
     if (rc != LKM_OK) return rc;
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[1], st));
     const int max_active = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
+    const int tile_rows = c1.tiled ? c1.tiled : c2.tiled;
+    const int max_tiles = tile_rows ? (int)(n_slots / tile_rows) + max_active : 0;
+    // weights are read once per step when an expert's rows fit one token tile
+    const int stream_nt = tile_rows ? ((n_slots / (size_t)(max_active > 0 ? max_active : 1)) <= (size_t)tile_rows) : 1;
 
     GemmParams p1{};
     p1.w = h->w13;
@@ -463,6 +511,10 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.active = a->active;
     p1.meta = a->meta;
     p1.sorted_slot = a->sorted_slot;
+    p1.tile_e = a->tile_e;
+    p1.tile_r0 = a->tile_r0;
+    p1.stream_nt = (h->t_dbg & 4) ? 0 : stream_nt;
+    p1.dbg = h->t_dbg;
     p1.out = a->act;
     p1.ldo = h->ld_act;
     p1.sk_stride = 0;
@@ -471,7 +523,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.act_type = h->cfg.activation_type;
     p1.alpha = h->cfg.swiglu_alpha;
     p1.limit = h->cfg.swiglu_limit;
-    rc = launch_gemm1(st, h->wf, h->adt, c1, p1, h->gated, max_active);
+    rc = c1.tiled ? launch_gemm1_tiled(st, h->wf, h->adt, c1, p1, h->gated, max_tiles)
+                  : launch_gemm1(st, h->wf, h->adt, c1, p1, h->gated, max_active);
     if (rc != LKM_OK) return rc;
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[2], st));
 
@@ -492,12 +545,17 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.active = a->active;
     p2.meta = a->meta;
     p2.sorted_slot = a->sorted_slot;
+    p2.tile_e = a->tile_e;
+    p2.tile_r0 = a->tile_r0;
+    p2.stream_nt = (h->t_dbg & 4) ? 0 : stream_nt;
+    p2.dbg = h->t_dbg;
     p2.out = a->y;
     p2.ldo = h->H;
     p2.sk_stride = n_slots * (size_t)h->H;
     p2.SK = c2.sk;
     p2.groups = h->T2 / c2.nt;
-    rc = launch_gemm2(st, h->wf, h->adt, c2, p2, max_active);
+    rc = c2.tiled ? launch_gemm2_tiled(st, h->wf, h->adt, c2, p2, max_tiles)
+                  : launch_gemm2(st, h->wf, h->adt, c2, p2, max_active);
     if (rc != LKM_OK) return rc;
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
 
@@ -508,9 +566,9 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         h->prof_valid = true;
     }
     snprintf(h->last_desc, sizeof(h->last_desc),
-             "M=%d K=%d | gemm1 nt=%d tb=%d kw=%d grid=(%d,%d) | gemm2 nt=%d tb=%d sk=%d grid=(%d,%d)",
-             M, K, c1.nt, c1.tb, c1.kw, p1.groups, max_active, c2.nt, c2.tb, c2.sk,
-             ceil_div(p2.groups * c2.sk, 4), max_active);
+             "M=%d K=%d | %s | gemm1 nt=%d tb=%d kw=%d waves=%d | gemm2 nt=%d tb=%d sk=%d waves=%d | nt_loads=%d",
+             M, K, c1.tiled ? (c1.tiled == 128 ? "tiled128" : "tiled64") : "skinny", c1.nt, c1.tb, c1.kw,
+             c1.waves, c2.nt, c2.tb, c2.sk, c2.waves, stream_nt);
     return LKM_OK;
 }
 
@@ -594,7 +652,7 @@ extern "C" int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots,
     int32_t* tmp = nullptr;
     LKM_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(int32_t) * ((size_t)E + 8)));
     int rc = launch_sort((hipStream_t)stream, ids, n_slots, E, counts, offsets, sorted_slot,
-                         pos_of_slot, tmp, tmp + E);
+                         pos_of_slot, tmp, tmp + E, 0, nullptr, nullptr);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(tmp);
     if (rc != LKM_OK) return rc;
@@ -634,6 +692,10 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "kw1")) h->t_kw1 = value;
     else if (!strcmp(key, "sk2")) h->t_sk2 = value;
     else if (!strcmp(key, "tbmax")) h->t_tb = value;
+    else if (!strcmp(key, "tiled")) h->t_tiled = value;
+    else if (!strcmp(key, "waves")) h->t_waves = value;
+    else if (!strcmp(key, "tmask")) h->t_tmask = value ? value : 3;
+    else if (!strcmp(key, "dbg")) h->t_dbg = value;
     else {
         set_error("lkm_set_tuning: unknown key '%s'", key);
         return LKM_E_INVALID;

@@ -11,6 +11,8 @@ namespace lkm {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -94,7 +96,8 @@ struct ActT<LKM_DT_BF16> {
     static __device__ __forceinline__ unsigned short from_f32(float f) { return f32_to_bf16_bits(f); }
     // pack two f32 -> two act elements in one dword (lo = a)
     static __device__ __forceinline__ unsigned pack2(float a, float b) {
-        return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
+        const f32x2 v = {a, b};   // one v_cvt_pk_bf16_f32 (RNE)
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
     }
 };
 template <>
@@ -107,7 +110,8 @@ struct ActT<LKM_DT_F16> {
     static __device__ __forceinline__ float to_f32(unsigned short h) { return f16_bits_to_f32(h); }
     static __device__ __forceinline__ unsigned short from_f32(float f) { return f32_to_f16_bits(f); }
     static __device__ __forceinline__ unsigned pack2(float a, float b) {
-        return (unsigned)f32_to_f16_bits(a) | ((unsigned)f32_to_f16_bits(b) << 16);
+        const f32x2 v = {a, b};   // one v_cvt_pk_f16_f32 (RNE)
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
     }
 };
 

@@ -20,7 +20,7 @@ int launch_repack_s_fp8(hipStream_t st, const void* src, void* dst, const Repack
 // ---- dispatch.hip
 int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
                 int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
-                int32_t* meta);
+                int32_t* meta, int tile_rows, int32_t* tile_e, int32_t* tile_r0);
 int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
                    const int32_t* pos_of_slot, const float* tw, int M, int K, int H, void* out,
                    int out_dt);
@@ -46,6 +46,10 @@ struct GemmParams {
     const int32_t* active;
     const int32_t* meta;
     const int32_t* sorted_slot;
+    const int32_t* tile_e;   // tiled kernels: work list of (expert, first row) token tiles
+    const int32_t* tile_r0;
+    int stream_nt;           // 1: weights are read once (decode) -> nontemporal loads
+    int dbg;                 // development switches
     // outputs
     void* out;  // GEMM1: act [rows][ldo] act dtype ; GEMM2: y [SK][sk_stride] fp32
     int ldo;
@@ -58,10 +62,18 @@ struct GemmParams {
 };
 struct LaunchCfg {
     int nt, tb, kw, sk;
+    int tiled;   // 0: skinny streamer (token operand straight from L2);
+                 // else token-tile rows (64 / 128): token operand staged through LDS
+    int waves;   // tiled: waves per workgroup (4 / 8)
 };
 int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                  bool gated, int max_active);
 int launch_gemm2(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                  int max_active);
+// tiled variants: grid.y = max_tiles (upper bound of the device-side work list)
+int launch_gemm1_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
+                       bool gated, int max_tiles);
+int launch_gemm2_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
+                       int max_tiles);
 
 }  // namespace lkm

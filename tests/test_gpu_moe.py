@@ -112,6 +112,47 @@ def test_dense_random_shapes_ragged(M, E, K, H, I):
     assert (out[dead] == 0).all()
 
 
+@pytest.mark.parametrize("M,E,K,H,I,tiled", [
+    (150, 2, 2, 256, 128, 128), (200, 64, 6, 128, 64, 64), (500, 4, 2, 136, 200, 128),
+    (90, 8, 2, 512, 256, 64), (1000, 16, 4, 256, 128, 0),
+])
+def test_dense_tiled_path_multi_tile_ragged(M, E, K, H, I, tiled):
+    """rows-per-expert > one token tile, ragged tails, tile counts not multiples of the wave group."""
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=M + E, drop=0.1, skew=0.5)
+    eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+    eng.engine.set_tuning(tiled=tiled)
+    out = _run_decode(eng, a, tw, ids)
+    assert "tiled" in eng.engine.describe()
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+    np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL)
+    eng.engine.set_tuning(tiled=-1)            # skinny streamer on the same inputs
+    np.testing.assert_allclose(_run_decode(eng, a, tw, ids), out, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("fmt", ["int4", "fp8"])
+def test_quantised_tiled_path(fmt):
+    M, E, K, H, I = 160, 4, 2, 256, 256
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=21)
+    if fmt == "int4":
+        q13, s13 = orc.quant_int4(torch_to_bits(w13), orc.BF16, 64)
+        q2, s2 = orc.quant_int4(torch_to_bits(w2), orc.BF16, 64)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="int4",
+                   w13_scale=bits_to_torch(s13, orc.BF16), w2_scale=bits_to_torch(s2, orc.BF16), group_n=1, group_k=64)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_INT4, groupN=1, groupK=64)
+    else:
+        q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+        q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
+                   w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128)
+    ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    for tiled in (64, 128, -1):
+        eng.engine.set_tuning(tiled=tiled)
+        out = _run_decode(eng, a, tw, ids)
+        np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=f"{fmt} tiled={tiled}")
+
+
 def test_relu2_non_gated():
     M, E, K, H, I = 19, 8, 2, 256, 128
     a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=5, gated=False)
@@ -132,9 +173,14 @@ def test_all_launch_geometries_agree():
         for nt2, sk in ((1, 1), (2, 4), (4, 2)):
             if nt2 * tb > 8:
                 continue
-            eng.engine.set_tuning(nt1=nt1, tbmax=tb, kw1=kw, nt2=nt2, sk2=sk)
+            eng.engine.set_tuning(tiled=-1, nt1=nt1, tbmax=tb, kw1=kw, nt2=nt2, sk2=sk)
             out = _run_decode(eng, a, tw, ids)
             np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())
+    # LDS-staged tiled kernels (gemm_tiled.h)
+    for tiled, waves, nt1, nt2 in ((64, 4, 1, 1), (64, 8, 1, 1), (64, 4, 1, 2), (128, 8, 1, 1), (128, 8, 1, 2)):
+        eng.engine.set_tuning(tiled=tiled, waves=waves, nt1=nt1, nt2=nt2, tbmax=0, kw1=0, sk2=0)
+        out = _run_decode(eng, a, tw, ids)
+        np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())
 
 
 def test_prefill_host_and_chunking():

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--g1", default="1:1:1,1:2:1,2:1:1,2:2:1,1:2:2,1:4:1,4:1:1", help="nt1:tb:kw list")
     ap.add_argument("--g2", default="1:1,1:2,1:4,2:1,2:2,2:4,2:8,4:2,4:4", help="nt2:sk list")
     ap.add_argument("--M", type=int, default=0)
+    ap.add_argument("--cfgs", default="", help="';'-separated tuning sets 'k=v,k=v' measured as whole steps (replaces --g1/--g2)")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
     if args.M:
@@ -61,6 +62,24 @@ def main():
         return acc
 
     print(f"# {args.workload} M={M} e_act={e_act} g1={g1_bytes/1e9:.3f} GB g2={g2_bytes/1e9:.3f} GB")
+    if args.cfgs:
+        keys = ("nt1", "nt2", "kw1", "sk2", "tbmax", "tiled", "waves")
+        for spec in args.cfgs.split(";"):
+            kv = {k: 0 for k in keys}
+            if spec.strip():
+                kv.update({k: int(v) for k, v in (x.split("=") for x in spec.split(","))})
+            try:
+                eng.engine.set_tuning(**kv)
+                p = measure()
+            except Exception as e:
+                print(f"[{spec}] FAILED {e}")
+                continue
+            tot = sum(p.values())
+            print(f"[{spec or 'auto'}] sort {p['sort']*1e3:.1f} gemm1 {p['gemm1']*1e3:.1f} ({g1_bytes/(p['gemm1']*1e-3)/1e9:.0f} GB/s) "
+                  f"gemm2 {p['gemm2']*1e3:.1f} ({g2_bytes/(p['gemm2']*1e-3)/1e9:.0f} GB/s) combine {p['combine']*1e3:.1f} "
+                  f"total {tot*1e3:.1f} us {M/(tot*1e-3):.0f} tok/s | {eng.engine.describe().split('|',2)[2]}")
+            print(json.dumps({"cfg": spec, **{k: v * 1e3 for k, v in p.items()}}))
+        return
     base = None
     for spec in args.g1.split(","):
         nt1, tb, kw = map(int, spec.split(":"))

@@ -36,6 +36,11 @@ WORKLOADS = {
     "mixtral8x7b_bf16_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="bf16"),
     "mixtral8x7b_int4g128_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="int4", g=128),
     "qwen3_30b_a3b_bf16_decode_m1": dict(E=128, K=8, H=2048, I=768, M=1, fmt="bf16"),
+    # per-rank slice of BASELINE.json configs[3] (DeepSeek-V3-style, EP=8): 32 local experts, the
+    # 256-token global batch x top-8 / 8 ranks = 256 routed rows per rank (rows arrive with top_k = 1)
+    "dsv3_ep8_rank_bf16_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="bf16"),
+    # BASELINE.json configs[4] shapes (GLM-4.5-Air prefill), bf16 weights stand in until fp8-W8A8 lands
+    "glm45air_bf16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="bf16"),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -72,6 +77,7 @@ def main():
     ap.add_argument("--workload", default="mixtral8x7b_bf16_decode_m32", choices=list(WORKLOADS))
     ap.add_argument("--ep-mode", default="a2a", choices=["a2a", "ar"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--force-ep", action="store_true", help="run the expert-parallel data path even with one rank (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     ap.add_argument("--tune", default="", help="comma list key=value for lkm_set_tuning (nt1,nt2,kw1,sk2,tbmax)")
@@ -84,8 +90,10 @@ def main():
         sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_ep = world > 1 or args.force_ep
+    if use_ep:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -117,7 +125,7 @@ def main():
     logits = torch.randn((M, E), generator=gen, device=dev, dtype=torch.float32)
     out = torch.empty((M, H), dtype=torch.float32, device=dev)
 
-    if world == 1:
+    if not use_ep:
         def step():
             tw, ids = ops.topk_softmax(logits, K, True)
             eng.decode(x, tw, ids, out=out)
@@ -128,10 +136,10 @@ def main():
 
         def step():
             tw, ids = ops.topk_softmax(logits, K, True)
-            out.copy_(ep.forward(x, tw, ids))
+            out.copy_(ep.forward(x, tw, ids, force_collectives=True))
 
     def barrier():
-        if world > 1:
+        if use_ep:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -141,7 +149,7 @@ def main():
     barrier()
     launch = "eager"
     graph = None
-    if world == 1 and not args.no_graph:
+    if not use_ep and not args.no_graph:
         try:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -167,7 +175,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_ep:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -249,12 +257,12 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if fmt == "bf16" else "int4-w/bf16-act", "data": "synthetic",
             "config": {"workload": args.workload, "experts": E, "top_k": K, "hidden": H,
                        "intermediate": I, "batch_per_gpu": M,
-                       "parallelism": "single" if world == 1 else f"ep{world}-{args.ep_mode}",
+                       "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}",
                        "launch": launch, "geometry": eng.engine.describe()},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_ep:
         dist.destroy_process_group()
 
 

@@ -159,6 +159,17 @@ int lkm_map_expert_ids(void* stream, const int32_t* ids, int64_t n, const int32_
                        int32_t E, int32_t* out);
 
 /*
+ * Expert-parallel dispatch pack (the MI355X replacement of the CPU-NUMA tier: experts sharded over
+ * the GPUs of a node).  Fixed capacity M*K rows per destination rank, so the following
+ * all-to-all needs no split-size exchange and no host synchronisation.  Placement = the reference's
+ * linear map (expert_map_manager.py:62-79).  send_x [ep][M*K][H] (activation dtype, 16-bit),
+ * send_ids int32 [ep][M*K] (local id at the destination, -1 = not routed there), send_w fp32.
+ */
+int lkm_ep_pack(void* stream, const void* hidden, const int32_t* topk_ids, const float* topk_weights,
+                int32_t M, int32_t K, int32_t H, int32_t num_experts, int32_t ep_size, void* send_x,
+                int32_t* send_ids, float* send_w);
+
+/*
  * Token->expert scatter metadata, exposed for tests and for the expert-parallel host code.
  * Stable counting sort of the n_slots = M*K assignments by expert
  * (csrc/cpu/cpu_fused_moe.cpp:200-227; moe_permute's stable sort, moe_permute_unpermute_kernel.cu:45-60).
@@ -191,6 +202,12 @@ int lkm_describe(LkmHandle h, char* buf, int32_t buf_len);
 /* tuning knobs (bench / tests): key in {"nt1","nt2","kw1","sk2","tbmax","tiled","waves"};
  * value 0 = auto ("tiled": -1 forces the skinny streamer, 64 / 128 force a token-tile size) */
 int lkm_set_tuning(LkmHandle h, const char* key, int32_t value);
+
+/* Measures the HBM *read* ceiling of the device with the access shape of the expert-weight stream
+ * (bench / DESIGN.md reference point): streams `bytes` of device memory `reps` times through
+ * n_blocks x 256 threads with `unroll` 1-KiB nontemporal loads in flight per wave. */
+int lkm_hbm_read_probe(void* stream, const void* device_buf, int64_t bytes, int32_t n_blocks,
+                       int32_t unroll, int32_t reps, float* ms_per_rep);
 
 #ifdef __cplusplus
 }

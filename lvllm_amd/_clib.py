@@ -59,6 +59,8 @@ _SIGS = {
                                    C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "lkm_map_expert_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                      C.c_void_p]),
+    "lkm_ep_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lkm_sort_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "lkm_last_error": (C.c_char_p, []),
@@ -69,6 +71,8 @@ _SIGS = {
     "lkm_weight_bytes": (C.c_int64, [C.c_void_p]),
     "lkm_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "lkm_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "lkm_hbm_read_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                     C.POINTER(C.c_float)]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -232,6 +232,45 @@ int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t*
     return LKM_OK;
 }
 
+// ------------------------------------------------------------------ HBM read ceiling probe
+// Pure streaming read of `bytes` with the same access shape as the GEMM weight stream (one 1-KiB
+// nontemporal global_load_dwordx4 per wave, `unroll` of them in flight, one contiguous 128-KiB
+// region per wave-iteration); the xor of everything is written so nothing is optimised away.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void read_probe_kernel(const u32x4* __restrict__ src, size_t n_vec,
+                                                        unsigned* __restrict__ sink) {
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    constexpr size_t CH = 8192;   // vectors per chunk = 128 KiB
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    for (size_t c = wave; c * CH < n_vec; c += n_waves) {
+        const u32x4* p = src + c * CH + lane;
+        for (size_t i = 0; i < CH / 64; i += UNROLL) {
+            u32x4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(p + (i + u) * 64);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = 1;   // practically never
+}
+
+int launch_read_probe(hipStream_t st, const void* src, size_t bytes, int n_blocks, int unroll,
+                      unsigned* sink) {
+    const size_t n_vec = bytes / 16 / 8192 * 8192;
+    dim3 grid(n_blocks), block(256);
+    if (unroll >= 8)
+        hipLaunchKernelGGL(read_probe_kernel<8>, grid, block, 0, st, (const u32x4*)src, n_vec, sink);
+    else if (unroll >= 4)
+        hipLaunchKernelGGL(read_probe_kernel<4>, grid, block, 0, st, (const u32x4*)src, n_vec, sink);
+    else
+        hipLaunchKernelGGL(read_probe_kernel<2>, grid, block, 0, st, (const u32x4*)src, n_vec, sink);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
 int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
                    const int32_t* pos_of_slot, const float* tw, int M, int K, int H, void* out,
                    int out_dt) {

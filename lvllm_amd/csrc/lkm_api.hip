@@ -660,6 +660,32 @@ extern "C" int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots,
     return LKM_OK;
 }
 
+extern "C" int lkm_hbm_read_probe(void* stream, const void* device_buf, int64_t bytes, int32_t n_blocks,
+                                  int32_t unroll, int32_t reps, float* ms_per_rep) {
+    LKM_REQUIRE(device_buf && bytes >= (int64_t)1 << 20 && n_blocks > 0 && reps > 0 && ms_per_rep, "read_probe: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* sink = nullptr;
+    LKM_HIP_CHECK(hipMalloc((void**)&sink, 4));
+    hipEvent_t e0, e1;
+    LKM_HIP_CHECK(hipEventCreate(&e0));
+    LKM_HIP_CHECK(hipEventCreate(&e1));
+    int rc = launch_read_probe(st, device_buf, (size_t)bytes, n_blocks, unroll, sink);   // warm-up
+    if (rc == LKM_OK) {
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < reps && rc == LKM_OK; ++i)
+            rc = launch_read_probe(st, device_buf, (size_t)bytes, n_blocks, unroll, sink);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *ms_per_rep = ms / reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    return rc;
+}
+
 extern "C" int lkm_set_profiling(LkmHandle h, int32_t enable) {
     LKM_REQUIRE(h, "null engine handle");
     h->prof = enable != 0;

@@ -25,6 +25,9 @@ int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
                    const int32_t* pos_of_slot, const float* tw, int M, int K, int H, void* out,
                    int out_dt);
 
+int launch_read_probe(hipStream_t st, const void* src, size_t bytes, int n_blocks, int unroll,
+                      unsigned* sink);
+
 // ---- gemm_skinny.hip
 struct GemmParams {
     // weights (pre-shuffled), scales (pre-shuffled or null)

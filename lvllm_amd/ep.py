@@ -3,10 +3,15 @@
 This replaces the reference's CPU-NUMA offload tier: instead of parking experts in host DRAM
 (lk_moe) each rank keeps E/ep experts resident in its 288 GB of HBM.  Two data paths:
 
-  "a2a"  (default, BASELINE.json north_star)  tokens stay DP-sharded; only the routed rows travel:
-         split sizes -> all_to_all_single -> rows + (local id, weight) -> local grouped GEMMs ->
-         reverse all_to_all -> local weighted sum.  On the 8-GPU xGMI full mesh all 7 links of a
-         GPU carry traffic concurrently.
+  "a2a"  (default, BASELINE.json north_star)  tokens stay DP-sharded; routed rows + (local id,
+         weight) travel by all_to_all_single -> local grouped GEMMs -> reverse all_to_all -> local
+         sum.  On the 8-GPU xGMI full mesh all 7 links of a GPU carry traffic concurrently
+         (SURVEY 8e).  Two flavours, chosen by size:
+           fixed   (decode, M*K <= fixed_capacity_slots): every peer gets M*K row slots, unrouted
+                   slots carry id -1; equal splits => NO split-size exchange and NO host sync.  At
+                   decode sizes the step is latency-bound (0.5 MB per peer ~ 4 us of xGMI time),
+                   so padding is free and removing the synchronisation is what matters.
+           ragged  (prefill): exact split sizes are exchanged first, only routed rows travel.
   "ar"   reference-compatible mode (what LvLLM does today, moe_runner.py:600,494 and
          routed_experts.py:1332-1342): every rank sees ALL tokens (all_gather), computes only
          its local experts (other ids -> -1), and the [M,H] partial outputs are summed with
@@ -27,6 +32,8 @@ from .ops import determine_expert_map
 
 # local_compute(rows [R,H] act dtype, local_ids int32 [R,1], weights fp32 [R,1]) -> fp32 [R,H]
 LocalCompute = Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor]
+# pack(hidden [M,H], weights [M,K], ids [M,K], num_experts, ep) -> (send_x [ep,MK,H], send_ids [ep,MK], send_w [ep,MK])
+PackFn = Callable[[torch.Tensor, torch.Tensor, torch.Tensor, int, int], tuple]
 
 
 def owner_of(ids: torch.Tensor, num_experts: int, ep_size: int) -> torch.Tensor:
@@ -44,10 +51,15 @@ def owner_of(ids: torch.Tensor, num_experts: int, ep_size: int) -> torch.Tensor:
 
 class ExpertParallelExperts:
     def __init__(self, local_compute: LocalCompute, num_experts: int, hidden_size: int,
-                 group: dist.ProcessGroup | None = None, mode: str = "a2a"):
+                 group: dist.ProcessGroup | None = None, mode: str = "a2a",
+                 pack: PackFn | None = None, fixed_capacity_slots: int = 2048):
         if mode not in ("a2a", "ar"):
             raise ValueError(f"unknown EP mode {mode!r} (expected 'a2a' or 'ar')")
         self.local_compute = local_compute
+        if pack is None:
+            from .ops import ep_pack as pack       # the HIP kernel (no CPU path)
+        self.pack = pack
+        self.fixed_capacity_slots = fixed_capacity_slots
         self.E, self.H = num_experts, hidden_size
         self.group = group
         self.ep = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -58,7 +70,25 @@ class ExpertParallelExperts:
         base, rem = divmod(num_experts, self.ep)
         self.first_expert = [r * base + min(r, rem) for r in range(self.ep)]
 
-    # -------------------------------------------------------------------------------- a2a
+    # -------------------------------------------------------------------------------- a2a, fixed
+    def _forward_a2a_fixed(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+        M, K = ids.shape
+        n = M * K
+        ep, dev = self.ep, hidden.device
+        send_x, send_ids, send_w = self.pack(hidden, tw, ids, self.E, ep)
+        recv_x = torch.empty_like(send_x)
+        recv_ids = torch.empty_like(send_ids)
+        recv_w = torch.empty_like(send_w)
+        dist.all_to_all_single(recv_x, send_x, group=self.group)        # equal splits: no host sync
+        dist.all_to_all_single(recv_ids, send_ids, group=self.group)
+        dist.all_to_all_single(recv_w, send_w, group=self.group)
+        y = self.local_compute(recv_x.view(ep * n, self.H), recv_ids.view(ep * n, 1), recv_w.view(ep * n, 1))
+        y_back = torch.empty((ep, n, self.H), dtype=torch.float32, device=dev)
+        dist.all_to_all_single(y_back, y.view(ep, n, self.H), group=self.group)
+        # every slot was computed by exactly one rank (rows of the others are zero): fixed-order fp32 sum
+        return y_back.view(ep, M, K, self.H).sum(dim=(0, 2))
+
+    # -------------------------------------------------------------------------------- a2a, ragged
     def _forward_a2a(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
         M, K = ids.shape
         dev = hidden.device
@@ -111,11 +141,14 @@ class ExpertParallelExperts:
         dist.reduce_scatter_tensor(out, part.contiguous(), group=self.group)
         return out
 
-    def forward(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
-        """hidden [M,H] (this rank's tokens), GLOBAL expert ids int32 [M,K] -> fp32 [M,H]."""
-        if self.ep == 1:
-            emap = self.expert_map.to(hidden.device)
+    def forward(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor,
+                force_collectives: bool = False) -> torch.Tensor:
+        """hidden [M,H] (this rank's tokens), GLOBAL expert ids int32 [M,K] -> fp32 [M,H].
+        force_collectives runs the collective data path even on a single rank (plumbing checks)."""
+        if self.ep == 1 and not force_collectives:
             return self.local_compute(hidden, topk_ids, topk_weights)
         if self.mode == "a2a":
+            if topk_ids.numel() <= self.fixed_capacity_slots:
+                return self._forward_a2a_fixed(hidden, topk_weights, topk_ids)
             return self._forward_a2a(hidden, topk_weights, topk_ids)
         return self._forward_ar(hidden, topk_weights, topk_ids)

@@ -138,6 +138,24 @@ def global_to_local_expert_ids(topk_ids: torch.Tensor, expert_map: torch.Tensor)
     return out
 
 
+def ep_pack(hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor, num_experts: int,
+            ep_size: int):
+    """Fixed-capacity EP dispatch pack -> (send_x [ep, M*K, H], send_ids int32 [ep, M*K] (-1 = not
+    routed to that rank), send_w fp32 [ep, M*K]); see lkm_ep_pack in include/lkm.h."""
+    _need_cuda(hidden, topk_weights, topk_ids)
+    M, K = topk_ids.shape
+    H = hidden.size(1)
+    dev = hidden.device
+    assert hidden.is_contiguous() and topk_ids.dtype == torch.int32 and topk_weights.dtype == torch.float32
+    send_x = torch.empty((ep_size, M * K, H), dtype=hidden.dtype, device=dev)
+    send_ids = torch.empty((ep_size, M * K), dtype=torch.int32, device=dev)
+    send_w = torch.empty((ep_size, M * K), dtype=torch.float32, device=dev)
+    _clib.check(_clib.lib().lkm_ep_pack(_stream(hidden), _ptr(hidden), _ptr(topk_ids.contiguous()),
+                                        _ptr(topk_weights.contiguous()), M, K, H, num_experts, ep_size,
+                                        _ptr(send_x), _ptr(send_ids), _ptr(send_w)))
+    return send_x, send_ids, send_w
+
+
 def sort_slots(topk_ids: torch.Tensor, num_experts: int):
     """Stable counting sort of the M*K slots by expert.
     -> counts [E], offsets [E+1], sorted_slot [M*K] (tail -1), pos_of_slot [M*K] (-1 = skipped)."""

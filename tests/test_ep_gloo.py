@@ -30,13 +30,32 @@ def _tokens(rank):
     return a, torch.from_numpy(tw), torch.from_numpy(ids)
 
 
+def _torch_pack(hidden, tw, ids, E_, ep):
+    """test double of ops.ep_pack (the HIP kernel) with identical semantics, for the CPU/gloo run"""
+    from lvllm_amd.ep import owner_of
+    M_, K_ = ids.shape
+    flat = ids.reshape(-1)
+    owner = owner_of(flat, E_, ep)
+    base, rem = divmod(E_, ep)
+    first = torch.tensor([r * base + min(r, rem) for r in range(ep)], dtype=torch.int64)
+    r = torch.arange(ep)[:, None]
+    mine = owner[None, :] == r
+    lid = flat.to(torch.int64) - first[owner.clamp(min=0)]
+    send_ids = torch.where(mine, lid[None, :], torch.full_like(lid, -1)[None, :]).to(torch.int32).contiguous()
+    send_w = torch.where(mine, tw.reshape(-1)[None, :], torch.zeros(())).contiguous()
+    send_x = hidden.repeat_interleave(K_, 0)[None].expand(ep, M_ * K_, hidden.size(1)).contiguous()
+    return send_x, send_ids, send_w
+
+
 def _worker(rank, world, port, mode, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lvllm_amd.ep import ExpertParallelExperts
         w13, w2 = _weights()
-        ep = ExpertParallelExperts(lambda *a: None, E, H, mode=mode)
+        real_mode = "a2a" if mode.startswith("a2a") else mode
+        ep = ExpertParallelExperts(lambda *a: None, E, H, mode=real_mode, pack=_torch_pack,
+                                   fixed_capacity_slots=0 if mode == "a2a_ragged" else 2048)
         lo = ep.first_expert[rank]
         n_loc = ep.local_num
         d = orc.MoeDesc(E=n_loc, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
@@ -64,7 +83,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("mode", ["a2a", "ar"])
+@pytest.mark.parametrize("mode", ["a2a", "a2a_ragged", "ar"])
 def test_ep_matches_single_rank_oracle(world, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

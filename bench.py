@@ -41,6 +41,9 @@ WORKLOADS = {
     "dsv3_ep8_rank_bf16_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="bf16"),
     # BASELINE.json configs[4] shapes (GLM-4.5-Air prefill), bf16 weights stand in until fp8-W8A8 lands
     "glm45air_bf16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="bf16"),
+    "dsv3_ep8_rank_fp8w8a8_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="fp8", fp8_mode=1),
+    "dsv3_ep8_rank_fp8w8a16_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="fp8", fp8_mode=0),
+    "mixtral8x7b_fp8w8a8_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="fp8", fp8_mode=1),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -67,6 +70,18 @@ def quantize_int4(w: torch.Tensor, g: int):
     q = q.view(E, N, K)
     packed = (q[..., 1::2] * 16 + q[..., ::2]).to(torch.uint8)
     return packed.contiguous(), s.contiguous()
+
+
+def quantize_fp8_block(w: torch.Tensor, blk: int = 128):
+    """128x128 block fp8 (e4m3fn) quantisation on the GPU: scale = amax/448 per block."""
+    E, N, K = w.shape
+    nb, kb = -(-N // blk), -(-K // blk)
+    wp = torch.zeros((E, nb * blk, kb * blk), dtype=torch.float32, device=w.device)
+    wp[:, :N, :K] = w.float()
+    t = wp.view(E, nb, blk, kb, blk)
+    s = t.abs().amax(dim=(2, 4)).clamp(min=1e-4) / 448.0
+    q = (t / s[:, :, None, :, None]).view(E, nb * blk, kb * blk)[:, :N, :K].contiguous().to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), s.contiguous()
 
 
 def main():
@@ -112,6 +127,13 @@ def main():
         q2, s2 = quantize_int4(w2, g)
         eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="int4",
                                       w13_scale=s13, w2_scale=s2, group_n=1, group_k=g,
+                                      max_num_seqs=max(256, M * world), num_processes=world, process_id=rank)
+    elif fmt == "fp8":
+        q13, s13 = quantize_fp8_block(w13)
+        q2, s2 = quantize_fp8_block(w2)
+        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
+                                      w13_scale=s13, w2_scale=s2, group_n=128, group_k=128,
+                                      fp8_mode=wl.get("fp8_mode", 0),
                                       max_num_seqs=max(256, M * world), num_processes=world, process_id=rank)
     else:
         eng = ops.RoutedExpertsEngine(w13, w2, top_k=K, act_dtype=torch.bfloat16, fmt="bf16",
@@ -201,8 +223,8 @@ def main():
         eng.engine.set_profiling(False)
         prof_ms = {k_: v / reps for k_, v in acc.items()}
         e_act = int(torch.unique(ids[ids >= 0]).numel())
-        bpe = {"bf16": 2.0, "int4": 0.5}[fmt]
-        scale_bytes = 0.0 if fmt == "bf16" else 2.0 / wl["g"]
+        bpe = {"bf16": 2.0, "int4": 0.5, "fp8": 1.0}[fmt]
+        scale_bytes = {"bf16": 0.0, "int4": 2.0 / wl.get("g", 128), "fp8": 4.0 / (128 * 128)}[fmt]
         g1_bytes = e_act * 2 * I * H * (bpe + scale_bytes)          # algorithmic weight bytes of GEMM1
         achieved = g1_bytes / (prof_ms["gemm1"] * 1e-3) / 1e9
         traffic = None
@@ -219,7 +241,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and fmt != "fp8":
         from oracle import oracle as orc
         tw, ids = ops.topk_softmax(logits, K, True)
         twn, idn = tw.cpu().numpy(), ids.cpu().numpy()
@@ -254,7 +276,7 @@ def main():
             "metric": "moe_layer_decode_tokens_per_s", "value": round(tokens_per_s, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if fmt == "bf16" else "int4-w/bf16-act", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act", "fp8": "fp8-w/" + ("fp8-act" if wl.get("fp8_mode") else "bf16-act")}[fmt], "data": "synthetic",
             "config": {"workload": args.workload, "experts": E, "top_k": K, "hidden": H,
                        "intermediate": I, "batch_per_gpu": M,
                        "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}",

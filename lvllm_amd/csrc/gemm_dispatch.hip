@@ -8,6 +8,10 @@ namespace lkm {
     int launch_gemm2_tiled_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 LKM_DECL(bf16) LKM_DECL(f16) LKM_DECL(int4_bf16) LKM_DECL(int4_f16) LKM_DECL(fp8_bf16) LKM_DECL(fp8_f16)
 #undef LKM_DECL
+int launch_gemm1_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
+int launch_gemm2_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
+int launch_gemm1_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
+int launch_gemm2_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 
 int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                  bool gated, int max_active) {
@@ -18,6 +22,8 @@ int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const Ge
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm1_int4_f16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm1_fp8_bf16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm1_fp8_f16(st, cfg, p, gated, max_active);
+    if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm1_fp8a8_bf16(st, cfg, p, gated, max_active);
+    if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm1_fp8a8_f16(st, cfg, p, gated, max_active);
     set_error("gemm1: unsupported weight format %d with activation dtype %d", wf, adt);
     return LKM_E_UNSUPPORTED;
 }
@@ -31,6 +37,8 @@ int launch_gemm2(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const Ge
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm2_int4_f16(st, cfg, p, max_active);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm2_fp8_bf16(st, cfg, p, max_active);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm2_fp8_f16(st, cfg, p, max_active);
+    if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm2_fp8a8_bf16(st, cfg, p, max_active);
+    if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm2_fp8a8_f16(st, cfg, p, max_active);
     set_error("gemm2: unsupported weight format %d with activation dtype %d", wf, adt);
     return LKM_E_UNSUPPORTED;
 }

@@ -23,6 +23,8 @@
 //     act-dtype intermediate in expert-sorted row order; GEMM2 writes fp32 split-K partials that the
 //     combine kernel (dispatch.hip) reduces together with the top-k weighting.
 #pragma once
+#include <type_traits>
+
 #include "lkm_kernels.h"
 
 namespace lkm {
@@ -34,7 +36,7 @@ struct Dec;
 template <int ADT>
 struct DecPlain {
     static constexpr int UNITK = 64, LOADS = 2, KSTEPS = 2;
-    static constexpr bool UNIT_SCALE = false;
+    static constexpr bool UNIT_SCALE = false, A8 = false;
     struct Aux {};
     static __device__ __forceinline__ void load_aux(Aux&, const void*, size_t, int, int) {}
     static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux&, int ks, int) {
@@ -49,7 +51,7 @@ struct Dec<LKM_W_F16, LKM_DT_F16> : DecPlain<LKM_DT_F16> {};
 template <int ADT>
 struct Dec<LKM_W_INT4_B8, ADT> {
     static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
-    static constexpr bool UNIT_SCALE = false;
+    static constexpr bool UNIT_SCALE = false, A8 = false;
     struct Aux {
         u32x2 raw;   // up to four act-dtype scales of this lane's weight row for the 128-k unit
     };
@@ -91,7 +93,7 @@ struct Dec<LKM_W_INT4_B8, ADT> {
 template <int ADT>
 struct Dec<LKM_W_FP8_E4M3, ADT> {
     static constexpr int UNITK = 128, LOADS = 2, KSTEPS = 4;
-    static constexpr bool UNIT_SCALE = true;
+    static constexpr bool UNIT_SCALE = true, A8 = false;
     struct Aux {
         f32x4 s;  // block scale of this lane's 4 output rows (g*4 + r)
     };
@@ -115,24 +117,49 @@ struct Dec<LKM_W_FP8_E4M3, ADT> {
     }
 };
 
-template <int LOADS, int KSTEPS, int NTT, int TB, typename Aux>
+// fp8 weights x fp8 activations on the native fp8 MFMA (W8A8): the A fragment is the raw 8 bytes,
+// no decode at all; weight block scale x token block scale is applied to the fp32 partial sum of
+// every 128-k unit (native_w8a8_block_matmul, tests/kernels/quant_utils.py:91-154).
+template <int ADT>
+struct Dec<LKM_W_FP8_A8, ADT> {
+    static constexpr int UNITK = 128, LOADS = 2, KSTEPS = 4;
+    static constexpr bool UNIT_SCALE = true, A8 = true;
+    struct Aux {
+        f32x4 s;
+    };
+    static __device__ __forceinline__ void load_aux(Aux& a, const void* sbase, size_t tu, int lane,
+                                                    int) {
+        a.s = *(const f32x4*)((const float*)sbase + tu * 16 + (lane >> 4) * 4);
+    }
+    static __device__ __forceinline__ long frag8(const u32x4 (&raw)[LOADS], int ks) {
+        const u32x2 v = {raw[ks >> 1][(ks & 1) * 2], raw[ks >> 1][(ks & 1) * 2 + 1]};
+        return __builtin_bit_cast(long, v);
+    }
+};
+
+template <typename D, int NTT, int TB>
 struct Stage {
-    u32x4 w[NTT][LOADS];
-    u32x4 x[TB][KSTEPS];
-    Aux aux[NTT];
+    typedef typename std::conditional<D::A8, u32x2, u32x4>::type XV;   // 8 fp8 or 8 bf16/f16 per lane
+    u32x4 w[NTT][D::LOADS];
+    XV x[TB][D::KSTEPS];
+    float xs[TB];          // A8: activation scale of this lane's token for the unit
+    typename D::Aux aux[NTT];
 };
 
 // Streams units [u0,u1) of NTT tiles against TB token blocks into acc[NTT][TB].
+// xp[b]  : byte pointer to this lane's token row of block b (fp8 rows when D::A8, else 16-bit rows)
+// xsp[b] : A8 only, pointer to that row's per-unit activation scales
 template <int WF, int ADT, int NTT, int TB>
 struct Streamer {
     typedef Dec<WF, ADT> D;
-    typedef Stage<D::LOADS, D::KSTEPS, NTT, TB, typename D::Aux> St;
+    typedef Stage<D, NTT, TB> St;
+    static constexpr int XB = D::A8 ? 1 : 2;
 
     static __device__ __forceinline__ void load(St& st, const u32x4* const (&wp)[NTT],
                                                 const void* sbase, const size_t (&stu)[NTT], int spu,
-                                                const unsigned short* const (&xp)[TB],
-                                                const bool (&xok)[TB], int u, int Kreal, int g8,
-                                                int lane, int ntb) {
+                                                const unsigned char* const (&xp)[TB],
+                                                const float* const (&xsp)[TB], int u, int Kreal,
+                                                int g8, int lane, int ntb) {
 #pragma unroll
         for (int t = 0; t < NTT; ++t) {
 #pragma unroll
@@ -147,14 +174,16 @@ struct Streamer {
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
             if (b < ntb) {
+                if constexpr (D::A8) st.xs[b] = xsp[b][u];
 #pragma unroll
                 for (int ks = 0; ks < D::KSTEPS; ++ks) {
                     const int k = u * D::UNITK + ks * 32 + g8;
+                    typedef typename St::XV XV;
                     if (!tail) {
-                        st.x[b][ks] = *(const u32x4*)(xp[b] + k);
+                        st.x[b][ks] = *(const XV*)(xp[b] + (size_t)k * XB);
                     } else {
-                        u32x4 v = {0u, 0u, 0u, 0u};
-                        if (k + 8 <= Kreal) v = *(const u32x4*)(xp[b] + k);
+                        XV v = {};
+                        if (k + 8 <= Kreal) v = *(const XV*)(xp[b] + (size_t)k * XB);
                         st.x[b][ks] = v;
                     }
                 }
@@ -173,16 +202,30 @@ struct Streamer {
             for (int ks = 0; ks < D::KSTEPS; ++ks)
 #pragma unroll
                 for (int t = 0; t < NTT; ++t) {
-                    const u32x4 a = D::frag(st.w[t], st.aux[t], ks, spu);
+                    if constexpr (D::A8) {
+                        const long a = D::frag8(st.w[t], ks);
 #pragma unroll
-                    for (int b = 0; b < TB; ++b)
-                        if (b < ntb) part[t][b] = ActT<ADT>::mfma(a, st.x[b][ks], part[t][b]);
+                        for (int b = 0; b < TB; ++b)
+                            if (b < ntb)
+                                part[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                                    a, __builtin_bit_cast(long, st.x[b][ks]), part[t][b], 0, 0, 0);
+                    } else {
+                        const u32x4 a = D::frag(st.w[t], st.aux[t], ks, spu);
+#pragma unroll
+                        for (int b = 0; b < TB; ++b)
+                            if (b < ntb) part[t][b] = ActT<ADT>::mfma(a, st.x[b][ks], part[t][b]);
+                    }
                 }
 #pragma unroll
             for (int t = 0; t < NTT; ++t)
 #pragma unroll
                 for (int b = 0; b < TB; ++b)
-                    if (b < ntb) acc[t][b] += st.aux[t].s * part[t][b];
+                    if (b < ntb) {
+                        if constexpr (D::A8)
+                            acc[t][b] += (st.aux[t].s * st.xs[b]) * part[t][b];
+                        else
+                            acc[t][b] += st.aux[t].s * part[t][b];
+                    }
         } else {
 #pragma unroll
             for (int ks = 0; ks < D::KSTEPS; ++ks)
@@ -198,19 +241,19 @@ struct Streamer {
 
     static __device__ __forceinline__ void run(f32x4 (&acc)[NTT][TB], const u32x4* const (&wp)[NTT],
                                                const void* sbase, const size_t (&stu)[NTT], int spu,
-                                               const unsigned short* const (&xp)[TB],
-                                               const bool (&xok)[TB], int u0, int u1, int Kreal,
+                                               const unsigned char* const (&xp)[TB],
+                                               const float* const (&xsp)[TB], int u0, int u1, int Kreal,
                                                int lane, int ntb) {
         const int g8 = (lane >> 4) * 8;
         St st[2];
-        if (u0 < u1) load(st[0], wp, sbase, stu, spu, xp, xok, u0, Kreal, g8, lane, ntb);
+        if (u0 < u1) load(st[0], wp, sbase, stu, spu, xp, xsp, u0, Kreal, g8, lane, ntb);
         for (int u = u0; u < u1; u += 2) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int uu = u + h;
                 if (uu < u1) {
                     if (uu + 1 < u1)
-                        load(st[h ^ 1], wp, sbase, stu, spu, xp, xok, uu + 1, Kreal, g8, lane, ntb);
+                        load(st[h ^ 1], wp, sbase, stu, spu, xp, xsp, uu + 1, Kreal, g8, lane, ntb);
                     compute(st[h], acc, ntb, spu);
                 }
             }
@@ -251,15 +294,16 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
     for (int sb = 0; sb < m_e; sb += 16 * TB) {
         const int rows = min(m_e - sb, 16 * TB);
         const int ntb = (rows + 15) >> 4;
-        const unsigned short* xp[TB];
-        bool xok[TB];
+        constexpr int XB = D::A8 ? 1 : 2;
+        const unsigned char* xp[TB];
+        const float* xsp[TB];
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
             const int r = sb + b * 16 + j;
-            xok[b] = r < m_e;
-            const int slot = p.sorted_slot[off_e + (xok[b] ? r : 0)];
+            const int slot = p.sorted_slot[off_e + (r < m_e ? r : 0)];
             const int tok = slot / p.top_k;
-            xp[b] = (const unsigned short*)p.x + (size_t)tok * p.ldx;
+            xp[b] = (const unsigned char*)p.x + (size_t)tok * p.ldx * XB;
+            xsp[b] = p.xscale + (size_t)tok * p.ld_xscale;
         }
         f32x4 acc[NTT][TB];
 #pragma unroll
@@ -267,7 +311,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        Streamer<WF, ADT, NTT, TB>::run(acc, wp, p.s, stu, p.spu, xp, xok, u0, u1, p.Kreal, lane, ntb);
+        Streamer<WF, ADT, NTT, TB>::run(acc, wp, p.s, stu, p.spu, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 
         if (KW > 1) {
             // fixed-order cross-wave sum: wave KW-1 stores, KW-2 .. 1 add, wave 0 takes the total
@@ -308,13 +352,18 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
                             float v[4];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const float a = acc[t][b][r];
+                                float a = acc[t][b][r];
+                                if (p.round_gemm1) a = ActT<ADT>::to_f32(ActT<ADT>::from_f32(a));
                                 if (GATED) {
-                                    const float up = acc[NT + t][b][r];
+                                    float up = acc[NT + t][b][r];
+                                    if (p.round_gemm1) up = ActT<ADT>::to_f32(ActT<ADT>::from_f32(up));
                                     if (p.act_type == LKM_ACT_SWIGLUOAI) {
                                         const float gg = fminf(a, p.limit);
                                         const float uu = fmaxf(fminf(up, p.limit), -p.limit);
                                         v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
+                                    } else if (p.round_gemm1) {
+                                        // T(silu_f32(g)) * u  (activation_kernels.cu:57-75,157-160)
+                                        v[r] = ActT<ADT>::to_f32(ActT<ADT>::from_f32(act_silu(a))) * up;
                                     } else {
                                         v[r] = act_silu(a) * up;
                                     }
@@ -369,13 +418,15 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
     for (int sb = 0; sb < m_e; sb += 16 * TB) {
         const int rows = min(m_e - sb, 16 * TB);
         const int ntb = (rows + 15) >> 4;
-        const unsigned short* xp[TB];
-        bool xok[TB];
+        constexpr int XB = D::A8 ? 1 : 2;
+        const unsigned char* xp[TB];
+        const float* xsp[TB];
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
             const int r = sb + b * 16 + j;
-            xok[b] = r < m_e;
-            xp[b] = (const unsigned short*)p.x + (size_t)(off_e + (xok[b] ? r : 0)) * p.ldx;
+            const size_t row = (size_t)(off_e + (r < m_e ? r : 0));
+            xp[b] = (const unsigned char*)p.x + row * p.ldx * XB;
+            xsp[b] = p.xscale + row * p.ld_xscale;
         }
         f32x4 acc[NT][TB];
 #pragma unroll
@@ -383,7 +434,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        Streamer<WF, ADT, NT, TB>::run(acc, wp, p.s, stu, p.spu, xp, xok, u0, u1, p.Kreal, lane, ntb);
+        Streamer<WF, ADT, NT, TB>::run(acc, wp, p.s, stu, p.spu, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 
 #pragma unroll
         for (int b = 0; b < TB; ++b) {

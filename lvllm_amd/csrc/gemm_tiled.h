@@ -25,6 +25,7 @@ __device__ __forceinline__ int x_swizzle(int row) {
 template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1>
 __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     typedef Dec<WF, ADT> D;
+    static_assert(!D::A8, "the LDS-staged kernels take 16-bit activations (W8A8 uses the streamer)");
     constexpr int NTT = (IS_G1 && GATED) ? 2 * NT : NT;
     constexpr int TM = TBW * 16;
     constexpr int THREADS = WAVES * 64;
@@ -209,13 +210,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float a = acc[t][b][r];
+                        float a = acc[t][b][r];
+                        if (p.round_gemm1) a = ActT<ADT>::to_f32(ActT<ADT>::from_f32(a));
                         if (GATED) {
-                            const float up = acc[NTT - NT + t][b][r];
+                            float up = acc[NTT - NT + t][b][r];
+                            if (p.round_gemm1) up = ActT<ADT>::to_f32(ActT<ADT>::from_f32(up));
                             if (p.act_type == LKM_ACT_SWIGLUOAI) {
                                 const float gg = fminf(a, p.limit);
                                 const float uu = fmaxf(fminf(up, p.limit), -p.limit);
                                 v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
+                            } else if (p.round_gemm1) {
+                                v[r] = ActT<ADT>::to_f32(ActT<ADT>::from_f32(act_silu(a))) * up;
                             } else {
                                 v[r] = act_silu(a) * up;
                             }

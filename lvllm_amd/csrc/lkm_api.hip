@@ -36,6 +36,9 @@ struct Arena {
     int32_t *sorted_slot = nullptr, *pos_of_slot = nullptr;
     int32_t *tile_e = nullptr, *tile_r0 = nullptr;   // [cap_slots/64 + E_cap + 8] each
     size_t tile_cap = 0;
+    unsigned char *xq = nullptr, *aq = nullptr;   // W8A8: fp8 activations (tokens / intermediate rows)
+    float *xqs = nullptr, *aqs = nullptr;         //       and their 1x128 scales
+    size_t xq_n = 0, aq_n = 0, xqs_n = 0, aqs_n = 0;
     void* act = nullptr;  // [cap_slots][ld_act] 16-bit
     float* y = nullptr;   // split-K partials
     std::vector<void*> retired;
@@ -58,7 +61,8 @@ static int grow(T*& ptr, size_t& have, size_t want, std::vector<void*>& retired)
     return LKM_OK;
 }
 
-static int arena_reserve(int device, int E, size_t slots, size_t act_elems, size_t y_elems, Arena** out) {
+static int arena_reserve(int device, int E, size_t slots, size_t act_elems, size_t y_elems,
+                         size_t xq_n, size_t xqs_n, size_t aq_n, size_t aqs_n, Arena** out) {
     std::lock_guard<std::mutex> lk(g_arena_mu);
     LKM_REQUIRE(device >= 0 && device < 64, "device ordinal %d out of range", device);
     Arena& a = g_arenas[device];
@@ -108,6 +112,10 @@ static int arena_reserve(int device, int E, size_t slots, size_t act_elems, size
         a.act = p;
     }
     if ((rc = grow(a.y, a.y_elems, y_elems, a.retired)) != LKM_OK) return rc;
+    if (xq_n && (rc = grow(a.xq, a.xq_n, xq_n, a.retired)) != LKM_OK) return rc;
+    if (xqs_n && (rc = grow(a.xqs, a.xqs_n, xqs_n, a.retired)) != LKM_OK) return rc;
+    if (aq_n && (rc = grow(a.aq, a.aq_n, aq_n, a.retired)) != LKM_OK) return rc;
+    if (aqs_n && (rc = grow(a.aqs, a.aqs_n, aqs_n, a.retired)) != LKM_OK) return rc;
     *out = &a;
     return LKM_OK;
 }
@@ -123,6 +131,8 @@ struct LkmEngine {
     int E, H, I, K;            // local experts, hidden, intermediate, top_k
     bool gated, interleaved;
     int wf, adt;
+    int wfk;                   // kernel format: wf, or LKM_W_FP8_A8 for fp8 W8A8
+    bool a8;
     // geometry
     int unitk;
     int T1_half, U1;           // w13: tiles per half, units along H
@@ -258,7 +268,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     LKM_REQUIRE(!(gated && cfg->activation_type == LKM_ACT_RELU2), "lkm_create: relu2 experts are non-gated (has_gate_proj must be 0)");
     LKM_REQUIRE(!(!gated && cfg->activation_type != LKM_ACT_RELU2), "lkm_create: non-gated experts support activation_type 2 (relu2) only");
     if (wf == LKM_W_FP8_E4M3) {
-        LKM_REQUIRE(cfg->fp8_mode == LKM_FP8_W8A16, "lkm_create: fp8 W8A8 mode is not built yet; use LKM_FP8_W8A16");
+        LKM_REQUIRE(cfg->fp8_mode == LKM_FP8_W8A16 || cfg->fp8_mode == LKM_FP8_W8A8, "lkm_create: bad fp8_mode %d", cfg->fp8_mode);
+        LKM_REQUIRE(cfg->fp8_mode != LKM_FP8_W8A8 || cfg->groupK == 128, "lkm_create: fp8 W8A8 quantises activations in 1x128 groups; groupK must be 128 (got %d)", cfg->groupK);
         LKM_REQUIRE(w13_scale && w2_scale, "lkm_create: fp8 weights need scales");
         LKM_REQUIRE(cfg->groupN > 0 && cfg->groupK > 0 && cfg->groupK % 128 == 0, "lkm_create: fp8 needs groupN>0 and groupK a multiple of 128 (got %d,%d)", cfg->groupN, cfg->groupK);
     }
@@ -290,6 +301,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     h->interleaved = gated && cfg->activation_type == LKM_ACT_SWIGLUOAI;
     h->wf = wf;
     h->adt = adt;
+    h->a8 = wf == LKM_W_FP8_E4M3 && cfg->fp8_mode == LKM_FP8_W8A8;
+    h->wfk = h->a8 ? LKM_W_FP8_A8 : wf;
     h->unitk = wf_unitk(wf);
     h->T1_half = round_up(ceil_div(h->I, 16), 4);
     h->U1 = ceil_div(h->H, h->unitk);
@@ -400,7 +413,12 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     h->cap_tokens = cap;
     const size_t slots = cap * h->K;
     const size_t y_rows = slots > 8 * (slots < 2048 ? slots : 2048) ? slots : 8 * (slots < 2048 ? slots : 2048);
-    LKM_TRY(arena_reserve(h->device, h->E, slots, slots * h->ld_act, y_rows * h->H, &h->arena));
+    {
+        const size_t kb1 = ceil_div(h->H, 128), kb2 = ceil_div(h->I, 128);
+        LKM_TRY(arena_reserve(h->device, h->E, slots, slots * h->ld_act, y_rows * h->H,
+                              h->a8 ? cap * h->H : 0, h->a8 ? cap * kb1 : 0, h->a8 ? slots * h->I : 0,
+                              h->a8 ? slots * kb2 : 0, &h->arena));
+    }
     for (auto& e : h->ev) LKM_TRY_HIP(hipEventCreate(&e));
     *out = h;
     return LKM_OK;
@@ -423,8 +441,8 @@ static void pick_cfg(const LkmEngine* h, int M, LaunchCfg* c1, LaunchCfg* c2, si
     // measured (profiles/r01_sweep_*): Mixtral bf16 M=64 (16 rows/expert) skinny 537 us vs tiled 570 us;
     // M=128 (32 rows/expert) skinny 714 us vs tiled64 585 us; 64-row tiles beat 128-row tiles up to
     // M=512 (875 vs 1023 us), 4 waves beat 8.
-    if (M > 32 && avg_rows > 24) tiled = 64;
-    if (h->t_tiled > 0) tiled = h->t_tiled;
+    if (M > 32 && avg_rows > 24 && !h->a8) tiled = 64;   // the LDS-staged kernels take 16-bit activations
+    if (h->t_tiled > 0 && !h->a8) tiled = h->t_tiled;
     if (h->t_tiled < 0) tiled = 0;
     if (tiled) {
         const int waves = h->t_waves > 0 ? h->t_waves : (tiled == 128 ? 8 : 4);
@@ -435,7 +453,11 @@ static void pick_cfg(const LkmEngine* h, int M, LaunchCfg* c1, LaunchCfg* c2, si
         if (h->t_tmask == 3) return;
     }
     const LaunchCfg t1 = *c1, t2 = *c2;
-    int tb = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    // token blocks held in registers: sized by the rows an expert is LIKELY to get (2x the mean + 8),
+    // not by M; a rare fuller expert loops super-blocks.  (DSv3 slice, 256 rows over 32 experts:
+    // tb=4 376 us, tb=2 316 us, tb=1 306 us -- fewer registers, more waves in flight.)
+    const size_t est_max = (size_t)M < 2 * avg_rows + 8 ? (size_t)M : 2 * avg_rows + 8;
+    int tb = est_max <= 16 ? 1 : (est_max <= 32 ? 2 : 4);
     if (h->t_tb > 0) tb = h->t_tb;
     // GEMM1 (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4; else nt*tb<=8)
     int nt1 = 1;
@@ -483,7 +505,14 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         h->prof_stream = st;
         LKM_HIP_CHECK(hipEventRecord(h->ev[0], st));
     }
-    int rc = launch_sort(st, ids, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot,
+    int rc = LKM_OK;
+    const int kb1 = ceil_div(h->H, 128), kb2 = ceil_div(h->I, 128);
+    if (h->a8) {   // dynamic 1x128 fp8 quantisation of the token rows (once per token, not per slot)
+        LKM_REQUIRE((size_t)M * h->H <= a->xq_n && n_slots * h->I <= a->aq_n, "fp8 activation scratch too small");
+        rc = launch_quant_fp8_rows(st, x, h->H, h->adt, M, h->H, a->xq, a->xqs);
+        if (rc != LKM_OK) return rc;
+    }
+    rc = launch_sort(st, ids, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot,
                          a->pos_of_slot, a->active, a->meta,
                          c1.tiled ? c1.tiled : (c2.tiled ? c2.tiled : 0), a->tile_e, a->tile_r0);
     if (rc != LKM_OK) return rc;
@@ -503,8 +532,11 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.U = h->U1;
     p1.Kreal = h->H;
     p1.n_real = h->I;
-    p1.x = x;
+    p1.x = h->a8 ? (const void*)a->xq : x;
     p1.ldx = h->H;
+    p1.xscale = a->xqs;
+    p1.ld_xscale = kb1;
+    p1.round_gemm1 = h->a8 ? 1 : 0;
     p1.top_k = K;
     p1.counts = a->counts;
     p1.offsets = a->offsets;
@@ -523,8 +555,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.act_type = h->cfg.activation_type;
     p1.alpha = h->cfg.swiglu_alpha;
     p1.limit = h->cfg.swiglu_limit;
-    rc = c1.tiled ? launch_gemm1_tiled(st, h->wf, h->adt, c1, p1, h->gated, max_tiles)
-                  : launch_gemm1(st, h->wf, h->adt, c1, p1, h->gated, max_active);
+    rc = c1.tiled ? launch_gemm1_tiled(st, h->wfk, h->adt, c1, p1, h->gated, max_tiles)
+                  : launch_gemm1(st, h->wfk, h->adt, c1, p1, h->gated, max_active);
     if (rc != LKM_OK) return rc;
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[2], st));
 
@@ -537,8 +569,14 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.U = h->U2;
     p2.Kreal = h->I;
     p2.n_real = h->H;
-    p2.x = a->act;
+    if (h->a8) {   // re-quantise the intermediate (per_token_group_quant of act_out, test_block_fp8.py:128)
+        rc = launch_quant_fp8_rows(st, a->act, h->ld_act, h->adt, (int)n_slots, h->I, a->aq, a->aqs);
+        if (rc != LKM_OK) return rc;
+    }
+    p2.x = h->a8 ? (const void*)a->aq : a->act;
     p2.ldx = h->ld_act;
+    p2.xscale = a->aqs;
+    p2.ld_xscale = kb2;
     p2.top_k = K;
     p2.counts = a->counts;
     p2.offsets = a->offsets;
@@ -554,8 +592,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.sk_stride = n_slots * (size_t)h->H;
     p2.SK = c2.sk;
     p2.groups = h->T2 / c2.nt;
-    rc = c2.tiled ? launch_gemm2_tiled(st, h->wf, h->adt, c2, p2, max_tiles)
-                  : launch_gemm2(st, h->wf, h->adt, c2, p2, max_active);
+    rc = c2.tiled ? launch_gemm2_tiled(st, h->wfk, h->adt, c2, p2, max_tiles)
+                  : launch_gemm2(st, h->wfk, h->adt, c2, p2, max_active);
     if (rc != LKM_OK) return rc;
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
 
@@ -585,6 +623,10 @@ static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, 
     size_t chunk = h->arena->cap_slots / (size_t)K;
     if (h->arena->act_elems / ((size_t)K * h->ld_act) < chunk) chunk = h->arena->act_elems / ((size_t)K * h->ld_act);
     if (h->arena->y_elems / ((size_t)K * h->H) < chunk) chunk = h->arena->y_elems / ((size_t)K * h->H);
+    if (h->a8) {
+        if (h->arena->xq_n / (size_t)h->H < chunk) chunk = h->arena->xq_n / (size_t)h->H;
+        if (h->arena->aq_n / ((size_t)K * h->I) < chunk) chunk = h->arena->aq_n / ((size_t)K * h->I);
+    }
     LKM_REQUIRE(chunk > 0, "scratch arena too small for top_k=%d", K);
     const size_t xrow = (size_t)h->H * 2, orow = (size_t)h->H * (out_dt == LKM_DT_F32 ? 4 : 2);
     for (size_t m0 = 0; m0 < (size_t)M; m0 += chunk) {

@@ -127,6 +127,11 @@ __host__ __device__ constexpr inline int64_t ceil_div64(int64_t a, int64_t b) { 
 //   bf16/f16 : UNITK = 64,  LOADS = 2 (load = kstep),          one dwordx4 = 8 elements
 //   fp8 e4m3 : UNITK = 128, LOADS = 2 (load l: .xy = kstep 2l, .zw = kstep 2l+1; 2 x 8 bytes)
 //   uint4b8  : UNITK = 128, LOADS = 1 (dword s = kstep s),     one dwordx4 = 4 x 8 nibbles
+// internal kernel-format code: fp8 weights consumed by the native fp8 MFMA against dynamically
+// quantised fp8 activations (W8A8, the in-tree operator's block-fp8 semantics); same HBM layout as
+// LKM_W_FP8_E4M3.
+#define LKM_W_FP8_A8 100
+
 template <int WF>
 struct WGeom;
 template <>

@@ -21,6 +21,8 @@ int launch_repack_s_fp8(hipStream_t st, const void* src, void* dst, const Repack
 int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
                 int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
                 int32_t* meta, int tile_rows, int32_t* tile_e, int32_t* tile_r0);
+int launch_quant_fp8_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, void* dst,
+                          float* scales);
 int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
                    const int32_t* pos_of_slot, const float* tw, int M, int K, int H, void* out,
                    int out_dt);
@@ -43,6 +45,10 @@ struct GemmParams {
     const void* x;  // GEMM1: hidden [M][H] ; GEMM2: act [rows][ldx]
     int ldx;        // row stride of x in elements
     int top_k;      // GEMM1: slot -> token = slot / top_k
+    const float* xscale;  // W8A8: per (token row, 128-k block) activation scales, row stride ld_xscale
+    int ld_xscale;
+    int round_gemm1;      // 1: round GEMM1 outputs to the act dtype before the activation (in-tree GPU
+                          //    operator, block-fp8 semantics), 0: keep fp32 (CPU operator)
     // routing metadata (device)
     const int32_t* counts;
     const int32_t* offsets;

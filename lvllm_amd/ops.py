@@ -189,7 +189,7 @@ class RoutedExpertsEngine:
                  has_gate_proj: bool = True, activation_type: int = 0, swiglu_alpha: float = 1.702,
                  swiglu_limit: float = 7.0, max_num_seqs: int = 256, max_batch_size: int = 8192,
                  group_max_len: int = 0, num_processes: int = 1, process_id: int = 0,
-                 gpu_id: int | None = None):
+                 gpu_id: int | None = None, fp8_mode: int = _clib.FP8_W8A16):
         E = w13.shape[0]
         H = w2.shape[1]
         inter = w13.shape[1] // (2 if has_gate_proj else 1)
@@ -204,6 +204,7 @@ class RoutedExpertsEngine:
         cfg.groupN, cfg.groupK = group_n, group_k
         cfg.activation_type = activation_type
         cfg.swiglu_alpha, cfg.swiglu_limit = swiglu_alpha, swiglu_limit
+        cfg.fp8_mode = fp8_mode
         self.cfg = cfg
         self.H, self.K, self.act_dtype = H, top_k, act_dtype
         cls = _CLS[(fmt, act_dtype)]

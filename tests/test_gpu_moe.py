@@ -85,6 +85,49 @@ def test_fp8_w8a16_golden_inputs():
         np.testing.assert_allclose(out, orc.bits_to_f32(c["out"], orc.BF16), atol=0.035, rtol=0.035)
 
 
+def test_fp8_w8a8_block_golden_and_oracle():
+    """fp8 weights x dynamically quantised fp8 activations on the native fp8 MFMA: the in-tree
+    operator's block-fp8 semantics.  vs the reference's torch_w8a8_block_fp8_moe at ITS tolerance
+    (0.035, test_block_fp8.py:205-207) and vs our oracle restatement (fp8 rounding decisions can flip
+    on last-bit differences of the bf16 intermediate, hence 1e-2 of the output scale)."""
+    from lvllm_amd import _clib
+    for i, c in load_golden("moe_fp8_block.npz"):
+        m, n, k, e, topk = [int(v) for v in c["meta"]]
+        eng = _eng(torch.from_numpy(c["w1"]), torch.from_numpy(c["w2"]), top_k=topk,
+                   act_dtype=torch.bfloat16, fmt="fp8", w13_scale=torch.from_numpy(c["w1s"]),
+                   w2_scale=torch.from_numpy(c["w2s"]), group_n=128, group_k=128, fp8_mode=_clib.FP8_W8A8)
+        out = _run_decode(eng, bits_to_torch(c["a"], orc.BF16), c["tw"], c["ids"])
+        gold = orc.bits_to_f32(c["out"], orc.BF16)
+        np.testing.assert_allclose(out, gold, atol=0.035, rtol=0.035, err_msg=f"case {i} vs reference")
+        d = orc.MoeDesc(E=e, H=k, I=n, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128,
+                        round_gemm1=True, w8a8=True)
+        # the oracle rounds the GEMM2 output to bf16 too (native_w8a8_block_matmul output_dtype)
+        ref = orc.moe(d, c["w1"], c["w2"], c["a"], c["ids"], c["tw"], s13=c["w1s"], s2=c["w2s"])
+        np.testing.assert_allclose(out, ref, atol=1e-2 * float(np.abs(ref).max()), rtol=2e-2,
+                                   err_msg=f"case {i} vs oracle")
+
+
+def test_fp8_w8a8_larger_random():
+    from lvllm_amd import _clib
+    M, E, K, H, I = 70, 8, 2, 512, 384
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=33, drop=0.1)
+    q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+    q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+    eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
+               w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128,
+               fp8_mode=_clib.FP8_W8A8)
+    out = _run_decode(eng, a, tw, ids)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128,
+                    round_gemm1=True, w8a8=True)
+    ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    np.testing.assert_allclose(out, ref, atol=1e-2 * float(np.abs(ref).max()), rtol=2e-2)
+    # and W8A8 stays within activation-quantisation noise of the weight-only result
+    eng16 = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
+                 w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128)
+    out16 = _run_decode(eng16, a, tw, ids)
+    np.testing.assert_allclose(out, out16, atol=0.035 * float(np.abs(out16).max()), rtol=0.035)
+
+
 def _rand_case(M, E, K, H, I, dtype, seed, gated=True, drop=0.0, skew=0.0):
     g = torch.Generator().manual_seed(seed)
     a = (torch.randn((M, H), generator=g) / 10).to(dtype)

@@ -1,0 +1,7 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -15
+echo "== mixtral fp8 w8a8 m32"; timeout 600 python tools/sweep.py --workload mixtral8x7b_fp8w8a8_decode_m32 --cfgs ";nt1=2;nt2=2,sk2=2" 2>&1 | grep -v '^{' | tail -3
+echo "== dsv3 fp8 w8a8"; timeout 600 python tools/sweep.py --workload dsv3_ep8_rank_fp8w8a8_rows256 --cfgs ";tbmax=2;tbmax=1" 2>&1 | grep -v '^{' | tail -3
+echo "== dsv3 fp8 w8a16"; timeout 600 python tools/sweep.py --workload dsv3_ep8_rank_fp8w8a16_rows256 --cfgs ";tiled=-1" 2>&1 | grep -v '^{' | tail -2

@@ -139,9 +139,11 @@ struct Dec<LKM_W_FP8_A8, ADT> {
 
 template <typename D, int NTT, int TB>
 struct Stage {
-    typedef typename std::conditional<D::A8, u32x2, u32x4>::type XV;   // 8 fp8 or 8 bf16/f16 per lane
+    // token operand: 16-bit activations -> one u32x4 (8 elements) per k-step;
+    //                fp8 activations    -> one u32x4 (16 bytes) per PAIR of k-steps
+    static constexpr int XN = D::A8 ? D::KSTEPS / 2 : D::KSTEPS;
     u32x4 w[NTT][D::LOADS];
-    XV x[TB][D::KSTEPS];
+    u32x4 x[TB][XN];
     float xs[TB];          // A8: activation scale of this lane's token for the unit
     typename D::Aux aux[NTT];
 };
@@ -159,7 +161,7 @@ struct Streamer {
                                                 const void* sbase, const size_t (&stu)[NTT], int spu,
                                                 const unsigned char* const (&xp)[TB],
                                                 const float* const (&xsp)[TB], int u, int Kreal,
-                                                int g8, int lane, int ntb) {
+                                                int gk, int lane, int ntb) {
 #pragma unroll
         for (int t = 0; t < NTT; ++t) {
 #pragma unroll
@@ -176,15 +178,16 @@ struct Streamer {
             if (b < ntb) {
                 if constexpr (D::A8) st.xs[b] = xsp[b][u];
 #pragma unroll
-                for (int ks = 0; ks < D::KSTEPS; ++ks) {
-                    const int k = u * D::UNITK + ks * 32 + g8;
-                    typedef typename St::XV XV;
+                for (int i = 0; i < St::XN; ++i) {
+                    // 16-byte token loads: 8 x 16-bit = k-step i, or 16 x fp8 = the k-step pair i;
+                    // the four g-lanes of a row are adjacent (64 contiguous bytes per row per load)
+                    const int k = u * D::UNITK + i * (64 / XB) + gk;
                     if (!tail) {
-                        st.x[b][ks] = *(const XV*)(xp[b] + (size_t)k * XB);
+                        st.x[b][i] = *(const u32x4*)(xp[b] + (size_t)k * XB);
                     } else {
-                        XV v = {};
-                        if (k + 8 <= Kreal) v = *(const XV*)(xp[b] + (size_t)k * XB);
-                        st.x[b][ks] = v;
+                        u32x4 v = {0u, 0u, 0u, 0u};
+                        if (k + 16 / XB <= Kreal) v = *(const u32x4*)(xp[b] + (size_t)k * XB);
+                        st.x[b][i] = v;
                     }
                 }
             }
@@ -208,7 +211,10 @@ struct Streamer {
                         for (int b = 0; b < TB; ++b)
                             if (b < ntb)
                                 part[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                                    a, __builtin_bit_cast(long, st.x[b][ks]), part[t][b], 0, 0, 0);
+                                    a,
+                                    __builtin_bit_cast(long, u32x2{st.x[b][ks >> 1][(ks & 1) * 2],
+                                                                   st.x[b][ks >> 1][(ks & 1) * 2 + 1]}),
+                                    part[t][b], 0, 0, 0);
                     } else {
                         const u32x4 a = D::frag(st.w[t], st.aux[t], ks, spu);
 #pragma unroll
@@ -244,16 +250,16 @@ struct Streamer {
                                                const unsigned char* const (&xp)[TB],
                                                const float* const (&xsp)[TB], int u0, int u1, int Kreal,
                                                int lane, int ntb) {
-        const int g8 = (lane >> 4) * 8;
+        const int gk = (lane >> 4) * (16 / XB);
         St st[2];
-        if (u0 < u1) load(st[0], wp, sbase, stu, spu, xp, xsp, u0, Kreal, g8, lane, ntb);
+        if (u0 < u1) load(st[0], wp, sbase, stu, spu, xp, xsp, u0, Kreal, gk, lane, ntb);
         for (int u = u0; u < u1; u += 2) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int uu = u + h;
                 if (uu < u1) {
                     if (uu + 1 < u1)
-                        load(st[h ^ 1], wp, sbase, stu, spu, xp, xsp, uu + 1, Kreal, g8, lane, ntb);
+                        load(st[h ^ 1], wp, sbase, stu, spu, xp, xsp, uu + 1, Kreal, gk, lane, ntb);
                     compute(st[h], acc, ntb, spu);
                 }
             }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
         } else {
             xrow[q] = (const unsigned short*)p.x + (size_t)(off_e + rr) * p.ldx;
         }
-        xsrc_off[q] = lslot * 8;
+        xsrc_off[q] = lslot * 8;   // slot ks*4+g holds k = ks*32 + g*8 .. +7
         xdst[q] = row * ROWB + pslot * 16;
     }
 

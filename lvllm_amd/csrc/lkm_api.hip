@@ -338,8 +338,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     LKM_TRY_HIP(hipMalloc(&h->w2, w2_vec * 16));
     h->weight_bytes = (int64_t)(w13_vec + w2_vec) * 16;
 
-    RepackDims d13{h->E, h->I, halves, h->interleaved ? 1 : 0, h->H, h->T1_half, h->U1};
-    RepackDims d2{h->E, h->H, 1, 0, h->I, h->T2, h->U2};
+    RepackDims d13{h->E, h->I, halves, h->interleaved ? 1 : 0, h->H, h->T1_half, h->U1, h->a8 ? 1 : 0};
+    RepackDims d2{h->E, h->H, 1, 0, h->I, h->T2, h->U2, h->a8 ? 1 : 0};
     {
         const size_t n13 = (size_t)h->E * halves * h->I, n2 = (size_t)h->E * h->H;
         const size_t b13 = n13 * h->H / 2 * wbytes_per_elem_x2(wf);

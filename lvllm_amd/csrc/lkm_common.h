@@ -123,7 +123,11 @@ __host__ __device__ constexpr inline int64_t ceil_div64(int64_t a, int64_t b) { 
 //   [tile = n/16][unit = k/UNITK][load][lane 0..63][16 bytes]
 // so that one wave-wide global_load_dwordx4 fetches 1 KiB of contiguous HBM that is already the
 // MFMA A-operand fragment(s) of mfma_f32_16x16x32: lane l = g*16 + i holds row tile*16+i,
-// k = unit*UNITK + kstep*32 + g*8 + (0..7).
+// k = unit*UNITK + kstep*32 + g*8 + (0..7): the four g-lanes of a row read 64 contiguous bytes of
+// a 16-bit token row per load.  (An MFMA sums over its 32 k-values, so any A/B-consistent k
+// assignment is valid.  Measured alternative -- each lane owning a contiguous 32-byte range -- was
+// 4 % slower on GEMM2: the loads become 32-byte strided.)  With fp8 ACTIVATIONS (W8A8) one 16-byte
+// token load feeds a PAIR of k-steps: k = unit*128 + pair*64 + g*16 + (0..15).
 //   bf16/f16 : UNITK = 64,  LOADS = 2 (load = kstep),          one dwordx4 = 8 elements
 //   fp8 e4m3 : UNITK = 128, LOADS = 2 (load l: .xy = kstep 2l, .zw = kstep 2l+1; 2 x 8 bytes)
 //   uint4b8  : UNITK = 128, LOADS = 1 (dword s = kstep s),     one dwordx4 = 4 x 8 nibbles

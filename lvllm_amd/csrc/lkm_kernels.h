@@ -10,6 +10,7 @@ struct RepackDims {
     int E, n_half, halves, interleaved;  // source rows N = n_half*halves
     int K;                               // source K (elements)
     int T_half, U;                       // dest tiles per half, units
+    int a8;                              // fp8 only: k mapping for fp8 activations (W8A8)
 };
 int launch_repack_w(hipStream_t st, int wf, const void* src, void* dst, const RepackDims& d);
 int launch_repack_s_int4(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group,

@@ -52,7 +52,10 @@ __global__ __launch_bounds__(256) void repack_w_kernel(const uint8_t* __restrict
             const uint8_t* p = src + ((size_t)e * N + n) * d.K;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {  // kstep = 2*ld + q
-                const int k0 = u * 128 + (2 * ld + q) * 32 + g * 8;
+                // 16-bit activations: k-step 2ld+q takes k = ks*32 + g*8 (4 lanes = 64 contiguous
+                // bytes of a token row).  fp8 activations (d.a8): one 16-byte token load feeds the
+                // k-step PAIR ld, so lane g owns k = ld*64 + g*16 + [0,16): bytes 0-7 -> step 2ld, 8-15 -> 2ld+1
+                const int k0 = d.a8 ? u * 128 + ld * 64 + g * 16 + q * 8 : u * 128 + (2 * ld + q) * 32 + g * 8;
                 unsigned lo = 0, hi = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {

@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--force-ep", action="store_true", help="run the expert-parallel data path even with one rank (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf"],
+                    help="router logits: randn (uniform-ish) or randn + Zipf(s=1) expert popularity bias (SURVEY 8d)")
     ap.add_argument("--tune", default="", help="comma list key=value for lkm_set_tuning (nt1,nt2,kw1,sk2,tbmax)")
     args = ap.parse_args()
 
@@ -145,6 +147,8 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     x = (torch.randn((M, H), generator=gen, device=dev) / 10).to(torch.bfloat16)
     logits = torch.randn((M, E), generator=gen, device=dev, dtype=torch.float32)
+    if args.routing == "zipf":      # log-popularity bias: p(e) ~ 1/(e+1)
+        logits = logits + torch.log(1.0 / torch.arange(1, E + 1, device=dev, dtype=torch.float32))[None, :]
     out = torch.empty((M, H), dtype=torch.float32, device=dev)
 
     if not use_ep:
@@ -234,9 +238,16 @@ def main():
                 traffic = json.loads(tf.read_text()).get(args.workload, {}).get("gemm1_bytes_per_launch")
             except Exception:
                 traffic = None
+        rows = int((ids >= 0).sum().item())
+        layer_flops = 6.0 * rows * H * I
+        layer_bytes = e_act * 3 * I * H * (bpe + scale_bytes)
         roofline = {"bound": "hbm", "kernel": "gemm1_act_kernel", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "algorithmic_bytes": g1_bytes,
+                    "layer": {"routed_rows": rows, "experts_hit": e_act, "weight_bytes": layer_bytes,
+                              "flops": layer_flops,
+                              "GBps_over_step": round(layer_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                              "TFLOPs_over_step": round(layer_flops / (ms_per_step * 1e-3) / 1e12, 2)},
                     "kernel_ms": {k_: round(v, 4) for k_, v in prof_ms.items()}}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores
@@ -278,7 +289,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act", "fp8": "fp8-w/" + ("fp8-act" if wl.get("fp8_mode") else "bf16-act")}[fmt], "data": "synthetic",
             "config": {"workload": args.workload, "experts": E, "top_k": K, "hidden": H,
-                       "intermediate": I, "batch_per_gpu": M,
+                       "intermediate": I, "batch_per_gpu": M, "routing": args.routing,
                        "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}",
                        "launch": launch, "geometry": eng.engine.describe()},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
     const int32_t* __restrict__ ids, int n_slots, int E, int32_t* __restrict__ counts,
     int32_t* __restrict__ offsets, int32_t* __restrict__ sorted_slot,
     int32_t* __restrict__ pos_of_slot, int32_t* __restrict__ active, int32_t* __restrict__ meta,
-    int tile_rows, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0) {
+    int tile_rows, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0) {
     constexpr int WAVES = THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     int32_t* cnt = smem;                 // [E]
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
         int e = base + tid;
         int c = (e < E) ? cnt[e] : 0;
         int a = c > 0 ? 1 : 0;
-        int t = tile_rows > 0 ? (c + tile_rows - 1) / tile_rows : 0;
+        int t = (tile_rows > 0 && c > tile_min) ? (c + tile_rows - 1) / tile_rows : 0;
         int sc = c, sa = a, stl = t;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -158,6 +158,160 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
     for (int p = total + tid; p < n_slots; p += THREADS) sorted_slot[p] = -1;
 }
 
+// ------------------------------------------------------------------ multi-workgroup sort (prefill sizes)
+// Same result as sort_slots_kernel, for M*K in the tens of thousands (one workgroup would need
+// ~1 ms): (1) per-1024-slot-chunk histograms, (2) one workgroup turns them into counts / offsets /
+// active list / tile list and per-chunk bases, (3) every chunk ranks its own slots (stable) and
+// scatters.  hist is [n_chunks][E].
+constexpr int kChunk = 1024;
+
+__global__ __launch_bounds__(kChunk) void sort_hist_kernel(const int32_t* __restrict__ ids, int n_slots,
+                                                          int E, int32_t* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    for (int e = threadIdx.x; e < E; e += kChunk) smem[e] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * kChunk + threadIdx.x;
+    if (i < n_slots) {
+        const int id = ids[i];
+        if (id >= 0 && id < E) atomicAdd(&smem[id], 1);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += kChunk) hist[(size_t)blockIdx.x * E + e] = smem[e];
+}
+
+__global__ __launch_bounds__(1024) void sort_scan_kernel(int n_chunks, int E, int32_t* __restrict__ hist,
+                                                        int32_t* __restrict__ counts,
+                                                        int32_t* __restrict__ offsets,
+                                                        int32_t* __restrict__ active,
+                                                        int32_t* __restrict__ meta, int tile_rows,
+                                                        int tile_min, int32_t* __restrict__ tile_e,
+                                                        int32_t* __restrict__ tile_r0) {
+    constexpr int THREADS = 1024, WAVES = 16;
+    __shared__ int32_t wsum[4 * WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int carry_cnt = 0, carry_act = 0, carry_til = 0, maxc = 0;
+    for (int base = 0; base < E; base += THREADS) {
+        const int e = base + tid;
+        int c = 0;
+        if (e < E)
+            for (int b = 0; b < n_chunks; ++b) c += hist[(size_t)b * E + e];
+        const int a = c > 0 ? 1 : 0;
+        const int t = (tile_rows > 0 && c > tile_min) ? (c + tile_rows - 1) / tile_rows : 0;
+        int sc = c, sa = a, stl = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int tc = __shfl_up(sc, d, 64), ta = __shfl_up(sa, d, 64), tt = __shfl_up(stl, d, 64);
+            if (lane >= d) {
+                sc += tc;
+                sa += ta;
+                stl += tt;
+            }
+        }
+        if (lane == 63) {
+            wsum[wv] = sc;
+            wsum[WAVES + wv] = sa;
+            wsum[2 * WAVES + wv] = stl;
+        }
+        __syncthreads();
+        int pc = 0, pa = 0, pt = 0, tot_c = 0, tot_a = 0, tot_t = 0;
+        for (int w = 0; w < WAVES; ++w) {
+            const int xc = wsum[w], xa = wsum[WAVES + w], xt = wsum[2 * WAVES + w];
+            if (w < wv) {
+                pc += xc;
+                pa += xa;
+                pt += xt;
+            }
+            tot_c += xc;
+            tot_a += xa;
+            tot_t += xt;
+        }
+        const int ex_c = carry_cnt + pc + sc - c;
+        const int ex_a = carry_act + pa + sa - a;
+        const int ex_t = carry_til + pt + stl - t;
+        if (e < E) {
+            counts[e] = c;
+            offsets[e] = ex_c;
+            if (a) active[ex_a] = e;
+            for (int i = 0; i < t; ++i) {
+                tile_e[ex_t + i] = e;
+                tile_r0[ex_t + i] = i * tile_rows;
+            }
+            // chunk bases: where chunk b's first slot of expert e lands
+            int run = ex_c;
+            for (int b = 0; b < n_chunks; ++b) {
+                const int hcnt = hist[(size_t)b * E + e];
+                hist[(size_t)b * E + e] = run;
+                run += hcnt;
+            }
+        }
+        maxc = max(maxc, c);
+        carry_cnt += tot_c;
+        carry_act += tot_a;
+        carry_til += tot_t;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) maxc = max(maxc, __shfl_xor(maxc, m, 64));
+    if (lane == 0) wsum[3 * WAVES + wv] = maxc;
+    __syncthreads();
+    if (tid == 0) {
+        int mm = 0;
+        for (int w = 0; w < WAVES; ++w) mm = max(mm, wsum[3 * WAVES + w]);
+        offsets[E] = carry_cnt;
+        meta[0] = carry_act;
+        meta[1] = carry_cnt;
+        meta[2] = mm;
+        meta[3] = carry_til;
+    }
+}
+
+__global__ __launch_bounds__(kChunk) void sort_scatter_kernel(const int32_t* __restrict__ ids, int n_slots,
+                                                             int E, const int32_t* __restrict__ hist,
+                                                             const int32_t* __restrict__ offsets,
+                                                             int32_t* __restrict__ sorted_slot,
+                                                             int32_t* __restrict__ pos_of_slot) {
+    constexpr int WAVES = kChunk / 64;
+    extern __shared__ __attribute__((aligned(16))) int32_t wcnt[];   // [WAVES][E]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int j = tid; j < WAVES * E; j += kChunk) wcnt[j] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * kChunk + tid;
+    int id = -1;
+    if (i < n_slots) {
+        id = ids[i];
+        if (id < 0 || id >= E) id = -1;
+    }
+    int rank = 0;
+    bool done = id < 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    while (true) {
+        const unsigned long long rem = __ballot(!done);
+        if (rem == 0ull) break;
+        const int leader = __ffsll((long long)rem) - 1;
+        const int v = __shfl(id, leader, 64);
+        const unsigned long long m = __ballot(!done && id == v);
+        if (!done && id == v) {
+            rank = __popcll(m & lt);
+            done = true;
+            if (rank == 0) wcnt[wv * E + v] = __popcll(m);
+        }
+    }
+    __syncthreads();
+    if (i < n_slots) {
+        int p = -1;
+        if (id >= 0) {
+            int before = 0;
+            for (int w = 0; w < wv; ++w) before += wcnt[w * E + id];
+            p = hist[(size_t)blockIdx.x * E + id] + before + rank;
+            sorted_slot[p] = i;
+        }
+        pos_of_slot[i] = p;
+    }
+    // tail of sorted_slot: positions >= total hold -1
+    const int total = offsets[E];
+    if (i < n_slots && i >= total) sorted_slot[i] = -1;
+}
+
 // out[m][h] = sum_k w[m,k] * sum_s y[s][pos(m,k)][h]   (fp32; s ascending, then k ascending)
 template <typename OutT>
 __device__ __forceinline__ void store4(OutT* p, f32x4 v);
@@ -208,26 +362,39 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
 template <int THREADS>
 static void launch_sort_t(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
                           int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot,
-                          int32_t* active, int32_t* meta, int tile_rows, int32_t* tile_e,
-                          int32_t* tile_r0) {
+                          int32_t* active, int32_t* meta, int tile_rows, int tile_min,
+                          int32_t* tile_e, int32_t* tile_r0) {
     constexpr int WAVES = THREADS / 64;
     size_t lds = sizeof(int32_t) * ((size_t)3 * E + 4 * WAVES + (size_t)WAVES * E);
     hipLaunchKernelGGL(sort_slots_kernel<THREADS>, dim3(1), dim3(THREADS), lds, st, ids, n_slots, E,
-                       counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_e,
+                       counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e,
                        tile_r0);
 }
 
 int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
                 int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
-                int32_t* meta, int tile_rows, int32_t* tile_e, int32_t* tile_r0) {
+                int32_t* meta, int tile_rows, int tile_min, int32_t* tile_e, int32_t* tile_r0,
+                int32_t* hist, size_t hist_cap) {
     LKM_REQUIRE(E > 0 && E <= kMaxLocalExperts, "sort: local experts E=%d out of range (1..%d)", E, kMaxLocalExperts);
     LKM_REQUIRE(tile_rows == 0 || (tile_e && tile_r0), "sort: tile list requested without buffers");
+    const int n_chunks = ceil_div(n_slots, kChunk);
+    if (n_slots > 4 * kChunk && hist && (size_t)n_chunks * E <= hist_cap) {
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(n_chunks), dim3(kChunk), sizeof(int32_t) * E, st, ids,
+                           n_slots, E, hist);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, st, n_chunks, E, hist, counts, offsets,
+                           active, meta, tile_rows, tile_min, tile_e, tile_r0);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(n_chunks), dim3(kChunk),
+                           sizeof(int32_t) * (kChunk / 64) * E, st, ids, n_slots, E, hist, offsets,
+                           sorted_slot, pos_of_slot);
+        LKM_HIP_CHECK(hipGetLastError());
+        return LKM_OK;
+    }
     if (n_slots <= 64 && E <= 64)
-        launch_sort_t<64>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_e, tile_r0);
+        launch_sort_t<64>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e, tile_r0);
     else if (n_slots <= 512 && E <= 256)
-        launch_sort_t<256>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_e, tile_r0);
+        launch_sort_t<256>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e, tile_r0);
     else
-        launch_sort_t<1024>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_e, tile_r0);
+        launch_sort_t<1024>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e, tile_r0);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

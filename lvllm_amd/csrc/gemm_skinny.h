@@ -281,6 +281,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
     if (ai >= p.meta[0]) return;
     const int e = p.active[ai];
     const int m_e = p.counts[e], off_e = p.offsets[e];
+    if (p.max_rows > 0 && m_e > p.max_rows) return;   // workgroup-uniform: the tiled kernel owns this expert
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, KW = blockDim.x >> 6;
     const int g = lane >> 4, j = lane & 15;
     const int tile0 = blockIdx.x * NT;
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
     if (ai >= p.meta[0]) return;
     const int e = p.active[ai];
     const int m_e = p.counts[e], off_e = p.offsets[e];
+    if (p.max_rows > 0 && m_e > p.max_rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, j = lane & 15;
     const int uid = blockIdx.x * 4 + wave;

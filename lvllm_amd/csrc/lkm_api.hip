@@ -36,6 +36,8 @@ struct Arena {
     int32_t *sorted_slot = nullptr, *pos_of_slot = nullptr;
     int32_t *tile_e = nullptr, *tile_r0 = nullptr;   // [cap_slots/64 + E_cap + 8] each
     size_t tile_cap = 0;
+    int32_t* hist = nullptr;                         // multi-workgroup sort: [chunks][E]
+    size_t hist_cap = 0;
     unsigned char *xq = nullptr, *aq = nullptr;   // W8A8: fp8 activations (tokens / intermediate rows)
     float *xqs = nullptr, *aqs = nullptr;         //       and their 1x128 scales
     size_t xq_n = 0, aq_n = 0, xqs_n = 0, aqs_n = 0;
@@ -107,6 +109,10 @@ static int arena_reserve(int device, int E, size_t slots, size_t act_elems, size
         }
     }
     {
+        const size_t want = (a.cap_slots / 1024 + 1) * (size_t)a.E_cap;
+        if (a.cap_slots > 4096 && (rc = grow(a.hist, a.hist_cap, want > a.hist_cap ? want : a.hist_cap, a.retired)) != LKM_OK) return rc;
+    }
+    {
         unsigned short* p = (unsigned short*)a.act;
         if ((rc = grow(p, a.act_elems, act_elems, a.retired)) != LKM_OK) return rc;
         a.act = p;
@@ -149,7 +155,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_tmask = 3, t_dbg = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_tmask = 3, t_dbg = 0, t_hybrid = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -427,39 +433,52 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
 }
 
 // ------------------------------------------------------------------ launch geometry heuristics
-static void pick_cfg(const LkmEngine* h, int M, LaunchCfg* c1, LaunchCfg* c2, size_t n_slots) {
-    // Measured on MI355X (profiles/sweep_r01_*.log): one 16-row tile per wave streams best
-    // (7168 waves x 64 threads for Mixtral GEMM1: 6.7 TB/s vs 6.4 TB/s at two tiles); wider tiles
-    // only pay when the token operand traffic (TB blocks) starts to matter.
+// Launch plan of one step.  skinny: weight streamer, token operand straight from L2 (few rows per
+// expert).  tiled: token operand staged through LDS (many rows per expert).  hybrid: both kernels run,
+// the skinny one skips experts with more than `split_rows` rows and the tile list holds only those.
+struct Plan {
+    LaunchCfg s1, s2;   // skinny GEMM1 / GEMM2 (s1.tb == 0: not launched)
+    LaunchCfg t1, t2;   // tiled  GEMM1 / GEMM2 (t1.tiled == 0: not launched)
+    int split_rows;     // hybrid threshold (0: no split)
+};
+
+static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
+    // Measured on MI355X (profiles/r01_sweep_*): one 16-row tile per wave streams best (7168 waves x 64
+    // threads for Mixtral GEMM1: 6.7 TB/s vs 6.4 TB/s at two tiles); two tiles only for sub-16-bit
+    // weights, where the token operand dominates the load instructions.
     const int kMinWaves = 2048;
     const int n_act = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
-    // More than two 16-token blocks per expert possible -> stage the token operand through LDS
-    // (gemm_tiled.h); measured: at M=128 the skinny streamer drops to 4.6 TB/s (bf16) / 1.3 TB/s (int4)
-    // because every wave re-reads the token rows from L2.
-    int tiled = 0;
     const size_t avg_rows = n_slots / (size_t)(n_act > 0 ? n_act : 1);
-    // measured (profiles/r01_sweep_*): Mixtral bf16 M=64 (16 rows/expert) skinny 537 us vs tiled 570 us;
-    // M=128 (32 rows/expert) skinny 714 us vs tiled64 585 us; 64-row tiles beat 128-row tiles up to
-    // M=512 (875 vs 1023 us), 4 waves beat 8.
-    if (M > 32 && avg_rows > 24 && !h->a8) tiled = 64;   // the LDS-staged kernels take 16-bit activations
-    if (h->t_tiled > 0 && !h->a8) tiled = h->t_tiled;
-    if (h->t_tiled < 0) tiled = 0;
-    if (tiled) {
-        const int waves = h->t_waves > 0 ? h->t_waves : (tiled == 128 ? 8 : 4);
-        int nt1 = h->t_nt1 > 0 ? h->t_nt1 : 1;
-        int nt2 = h->t_nt2 > 0 ? h->t_nt2 : 1;
-        *c1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves};
-        *c2 = LaunchCfg{nt2, tiled / 16, 1, 1, tiled, waves};
-        if (h->t_tmask == 3) return;
-    }
-    const LaunchCfg t1 = *c1, t2 = *c2;
     // token blocks held in registers: sized by the rows an expert is LIKELY to get (2x the mean + 8),
-    // not by M; a rare fuller expert loops super-blocks.  (DSv3 slice, 256 rows over 32 experts:
-    // tb=4 376 us, tb=2 316 us, tb=1 306 us -- fewer registers, more waves in flight.)
+    // not by M; a rare fuller expert goes to the tiled kernel (hybrid) or loops super-blocks.
+    // (DSv3 slice, 256 rows over 32 experts: tb=4 376 us, tb=2 316 us, tb=1 306 us.)
     const size_t est_max = (size_t)M < 2 * avg_rows + 8 ? (size_t)M : 2 * avg_rows + 8;
     int tb = est_max <= 16 ? 1 : (est_max <= 32 ? 2 : 4);
     if (h->t_tb > 0) tb = h->t_tb;
-    // GEMM1 (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4; else nt*tb<=8)
+
+    // ---- which kernels
+    // Mixtral bf16: M=64 (16 rows/expert) skinny 537 us vs tiled 570 us; M=128 (32 rows/expert) skinny
+    // 714 us vs tiled64 585 us; 64-row tiles beat 128-row tiles up to M=512, 4 waves beat 8.
+    int tiled = 0, split = 0;
+    if (!h->a8) {   // the LDS-staged kernels take 16-bit activations
+        if (M > 32 && avg_rows > 24) tiled = 64;
+        else if (M > 16 * tb && h->t_hybrid >= 0) { tiled = 64; split = 16 * tb; }
+        if (h->t_tiled > 0) { tiled = h->t_tiled; split = 0; }
+        if (h->t_tiled < 0) { tiled = 0; split = 0; }
+    }
+    pl->split_rows = split;
+    pl->t1 = pl->t2 = LaunchCfg{0, 0, 0, 0, 0, 0};
+    pl->s1 = pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0};
+    if (tiled) {
+        const int waves = h->t_waves > 0 ? h->t_waves : (tiled == 128 ? 8 : 4);
+        const int nt1 = (h->t_nt1 > 0 && !split) ? h->t_nt1 : 1;
+        const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : 1;
+        pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves};
+        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, 1, tiled, waves};
+        if (!split && h->t_tmask == 3) return;
+    }
+    // ---- skinny geometry (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4;
+    // otherwise nt*tb<=8)
     int nt1 = 1;
     if (tb >= 4 && !h->gated && (long long)n_act * (h->T1_half / 2) >= 2 * kMinWaves) nt1 = 2;
     if (h->t_nt1 > 0) nt1 = h->t_nt1;
@@ -469,8 +488,7 @@ static void pick_cfg(const LkmEngine* h, int M, LaunchCfg* c1, LaunchCfg* c2, si
         while (kw < 8 && waves * kw < kMinWaves && h->U1 / (kw * 2) >= 2) kw *= 2;
     }
     if (h->t_kw1 > 0) kw = h->t_kw1;
-    *c1 = LaunchCfg{nt1, tb, kw, 1, 0, 0};
-    // GEMM2
+    pl->s1 = LaunchCfg{nt1, tb, kw, 1, 0, 0};
     // sub-16-bit weights: two tiles per wave halve the token-operand loads per weight byte
     // (int4 M=32: gemm2 120 us -> 85 us)
     int nt2 = (h->wf == LKM_W_INT4_B8 || h->wf == LKM_W_FP8_E4M3) && tb >= 2 ? 2 : 1;
@@ -482,14 +500,15 @@ static void pick_cfg(const LkmEngine* h, int M, LaunchCfg* c1, LaunchCfg* c2, si
         while (sk < 8 && waves * sk < kMinWaves && h->U2 / (sk * 2) >= 2) sk *= 2;
     }
     if (h->t_sk2 > 0) sk = h->t_sk2;
+    if (split) sk = 1;   // the tiled GEMM2 writes slab 0 only
     // split-K slabs must fit the partial buffer
     const size_t y_rows = h->arena->y_elems / h->H;
     while (sk > 1 && (size_t)sk * n_slots > y_rows) sk /= 2;
-    *c2 = LaunchCfg{nt2, tb, 1, sk, 0, 0};
-    if (tiled) {   // debug: tiled on one GEMM only (the sort still emits the tile list)
-        if (h->t_tmask & 1) *c1 = t1; else c1->tiled = 0;
-        if (h->t_tmask & 2) *c2 = t2; else c2->tiled = 0;
-        if (!(h->t_tmask & 1)) c1->waves = -tiled;   // carries the tile size for the sort
+    pl->s2 = LaunchCfg{nt2, tb, 1, sk, 0, 0};
+    if (tiled && !split) {   // development: tiled on one GEMM only
+        if (h->t_tmask & 1) pl->s1.tb = 0; else pl->t1.tiled = 0;
+        if (h->t_tmask & 2) { pl->s2.tb = 0; } else pl->t2.tiled = 0;
+        if (pl->t2.tiled == 0) {} else pl->s2.sk = 1;
     }
 }
 
@@ -498,8 +517,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
                      const float* tw, void* out, int out_dt) {
     Arena* a = h->arena;
     const size_t n_slots = (size_t)M * K;
-    LaunchCfg c1, c2;
-    pick_cfg(h, M, &c1, &c2, n_slots);
+    Plan pl;
+    pick_cfg(h, M, n_slots, &pl);
     const bool prof = h->prof;
     if (prof) {
         h->prof_stream = st;
@@ -512,16 +531,18 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         rc = launch_quant_fp8_rows(st, x, h->H, h->adt, M, h->H, a->xq, a->xqs);
         if (rc != LKM_OK) return rc;
     }
-    rc = launch_sort(st, ids, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot,
-                         a->pos_of_slot, a->active, a->meta,
-                         c1.tiled ? c1.tiled : (c2.tiled ? c2.tiled : 0), a->tile_e, a->tile_r0);
+    const int tile_rows = pl.t1.tiled ? pl.t1.tiled : pl.t2.tiled;
+    rc = launch_sort(st, ids, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
+                     a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, a->hist,
+                     a->hist_cap);
     if (rc != LKM_OK) return rc;
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[1], st));
     const int max_active = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
-    const int tile_rows = c1.tiled ? c1.tiled : c2.tiled;
     const int max_tiles = tile_rows ? (int)(n_slots / tile_rows) + max_active : 0;
     // weights are read once per step when an expert's rows fit one token tile
-    const int stream_nt = tile_rows ? ((n_slots / (size_t)(max_active > 0 ? max_active : 1)) <= (size_t)tile_rows) : 1;
+    const int stream_nt = tile_rows && !pl.split_rows
+                              ? ((n_slots / (size_t)(max_active > 0 ? max_active : 1)) <= (size_t)tile_rows)
+                              : 1;
 
     GemmParams p1{};
     p1.w = h->w13;
@@ -545,19 +566,25 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.sorted_slot = a->sorted_slot;
     p1.tile_e = a->tile_e;
     p1.tile_r0 = a->tile_r0;
+    p1.max_rows = pl.split_rows;
     p1.stream_nt = (h->t_dbg & 4) ? 0 : stream_nt;
     p1.dbg = h->t_dbg;
     p1.out = a->act;
     p1.ldo = h->ld_act;
     p1.sk_stride = 0;
     p1.SK = 1;
-    p1.groups = h->T1_half / c1.nt;
     p1.act_type = h->cfg.activation_type;
     p1.alpha = h->cfg.swiglu_alpha;
     p1.limit = h->cfg.swiglu_limit;
-    rc = c1.tiled ? launch_gemm1_tiled(st, h->wfk, h->adt, c1, p1, h->gated, max_tiles)
-                  : launch_gemm1(st, h->wfk, h->adt, c1, p1, h->gated, max_active);
-    if (rc != LKM_OK) return rc;
+    if (pl.s1.tb) {
+        p1.groups = h->T1_half / pl.s1.nt;
+        rc = launch_gemm1(st, h->wfk, h->adt, pl.s1, p1, h->gated, max_active);
+        if (rc != LKM_OK) return rc;
+    }
+    if (pl.t1.tiled) {
+        rc = launch_gemm1_tiled(st, h->wfk, h->adt, pl.t1, p1, h->gated, max_tiles);
+        if (rc != LKM_OK) return rc;
+    }
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[2], st));
 
     GemmParams p2{};
@@ -585,28 +612,36 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.sorted_slot = a->sorted_slot;
     p2.tile_e = a->tile_e;
     p2.tile_r0 = a->tile_r0;
+    p2.max_rows = pl.split_rows;
     p2.stream_nt = (h->t_dbg & 4) ? 0 : stream_nt;
     p2.dbg = h->t_dbg;
     p2.out = a->y;
     p2.ldo = h->H;
     p2.sk_stride = n_slots * (size_t)h->H;
-    p2.SK = c2.sk;
-    p2.groups = h->T2 / c2.nt;
-    rc = c2.tiled ? launch_gemm2_tiled(st, h->wfk, h->adt, c2, p2, max_tiles)
-                  : launch_gemm2(st, h->wfk, h->adt, c2, p2, max_active);
-    if (rc != LKM_OK) return rc;
+    const int sk = pl.s2.tb ? pl.s2.sk : 1;
+    p2.SK = sk;
+    if (pl.s2.tb) {
+        p2.groups = h->T2 / pl.s2.nt;
+        rc = launch_gemm2(st, h->wfk, h->adt, pl.s2, p2, max_active);
+        if (rc != LKM_OK) return rc;
+    }
+    if (pl.t2.tiled) {
+        rc = launch_gemm2_tiled(st, h->wfk, h->adt, pl.t2, p2, max_tiles);
+        if (rc != LKM_OK) return rc;
+    }
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
 
-    rc = launch_combine(st, a->y, c2.sk, p2.sk_stride, a->pos_of_slot, tw, M, K, h->H, out, out_dt);
+    rc = launch_combine(st, a->y, sk, p2.sk_stride, a->pos_of_slot, tw, M, K, h->H, out, out_dt);
     if (rc != LKM_OK) return rc;
     if (prof) {
         LKM_HIP_CHECK(hipEventRecord(h->ev[4], st));
         h->prof_valid = true;
     }
     snprintf(h->last_desc, sizeof(h->last_desc),
-             "M=%d K=%d | %s | gemm1 nt=%d tb=%d kw=%d waves=%d | gemm2 nt=%d tb=%d sk=%d waves=%d | nt_loads=%d",
-             M, K, c1.tiled ? (c1.tiled == 128 ? "tiled128" : "tiled64") : "skinny", c1.nt, c1.tb, c1.kw,
-             c1.waves, c2.nt, c2.tb, c2.sk, c2.waves, stream_nt);
+             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2 nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d split=%d | nt_loads=%d",
+             M, K, pl.s1.tb ? "skinny" : "", pl.t1.tiled ? (pl.s1.tb ? "+tiled" : "tiled") : "", pl.s1.nt,
+             pl.s1.tb, pl.s1.kw, pl.s2.nt, pl.s2.tb, pl.s2.sk, pl.t1.nt, pl.t2.nt, tile_rows, pl.t1.waves,
+             pl.split_rows, stream_nt);
     return LKM_OK;
 }
 
@@ -692,9 +727,11 @@ extern "C" int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots,
     LKM_REQUIRE(n_slots >= 0 && E > 0, "sort_slots: bad sizes");
     // active/meta scratch: borrow the tail of a temporary allocation
     int32_t* tmp = nullptr;
-    LKM_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(int32_t) * ((size_t)E + 8)));
+    const size_t hist_cap = n_slots > 4096 ? ((size_t)n_slots / 1024 + 1) * E : 0;
+    LKM_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(int32_t) * ((size_t)E + 8 + hist_cap)));
+    int32_t* hist = hist_cap ? tmp + E + 8 : nullptr;
     int rc = launch_sort((hipStream_t)stream, ids, n_slots, E, counts, offsets, sorted_slot,
-                         pos_of_slot, tmp, tmp + E, 0, nullptr, nullptr);
+                         pos_of_slot, tmp, tmp + E, 0, 0, nullptr, nullptr, hist, hist_cap);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(tmp);
     if (rc != LKM_OK) return rc;
@@ -764,6 +801,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "waves")) h->t_waves = value;
     else if (!strcmp(key, "tmask")) h->t_tmask = value ? value : 3;
     else if (!strcmp(key, "dbg")) h->t_dbg = value;
+    else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else {
         set_error("lkm_set_tuning: unknown key '%s'", key);
         return LKM_E_INVALID;

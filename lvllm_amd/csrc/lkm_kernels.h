@@ -21,7 +21,8 @@ int launch_repack_s_fp8(hipStream_t st, const void* src, void* dst, const Repack
 // ---- dispatch.hip
 int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
                 int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
-                int32_t* meta, int tile_rows, int32_t* tile_e, int32_t* tile_r0);
+                int32_t* meta, int tile_rows, int tile_min, int32_t* tile_e, int32_t* tile_r0,
+                int32_t* hist, size_t hist_cap);
 int launch_quant_fp8_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, void* dst,
                           float* scales);
 int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
@@ -58,6 +59,8 @@ struct GemmParams {
     const int32_t* sorted_slot;
     const int32_t* tile_e;   // tiled kernels: work list of (expert, first row) token tiles
     const int32_t* tile_r0;
+    int max_rows;            // skinny kernels: skip experts with more rows than this (0 = no limit);
+                             // they are handled by the tiled kernels of the same step (hybrid dispatch)
     int stream_nt;           // 1: weights are read once (decode) -> nontemporal loads
     int dbg;                 // development switches
     // outputs

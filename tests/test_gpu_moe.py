@@ -173,6 +173,26 @@ def test_dense_tiled_path_multi_tile_ragged(M, E, K, H, I, tiled):
     np.testing.assert_allclose(_run_decode(eng, a, tw, ids), out, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("M,E,K,H,I,skew", [(100, 16, 2, 256, 128, 3.0), (256, 32, 1, 512, 256, 2.0),
+                                              (90, 64, 4, 128, 64, 4.0)])
+def test_hybrid_dispatch_skewed_routing(M, E, K, H, I, skew):
+    """Zipf-skewed routing: a few experts get many rows (tiled kernel), most get few (streamer);
+    both kernels run in the same step on disjoint experts."""
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=M + 3, skew=skew)
+    counts = np.bincount(ids[ids >= 0].ravel(), minlength=E)
+    eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+    out = _run_decode(eng, a, tw, ids)
+    desc = eng.engine.describe()
+    assert "skinny+tiled" in desc, desc
+    split = int(desc.split("split=")[1].split()[0])
+    assert counts.max() > split > counts.min(), (counts, split)      # both kernels really had work
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+    np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL)
+    eng.engine.set_tuning(hybrid=-1)
+    np.testing.assert_allclose(_run_decode(eng, a, tw, ids), out, atol=1e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize("fmt", ["int4", "fp8"])
 def test_quantised_tiled_path(fmt):
     M, E, K, H, I = 160, 4, 2, 256, 256

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Runs bench.py over every BASELINE.json configuration that fits one GPU (and the per-rank slice of
+the EP=8 one), uniform and Zipf routing, and writes a markdown table + the raw JSON lines.
+  python tools/report.py [out_dir]          (on the GPU box)
+"""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+OUT = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out"
+RUNS = [
+    ("1 Qwen3-30B-A3B bf16 M=1", "qwen3_30b_a3b_bf16_decode_m1", 300, 2.5e3, 2.0),
+    ("2 Mixtral-8x7B bf16 M=32", "mixtral8x7b_bf16_decode_m32", 200, 2.5e3, 2.0),
+    ("2b Mixtral-8x7B fp8-W8A8 M=32", "mixtral8x7b_fp8w8a8_decode_m32", 200, 2.5e3, 1.0),
+    ("3 Mixtral-8x7B int4-g128 M=128", "mixtral8x7b_int4g128_decode_m128", 200, 2.5e3, 0.5),
+    ("4 DSv3-style fp8-W8A8, EP=8 rank slice (32 experts, 256 rows)", "dsv3_ep8_rank_fp8w8a8_rows256", 200, 2.5e3, 1.0),
+    ("4b same, fp8-W8A16 (lk_moe semantics)", "dsv3_ep8_rank_fp8w8a16_rows256", 200, 2.5e3, 1.0),
+    ("5 GLM-4.5-Air prefill M=8192 (bf16 weights)", "glm45air_bf16_prefill_m8192", 20, 2.5e3, 2.0),
+]
+
+
+def run(workload, steps, routing):
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", workload, "--steps", str(steps), "--warmup",
+           "5", "--no-cpu-baseline", "--routing", routing]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            return json.loads(line)
+    raise RuntimeError(f"{workload}: no JSON line\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    rows, raw = [], []
+    for name, wl, steps, mfma_peak, _ in RUNS:
+        for routing in ("uniform", "zipf"):
+            try:
+                j = run(wl, steps, routing)
+            except Exception as e:  # keep going: one failing config must not hide the others
+                rows.append(f"| {name} | {routing} | FAILED: {str(e)[:80]} |")
+                continue
+            raw.append(j)
+            rf, lay, km = j["roofline"], j["roofline"]["layer"], j["roofline"]["kernel_ms"]
+            g1 = rf["achieved"]
+            rows.append(
+                f"| {name} | {routing} | {j['ms_per_step']*1e3:.1f} | {j['value']:.0f} | {lay['routed_rows']} / {lay['experts_hit']} | "
+                f"{km['sort']*1e3:.1f} / {km['gemm1']*1e3:.1f} / {km['gemm2']*1e3:.1f} / {km['combine']*1e3:.1f} | "
+                f"{g1:.0f} ({g1/80:.1f} %) | {lay['GBps_over_step']:.0f} ({lay['GBps_over_step']/80:.1f} %) | "
+                f"{lay['TFLOPs_over_step']:.1f} ({lay['TFLOPs_over_step']/mfma_peak*100:.2f} %) | {j['config']['geometry'].split('|',2)[2].strip()} |")
+    hdr = ("| config | routing | step µs (graph, incl. router) | tokens/s | routed rows / experts hit | "
+           "kernel µs sort / gemm1 / gemm2 / combine (HIP events) | GEMM1 GB/s (% of 8 TB/s) | layer weight GB/s over the whole step (%) | "
+           "layer TFLOP/s (% of 2.5 PF bf16 MFMA) | geometry |\n|---|---|---|---|---|---|---|---|---|---|")
+    md = hdr + "\n" + "\n".join(rows) + "\n"
+    (OUT / "report.md").write_text(md)
+    (OUT / "report.jsonl").write_text("\n".join(json.dumps(x) for x in raw) + "\n")
+    print(md)
+
+
+if __name__ == "__main__":
+    main()

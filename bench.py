@@ -44,6 +44,8 @@ WORKLOADS = {
     "dsv3_ep8_rank_fp8w8a8_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="fp8", fp8_mode=1),
     "dsv3_ep8_rank_fp8w8a16_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="fp8", fp8_mode=0),
     "mixtral8x7b_fp8w8a8_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="fp8", fp8_mode=1),
+    "glm45air_fp8w8a16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=0),
+    "glm45air_fp8w8a8_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=1),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 

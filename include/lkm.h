@@ -199,8 +199,9 @@ int lkm_get_profile(LkmHandle h, float* ms /* [LKM_PROF_N] */);
 /* HBM bytes held by this engine (weights + scales), and its launch geometry as text. */
 int64_t lkm_weight_bytes(LkmHandle h);
 int lkm_describe(LkmHandle h, char* buf, int32_t buf_len);
-/* tuning knobs (bench / tests): key in {"nt1","nt2","kw1","sk2","tbmax","tiled","waves"};
- * value 0 = auto ("tiled": -1 forces the skinny streamer, 64 / 128 force a token-tile size) */
+/* tuning knobs (bench / tests): key in {"nt1","nt2","kw1","sk2","tbmax","tiled","waves","hybrid"};
+ * value 0 = auto ("tiled": -1 forces the skinny streamer, 64 / 128 force a token-tile size;
+ * "hybrid": -1 disables the skinny+tiled split by rows-per-expert) */
 int lkm_set_tuning(LkmHandle h, const char* key, int32_t value);
 
 /* Measures the HBM *read* ceiling of the device with the access shape of the expert-weight stream

@@ -155,7 +155,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_tmask = 3, t_dbg = 0, t_hybrid = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -461,7 +461,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
     // 714 us vs tiled64 585 us; 64-row tiles beat 128-row tiles up to M=512, 4 waves beat 8.
     int tiled = 0, split = 0;
     if (!h->a8) {   // the LDS-staged kernels take 16-bit activations
-        if (M > 32 && avg_rows > 24) tiled = 64;
+        if (M > 32 && avg_rows > 24) tiled = avg_rows >= 192 ? 128 : 64;   // GLM prefill (512 rows/expert): 128-row tiles 4.1 ms vs 5.3-5.7 ms
         else if (M > 16 * tb && h->t_hybrid >= 0) { tiled = 64; split = 16 * tb; }
         if (h->t_tiled > 0) { tiled = h->t_tiled; split = 0; }
         if (h->t_tiled < 0) { tiled = 0; split = 0; }
@@ -475,7 +475,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
         const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : 1;
         pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves};
         pl->t2 = LaunchCfg{nt2, tiled / 16, 1, 1, tiled, waves};
-        if (!split && h->t_tmask == 3) return;
+        if (!split) return;
     }
     // ---- skinny geometry (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4;
     // otherwise nt*tb<=8)
@@ -505,11 +505,6 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
     const size_t y_rows = h->arena->y_elems / h->H;
     while (sk > 1 && (size_t)sk * n_slots > y_rows) sk /= 2;
     pl->s2 = LaunchCfg{nt2, tb, 1, sk, 0, 0};
-    if (tiled && !split) {   // development: tiled on one GEMM only
-        if (h->t_tmask & 1) pl->s1.tb = 0; else pl->t1.tiled = 0;
-        if (h->t_tmask & 2) { pl->s2.tb = 0; } else pl->t2.tiled = 0;
-        if (pl->t2.tiled == 0) {} else pl->s2.sk = 1;
-    }
 }
 
 // one chunk: rows [0,M) of the given pointers
@@ -567,8 +562,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.tile_e = a->tile_e;
     p1.tile_r0 = a->tile_r0;
     p1.max_rows = pl.split_rows;
-    p1.stream_nt = (h->t_dbg & 4) ? 0 : stream_nt;
-    p1.dbg = h->t_dbg;
+    p1.stream_nt = stream_nt;
     p1.out = a->act;
     p1.ldo = h->ld_act;
     p1.sk_stride = 0;
@@ -613,8 +607,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.tile_e = a->tile_e;
     p2.tile_r0 = a->tile_r0;
     p2.max_rows = pl.split_rows;
-    p2.stream_nt = (h->t_dbg & 4) ? 0 : stream_nt;
-    p2.dbg = h->t_dbg;
+    p2.stream_nt = stream_nt;
     p2.out = a->y;
     p2.ldo = h->H;
     p2.sk_stride = n_slots * (size_t)h->H;
@@ -799,8 +792,6 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "tbmax")) h->t_tb = value;
     else if (!strcmp(key, "tiled")) h->t_tiled = value;
     else if (!strcmp(key, "waves")) h->t_waves = value;
-    else if (!strcmp(key, "tmask")) h->t_tmask = value ? value : 3;
-    else if (!strcmp(key, "dbg")) h->t_dbg = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else {
         set_error("lkm_set_tuning: unknown key '%s'", key);

@@ -62,7 +62,6 @@ struct GemmParams {
     int max_rows;            // skinny kernels: skip experts with more rows than this (0 = no limit);
                              // they are handled by the tiled kernels of the same step (hybrid dispatch)
     int stream_nt;           // 1: weights are read once (decode) -> nontemporal loads
-    int dbg;                 // development switches
     // outputs
     void* out;  // GEMM1: act [rows][ldo] act dtype ; GEMM2: y [SK][sk_stride] fp32
     int ldo;

@@ -12,6 +12,10 @@ int launch_gemm1_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, bo
 int launch_gemm2_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 int launch_gemm1_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
 int launch_gemm2_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
+int launch_gemm1_tiled_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
+int launch_gemm2_tiled_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
+int launch_gemm1_tiled_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
+int launch_gemm2_tiled_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 
 int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                  bool gated, int max_active) {
@@ -52,6 +56,8 @@ int launch_gemm1_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, co
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm1_tiled_int4_f16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm1_tiled_fp8_bf16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm1_tiled_fp8_f16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm1_tiled_fp8a8_bf16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm1_tiled_fp8a8_f16(st, cfg, p, gated, max_tiles);
     set_error("gemm1 tiled: unsupported weight format %d with activation dtype %d", wf, adt);
     return LKM_E_UNSUPPORTED;
 }
@@ -65,6 +71,8 @@ int launch_gemm2_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, co
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm2_tiled_int4_f16(st, cfg, p, max_tiles);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm2_tiled_fp8_bf16(st, cfg, p, max_tiles);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm2_tiled_fp8_f16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm2_tiled_fp8a8_bf16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm2_tiled_fp8a8_f16(st, cfg, p, max_tiles);
     set_error("gemm2 tiled: unsupported weight format %d with activation dtype %d", wf, adt);
     return LKM_E_UNSUPPORTED;
 }

@@ -25,15 +25,16 @@ __device__ __forceinline__ int x_swizzle(int row) {
 template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1>
 __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     typedef Dec<WF, ADT> D;
-    static_assert(!D::A8, "the LDS-staged kernels take 16-bit activations (W8A8 uses the streamer)");
     constexpr int NTT = (IS_G1 && GATED) ? 2 * NT : NT;
     constexpr int TM = TBW * 16;
     constexpr int THREADS = WAVES * 64;
-    constexpr int ROWB = D::UNITK * 2;   // bytes of one token row per K unit
+    constexpr int XB = D::A8 ? 1 : 2;            // bytes per activation element (fp8 when W8A8)
+    constexpr int ROWB = D::UNITK * XB;          // bytes of one token row per K unit
     constexpr int SLOTS = ROWB / 16;
+    constexpr int BUFB = TM * ROWB + (D::A8 ? TM * 4 : 0);   // + per-row activation scales (W8A8)
     constexpr int PIECES = TM * SLOTS / THREADS;
     static_assert(PIECES >= 1 && TM * SLOTS % THREADS == 0, "staging split");
-    extern __shared__ __attribute__((aligned(16))) char xlds[];   // [2][TM][ROWB]
+    extern __shared__ __attribute__((aligned(16))) char xlds[];   // [2]{[TM][ROWB], A8: float[TM]}
 
     // Work mapping: blockIdx.x = row group (fastest), blockIdx.y = (expert, token tile) item, default
     // round-robin XCD placement.  Measured and NOT used: (1) a "contiguous run of items per XCD" remap
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     }
 
     // staging assignment of this thread: PIECES 16-byte pieces per unit
-    const unsigned short* xrow[PIECES];
-    int xsrc_off[PIECES];   // element offset of the piece inside the unit (logical slot * 8)
+    const unsigned char* xrow[PIECES];
+    int xsrc_off[PIECES];   // element offset of the piece inside the unit
     int xdst[PIECES];       // byte offset inside one LDS buffer
 #pragma unroll
     for (int q = 0; q < PIECES; ++q) {
@@ -74,13 +75,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
         const int rr = r < m_e ? r : r0;
         if (IS_G1) {
             const int slot = p.sorted_slot[off_e + rr];
-            xrow[q] = (const unsigned short*)p.x + (size_t)(slot / p.top_k) * p.ldx;
+            xrow[q] = (const unsigned char*)p.x + (size_t)(slot / p.top_k) * p.ldx * XB;
         } else {
-            xrow[q] = (const unsigned short*)p.x + (size_t)(off_e + rr) * p.ldx;
+            xrow[q] = (const unsigned char*)p.x + (size_t)(off_e + rr) * p.ldx * XB;
         }
-        xsrc_off[q] = lslot * 8;   // slot ks*4+g holds k = ks*32 + g*8 .. +7
+        // 16-bit: slot ks*4+g holds k = ks*32 + g*8 .. +7;  fp8: slot i*4+g holds k = i*64 + g*16 .. +15
+        xsrc_off[q] = lslot * (16 / XB);
         xdst[q] = row * ROWB + pslot * 16;
     }
+    // W8A8: thread `tid` < TM also stages the activation scale of token row tid for the unit
+    const float* xsrow = nullptr;
+    if (D::A8 && tid < TM) {
+        const int r = r0 + tid;
+        const int rr = r < m_e ? r : r0;
+        const size_t rowidx = IS_G1 ? (size_t)(p.sorted_slot[off_e + rr] / p.top_k) : (size_t)(off_e + rr);
+        xsrow = p.xscale + rowidx * p.ld_xscale;
+    }
+    float xsv = 0.0f;
 
     f32x4 acc[NTT][TBW];
 #pragma unroll
@@ -103,13 +114,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
         for (int q = 0; q < PIECES; ++q) {
             const int k = u * D::UNITK + xsrc_off[q];
             if (!tail) {
-                xs[q] = *(const u32x4*)(xrow[q] + k);
+                xs[q] = *(const u32x4*)(xrow[q] + (size_t)k * XB);
             } else {
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (k + 8 <= p.Kreal) v = *(const u32x4*)(xrow[q] + k);
+                if (k + 16 / XB <= p.Kreal) v = *(const u32x4*)(xrow[q] + (size_t)k * XB);
                 xs[q] = v;
             }
         }
+        if (D::A8 && tid < TM) xsv = xsrow[u];
     };
     auto load_w = [&](WStage& s, int u) {
         if (wave_on) {
@@ -126,12 +138,46 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     };
     auto store_x = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < PIECES; ++q) *(u32x4*)(xlds + buf * (TM * ROWB) + xdst[q]) = xs[q];
+        for (int q = 0; q < PIECES; ++q) *(u32x4*)(xlds + buf * BUFB + xdst[q]) = xs[q];
+        if (D::A8 && tid < TM) *(float*)(xlds + buf * BUFB + TM * ROWB + tid * 4) = xsv;
     };
     auto compute = [&](const WStage& s, int buf) {
         if (!wave_on) return;
-        const char* xb = xlds + buf * (TM * ROWB);
-        if constexpr (D::UNIT_SCALE) {
+        const char* xb = xlds + buf * BUFB;
+        if constexpr (D::A8) {
+            // fp8 x fp8: one ds_read_b128 = the token operand of a PAIR of k-steps
+            f32x4 part[NTT][TBW];
+#pragma unroll
+            for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                for (int b = 0; b < TBW; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < D::KSTEPS / 2; ++i) {
+                u32x4 bf[TBW];
+#pragma unroll
+                for (int b = 0; b < TBW; ++b) {
+                    const int row = b * 16 + j;
+                    bf[b] = *(const u32x4*)(xb + row * ROWB + (((i * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) {
+                        const long a = D::frag8(s.w[t], 2 * i + q);
+#pragma unroll
+                        for (int b = 0; b < TBW; ++b)
+                            part[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                                a, __builtin_bit_cast(long, u32x2{bf[b][q * 2], bf[b][q * 2 + 1]}), part[t][b],
+                                0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int b = 0; b < TBW; ++b) {
+                const float xsc = *(const float*)(xb + TM * ROWB + (b * 16 + j) * 4);
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) acc[t][b] += (s.aux[t].s * xsc) * part[t][b];
+            }
+        } else if constexpr (D::UNIT_SCALE) {
             f32x4 part[NTT][TBW];
 #pragma unroll
             for (int t = 0; t < NTT; ++t)
@@ -254,8 +300,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
 
 template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1>
 static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
-    constexpr int ROWB = Dec<WF, ADT>::UNITK * 2;
-    constexpr size_t lds = (size_t)2 * TBW * 16 * ROWB;
+    constexpr int ROWB = Dec<WF, ADT>::UNITK * (Dec<WF, ADT>::A8 ? 1 : 2);
+    constexpr size_t lds = (size_t)2 * (TBW * 16 * ROWB + (Dec<WF, ADT>::A8 ? TBW * 16 * 4 : 0));
     dim3 grid(ceil_div(p.T_half, WAVES * NT), max_tiles), block(WAVES * 64);
     auto kern = gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1>;
     if (lds > 64 * 1024) {

@@ -460,8 +460,11 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
     // Mixtral bf16: M=64 (16 rows/expert) skinny 537 us vs tiled 570 us; M=128 (32 rows/expert) skinny
     // 714 us vs tiled64 585 us; 64-row tiles beat 128-row tiles up to M=512, 4 waves beat 8.
     int tiled = 0, split = 0;
-    if (!h->a8) {   // the LDS-staged kernels take 16-bit activations
-        if (M > 32 && avg_rows > 24) tiled = avg_rows >= 192 ? 128 : 64;   // GLM prefill (512 rows/expert): 128-row tiles 4.1 ms vs 5.3-5.7 ms
+    {
+        // 128-row tiles only for 16-bit weights at prefill sizes (GLM, 512 rows/expert: 4.1 ms vs
+        // 5.3-5.7 ms with 64-row tiles); the fp8/int4 decoders run out of registers there.
+        const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
+        if (M > 32 && avg_rows > 24) tiled = (avg_rows >= 192 && w16) ? 128 : 64;
         else if (M > 16 * tb && h->t_hybrid >= 0) { tiled = 64; split = 16 * tb; }
         if (h->t_tiled > 0) { tiled = h->t_tiled; split = 0; }
         if (h->t_tiled < 0) { tiled = 0; split = 0; }

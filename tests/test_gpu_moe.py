@@ -121,6 +121,12 @@ def test_fp8_w8a8_larger_random():
                     round_gemm1=True, w8a8=True)
     ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
     np.testing.assert_allclose(out, ref, atol=1e-2 * float(np.abs(ref).max()), rtol=2e-2)
+    # the LDS-staged tiled kernels compute the same thing (same 128-k partial sums, same scaling)
+    for tiled, waves in ((64, 4), (64, 8), (128, 8)):
+        eng.engine.set_tuning(tiled=tiled, waves=waves)
+        np.testing.assert_allclose(_run_decode(eng, a, tw, ids), out, atol=1e-5, rtol=1e-5,
+                                   err_msg=eng.engine.describe())
+    eng.engine.set_tuning(tiled=0, waves=0)
     # and W8A8 stays within activation-quantisation noise of the weight-only result
     eng16 = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
                  w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128)

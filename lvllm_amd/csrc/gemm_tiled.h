@@ -203,19 +203,26 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
 #pragma unroll
                 for (int b = 0; b < TBW; ++b) acc[t][b] += s.aux[t].s * part[t][b];
         } else {
+            // token fragments are read 8 blocks at a time so that the 256-row tile (TBW = 16) keeps
+            // its 2 x 16 accumulators in registers
+            constexpr int BCH = TBW > 8 ? 8 : TBW;
 #pragma unroll
             for (int ks = 0; ks < D::KSTEPS; ++ks) {
-                u32x4 bf[TBW];
+                u32x4 a[NTT];
 #pragma unroll
-                for (int b = 0; b < TBW; ++b) {
-                    const int row = b * 16 + j;
-                    bf[b] = *(const u32x4*)(xb + row * ROWB + (((ks * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
-                }
+                for (int t = 0; t < NTT; ++t) a[t] = D::frag(s.w[t], s.aux[t], ks, p.spu);
 #pragma unroll
-                for (int t = 0; t < NTT; ++t) {
-                    const u32x4 a = D::frag(s.w[t], s.aux[t], ks, p.spu);
+                for (int b0 = 0; b0 < TBW; b0 += BCH) {
+                    u32x4 bf[BCH];
 #pragma unroll
-                    for (int b = 0; b < TBW; ++b) acc[t][b] = ActT<ADT>::mfma(a, bf[b], acc[t][b]);
+                    for (int b = 0; b < BCH; ++b) {
+                        const int row = (b0 + b) * 16 + j;
+                        bf[b] = *(const u32x4*)(xb + row * ROWB + (((ks * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
+                    }
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                        for (int b = 0; b < BCH; ++b) acc[t][b0 + b] = ActT<ADT>::mfma(a[t], bf[b], acc[t][b0 + b]);
                 }
             }
         }
@@ -313,6 +320,16 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
 }
 
 // tiled variants built per format: (TM, WAVES, NT) = (64,4,1) (64,8,1) (128,8,1) (128,8,2 non-gated)
+// and, for 16-bit weights only, (256,8,1): the prefill tile (weights re-read once per 256 tokens)
+template <int WF>
+struct W16Only {
+    static constexpr bool value = WF == LKM_W_BF16 || WF == LKM_W_F16;
+};
+#define LKM_TILED_CASE_W16(TBW, WAVES, NT, G, IS1)                                              \
+    if constexpr (W16Only<WF_>::value) {                                                        \
+        if (cfg.tiled == TBW * 16 && cfg.waves == WAVES && cfg.nt == NT)                        \
+            return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1>(st, p, max_tiles);         \
+    }
 #define LKM_TILED_CASE(TBW, WAVES, NT, G, IS1)                                             \
     if (cfg.tiled == TBW * 16 && cfg.waves == WAVES && cfg.nt == NT)                      \
         return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1>(st, p, max_tiles);
@@ -325,11 +342,13 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
             LKM_TILED_CASE(4, 4, 1, true, true)                                                       \
             LKM_TILED_CASE(4, 8, 1, true, true)                                                       \
             LKM_TILED_CASE(8, 8, 1, true, true)                                                       \
+            LKM_TILED_CASE_W16(16, 8, 1, true, true)                                                  \
         } else {                                                                                      \
             LKM_TILED_CASE(4, 4, 1, false, true)                                                      \
             LKM_TILED_CASE(4, 8, 1, false, true)                                                      \
             LKM_TILED_CASE(8, 8, 1, false, true)                                                      \
             LKM_TILED_CASE(8, 8, 2, false, true)                                                      \
+            LKM_TILED_CASE_W16(16, 8, 1, false, true)                                                 \
         }                                                                                             \
         set_error("gemm1 tiled: variant tm=%d waves=%d nt=%d gated=%d not built", cfg.tiled,          \
                   cfg.waves, cfg.nt, (int)gated);                                                     \
@@ -343,6 +362,8 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
         LKM_TILED_CASE(4, 4, 2, false, false)                                                         \
         LKM_TILED_CASE(8, 8, 1, false, false)                                                         \
         LKM_TILED_CASE(8, 8, 2, false, false)                                                         \
+        LKM_TILED_CASE_W16(16, 8, 1, false, false)                                                    \
+        LKM_TILED_CASE_W16(16, 8, 2, false, false)                                                    \
         set_error("gemm2 tiled: variant tm=%d waves=%d nt=%d not built", cfg.tiled, cfg.waves,        \
                   cfg.nt);                                                                            \
         return LKM_E_INVALID;                                                                         \

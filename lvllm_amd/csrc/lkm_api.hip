@@ -465,6 +465,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
         // 5.3-5.7 ms with 64-row tiles); the fp8/int4 decoders run out of registers there.
         const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
         if (M > 32 && avg_rows > 24) tiled = (avg_rows >= 192 && w16) ? 128 : 64;
+        if (tiled == 128 && avg_rows >= 384) tiled = 256;
         else if (M > 16 * tb && h->t_hybrid >= 0) { tiled = 64; split = 16 * tb; }
         if (h->t_tiled > 0) { tiled = h->t_tiled; split = 0; }
         if (h->t_tiled < 0) { tiled = 0; split = 0; }
@@ -473,9 +474,9 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
     pl->t1 = pl->t2 = LaunchCfg{0, 0, 0, 0, 0, 0};
     pl->s1 = pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0};
     if (tiled) {
-        const int waves = h->t_waves > 0 ? h->t_waves : (tiled == 128 ? 8 : 4);
+        const int waves = h->t_waves > 0 ? h->t_waves : (tiled >= 128 ? 8 : 4);
         const int nt1 = (h->t_nt1 > 0 && !split) ? h->t_nt1 : 1;
-        const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : 1;
+        const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : (tiled == 256 ? 2 : 1);   // GLM: 3.61 vs 3.81 ms
         pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves};
         pl->t2 = LaunchCfg{nt2, tiled / 16, 1, 1, tiled, waves};
         if (!split) return;

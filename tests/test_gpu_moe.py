@@ -162,7 +162,7 @@ def test_dense_random_shapes_ragged(M, E, K, H, I):
 
 
 @pytest.mark.parametrize("M,E,K,H,I,tiled", [
-    (150, 2, 2, 256, 128, 128), (200, 64, 6, 128, 64, 64), (500, 4, 2, 136, 200, 128),
+    (150, 2, 2, 256, 128, 128), (200, 64, 6, 128, 64, 64), (500, 4, 2, 136, 200, 128), (700, 2, 2, 256, 128, 256),
     (90, 8, 2, 512, 256, 64), (1000, 16, 4, 256, 128, 0),
 ])
 def test_dense_tiled_path_multi_tile_ragged(M, E, K, H, I, tiled):
@@ -246,7 +246,8 @@ def test_all_launch_geometries_agree():
             out = _run_decode(eng, a, tw, ids)
             np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())
     # LDS-staged tiled kernels (gemm_tiled.h)
-    for tiled, waves, nt1, nt2 in ((64, 4, 1, 1), (64, 8, 1, 1), (64, 4, 1, 2), (128, 8, 1, 1), (128, 8, 1, 2)):
+    for tiled, waves, nt1, nt2 in ((64, 4, 1, 1), (64, 8, 1, 1), (64, 4, 1, 2), (128, 8, 1, 1), (128, 8, 1, 2),
+                                   (256, 8, 1, 1), (256, 8, 1, 2)):
         eng.engine.set_tuning(tiled=tiled, waves=waves, nt1=nt1, nt2=nt2, tbmax=0, kw1=0, sk2=0)
         out = _run_decode(eng, a, tw, ids)
         np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())

@@ -464,9 +464,14 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
         // 128-row tiles only for 16-bit weights at prefill sizes (GLM, 512 rows/expert: 4.1 ms vs
         // 5.3-5.7 ms with 64-row tiles); the fp8/int4 decoders run out of registers there.
         const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
-        if (M > 32 && avg_rows > 24) tiled = (avg_rows >= 192 && w16) ? 128 : 64;
-        if (tiled == 128 && avg_rows >= 384) tiled = 256;
-        else if (M > 16 * tb && h->t_hybrid >= 0) { tiled = 64; split = 16 * tb; }
+        if (M > 32 && avg_rows > 24) {
+            tiled = 64;
+            if (w16 && avg_rows >= 192) tiled = 128;
+            if (w16 && avg_rows >= 384) tiled = 256;   // GLM: 3.6 ms vs 4.1 ms (128) vs 5.3 ms (64)
+        } else if (M > 16 * tb && h->t_hybrid >= 0) {
+            tiled = 64;
+            split = 16 * tb;
+        }
         if (h->t_tiled > 0) { tiled = h->t_tiled; split = 0; }
         if (h->t_tiled < 0) { tiled = 0; split = 0; }
     }

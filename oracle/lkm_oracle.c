@@ -432,23 +432,39 @@ static void dequant_row(const OrMoeDesc* d, const void* w, const void* scale, in
     }
 }
 
-/* dot of one f32 weight row against R f32 activation rows, 16-lane partial sums
-   (fixed order -> deterministic; vectorises without -ffast-math) */
+/* dot of one f32 weight row against R f32 activation rows.  16-lane partial sums per row, rows
+   processed 8 at a time so that the 8 accumulator chains are independent (the summation order per
+   row is fixed -> deterministic; vectorises without -ffast-math). */
 __attribute__((target_clones("avx512f", "default")))
 static void dot_rows(const float* w, const float* x, int64_t ldx, int R, int64_t K,
                      float* out) {
-    for (int r = 0; r < R; ++r) {
-        const float* xr = x + (size_t)r * ldx;
-        float acc[16];
-        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    for (int r0 = 0; r0 < R; r0 += 8) {
+        const int rn = R - r0 < 8 ? R - r0 : 8;
+        float acc[8][16];
+        for (int r = 0; r < 8; ++r)
+            for (int j = 0; j < 16; ++j) acc[r][j] = 0.0f;
         int64_t k = 0;
-        for (; k + 16 <= K; k += 16)
-            for (int j = 0; j < 16; ++j) acc[j] += w[k + j] * xr[k + j];
-        float t = 0.0f;
-        for (; k < K; ++k) t += w[k] * xr[k];
-        for (int s = 8; s > 0; s >>= 1)
-            for (int j = 0; j < s; ++j) acc[j] += acc[j + s];
-        out[r] = acc[0] + t;
+        if (rn == 8) {
+            for (; k + 16 <= K; k += 16)
+                for (int r = 0; r < 8; ++r) {
+                    const float* xr = x + (size_t)(r0 + r) * ldx + k;
+                    for (int j = 0; j < 16; ++j) acc[r][j] += w[k + j] * xr[j];
+                }
+        } else {
+            for (; k + 16 <= K; k += 16)
+                for (int r = 0; r < rn; ++r) {
+                    const float* xr = x + (size_t)(r0 + r) * ldx + k;
+                    for (int j = 0; j < 16; ++j) acc[r][j] += w[k + j] * xr[j];
+                }
+        }
+        for (int r = 0; r < rn; ++r) {
+            const float* xr = x + (size_t)(r0 + r) * ldx;
+            float t = 0.0f;
+            for (int64_t kk = k; kk < K; ++kk) t += w[kk] * xr[kk];
+            for (int s = 8; s > 0; s >>= 1)
+                for (int j = 0; j < s; ++j) acc[r][j] += acc[r][j + s];
+            out[r0 + r] = acc[r][0] + t;
+        }
     }
 }
 
@@ -524,7 +540,7 @@ LKM_OR_API int lkm_or_moe(const OrMoeDesc* d, const void* w13, const void* w2, c
     {
         float* wrow = (float*)malloc(sizeof(float) * (size_t)(H > I ? H : I));
         float* tmp = (float*)malloc(sizeof(float) * 4096);
-#pragma omp for schedule(dynamic, 64) collapse(1)
+#pragma omp for schedule(runtime)
         for (int64_t task = 0; task < E * N1; ++task) {
             int64_t e = task / N1, n = task % N1;
             int R = counts[e];
@@ -597,7 +613,7 @@ LKM_OR_API int lkm_or_moe(const OrMoeDesc* d, const void* w13, const void* w2, c
     {
         float* wrow = (float*)malloc(sizeof(float) * (size_t)(H > I ? H : I));
         float* tmp = (float*)malloc(sizeof(float) * 4096);
-#pragma omp for schedule(dynamic, 64)
+#pragma omp for schedule(runtime)
         for (int64_t task = 0; task < E * H; ++task) {
             int64_t e = task / H, h = task % H;
             int R = counts[e];
@@ -730,6 +746,16 @@ LKM_OR_API void lkm_or_fp8_to_f32(const uint8_t* src, int64_t n, float* dst) {
 }
 LKM_OR_API void lkm_or_f32_to_fp8(const float* src, int64_t n, uint8_t* dst) {
     for (int64_t i = 0; i < n; ++i) dst[i] = f32_to_fp8e4m3(src[i]);
+}
+
+/* threads > 0 sets the OpenMP team size; the GEMM task loops use schedule(runtime) = dynamic,64 */
+LKM_OR_API void lkm_or_configure(int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+    omp_set_schedule(omp_sched_dynamic, 64);
+#else
+    (void)threads;
+#endif
 }
 
 LKM_OR_API int lkm_or_num_threads(void) {

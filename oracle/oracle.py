@@ -47,6 +47,7 @@ def lib() -> C.CDLL:
         _lib.lkm_or_expert_map.restype = C.c_int
         _lib.lkm_or_moe.restype = C.c_int
         _lib.lkm_or_num_threads.restype = C.c_int
+        _lib.lkm_or_configure(C.c_int(0))
     return _lib
 
 
@@ -226,6 +227,10 @@ def quant_fp8_block(w: np.ndarray, gN: int, gK: int):
         lib().lkm_or_quant_fp8_block(_p(w[e]), C.c_int64(N), C.c_int64(K), C.c_int(gN), C.c_int(gK),
                                      _p(q[e]), _p(s[e]))
     return q, s
+
+
+def set_threads(n: int) -> None:
+    lib().lkm_or_configure(C.c_int(int(n)))
 
 
 def num_threads() -> int:

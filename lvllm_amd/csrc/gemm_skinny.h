@@ -24,6 +24,7 @@
 //     combine kernel (dispatch.hip) reduces together with the top-k weighting.
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "lkm_kernels.h"
 
@@ -39,6 +40,10 @@ struct DecPlain {
     static constexpr bool UNIT_SCALE = false, A8 = false;
     struct Aux {};
     static __device__ __forceinline__ void load_aux(Aux&, const void*, size_t, int, int) {}
+    // pointer form (tiled kernels): aux_ptr(unit 0 of a tile) + u * aux_step(spu)
+    static __device__ __forceinline__ const char* aux_ptr(const void*, size_t, int, int) { return nullptr; }
+    static __device__ __forceinline__ int aux_step(int) { return 0; }
+    static __device__ __forceinline__ void load_aux_at(Aux&, const char*) {}
     static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux&, int ks, int) {
         return raw[ks];
     }
@@ -62,6 +67,13 @@ struct Dec<LKM_W_INT4_B8, ADT> {
     static __device__ __forceinline__ void load_aux(Aux& a, const void* sbase, size_t tu, int lane,
                                                     int spu) {
         const unsigned short* p = (const unsigned short*)sbase + (tu * 16 + (lane & 15)) * spu;
+        a.raw = *(const u32x2_unaligned*)p;
+    }
+    static __device__ __forceinline__ const char* aux_ptr(const void* sbase, size_t tu, int lane, int spu) {
+        return (const char*)((const unsigned short*)sbase + (tu * 16 + (lane & 15)) * spu);
+    }
+    static __device__ __forceinline__ int aux_step(int spu) { return 32 * spu; }
+    static __device__ __forceinline__ void load_aux_at(Aux& a, const char* p) {
         a.raw = *(const u32x2_unaligned*)p;
     }
     static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux& a, int ks,
@@ -102,6 +114,11 @@ struct Dec<LKM_W_FP8_E4M3, ADT> {
                                                     int) {
         a.s = *(const f32x4*)((const float*)sbase + tu * 16 + (lane >> 4) * 4);
     }
+    static __device__ __forceinline__ const char* aux_ptr(const void* sbase, size_t tu, int lane, int) {
+        return (const char*)((const float*)sbase + tu * 16 + (lane >> 4) * 4);
+    }
+    static __device__ __forceinline__ int aux_step(int) { return 64; }
+    static __device__ __forceinline__ void load_aux_at(Aux& a, const char* p) { a.s = *(const f32x4*)p; }
     static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux&, int ks, int) {
         const unsigned d0 = raw[ks >> 1][(ks & 1) * 2], d1 = raw[ks >> 1][(ks & 1) * 2 + 1];
         f32x2 p0 = __builtin_amdgcn_cvt_pk_f32_fp8(d0, false);
@@ -131,6 +148,11 @@ struct Dec<LKM_W_FP8_A8, ADT> {
                                                     int) {
         a.s = *(const f32x4*)((const float*)sbase + tu * 16 + (lane >> 4) * 4);
     }
+    static __device__ __forceinline__ const char* aux_ptr(const void* sbase, size_t tu, int lane, int) {
+        return (const char*)((const float*)sbase + tu * 16 + (lane >> 4) * 4);
+    }
+    static __device__ __forceinline__ int aux_step(int) { return 64; }
+    static __device__ __forceinline__ void load_aux_at(Aux& a, const char* p) { a.s = *(const f32x4*)p; }
     static __device__ __forceinline__ long frag8(const u32x4 (&raw)[LOADS], int ks) {
         const u32x2 v = {raw[ks >> 1][(ks & 1) * 2], raw[ks >> 1][(ks & 1) * 2 + 1]};
         return __builtin_bit_cast(long, v);
@@ -157,50 +179,52 @@ struct Streamer {
     typedef Stage<D, NTT, TB> St;
     static constexpr int XB = D::A8 ? 1 : 2;
 
+    // NTB = token blocks actually in use (compile time): the loop below contains no conditional load,
+    // which is what lets s_waitcnt leave the next stage in flight -- vector-memory loads retire in
+    // order and are counted, so a load under a branch anywhere in the loop turns every wait into
+    // vmcnt(0).  STEADY: the unit is not the last one of the K range, i.e. never a ragged K tail.
+    template <int NTB, bool STEADY>
     static __device__ __forceinline__ void load(St& st, const u32x4* const (&wp)[NTT],
-                                                const void* sbase, const size_t (&stu)[NTT], int spu,
+                                                const char* const (&auxp)[NTT], int aux_step,
                                                 const unsigned char* const (&xp)[TB],
-                                                const float* const (&xsp)[TB], int u, int Kreal,
-                                                int gk, int lane, int ntb) {
+                                                const float* const (&xsp)[TB], int u, int Kreal, int gk) {
 #pragma unroll
         for (int t = 0; t < NTT; ++t) {
 #pragma unroll
             for (int l = 0; l < D::LOADS; ++l)
                 st.w[t][l] = __builtin_nontemporal_load(wp[t] + ((size_t)u * D::LOADS + l) * 64);
-            D::load_aux(st.aux[t], sbase, stu[t] + u, lane, spu);
+            D::load_aux_at(st.aux[t], auxp[t] + (size_t)u * aux_step);
         }
         // Token rows beyond the expert's count point at a valid row (their D columns are never
-        // stored, and a B column cannot contaminate another), so the loads are unconditional:
-        // no exec-mask branches in the streaming loop.  Only a ragged K tail needs zero fill.
-        const bool tail = (u + 1) * D::UNITK > Kreal;   // wave-uniform, false for every model shape
+        // stored, and a B column cannot contaminate another), so the loads are unconditional.
+        const bool tail = !STEADY && (u + 1) * D::UNITK > Kreal;   // wave-uniform
 #pragma unroll
-        for (int b = 0; b < TB; ++b) {
-            if (b < ntb) {
-                if constexpr (D::A8) st.xs[b] = xsp[b][u];
+        for (int b = 0; b < NTB; ++b) {
+            if constexpr (D::A8) st.xs[b] = xsp[b][u];
 #pragma unroll
-                for (int i = 0; i < St::XN; ++i) {
-                    // 16-byte token loads: 8 x 16-bit = k-step i, or 16 x fp8 = the k-step pair i;
-                    // the four g-lanes of a row are adjacent (64 contiguous bytes per row per load)
-                    const int k = u * D::UNITK + i * (64 / XB) + gk;
-                    if (!tail) {
-                        st.x[b][i] = *(const u32x4*)(xp[b] + (size_t)k * XB);
-                    } else {
-                        u32x4 v = {0u, 0u, 0u, 0u};
-                        if (k + 16 / XB <= Kreal) v = *(const u32x4*)(xp[b] + (size_t)k * XB);
-                        st.x[b][i] = v;
-                    }
+            for (int i = 0; i < St::XN; ++i) {
+                // 16-byte token loads: 8 x 16-bit = k-step i, or 16 x fp8 = the k-step pair i;
+                // the four g-lanes of a row are adjacent (64 contiguous bytes per row per load)
+                const int k = u * D::UNITK + i * (64 / XB) + gk;
+                if (!tail) {
+                    st.x[b][i] = *(const u32x4*)(xp[b] + (size_t)k * XB);
+                } else {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (k + 16 / XB <= Kreal) v = *(const u32x4*)(xp[b] + (size_t)k * XB);
+                    st.x[b][i] = v;
                 }
             }
         }
     }
 
-    static __device__ __forceinline__ void compute(const St& st, f32x4 (&acc)[NTT][TB], int ntb, int spu) {
+    template <int NTB>
+    static __device__ __forceinline__ void compute(const St& st, f32x4 (&acc)[NTT][TB], int spu) {
         if constexpr (D::UNIT_SCALE) {
-            f32x4 part[NTT][TB];
+            f32x4 part[NTT][NTB];
 #pragma unroll
             for (int t = 0; t < NTT; ++t)
 #pragma unroll
-                for (int b = 0; b < TB; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < NTB; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < D::KSTEPS; ++ks)
 #pragma unroll
@@ -208,30 +232,27 @@ struct Streamer {
                     if constexpr (D::A8) {
                         const long a = D::frag8(st.w[t], ks);
 #pragma unroll
-                        for (int b = 0; b < TB; ++b)
-                            if (b < ntb)
-                                part[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                                    a,
-                                    __builtin_bit_cast(long, u32x2{st.x[b][ks >> 1][(ks & 1) * 2],
-                                                                   st.x[b][ks >> 1][(ks & 1) * 2 + 1]}),
-                                    part[t][b], 0, 0, 0);
+                        for (int b = 0; b < NTB; ++b)
+                            part[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                                a,
+                                __builtin_bit_cast(long, u32x2{st.x[b][ks >> 1][(ks & 1) * 2],
+                                                               st.x[b][ks >> 1][(ks & 1) * 2 + 1]}),
+                                part[t][b], 0, 0, 0);
                     } else {
                         const u32x4 a = D::frag(st.w[t], st.aux[t], ks, spu);
 #pragma unroll
-                        for (int b = 0; b < TB; ++b)
-                            if (b < ntb) part[t][b] = ActT<ADT>::mfma(a, st.x[b][ks], part[t][b]);
+                        for (int b = 0; b < NTB; ++b) part[t][b] = ActT<ADT>::mfma(a, st.x[b][ks], part[t][b]);
                     }
                 }
 #pragma unroll
             for (int t = 0; t < NTT; ++t)
 #pragma unroll
-                for (int b = 0; b < TB; ++b)
-                    if (b < ntb) {
-                        if constexpr (D::A8)
-                            acc[t][b] += (st.aux[t].s * st.xs[b]) * part[t][b];
-                        else
-                            acc[t][b] += st.aux[t].s * part[t][b];
-                    }
+                for (int b = 0; b < NTB; ++b) {
+                    if constexpr (D::A8)
+                        acc[t][b] += (st.aux[t].s * st.xs[b]) * part[t][b];
+                    else
+                        acc[t][b] += st.aux[t].s * part[t][b];
+                }
         } else {
 #pragma unroll
             for (int ks = 0; ks < D::KSTEPS; ++ks)
@@ -239,30 +260,71 @@ struct Streamer {
                 for (int t = 0; t < NTT; ++t) {
                     const u32x4 a = D::frag(st.w[t], st.aux[t], ks, spu);
 #pragma unroll
-                    for (int b = 0; b < TB; ++b)
-                        if (b < ntb) acc[t][b] = ActT<ADT>::mfma(a, st.x[b][ks], acc[t][b]);
+                    for (int b = 0; b < NTB; ++b) acc[t][b] = ActT<ADT>::mfma(a, st.x[b][ks], acc[t][b]);
                 }
         }
     }
 
-    static __device__ __forceinline__ void run(f32x4 (&acc)[NTT][TB], const u32x4* const (&wp)[NTT],
-                                               const void* sbase, const size_t (&stu)[NTT], int spu,
-                                               const unsigned char* const (&xp)[TB],
-                                               const float* const (&xsp)[TB], int u0, int u1, int Kreal,
-                                               int lane, int ntb) {
+    template <int NTB>
+    static __device__ __forceinline__ void run_n(f32x4 (&acc)[NTT][TB], const u32x4* const (&wp)[NTT],
+                                                 const char* const (&auxp)[NTT], int aux_step, int spu,
+                                                 const unsigned char* const (&xp)[TB],
+                                                 const float* const (&xsp)[TB], int u0, int u1, int Kreal,
+                                                 int lane) {
         const int gk = (lane >> 4) * (16 / XB);
         St st[2];
-        if (u0 < u1) load(st[0], wp, sbase, stu, spu, xp, xsp, u0, Kreal, gk, lane, ntb);
-        for (int u = u0; u < u1; u += 2) {
+        if (u0 >= u1) return;
+        load<NTB, false>(st[0], wp, auxp, aux_step, xp, xsp, u0, Kreal, gk);
+        // steady pairs: both look-ahead units stay below u1 - 1
+        const int um = u1 - 2 - u0 > 0 ? u0 + (u1 - 2 - u0) / 2 * 2 : u0;
+        int u = u0;
+        for (; u < um; u += 2) {
+            // sched_barrier: the next stage's loads are ISSUED before this stage's MFMAs (the
+            // scheduler otherwise sinks them below the MFMAs that last read those registers and the
+            // prefetch distance shrinks from a stage to a few instructions)
+            load<NTB, true>(st[1], wp, auxp, aux_step, xp, xsp, u + 1, Kreal, gk);
+            __builtin_amdgcn_sched_barrier(0);
+            compute<NTB>(st[0], acc, spu);
+            __builtin_amdgcn_sched_barrier(0);
+            load<NTB, true>(st[0], wp, auxp, aux_step, xp, xsp, u + 2, Kreal, gk);
+            __builtin_amdgcn_sched_barrier(0);
+            compute<NTB>(st[1], acc, spu);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (; u < u1; u += 2) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int uu = u + h;
                 if (uu < u1) {
-                    if (uu + 1 < u1)
-                        load(st[h ^ 1], wp, sbase, stu, spu, xp, xsp, uu + 1, Kreal, gk, lane, ntb);
-                    compute(st[h], acc, ntb, spu);
+                    if (uu + 1 < u1) load<NTB, false>(st[h ^ 1], wp, auxp, aux_step, xp, xsp, uu + 1, Kreal, gk);
+                    compute<NTB>(st[h], acc, spu);
                 }
             }
+        }
+    }
+
+    // ntb (wave-uniform) selects the statically sized loop; 3 blocks run as 4 (the 4th block's rows
+    // alias valid rows and are never stored)
+    static __device__ __forceinline__ void run(f32x4 (&acc)[NTT][TB], const u32x4* const (&wp)[NTT],
+                                               const char* const (&auxp)[NTT], int aux_step, int spu,
+                                               const unsigned char* const (&xp)[TB],
+                                               const float* const (&xsp)[TB], int u0, int u1, int Kreal,
+                                               int lane, int ntb) {
+        if constexpr (TB == 1) {
+            run_n<1>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+        } else if constexpr (TB == 2) {
+            if (ntb <= 1)
+                run_n<1>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+            else
+                run_n<2>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+        } else {
+            static_assert(TB == 4, "token blocks per wave: 1, 2 or 4");
+            if (ntb <= 1)
+                run_n<1>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+            else if (ntb == 2)
+                run_n<2>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+            else
+                run_n<4>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
         }
     }
 };
@@ -288,13 +350,14 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
     const int T_all = p.T_half * p.halves;
 
     const u32x4* wp[NTT];
-    size_t stu[NTT];
+    const char* auxp[NTT];
+    const int aux_step = D::aux_step(p.spu);
 #pragma unroll
     for (int t = 0; t < NTT; ++t) {
         const int tile = (GATED && t >= NT) ? p.T_half + tile0 + (t - NT) : tile0 + t;
         const size_t tl = (size_t)e * T_all + tile;
         wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
-        stu[t] = tl * p.U;
+        auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
     const int u0 = (int)((long long)wave * p.U / KW), u1 = (int)((long long)(wave + 1) * p.U / KW);
 
@@ -318,7 +381,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        Streamer<WF, ADT, NTT, TB>::run(acc, wp, p.s, stu, p.spu, xp, xsp, u0, u1, p.Kreal, lane, ntb);
+        Streamer<WF, ADT, NTT, TB>::run(acc, wp, auxp, aux_step, p.spu, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 
         if (KW > 1) {
             // fixed-order cross-wave sum: wave KW-1 stores, KW-2 .. 1 add, wave 0 takes the total
@@ -414,12 +477,13 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
     const int tile0 = grp * NT;
 
     const u32x4* wp[NT];
-    size_t stu[NT];
+    const char* auxp[NT];
+    const int aux_step = D::aux_step(p.spu);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const size_t tl = (size_t)e * p.T_half + tile0 + t;
         wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
-        stu[t] = tl * p.U;
+        auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
     const int u0 = (int)((long long)sk * p.U / p.SK), u1 = (int)((long long)(sk + 1) * p.U / p.SK);
 
@@ -442,7 +506,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        Streamer<WF, ADT, NT, TB>::run(acc, wp, p.s, stu, p.spu, xp, xsp, u0, u1, p.Kreal, lane, ntb);
+        Streamer<WF, ADT, NT, TB>::run(acc, wp, auxp, aux_step, p.spu, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 
 #pragma unroll
         for (int b = 0; b < TB; ++b) {

@@ -22,9 +22,28 @@ __device__ __forceinline__ int x_swizzle(int row) {
     return ROWB == 128 ? ((row >> 1) & 7) : (row & 15);
 }
 
-template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1>
+template <int I>
+struct IC {
+    static constexpr int v = I;
+};
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(IC<I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1, int PD, bool NTL>
 __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     typedef Dec<WF, ADT> D;
+    // PD = weight register stages (prefetch distance PD-1 units), XD = token-row register stages
+    // (prefetch distance XD units).  The products of (resident waves) x (bytes in flight per wave)
+    // must cover HBM latency x bandwidth (~16 MB chip-wide): a sub-16-bit unit is only 1 KiB per
+    // tile, so those formats need the deeper ring.
+    static_assert(PD >= 2 && PD % 2 == 0, "PD even: the LDS buffer parity is the unroll index parity");
+    constexpr int XD = PD > 2 ? 2 : 1;
     constexpr int NTT = (IS_G1 && GATED) ? 2 * NT : NT;
     constexpr int TM = TBW * 16;
     constexpr int THREADS = WAVES * 64;
@@ -52,14 +71,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     const bool wave_on = tile0 < p.T_half;            // tail group of a padded tile count
     const int T_all = p.T_half * p.halves;
 
+    // a wave past the padded tile count (wave_on == false) streams tile 0 of the expert and drops the
+    // result: every load of the K loop is unconditional (see the loop comment)
     const u32x4* wp[NTT];
-    size_t stu[NTT];
+    const char* auxp[NTT];
+    const int aux_step = D::aux_step(p.spu);
 #pragma unroll
     for (int t = 0; t < NTT; ++t) {
         const int tile = (IS_G1 && GATED && t >= NT) ? p.T_half + tile0 + (t - NT) : tile0 + t;
         const size_t tl = (size_t)e * T_all + (wave_on ? tile : 0);
         wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
-        stu[t] = tl * p.U;
+        auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
 
     // staging assignment of this thread: PIECES 16-byte pieces per unit
@@ -85,13 +107,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     }
     // W8A8: thread `tid` < TM also stages the activation scale of token row tid for the unit
     const float* xsrow = nullptr;
-    if (D::A8 && tid < TM) {
-        const int r = r0 + tid;
+    if (D::A8) {   // threads >= TM fetch row TM-1's scale too (unconditional load) and drop it
+        const int r = r0 + (tid < TM ? tid : TM - 1);
         const int rr = r < m_e ? r : r0;
         const size_t rowidx = IS_G1 ? (size_t)(p.sorted_slot[off_e + rr] / p.top_k) : (size_t)(off_e + rr);
         xsrow = p.xscale + rowidx * p.ld_xscale;
     }
-    float xsv = 0.0f;
+    float xsv[XD] = {};
 
     f32x4 acc[NTT][TBW];
 #pragma unroll
@@ -103,13 +125,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
         u32x4 w[NTT][D::LOADS];
         typename D::Aux aux[NTT];
     };
-    WStage ws[2];
-    u32x4 xs[PIECES];
+    WStage ws[PD];
+    u32x4 xs[XD][PIECES];
 
     // rows beyond the expert's count read a valid row (their D columns are never stored): the loads
     // are unconditional; only a ragged K tail (never for the model shapes) is zero-filled.
-    auto load_x = [&](int u) {
-        const bool tail = (u + 1) * D::UNITK > p.Kreal;   // workgroup-uniform
+    // STEADY: the unit is not the last one, so it cannot be a ragged K tail -> no branch at all
+    auto load_x = [&](u32x4 (&xs)[PIECES], float& xsv, int u, auto STEADY) {
+        const bool tail = !decltype(STEADY)::value && (u + 1) * D::UNITK > p.Kreal;   // workgroup-uniform
 #pragma unroll
         for (int q = 0; q < PIECES; ++q) {
             const int k = u * D::UNITK + xsrc_off[q];
@@ -121,22 +144,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
                 xs[q] = v;
             }
         }
-        if (D::A8 && tid < TM) xsv = xsrow[u];
+        if constexpr (D::A8) xsv = xsrow[u];
     };
     auto load_w = [&](WStage& s, int u) {
-        if (wave_on) {
 #pragma unroll
-            for (int t = 0; t < NTT; ++t) {
+        for (int t = 0; t < NTT; ++t) {
 #pragma unroll
-                for (int l = 0; l < D::LOADS; ++l) {
-                    const u32x4* a = wp[t] + ((size_t)u * D::LOADS + l) * 64;
-                    s.w[t][l] = p.stream_nt ? __builtin_nontemporal_load(a) : *a;
-                }
-                D::load_aux(s.aux[t], p.s, stu[t] + u, lane, p.spu);
+            for (int l = 0; l < D::LOADS; ++l) {
+                const u32x4* a = wp[t] + ((size_t)u * D::LOADS + l) * 64;
+                s.w[t][l] = NTL ? __builtin_nontemporal_load(a) : *a;
             }
+            D::load_aux_at(s.aux[t], auxp[t] + (size_t)u * aux_step);
         }
     };
-    auto store_x = [&](int buf) {
+    auto store_x = [&](const u32x4 (&xs)[PIECES], float xsv, int buf) {
 #pragma unroll
         for (int q = 0; q < PIECES; ++q) *(u32x4*)(xlds + buf * BUFB + xdst[q]) = xs[q];
         if (D::A8 && tid < TM) *(float*)(xlds + buf * BUFB + TM * ROWB + tid * 4) = xsv;
@@ -228,26 +249,50 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
         }
     };
 
+    // K loop.  The hardware retires vector-memory loads in order and s_waitcnt counts them, so the
+    // compiler can only leave the prefetched stages in flight if the number of loads issued after them
+    // is the same on every path: one conditional load anywhere in the loop degrades every wait to
+    // vmcnt(0) and the ring to no prefetch at all (measured: depth 2/4/8 identical until the steady
+    // loop below was made branch-free).  Hence: steady loop = units whose look-ahead stays inside the
+    // K range and away from the (possibly ragged) last unit, all loads unconditional; the last few
+    // units run in the drain loop with the bounds checks.
     const int U = p.U;
-    load_x(0);
-    load_w(ws[0], 0);
-    store_x(0);
-    __syncthreads();
-    for (int u = 0; u < U; u += 2) {
+    typedef std::true_type Steady;
+    typedef std::false_type Drain;
+    load_x(xs[0], xsv[0], 0, Drain{});
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+    for (int s = 0; s < PD - 1; ++s)
+        if (s < U) load_w(ws[s], s);
+    store_x(xs[0], xsv[0], 0);
+    if (XD == 2 && 1 < U) load_x(xs[1], xsv[1], 1, Drain{});
+    __syncthreads();
+    constexpr int LOOK = PD - 1 > XD ? PD - 1 : XD;
+    const int Um = U - 1 - LOOK > 0 ? (U - 1 - LOOK) / PD * PD : 0;
+    int u = 0;
+    for (; u < Um; u += PD) {
+        static_for<PD>([&](auto H) {
+            constexpr int h = decltype(H)::v;
+            const int uu = u + h;
+            load_x(xs[h % XD], xsv[h % XD], uu + XD, Steady{});   // token rows first: their wait
+            load_w(ws[(h + PD - 1) % PD], uu + PD - 1);           // leaves the weights in flight
+            __builtin_amdgcn_sched_barrier(0);                    // loads are issued before the MFMAs
+            compute(ws[h], h & 1);
+            store_x(xs[(h + 1) % XD], xsv[(h + 1) % XD], (h + 1) & 1);
+            __syncthreads();
+        });
+    }
+    for (; u < U; u += PD) {
+        static_for<PD>([&](auto H) {
+            constexpr int h = decltype(H)::v;
             const int uu = u + h;
             if (uu < U) {
-                const bool more = uu + 1 < U;
-                if (more) {
-                    load_x(uu + 1);            // token rows first: their wait leaves the weights in flight
-                    load_w(ws[h ^ 1], uu + 1);
-                }
-                compute(ws[h], h);
-                if (more) store_x(h ^ 1);
+                if (uu + XD < U) load_x(xs[h % XD], xsv[h % XD], uu + XD, Drain{});
+                if (uu + PD - 1 < U) load_w(ws[(h + PD - 1) % PD], uu + PD - 1);
+                compute(ws[h], h & 1);
+                if (uu + 1 < U) store_x(xs[(h + 1) % XD], xsv[(h + 1) % XD], (h + 1) & 1);
                 __syncthreads();
             }
-        }
+        });
     }
 
     // epilogue: D layout lane (g,j): rows tile*16 + g*4 + r, token column j of block b
@@ -305,12 +350,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     }
 }
 
-template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1>
+template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1, int PD>
 static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr int ROWB = Dec<WF, ADT>::UNITK * (Dec<WF, ADT>::A8 ? 1 : 2);
     constexpr size_t lds = (size_t)2 * (TBW * 16 * ROWB + (Dec<WF, ADT>::A8 ? TBW * 16 * 4 : 0));
     dim3 grid(ceil_div(p.T_half, WAVES * NT), max_tiles), block(WAVES * 64);
-    auto kern = gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1>;
+    auto kern = p.stream_nt ? gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1, PD, true>
+                            : gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1, PD, false>;
     if (lds > 64 * 1024) {
         LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -327,12 +373,17 @@ struct W16Only {
 };
 #define LKM_TILED_CASE_W16(TBW, WAVES, NT, G, IS1)                                              \
     if constexpr (W16Only<WF_>::value) {                                                        \
-        if (cfg.tiled == TBW * 16 && cfg.waves == WAVES && cfg.nt == NT)                        \
-            return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1>(st, p, max_tiles);         \
+        if (cfg.tiled == TBW * 16 && cfg.waves == WAVES && cfg.nt == NT) {                      \
+            if (cfg.pd == 4) return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1, 4>(st, p, max_tiles); \
+            return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1, 2>(st, p, max_tiles);      \
+        }                                                                                       \
     }
 #define LKM_TILED_CASE(TBW, WAVES, NT, G, IS1)                                             \
-    if (cfg.tiled == TBW * 16 && cfg.waves == WAVES && cfg.nt == NT)                      \
-        return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1>(st, p, max_tiles);
+    if (cfg.tiled == TBW * 16 && cfg.waves == WAVES && cfg.nt == NT) {                                  \
+        if (TBW == 4 && cfg.pd == 8) return launch_tiled_t<WF_, ADT_, NT, 4, WAVES, G, IS1, 8>(st, p, max_tiles); \
+        if (cfg.pd >= 4) return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1, 4>(st, p, max_tiles); \
+        return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1, 2>(st, p, max_tiles);                 \
+    }
 
 #define LKM_DEFINE_TILED_LAUNCHERS(SUFFIX, WF, ADT)                                                   \
     int launch_gemm1_tiled_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \

@@ -155,7 +155,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -476,14 +476,25 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
         if (h->t_tiled < 0) { tiled = 0; split = 0; }
     }
     pl->split_rows = split;
-    pl->t1 = pl->t2 = LaunchCfg{0, 0, 0, 0, 0, 0};
-    pl->s1 = pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0};
+    pl->t1 = pl->t2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0};
+    pl->s1 = pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0};
     if (tiled) {
         const int waves = h->t_waves > 0 ? h->t_waves : (tiled >= 128 ? 8 : 4);
         const int nt1 = (h->t_nt1 > 0 && !split) ? h->t_nt1 : 1;
         const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : (tiled == 256 ? 2 : 1);   // GLM: 3.61 vs 3.81 ms
-        pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves};
-        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, 1, tiled, waves};
+        // weight/token register ring depth (64-row tiles; the larger tiles have no registers to spare).
+        // Measured at M=128 (profiles/r01_prefetch_depth.log): bf16 4/4 (473 vs 525 us at 2/2),
+        // int4 4/8 (314 vs 378 us), fp8 2/4.
+        int pd1 = 2, pd2 = 2;
+        if (tiled == 64) {
+            const bool f8 = h->wf == LKM_W_FP8_E4M3;
+            pd1 = f8 ? 2 : 4;
+            pd2 = h->wf == LKM_W_INT4_B8 ? 8 : 4;
+        }
+        if (h->t_pd1 > 0) pd1 = h->t_pd1;
+        if (h->t_pd2 > 0) pd2 = h->t_pd2;
+        pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves, pd1};
+        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, 1, tiled, waves, pd2};
         if (!split) return;
     }
     // ---- skinny geometry (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4;
@@ -497,7 +508,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
         while (kw < 8 && waves * kw < kMinWaves && h->U1 / (kw * 2) >= 2) kw *= 2;
     }
     if (h->t_kw1 > 0) kw = h->t_kw1;
-    pl->s1 = LaunchCfg{nt1, tb, kw, 1, 0, 0};
+    pl->s1 = LaunchCfg{nt1, tb, kw, 1, 0, 0, 0};
     // sub-16-bit weights: two tiles per wave halve the token-operand loads per weight byte
     // (int4 M=32: gemm2 120 us -> 85 us)
     int nt2 = (h->wf == LKM_W_INT4_B8 || h->wf == LKM_W_FP8_E4M3) && tb >= 2 ? 2 : 1;
@@ -513,7 +524,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
     // split-K slabs must fit the partial buffer
     const size_t y_rows = h->arena->y_elems / h->H;
     while (sk > 1 && (size_t)sk * n_slots > y_rows) sk /= 2;
-    pl->s2 = LaunchCfg{nt2, tb, 1, sk, 0, 0};
+    pl->s2 = LaunchCfg{nt2, tb, 1, sk, 0, 0, 0};
 }
 
 // one chunk: rows [0,M) of the given pointers
@@ -640,10 +651,10 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         h->prof_valid = true;
     }
     snprintf(h->last_desc, sizeof(h->last_desc),
-             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2 nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d split=%d | nt_loads=%d",
+             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2 nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d pd=%d/%d split=%d | nt_loads=%d",
              M, K, pl.s1.tb ? "skinny" : "", pl.t1.tiled ? (pl.s1.tb ? "+tiled" : "tiled") : "", pl.s1.nt,
              pl.s1.tb, pl.s1.kw, pl.s2.nt, pl.s2.tb, pl.s2.sk, pl.t1.nt, pl.t2.nt, tile_rows, pl.t1.waves,
-             pl.split_rows, stream_nt);
+             pl.t1.pd, pl.t2.pd, pl.split_rows, stream_nt);
     return LKM_OK;
 }
 
@@ -801,6 +812,8 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "tbmax")) h->t_tb = value;
     else if (!strcmp(key, "tiled")) h->t_tiled = value;
     else if (!strcmp(key, "waves")) h->t_waves = value;
+    else if (!strcmp(key, "pd1")) h->t_pd1 = value;
+    else if (!strcmp(key, "pd2")) h->t_pd2 = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else {
         set_error("lkm_set_tuning: unknown key '%s'", key);

@@ -77,6 +77,7 @@ struct LaunchCfg {
     int tiled;   // 0: skinny streamer (token operand straight from L2);
                  // else token-tile rows (64 / 128): token operand staged through LDS
     int waves;   // tiled: waves per workgroup (4 / 8)
+    int pd;      // tiled: weight register stages (2 / 4 / 8; prefetch distance pd-1 K units)
 };
 int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                  bool gated, int max_active);

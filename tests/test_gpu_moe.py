@@ -222,6 +222,38 @@ def test_quantised_tiled_path(fmt):
         np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=f"{fmt} tiled={tiled}")
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "int4", "fp8", "fp8a8"])
+def test_tiled_prefetch_depth_is_bit_identical(fmt):
+    """the weight/token prefetch rings (pd = 2 / 4 / 8 register stages) only move loads earlier: the
+    arithmetic and its order are unchanged, so every depth must give the SAME bits -- also when the
+    ring is deeper than the K loop (U < pd) and when U is not a multiple of pd."""
+    from lvllm_amd import _clib
+    for (M, E, K, H, I) in ((100, 4, 2, 1152, 384), (70, 3, 2, 256, 128)):
+        a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=77)
+        if fmt == "bf16":
+            eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+        elif fmt == "int4":
+            q13, s13 = orc.quant_int4(torch_to_bits(w13), orc.BF16, 128)
+            q2, s2 = orc.quant_int4(torch_to_bits(w2), orc.BF16, 128)
+            eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="int4",
+                       w13_scale=bits_to_torch(s13, orc.BF16), w2_scale=bits_to_torch(s2, orc.BF16), group_n=1,
+                       group_k=128)
+        else:
+            q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+            q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+            eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
+                       w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128,
+                       fp8_mode=_clib.FP8_W8A8 if fmt == "fp8a8" else _clib.FP8_W8A16)
+        for tiled, waves, depths in ((64, 4, (4, 8)), (64, 8, (4, 8)), (128, 8, (4,))):
+            eng.engine.set_tuning(tiled=tiled, waves=waves, pd1=2, pd2=2)
+            base = _run_decode(eng, a, tw, ids)
+            assert np.isfinite(base).all() and np.abs(base).max() > 0
+            for pd in depths:
+                eng.engine.set_tuning(tiled=tiled, waves=waves, pd1=pd, pd2=pd)
+                out = _run_decode(eng, a, tw, ids)
+                assert np.array_equal(out, base), f"{fmt} {eng.engine.describe()}"
+
+
 def test_relu2_non_gated():
     M, E, K, H, I = 19, 8, 2, 256, 128
     a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=5, gated=False)

@@ -44,6 +44,10 @@ WORKLOADS = {
     "dsv3_ep8_rank_fp8w8a8_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="fp8", fp8_mode=1),
     "dsv3_ep8_rank_fp8w8a16_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="fp8", fp8_mode=0),
     "mixtral8x7b_fp8w8a8_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="fp8", fp8_mode=1),
+    # E2M1 expert formats (decoded by the gfx950 scaled-conversion instructions)
+    "mixtral8x7b_mxfp4_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="mxfp4"),
+    "mixtral8x7b_mxfp4_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="mxfp4"),
+    "mixtral8x7b_nvfp4_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="nvfp4"),
     "glm45air_fp8w8a16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=0),
     "glm45air_fp8w8a8_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=1),
 }
@@ -86,6 +90,76 @@ def quantize_fp8_block(w: torch.Tensor, blk: int = 128):
     return q.view(torch.uint8), s.contiguous()
 
 
+_E2M1_MIDPOINTS = (0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0)
+
+
+def _to_e2m1_codes(v: torch.Tensor) -> torch.Tensor:
+    """f32 values (already divided by the block scale) -> E2M1 codes (nearest, saturating at 6)."""
+    mid = torch.tensor(_E2M1_MIDPOINTS, device=v.device, dtype=torch.float32)
+    code = torch.bucketize(v.abs().contiguous(), mid).to(torch.uint8)
+    return code | ((v < 0).to(torch.uint8) << 3)
+
+
+def quantize_mxfp4(w: torch.Tensor):
+    """OCP MXFP4 on the GPU: E8M0 scale 2^(floor(log2(amax)) - 2) per 32 k, E2M1 elements."""
+    E, N, K = w.shape
+    wg = w.float().view(E, N, K // 32, 32)
+    amax = wg.abs().amax(dim=-1).clamp(min=2.0 ** -100)
+    e = torch.floor(torch.log2(amax)) - 2
+    codes = _to_e2m1_codes(wg / torch.exp2(e)[..., None]).view(E, N, K)
+    packed = (codes[..., 1::2] << 4 | codes[..., ::2]).contiguous()
+    return packed, (e + 127).clamp(0, 254).to(torch.uint8).contiguous()
+
+
+def quantize_nvfp4(w: torch.Tensor):
+    """NVFP4 on the GPU: per-expert global scale, e4m3fn scale per 16 k, E2M1 elements.  Returns
+    (packed, block scales as uint8, per-expert f32 multiplier = 1/global_scale)."""
+    E, N, K = w.shape
+    wf = w.float()
+    gscale = (448.0 * 6.0) / wf.abs().amax(dim=(1, 2)).clamp(min=1e-8)            # [E]
+    wg = wf.view(E, N, K // 16, 16)
+    sf = (wg.abs().amax(dim=-1) / 6.0 * gscale[:, None, None]).to(torch.float8_e4m3fn)
+    sff = sf.float().clamp(min=2.0 ** -9) / gscale[:, None, None]
+    codes = _to_e2m1_codes(wg / sff[..., None]).view(E, N, K)
+    packed = (codes[..., 1::2] << 4 | codes[..., ::2]).contiguous()
+    return packed, sf.view(torch.uint8).contiguous(), (1.0 / gscale).float().contiguous()
+
+
+def build_engine(ops, wl, w13, w2, **kw):
+    """engine for a WORKLOADS entry from bf16 master weights; returns (engine, weight bytes per element,
+    oracle descriptor kwargs + arrays for the CPU baseline or None)."""
+    fmt, K = wl["fmt"], wl["K"]
+    if fmt == "int4":
+        g = wl["g"]
+        q13, s13 = quantize_int4(w13, g)
+        q2, s2 = quantize_int4(w2, g)
+        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="int4", w13_scale=s13,
+                                      w2_scale=s2, group_n=1, group_k=g, **kw)
+        return eng, 0.5 + 2.0 / g, dict(wfmt="W_INT4", groupN=1, groupK=g, w13=q13, w2=q2, s13=s13, s2=s2)
+    if fmt == "mxfp4":
+        q13, s13 = quantize_mxfp4(w13)
+        q2, s2 = quantize_mxfp4(w2)
+        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="mxfp4", w13_scale=s13,
+                                      w2_scale=s2, group_n=1, group_k=32, **kw)
+        return eng, 0.5 + 1.0 / 32, dict(wfmt="W_MXFP4", groupN=1, groupK=32, w13=q13, w2=q2, s13=s13, s2=s2)
+    if fmt == "nvfp4":
+        q13, s13, g13 = quantize_nvfp4(w13)
+        q2, s2, g2 = quantize_nvfp4(w2)
+        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="nvfp4", w13_scale=s13,
+                                      w2_scale=s2, group_n=1, group_k=16, w13_global_scale=g13,
+                                      w2_global_scale=g2, **kw)
+        return eng, 0.5 + 1.0 / 16, dict(wfmt="W_NVFP4", groupN=1, groupK=16, w13=q13, w2=q2, s13=s13, s2=s2,
+                                         gs13=g13, gs2=g2)
+    if fmt == "fp8":
+        q13, s13 = quantize_fp8_block(w13)
+        q2, s2 = quantize_fp8_block(w2)
+        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="fp8", w13_scale=s13,
+                                      w2_scale=s2, group_n=128, group_k=128, fp8_mode=wl.get("fp8_mode", 0), **kw)
+        return eng, 1.0 + 4.0 / (128 * 128), None
+    eng = ops.RoutedExpertsEngine(w13, w2, top_k=K, act_dtype=torch.bfloat16, fmt="bf16", **kw)
+    return eng, 2.0, dict(wfmt="W_BF16", groupN=0, groupK=0, w13=w13, w2=w2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,23 +199,8 @@ def main():
     E_local = E // world
     first = rank * E_local
     w13, w2 = make_weights(E_local, first, H, I, dev, fmt)
-    if fmt == "int4":
-        g = wl["g"]
-        q13, s13 = quantize_int4(w13, g)
-        q2, s2 = quantize_int4(w2, g)
-        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="int4",
-                                      w13_scale=s13, w2_scale=s2, group_n=1, group_k=g,
-                                      max_num_seqs=max(256, M * world), num_processes=world, process_id=rank)
-    elif fmt == "fp8":
-        q13, s13 = quantize_fp8_block(w13)
-        q2, s2 = quantize_fp8_block(w2)
-        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
-                                      w13_scale=s13, w2_scale=s2, group_n=128, group_k=128,
-                                      fp8_mode=wl.get("fp8_mode", 0),
-                                      max_num_seqs=max(256, M * world), num_processes=world, process_id=rank)
-    else:
-        eng = ops.RoutedExpertsEngine(w13, w2, top_k=K, act_dtype=torch.bfloat16, fmt="bf16",
-                                      max_num_seqs=max(256, M * world), num_processes=world, process_id=rank)
+    eng, bpe, oracle_in = build_engine(ops, wl, w13, w2, max_num_seqs=max(256, M * world),
+                                       num_processes=world, process_id=rank)
     if args.tune:
         eng.engine.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
@@ -229,8 +288,7 @@ def main():
         eng.engine.set_profiling(False)
         prof_ms = {k_: v / reps for k_, v in acc.items()}
         e_act = int(torch.unique(ids[ids >= 0]).numel())
-        bpe = {"bf16": 2.0, "int4": 0.5, "fp8": 1.0}[fmt]
-        scale_bytes = {"bf16": 0.0, "int4": 2.0 / wl.get("g", 128), "fp8": 4.0 / (128 * 128)}[fmt]
+        scale_bytes = 0.0                                           # bpe (build_engine) includes the scales
         g1_bytes = e_act * 2 * I * H * (bpe + scale_bytes)          # algorithmic weight bytes of GEMM1
         achieved = g1_bytes / (prof_ms["gemm1"] * 1e-3) / 1e9
         traffic = None
@@ -254,21 +312,18 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and fmt != "fp8":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and oracle_in is not None:
         from oracle import oracle as orc
         tw, ids = ops.topk_softmax(logits, K, True)
         twn, idn = tw.cpu().numpy(), ids.cpu().numpy()
         xb = x.cpu().view(torch.int16).numpy().view(np.uint16)
-        if fmt == "bf16":
-            d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
-            a13 = w13.cpu().view(torch.int16).numpy().view(np.uint16)
-            a2 = w2.cpu().view(torch.int16).numpy().view(np.uint16)
-            cargs = dict(w13=a13, w2=a2)
-        else:
-            d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_INT4, groupN=1, groupK=wl["g"])
-            cargs = dict(w13=q13.cpu().numpy(), w2=q2.cpu().numpy(),
-                         s13=s13.cpu().view(torch.int16).numpy().view(np.uint16),
-                         s2=s2.cpu().view(torch.int16).numpy().view(np.uint16))
+        def _np(t):
+            t = t.cpu()
+            return t.view(torch.int16).numpy().view(np.uint16) if t.dtype == torch.bfloat16 else t.numpy()
+        oi = dict(oracle_in)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=getattr(orc, oi.pop("wfmt")),
+                        groupN=oi.pop("groupN"), groupK=oi.pop("groupK"))
+        cargs = {k_: _np(v) for k_, v in oi.items()}
         ref = orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)            # untimed first pass (page-in)
         # The host may expose more logical CPUs than the container can actually run (measured on the
         # bench box: 32 threads 49 ms, 64 threads 77 ms, 128 threads 137 ms, 256 threads 960 ms per

@@ -43,8 +43,9 @@ extern "C" {
 #define LKM_W_F16 1      /* MOE_FP16          : same in fp16                                   */
 #define LKM_W_FP8_E4M3 2 /* MOE_FP8[_FP16]    : e4m3fn + fp32 block scales [E,N/gN,K/gK]       */
 #define LKM_W_INT4_B8 3  /* MOE_WNA16[_FP16]  : uint4b8 bytes [E,N,K/2] + act-dtype scales     */
-#define LKM_W_NVFP4 4    /* MOE_NVFP4[_FP16]  : SURVEY 8(f3), not built -> LKM_E_UNSUPPORTED   */
-#define LKM_W_MXFP4 5    /* MOE_MXFP4[_FP16]  : SURVEY 8(f3), not built -> LKM_E_UNSUPPORTED   */
+#define LKM_W_NVFP4 4    /* MOE_NVFP4[_FP16]  : E2M1 bytes [E,N,K/2] + fp8 e4m3fn block scales       *
+                          *   [E,N,K/16] (linear) + per-expert f32 multipliers [E] (global)  */
+#define LKM_W_MXFP4 5    /* MOE_MXFP4[_FP16]  : E2M1 bytes [E,N,K/2] + uint8 E8M0 scales [E,N,K/32]  */
 
 /* MOEConfigV2.activation_type (routed_experts.py:160-164) */
 #define LKM_ACT_SILU 0

@@ -7,6 +7,7 @@ namespace lkm {
     int launch_gemm1_tiled_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);   \
     int launch_gemm2_tiled_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 LKM_DECL(bf16) LKM_DECL(f16) LKM_DECL(int4_bf16) LKM_DECL(int4_f16) LKM_DECL(fp8_bf16) LKM_DECL(fp8_f16)
+LKM_DECL(mxfp4_bf16) LKM_DECL(mxfp4_f16) LKM_DECL(nvfp4_bf16) LKM_DECL(nvfp4_f16)
 #undef LKM_DECL
 int launch_gemm1_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
 int launch_gemm2_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
@@ -24,6 +25,10 @@ int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const Ge
     if (wf == LKM_W_F16 && adt == LKM_DT_F16) return launch_gemm1_f16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_gemm1_int4_bf16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm1_int4_f16(st, cfg, p, gated, max_active);
+    if (wf == LKM_W_MXFP4 && adt == LKM_DT_BF16) return launch_gemm1_mxfp4_bf16(st, cfg, p, gated, max_active);
+    if (wf == LKM_W_MXFP4 && adt == LKM_DT_F16) return launch_gemm1_mxfp4_f16(st, cfg, p, gated, max_active);
+    if (wf == LKM_W_NVFP4 && adt == LKM_DT_BF16) return launch_gemm1_nvfp4_bf16(st, cfg, p, gated, max_active);
+    if (wf == LKM_W_NVFP4 && adt == LKM_DT_F16) return launch_gemm1_nvfp4_f16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm1_fp8_bf16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm1_fp8_f16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm1_fp8a8_bf16(st, cfg, p, gated, max_active);
@@ -39,6 +44,10 @@ int launch_gemm2(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const Ge
     if (wf == LKM_W_F16 && adt == LKM_DT_F16) return launch_gemm2_f16(st, cfg, p, max_active);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_gemm2_int4_bf16(st, cfg, p, max_active);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm2_int4_f16(st, cfg, p, max_active);
+    if (wf == LKM_W_MXFP4 && adt == LKM_DT_BF16) return launch_gemm2_mxfp4_bf16(st, cfg, p, max_active);
+    if (wf == LKM_W_MXFP4 && adt == LKM_DT_F16) return launch_gemm2_mxfp4_f16(st, cfg, p, max_active);
+    if (wf == LKM_W_NVFP4 && adt == LKM_DT_BF16) return launch_gemm2_nvfp4_bf16(st, cfg, p, max_active);
+    if (wf == LKM_W_NVFP4 && adt == LKM_DT_F16) return launch_gemm2_nvfp4_f16(st, cfg, p, max_active);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm2_fp8_bf16(st, cfg, p, max_active);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm2_fp8_f16(st, cfg, p, max_active);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm2_fp8a8_bf16(st, cfg, p, max_active);
@@ -54,6 +63,10 @@ int launch_gemm1_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, co
     if (wf == LKM_W_F16 && adt == LKM_DT_F16) return launch_gemm1_tiled_f16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_gemm1_tiled_int4_bf16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm1_tiled_int4_f16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_MXFP4 && adt == LKM_DT_BF16) return launch_gemm1_tiled_mxfp4_bf16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_MXFP4 && adt == LKM_DT_F16) return launch_gemm1_tiled_mxfp4_f16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_NVFP4 && adt == LKM_DT_BF16) return launch_gemm1_tiled_nvfp4_bf16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_NVFP4 && adt == LKM_DT_F16) return launch_gemm1_tiled_nvfp4_f16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm1_tiled_fp8_bf16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm1_tiled_fp8_f16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm1_tiled_fp8a8_bf16(st, cfg, p, gated, max_tiles);
@@ -69,6 +82,10 @@ int launch_gemm2_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, co
     if (wf == LKM_W_F16 && adt == LKM_DT_F16) return launch_gemm2_tiled_f16(st, cfg, p, max_tiles);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_gemm2_tiled_int4_bf16(st, cfg, p, max_tiles);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm2_tiled_int4_f16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_MXFP4 && adt == LKM_DT_BF16) return launch_gemm2_tiled_mxfp4_bf16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_MXFP4 && adt == LKM_DT_F16) return launch_gemm2_tiled_mxfp4_f16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_NVFP4 && adt == LKM_DT_BF16) return launch_gemm2_tiled_nvfp4_bf16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_NVFP4 && adt == LKM_DT_F16) return launch_gemm2_tiled_nvfp4_f16(st, cfg, p, max_tiles);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm2_tiled_fp8_bf16(st, cfg, p, max_tiles);
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm2_tiled_fp8_f16(st, cfg, p, max_tiles);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm2_tiled_fp8a8_bf16(st, cfg, p, max_tiles);

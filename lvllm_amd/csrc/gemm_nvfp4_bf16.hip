@@ -1,0 +1,6 @@
+// gemm_nvfp4_bf16.hip -- instantiates the skinny streamer kernels (gemm_skinny.h) for one
+// (weight format, activation dtype) pair.
+#include "gemm_skinny.h"
+namespace lkm {
+LKM_DEFINE_GEMM_LAUNCHERS(nvfp4_bf16, LKM_W_NVFP4, LKM_DT_BF16)
+}  // namespace lkm

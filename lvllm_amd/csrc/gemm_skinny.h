@@ -134,6 +134,86 @@ struct Dec<LKM_W_FP8_E4M3, ADT> {
     }
 };
 
+// OCP MXFP4 (E2M1 values, one E8M0 scale per 32 k = per MFMA k-step): gfx950 converts a packed pair
+// of FP4 straight to the activation dtype AND applies the power-of-two scale in one instruction
+// (v_cvt_scalef32_pk_{bf16,f16}_fp4; only the exponent of the f32 scale operand is used -- measured,
+// tools/probe_cvt.hip), i.e. 4 VALU per 16x32 fragment against ~21 for uint4b8.  Exact: an E2M1 value
+// has 2 significant bits (reference_mxfp4.py:91-117 computes the same product in the act dtype).
+template <int ADT>
+struct Dec<LKM_W_MXFP4, ADT> {
+    static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
+    static constexpr bool UNIT_SCALE = false, A8 = false;
+    struct Aux {
+        unsigned raw;   // the four E8M0 scales (k-steps 0..3 of the unit) of this lane's weight row
+    };
+    // scales: [tile][unit][16 rows][4] bytes
+    static __device__ __forceinline__ void load_aux(Aux& a, const void* sbase, size_t tu, int lane, int) {
+        a.raw = ((const unsigned*)sbase)[tu * 16 + (lane & 15)];
+    }
+    static __device__ __forceinline__ const char* aux_ptr(const void* sbase, size_t tu, int lane, int) {
+        return (const char*)((const unsigned*)sbase + tu * 16 + (lane & 15));
+    }
+    static __device__ __forceinline__ int aux_step(int) { return 64; }
+    static __device__ __forceinline__ void load_aux_at(Aux& a, const char* p) { a.raw = *(const unsigned*)p; }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux& a, int ks, int) {
+        const unsigned w = raw[0][ks];
+        // E8M0 e -> the f32 whose exponent field is e (2^(e-127))
+        const float sc = __builtin_bit_cast(float, ((a.raw >> (8 * ks)) & 0xffu) << 23);
+        u32x4 o;
+        if constexpr (ADT == LKM_DT_BF16) {
+            o.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 0));
+            o.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 1));
+            o.z = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 2));
+            o.w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, sc, 3));
+        } else {
+            o.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, sc, 0));
+            o.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, sc, 1));
+            o.z = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, sc, 2));
+            o.w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, sc, 3));
+        }
+        return o;
+    }
+};
+
+// NVFP4 (E2M1 values, e4m3fn scale per 16 k, per-expert f32 multiplier): w = T(fp4 * (f32(sf) * gs))
+// (nvfp4_utils.py:39-66).  The 8 k-values of a lane lie in ONE 16-k group (group 2*kstep + g/2), so a
+// fragment needs one scale per lane: fp4 -> f32 pairs (exact), one packed multiply, one RNE pack.
+// `gsbits` = the expert's multiplier as f32 bits (passed where uint4b8 passes scales-per-unit).
+template <int ADT>
+struct Dec<LKM_W_NVFP4, ADT> {
+    static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
+    static constexpr bool UNIT_SCALE = false, A8 = false;
+    struct Aux {
+        u32x2 raw;   // the eight e4m3fn block scales of this lane's weight row for the 128-k unit
+    };
+    // scales: [tile][unit][16 rows][8] bytes
+    static __device__ __forceinline__ void load_aux(Aux& a, const void* sbase, size_t tu, int lane, int) {
+        a.raw = ((const u32x2*)sbase)[tu * 16 + (lane & 15)];
+    }
+    static __device__ __forceinline__ const char* aux_ptr(const void* sbase, size_t tu, int lane, int) {
+        return (const char*)((const u32x2*)sbase + tu * 16 + (lane & 15));
+    }
+    static __device__ __forceinline__ int aux_step(int) { return 128; }
+    static __device__ __forceinline__ void load_aux_at(Aux& a, const char* p) { a.raw = *(const u32x2*)p; }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux& a, int ks, int gsbits) {
+        const unsigned w = raw[0][ks];
+        const int grp = 2 * ks + ((threadIdx.x >> 5) & 1);   // lane bit 5 = g/2
+        const unsigned long long bits = ((unsigned long long)a.raw.y << 32 | a.raw.x) >> (8 * grp);
+        const float s = __builtin_amdgcn_cvt_f32_fp8((int)(unsigned)bits, 0) * __builtin_bit_cast(float, gsbits);
+        u32x4 o;
+        f32x2 v;
+        v = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 0);
+        o.x = ActT<ADT>::pack2(v.x * s, v.y * s);
+        v = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 1);
+        o.y = ActT<ADT>::pack2(v.x * s, v.y * s);
+        v = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 2);
+        o.z = ActT<ADT>::pack2(v.x * s, v.y * s);
+        v = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 3);
+        o.w = ActT<ADT>::pack2(v.x * s, v.y * s);
+        return o;
+    }
+};
+
 // fp8 weights x fp8 activations on the native fp8 MFMA (W8A8): the A fragment is the raw 8 bytes,
 // no decode at all; weight block scale x token block scale is applied to the fp32 partial sum of
 // every 128-k unit (native_w8a8_block_matmul, tests/kernels/quant_utils.py:91-154).
@@ -360,6 +440,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
         auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
     const int u0 = (int)((long long)wave * p.U / KW), u1 = (int)((long long)(wave + 1) * p.U / KW);
+    const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
 
     for (int sb = 0; sb < m_e; sb += 16 * TB) {
         const int rows = min(m_e - sb, 16 * TB);
@@ -381,7 +462,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        Streamer<WF, ADT, NTT, TB>::run(acc, wp, auxp, aux_step, p.spu, xp, xsp, u0, u1, p.Kreal, lane, ntb);
+        Streamer<WF, ADT, NTT, TB>::run(acc, wp, auxp, aux_step, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 
         if (KW > 1) {
             // fixed-order cross-wave sum: wave KW-1 stores, KW-2 .. 1 add, wave 0 takes the total
@@ -486,6 +567,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
         auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
     const int u0 = (int)((long long)sk * p.U / p.SK), u1 = (int)((long long)(sk + 1) * p.U / p.SK);
+    const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
 
     for (int sb = 0; sb < m_e; sb += 16 * TB) {
         const int rows = min(m_e - sb, 16 * TB);
@@ -506,7 +588,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        Streamer<WF, ADT, NT, TB>::run(acc, wp, auxp, aux_step, p.spu, xp, xsp, u0, u1, p.Kreal, lane, ntb);
+        Streamer<WF, ADT, NT, TB>::run(acc, wp, auxp, aux_step, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 
 #pragma unroll
         for (int b = 0; b < TB; ++b) {

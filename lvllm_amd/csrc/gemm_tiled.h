@@ -70,6 +70,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     const int tile0 = (blockIdx.x * WAVES + wave) * NT;
     const bool wave_on = tile0 < p.T_half;            // tail group of a padded tile count
     const int T_all = p.T_half * p.halves;
+    const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
 
     // a wave past the padded tile count (wave_on == false) streams tile 0 of the expert and drops the
     // result: every load of the K loop is unconditional (see the loop comment)
@@ -121,178 +122,237 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
 #pragma unroll
         for (int b = 0; b < TBW; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    struct WStage {
-        u32x4 w[NTT][D::LOADS];
-        typename D::Aux aux[NTT];
-    };
-    WStage ws[PD];
-    u32x4 xs[XD][PIECES];
+    // The K loop is specialised on the number of 16-token blocks that actually hold rows (NB): a
+    // partially filled tile (decode at large batch: ~32 rows in a 64-row tile) stages, reads and
+    // multiplies only those blocks.  The choice is workgroup-uniform and made once, so every variant
+    // keeps a branch-free steady loop (a runtime "skip empty blocks" test inside the loop measured
+    // slower, see above).  Staging piece q of a thread covers rows [q*RPP, (q+1)*RPP).
+    auto run = [&](auto NBC) __attribute__((always_inline)) {
+        constexpr int NB = decltype(NBC)::v;
+        constexpr int PCS = NB * 16 * SLOTS / THREADS;
+        static_assert(PCS >= 1 && PCS <= PIECES && (NB * 16 * SLOTS) % THREADS == 0, "block granularity");
+        struct WStage {
+            u32x4 w[NTT][D::LOADS];
+            typename D::Aux aux[NTT];
+        };
+        WStage ws[PD];
+        u32x4 xs[XD][PIECES];
 
-    // rows beyond the expert's count read a valid row (their D columns are never stored): the loads
-    // are unconditional; only a ragged K tail (never for the model shapes) is zero-filled.
-    // STEADY: the unit is not the last one, so it cannot be a ragged K tail -> no branch at all
-    auto load_x = [&](u32x4 (&xs)[PIECES], float& xsv, int u, auto STEADY) {
-        const bool tail = !decltype(STEADY)::value && (u + 1) * D::UNITK > p.Kreal;   // workgroup-uniform
-#pragma unroll
-        for (int q = 0; q < PIECES; ++q) {
-            const int k = u * D::UNITK + xsrc_off[q];
-            if (!tail) {
-                xs[q] = *(const u32x4*)(xrow[q] + (size_t)k * XB);
-            } else {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (k + 16 / XB <= p.Kreal) v = *(const u32x4*)(xrow[q] + (size_t)k * XB);
-                xs[q] = v;
-            }
-        }
-        if constexpr (D::A8) xsv = xsrow[u];
-    };
-    auto load_w = [&](WStage& s, int u) {
-#pragma unroll
-        for (int t = 0; t < NTT; ++t) {
-#pragma unroll
-            for (int l = 0; l < D::LOADS; ++l) {
-                const u32x4* a = wp[t] + ((size_t)u * D::LOADS + l) * 64;
-                s.w[t][l] = NTL ? __builtin_nontemporal_load(a) : *a;
-            }
-            D::load_aux_at(s.aux[t], auxp[t] + (size_t)u * aux_step);
-        }
-    };
-    auto store_x = [&](const u32x4 (&xs)[PIECES], float xsv, int buf) {
-#pragma unroll
-        for (int q = 0; q < PIECES; ++q) *(u32x4*)(xlds + buf * BUFB + xdst[q]) = xs[q];
-        if (D::A8 && tid < TM) *(float*)(xlds + buf * BUFB + TM * ROWB + tid * 4) = xsv;
-    };
-    auto compute = [&](const WStage& s, int buf) {
-        if (!wave_on) return;
-        const char* xb = xlds + buf * BUFB;
-        if constexpr (D::A8) {
-            // fp8 x fp8: one ds_read_b128 = the token operand of a PAIR of k-steps
-            f32x4 part[NTT][TBW];
-#pragma unroll
-            for (int t = 0; t < NTT; ++t)
-#pragma unroll
-                for (int b = 0; b < TBW; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < D::KSTEPS / 2; ++i) {
-                u32x4 bf[TBW];
-#pragma unroll
-                for (int b = 0; b < TBW; ++b) {
-                    const int row = b * 16 + j;
-                    bf[b] = *(const u32x4*)(xb + row * ROWB + (((i * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
+        // rows beyond the expert's count read a valid row (their D columns are never stored): the loads
+        // are unconditional; only a ragged K tail (never for the model shapes) is zero-filled.
+        // STEADY: the unit is not the last one, so it cannot be a ragged K tail -> no branch at all
+        auto load_x = [&](u32x4 (&xs)[PIECES], float& xsv, int u, auto STEADY) __attribute__((always_inline)) {
+            const bool tail = !decltype(STEADY)::value && (u + 1) * D::UNITK > p.Kreal;   // workgroup-uniform
+    #pragma unroll
+            for (int q = 0; q < PCS; ++q) {
+                const int k = u * D::UNITK + xsrc_off[q];
+                if (!tail) {
+                    xs[q] = *(const u32x4*)(xrow[q] + (size_t)k * XB);
+                } else {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (k + 16 / XB <= p.Kreal) v = *(const u32x4*)(xrow[q] + (size_t)k * XB);
+                    xs[q] = v;
                 }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int t = 0; t < NTT; ++t) {
-                        const long a = D::frag8(s.w[t], 2 * i + q);
-#pragma unroll
-                        for (int b = 0; b < TBW; ++b)
-                            part[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                                a, __builtin_bit_cast(long, u32x2{bf[b][q * 2], bf[b][q * 2 + 1]}), part[t][b],
-                                0, 0, 0);
+            }
+            if constexpr (D::A8) xsv = xsrow[u];
+        };
+        auto load_w = [&](WStage& s, int u) __attribute__((always_inline)) {
+    #pragma unroll
+            for (int t = 0; t < NTT; ++t) {
+    #pragma unroll
+                for (int l = 0; l < D::LOADS; ++l) {
+                    const u32x4* a = wp[t] + ((size_t)u * D::LOADS + l) * 64;
+                    s.w[t][l] = NTL ? __builtin_nontemporal_load(a) : *a;
+                }
+                D::load_aux_at(s.aux[t], auxp[t] + (size_t)u * aux_step);
+            }
+        };
+        auto store_x = [&](const u32x4 (&xs)[PIECES], float xsv, int buf) __attribute__((always_inline)) {
+    #pragma unroll
+            for (int q = 0; q < PCS; ++q) *(u32x4*)(xlds + buf * BUFB + xdst[q]) = xs[q];
+            if (D::A8 && tid < TM) *(float*)(xlds + buf * BUFB + TM * ROWB + tid * 4) = xsv;
+        };
+        auto compute = [&](const WStage& s, int buf) __attribute__((always_inline)) {
+            if (!wave_on) return;
+            const char* xb = xlds + buf * BUFB;
+            if constexpr (D::A8) {
+                // fp8 x fp8: one ds_read_b128 = the token operand of a PAIR of k-steps
+                f32x4 part[NTT][NB];
+    #pragma unroll
+                for (int t = 0; t < NTT; ++t)
+    #pragma unroll
+                    for (int b = 0; b < NB; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int i = 0; i < D::KSTEPS / 2; ++i) {
+                    u32x4 bf[NB];
+    #pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const int row = b * 16 + j;
+                        bf[b] = *(const u32x4*)(xb + row * ROWB + (((i * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
                     }
-            }
-#pragma unroll
-            for (int b = 0; b < TBW; ++b) {
-                const float xsc = *(const float*)(xb + TM * ROWB + (b * 16 + j) * 4);
-#pragma unroll
-                for (int t = 0; t < NTT; ++t) acc[t][b] += (s.aux[t].s * xsc) * part[t][b];
-            }
-        } else if constexpr (D::UNIT_SCALE) {
-            f32x4 part[NTT][TBW];
-#pragma unroll
-            for (int t = 0; t < NTT; ++t)
-#pragma unroll
-                for (int b = 0; b < TBW; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < D::KSTEPS; ++ks) {
-                u32x4 bf[TBW];
-#pragma unroll
-                for (int b = 0; b < TBW; ++b) {
-                    const int row = b * 16 + j;
-                    bf[b] = *(const u32x4*)(xb + row * ROWB + (((ks * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q)
+    #pragma unroll
+                        for (int t = 0; t < NTT; ++t) {
+                            const long a = D::frag8(s.w[t], 2 * i + q);
+    #pragma unroll
+                            for (int b = 0; b < NB; ++b)
+                                part[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                                    a, __builtin_bit_cast(long, u32x2{bf[b][q * 2], bf[b][q * 2 + 1]}), part[t][b],
+                                    0, 0, 0);
+                        }
                 }
-#pragma unroll
-                for (int t = 0; t < NTT; ++t) {
-                    const u32x4 a = D::frag(s.w[t], s.aux[t], ks, p.spu);
-#pragma unroll
-                    for (int b = 0; b < TBW; ++b) part[t][b] = ActT<ADT>::mfma(a, bf[b], part[t][b]);
+    #pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const float xsc = *(const float*)(xb + TM * ROWB + (b * 16 + j) * 4);
+    #pragma unroll
+                    for (int t = 0; t < NTT; ++t) acc[t][b] += (s.aux[t].s * xsc) * part[t][b];
                 }
-            }
-#pragma unroll
-            for (int t = 0; t < NTT; ++t)
-#pragma unroll
-                for (int b = 0; b < TBW; ++b) acc[t][b] += s.aux[t].s * part[t][b];
-        } else {
-            // token fragments are read 8 blocks at a time so that the 256-row tile (TBW = 16) keeps
-            // its 2 x 16 accumulators in registers
-            constexpr int BCH = TBW > 8 ? 8 : TBW;
-#pragma unroll
-            for (int ks = 0; ks < D::KSTEPS; ++ks) {
-                u32x4 a[NTT];
-#pragma unroll
-                for (int t = 0; t < NTT; ++t) a[t] = D::frag(s.w[t], s.aux[t], ks, p.spu);
-#pragma unroll
-                for (int b0 = 0; b0 < TBW; b0 += BCH) {
-                    u32x4 bf[BCH];
-#pragma unroll
-                    for (int b = 0; b < BCH; ++b) {
-                        const int row = (b0 + b) * 16 + j;
+            } else if constexpr (D::UNIT_SCALE) {
+                f32x4 part[NTT][NB];
+    #pragma unroll
+                for (int t = 0; t < NTT; ++t)
+    #pragma unroll
+                    for (int b = 0; b < NB; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int ks = 0; ks < D::KSTEPS; ++ks) {
+                    u32x4 bf[NB];
+    #pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const int row = b * 16 + j;
                         bf[b] = *(const u32x4*)(xb + row * ROWB + (((ks * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
                     }
-#pragma unroll
+    #pragma unroll
+                    for (int t = 0; t < NTT; ++t) {
+                        const u32x4 a = D::frag(s.w[t], s.aux[t], ks, dparam);
+    #pragma unroll
+                        for (int b = 0; b < NB; ++b) part[t][b] = ActT<ADT>::mfma(a, bf[b], part[t][b]);
+                    }
+                }
+    #pragma unroll
+                for (int t = 0; t < NTT; ++t)
+    #pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[t][b] += s.aux[t].s * part[t][b];
+            } else if constexpr (WF == LKM_W_INT4_B8) {
+                // in-register decode costs ~21 VALU per fragment against 4 x TBW/4 MFMAs: decode k-step
+                // ks+1 while the MFMAs of k-step ks occupy the matrix pipe (one MFMA : DEC_PER VALU)
+                static_assert(TBW <= 8, "int4 tiles: 64 or 128 rows");
+                u32x4 a[2][NTT];
+    #pragma unroll
+                for (int t = 0; t < NTT; ++t) a[0][t] = D::frag(s.w[t], s.aux[t], 0, dparam);
+    #pragma unroll
+                for (int ks = 0; ks < D::KSTEPS; ++ks) {
+                    u32x4 bf[NB];
+    #pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const int row = b * 16 + j;
+                        bf[b] = *(const u32x4*)(xb + row * ROWB + (((ks * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
+                    }
+                    if (ks + 1 < D::KSTEPS) {
+    #pragma unroll
+                        for (int t = 0; t < NTT; ++t) a[(ks + 1) & 1][t] = D::frag(s.w[t], s.aux[t], ks + 1, dparam);
+                    }
+    #pragma unroll
                     for (int t = 0; t < NTT; ++t)
-#pragma unroll
-                        for (int b = 0; b < BCH; ++b) acc[t][b0 + b] = ActT<ADT>::mfma(a[t], bf[b], acc[t][b0 + b]);
+    #pragma unroll
+                        for (int b = 0; b < NB; ++b) acc[t][b] = ActT<ADT>::mfma(a[ks & 1][t], bf[b], acc[t][b]);
+                    if (ks + 1 < D::KSTEPS) {
+                        constexpr int DEC_PER = (21 * NTT + NTT * NB - 1) / (NTT * NB);
+    #pragma unroll
+                        for (int i = 0; i < NTT * NB; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, DEC_PER, 0);   // then decode VALU
+                        }
+                    }
+                }
+            } else {
+                // token fragments are read 8 blocks at a time so that the 256-row tile (TBW = 16) keeps
+                // its 2 x 16 accumulators in registers
+                constexpr int BCH = NB > 8 ? 8 : NB;
+    #pragma unroll
+                for (int ks = 0; ks < D::KSTEPS; ++ks) {
+                    u32x4 a[NTT];
+    #pragma unroll
+                    for (int t = 0; t < NTT; ++t) a[t] = D::frag(s.w[t], s.aux[t], ks, dparam);
+    #pragma unroll
+                    for (int b0 = 0; b0 < NB; b0 += BCH) {
+                        u32x4 bf[BCH];
+    #pragma unroll
+                        for (int b = 0; b < BCH; ++b) {
+                            const int row = (b0 + b) * 16 + j;
+                            bf[b] = *(const u32x4*)(xb + row * ROWB + (((ks * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
+                        }
+    #pragma unroll
+                        for (int t = 0; t < NTT; ++t)
+    #pragma unroll
+                            for (int b = 0; b < BCH; ++b) acc[t][b0 + b] = ActT<ADT>::mfma(a[t], bf[b], acc[t][b0 + b]);
+                    }
                 }
             }
-        }
-    };
+        };
 
-    // K loop.  The hardware retires vector-memory loads in order and s_waitcnt counts them, so the
-    // compiler can only leave the prefetched stages in flight if the number of loads issued after them
-    // is the same on every path: one conditional load anywhere in the loop degrades every wait to
-    // vmcnt(0) and the ring to no prefetch at all (measured: depth 2/4/8 identical until the steady
-    // loop below was made branch-free).  Hence: steady loop = units whose look-ahead stays inside the
-    // K range and away from the (possibly ragged) last unit, all loads unconditional; the last few
-    // units run in the drain loop with the bounds checks.
-    const int U = p.U;
-    typedef std::true_type Steady;
-    typedef std::false_type Drain;
-    load_x(xs[0], xsv[0], 0, Drain{});
-#pragma unroll
-    for (int s = 0; s < PD - 1; ++s)
-        if (s < U) load_w(ws[s], s);
-    store_x(xs[0], xsv[0], 0);
-    if (XD == 2 && 1 < U) load_x(xs[1], xsv[1], 1, Drain{});
-    __syncthreads();
-    constexpr int LOOK = PD - 1 > XD ? PD - 1 : XD;
-    const int Um = U - 1 - LOOK > 0 ? (U - 1 - LOOK) / PD * PD : 0;
-    int u = 0;
-    for (; u < Um; u += PD) {
-        static_for<PD>([&](auto H) {
-            constexpr int h = decltype(H)::v;
-            const int uu = u + h;
-            load_x(xs[h % XD], xsv[h % XD], uu + XD, Steady{});   // token rows first: their wait
-            load_w(ws[(h + PD - 1) % PD], uu + PD - 1);           // leaves the weights in flight
-            __builtin_amdgcn_sched_barrier(0);                    // loads are issued before the MFMAs
-            compute(ws[h], h & 1);
-            store_x(xs[(h + 1) % XD], xsv[(h + 1) % XD], (h + 1) & 1);
-            __syncthreads();
-        });
-    }
-    for (; u < U; u += PD) {
-        static_for<PD>([&](auto H) {
-            constexpr int h = decltype(H)::v;
-            const int uu = u + h;
-            if (uu < U) {
-                if (uu + XD < U) load_x(xs[h % XD], xsv[h % XD], uu + XD, Drain{});
-                if (uu + PD - 1 < U) load_w(ws[(h + PD - 1) % PD], uu + PD - 1);
+        // K loop.  The hardware retires vector-memory loads in order and s_waitcnt counts them, so the
+        // compiler can only leave the prefetched stages in flight if the number of loads issued after them
+        // is the same on every path: one conditional load anywhere in the loop degrades every wait to
+        // vmcnt(0) and the ring to no prefetch at all (measured: depth 2/4/8 identical until the steady
+        // loop below was made branch-free).  Hence: steady loop = units whose look-ahead stays inside the
+        // K range and away from the (possibly ragged) last unit, all loads unconditional; the last few
+        // units run in the drain loop with the bounds checks.
+        const int U = p.U;
+        typedef std::true_type Steady;
+        typedef std::false_type Drain;
+        load_x(xs[0], xsv[0], 0, Drain{});
+    #pragma unroll
+        for (int s = 0; s < PD - 1; ++s)
+            if (s < U) load_w(ws[s], s);
+        store_x(xs[0], xsv[0], 0);
+        if (XD == 2 && 1 < U) load_x(xs[1], xsv[1], 1, Drain{});
+        __syncthreads();
+        constexpr int LOOK = PD - 1 > XD ? PD - 1 : XD;
+        const int Um = U - 1 - LOOK > 0 ? (U - 1 - LOOK) / PD * PD : 0;
+        int u = 0;
+        for (; u < Um; u += PD) {
+            static_for<PD>([&](auto H) __attribute__((always_inline)) {
+                constexpr int h = decltype(H)::v;
+                const int uu = u + h;
+                load_x(xs[h % XD], xsv[h % XD], uu + XD, Steady{});   // token rows first: their wait
+                load_w(ws[(h + PD - 1) % PD], uu + PD - 1);           // leaves the weights in flight
+                __builtin_amdgcn_sched_barrier(0);                    // loads are issued before the MFMAs
                 compute(ws[h], h & 1);
-                if (uu + 1 < U) store_x(xs[(h + 1) % XD], xsv[(h + 1) % XD], (h + 1) & 1);
+                store_x(xs[(h + 1) % XD], xsv[(h + 1) % XD], (h + 1) & 1);
                 __syncthreads();
-            }
-        });
+            });
+        }
+        for (; u < U; u += PD) {
+            static_for<PD>([&](auto H) __attribute__((always_inline)) {
+                constexpr int h = decltype(H)::v;
+                const int uu = u + h;
+                if (uu < U) {
+                    if (uu + XD < U) load_x(xs[h % XD], xsv[h % XD], uu + XD, Drain{});
+                    if (uu + PD - 1 < U) load_w(ws[(h + PD - 1) % PD], uu + PD - 1);
+                    compute(ws[h], h & 1);
+                    if (uu + 1 < U) store_x(xs[(h + 1) % XD], xsv[(h + 1) % XD], (h + 1) & 1);
+                    __syncthreads();
+                }
+            });
+        }
+
+    };
+    {
+        constexpr int GRAN = THREADS / (16 * SLOTS) > 1 ? THREADS / (16 * SLOTS) : 1;   // blocks per staging piece
+        const int rows_here = m_e - r0 < TM ? m_e - r0 : TM;
+        const int nb = (rows_here + 15) >> 4;
+        if constexpr (TBW == 4 && GRAN == 1) {
+            if (nb <= 1) run(IC<1>{});
+            else if (nb == 2) run(IC<2>{});
+            else if (nb == 3) run(IC<3>{});
+            else run(IC<4>{});
+        } else if constexpr (TBW == 4 && GRAN == 2) {
+            if (nb <= 2) run(IC<2>{});
+            else run(IC<4>{});
+        } else {
+            run(IC<TBW>{});
+        }
     }
 
     // epilogue: D layout lane (g,j): rows tile*16 + g*4 + r, token column j of block b
@@ -380,7 +440,6 @@ struct W16Only {
     }
 #define LKM_TILED_CASE(TBW, WAVES, NT, G, IS1)                                             \
     if (cfg.tiled == TBW * 16 && cfg.waves == WAVES && cfg.nt == NT) {                                  \
-        if (TBW == 4 && cfg.pd == 8) return launch_tiled_t<WF_, ADT_, NT, 4, WAVES, G, IS1, 8>(st, p, max_tiles); \
         if (cfg.pd >= 4) return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1, 4>(st, p, max_tiles); \
         return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1, 2>(st, p, max_tiles);                 \
     }

@@ -147,6 +147,7 @@ struct LkmEngine {
     int spu;                   // int4 scales per unit
     // HBM
     void *w13 = nullptr, *w2 = nullptr, *s13 = nullptr, *s2 = nullptr;
+    float *gs13 = nullptr, *gs2 = nullptr;   // NVFP4 per-expert multipliers
     int64_t weight_bytes = 0;
     // scratch
     Arena* arena = nullptr;
@@ -238,6 +239,8 @@ extern "C" void lkm_destroy(LkmHandle h) {
     if (h->w2) (void)hipFree(h->w2);
     if (h->s13) (void)hipFree(h->s13);
     if (h->s2) (void)hipFree(h->s2);
+    if (h->gs13) (void)hipFree(h->gs13);
+    if (h->gs2) (void)hipFree(h->gs2);
     if (h->io_x) (void)hipFree(h->io_x);
     if (h->io_ids) (void)hipFree(h->io_ids);
     if (h->io_w) (void)hipFree(h->io_w);
@@ -253,14 +256,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     LKM_REQUIRE(cfg && out, "lkm_create: null argument");
     *out = nullptr;
     LKM_REQUIRE(cfg->abi_version == LKM_ABI_VERSION, "lkm_create: ABI version %d != %d", cfg->abi_version, LKM_ABI_VERSION);
-    (void)w13_gs;
-    (void)w2_gs;
-    if (cfg->weight_format == LKM_W_NVFP4 || cfg->weight_format == LKM_W_MXFP4) {
-        set_error("lkm_create: NVFP4/MXFP4 expert formats are not built yet (SURVEY 8 f3)");
-        return LKM_E_UNSUPPORTED;
-    }
     const int wf = cfg->weight_format, adt = cfg->act_dtype;
-    LKM_REQUIRE(wf >= LKM_W_BF16 && wf <= LKM_W_INT4_B8, "lkm_create: bad weight_format %d", wf);
+    LKM_REQUIRE(wf >= LKM_W_BF16 && wf <= LKM_W_MXFP4, "lkm_create: bad weight_format %d", wf);
     LKM_REQUIRE(adt == LKM_DT_BF16 || adt == LKM_DT_F16, "lkm_create: act_dtype must be bf16 or fp16");
     LKM_REQUIRE(!(wf == LKM_W_BF16 && adt != LKM_DT_BF16) && !(wf == LKM_W_F16 && adt != LKM_DT_F16),
                 "lkm_create: unquantised weights must have the activation dtype");
@@ -278,6 +275,12 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
         LKM_REQUIRE(cfg->fp8_mode != LKM_FP8_W8A8 || cfg->groupK == 128, "lkm_create: fp8 W8A8 quantises activations in 1x128 groups; groupK must be 128 (got %d)", cfg->groupK);
         LKM_REQUIRE(w13_scale && w2_scale, "lkm_create: fp8 weights need scales");
         LKM_REQUIRE(cfg->groupN > 0 && cfg->groupK > 0 && cfg->groupK % 128 == 0, "lkm_create: fp8 needs groupN>0 and groupK a multiple of 128 (got %d,%d)", cfg->groupN, cfg->groupK);
+    }
+    if (wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4) {
+        const int g = wf == LKM_W_MXFP4 ? 32 : 16;
+        LKM_REQUIRE(w13_scale && w2_scale, "lkm_create: fp4 weights need block scales");
+        LKM_REQUIRE(cfg->groupK == g && cfg->groupN == 1, "lkm_create: %s block scales are 1 x %d (got groupN=%d groupK=%d)", wf == LKM_W_MXFP4 ? "MXFP4" : "NVFP4", g, cfg->groupN, cfg->groupK);
+        LKM_REQUIRE(cfg->hidden_size % 32 == 0 && cfg->intermediate_size % 32 == 0, "lkm_create: fp4 formats need hidden and intermediate sizes that are multiples of 32");
     }
     if (wf == LKM_W_INT4_B8) {
         LKM_REQUIRE(w13_scale && w2_scale, "lkm_create: int4 weights need scales");
@@ -386,6 +389,40 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
         if (tmp) (void)hipFree(tmp);
         if (rc != LKM_OK) return fail(rc);
         LKM_TRY_HIP(se);
+    } else if (wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4) {
+        const int g = cfg->groupK, spu = 128 / g;
+        const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16 * spu;
+        const size_t n2 = (size_t)h->E * h->T2 * h->U2 * 16 * spu;
+        LKM_TRY_HIP(hipMalloc(&h->s13, n13));
+        LKM_TRY_HIP(hipMalloc(&h->s2, n2));
+        h->weight_bytes += (int64_t)(n13 + n2);
+        const int pad = wf == LKM_W_MXFP4 ? 127 : 0x38;   // 1.0 in E8M0 / e4m3fn (the padded weights are 0)
+        const void* dsrc;
+        void* tmp;
+        LKM_TRY(to_device(w13_scale, (size_t)h->E * halves * h->I * (h->H / g), &dsrc, &tmp));
+        rc = launch_repack_s_fp4(nullptr, dsrc, h->s13, d13, g, pad);
+        hipError_t se = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (rc != LKM_OK) return fail(rc);
+        LKM_TRY_HIP(se);
+        LKM_TRY(to_device(w2_scale, (size_t)h->E * h->H * (h->I / g), &dsrc, &tmp));
+        rc = launch_repack_s_fp4(nullptr, dsrc, h->s2, d2, g, pad);
+        se = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (rc != LKM_OK) return fail(rc);
+        LKM_TRY_HIP(se);
+        if (wf == LKM_W_NVFP4) {   // per-expert multipliers (NULL = 1.0)
+            for (int which = 0; which < 2; ++which) {
+                const void* src = which ? w2_gs : w13_gs;
+                float** dst = which ? &h->gs2 : &h->gs13;
+                if (!src) continue;
+                LKM_TRY(to_device(src, (size_t)h->E * 4, &dsrc, &tmp));
+                LKM_TRY_HIP(hipMalloc(dst, (size_t)h->E * 4));
+                hipError_t ce = hipMemcpy(*dst, dsrc, (size_t)h->E * 4, hipMemcpyDeviceToDevice);
+                if (tmp) (void)hipFree(tmp);
+                LKM_TRY_HIP(ce);
+            }
+        }
     } else if (wf == LKM_W_FP8_E4M3) {
         const int gN = cfg->groupN, gK = cfg->groupK;
         const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16;
@@ -483,13 +520,14 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
         const int nt1 = (h->t_nt1 > 0 && !split) ? h->t_nt1 : 1;
         const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : (tiled == 256 ? 2 : 1);   // GLM: 3.61 vs 3.81 ms
         // weight/token register ring depth (64-row tiles; the larger tiles have no registers to spare).
-        // Measured at M=128 (profiles/r01_prefetch_depth.log): bf16 4/4 (473 vs 525 us at 2/2),
-        // int4 4/8 (314 vs 378 us), fp8 2/4.
+        // Measured at M=128 (profiles/r01_prefetch_depth.log): bf16 4/4 (473 vs 525 us at 2/2); the
+        // formats that decode in registers keep GEMM1 at 2 (occupancy): int4 2/4 260 us vs 4/4 291 us,
+        // MXFP4 205 vs 221 us, fp8 293 vs 298 us.
         int pd1 = 2, pd2 = 2;
         if (tiled == 64) {
-            const bool f8 = h->wf == LKM_W_FP8_E4M3;
-            pd1 = f8 ? 2 : 4;
-            pd2 = h->wf == LKM_W_INT4_B8 ? 8 : 4;
+            const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
+            pd1 = w16 ? 4 : 2;
+            pd2 = 4;
         }
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;
@@ -501,6 +539,9 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
     // otherwise nt*tb<=8)
     int nt1 = 1;
     if (tb >= 4 && !h->gated && (long long)n_act * (h->T1_half / 2) >= 2 * kMinWaves) nt1 = 2;
+    // 4-bit weights: a tile-unit is only 1 KiB, two tiles per wave double the bytes in flight per wave
+    // and halve the token-operand loads per weight byte (MXFP4 M=32: gemm1 110 -> 88 us)
+    if (wf_is_4bit(h->wf) && tb == 2 && (long long)n_act * (h->T1_half / 2) >= kMinWaves) nt1 = 2;
     if (h->t_nt1 > 0) nt1 = h->t_nt1;
     int kw = 1;
     {
@@ -511,7 +552,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
     pl->s1 = LaunchCfg{nt1, tb, kw, 1, 0, 0, 0};
     // sub-16-bit weights: two tiles per wave halve the token-operand loads per weight byte
     // (int4 M=32: gemm2 120 us -> 85 us)
-    int nt2 = (h->wf == LKM_W_INT4_B8 || h->wf == LKM_W_FP8_E4M3) && tb >= 2 ? 2 : 1;
+    int nt2 = (wf_is_4bit(h->wf) || h->wf == LKM_W_FP8_E4M3) && tb >= 2 ? 2 : 1;
     if (tb >= 4 && (long long)n_act * (h->T2 / 2) >= 2 * kMinWaves) nt2 = 2;
     if (h->t_nt2 > 0) nt2 = h->t_nt2;
     int sk = 1;
@@ -563,6 +604,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.w = h->w13;
     p1.s = h->s13;
     p1.spu = h->spu;
+    p1.gs = h->gs13;
     p1.T_half = h->T1_half;
     p1.halves = h->gated ? 2 : 1;
     p1.U = h->U1;
@@ -605,6 +647,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.w = h->w2;
     p2.s = h->s2;
     p2.spu = h->spu;
+    p2.gs = h->gs2;
     p2.T_half = h->T2;
     p2.halves = 1;
     p2.U = h->U2;

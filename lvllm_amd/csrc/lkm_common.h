@@ -130,7 +130,7 @@ __host__ __device__ constexpr inline int64_t ceil_div64(int64_t a, int64_t b) { 
 // token load feeds a PAIR of k-steps: k = unit*128 + pair*64 + g*16 + (0..15).
 //   bf16/f16 : UNITK = 64,  LOADS = 2 (load = kstep),          one dwordx4 = 8 elements
 //   fp8 e4m3 : UNITK = 128, LOADS = 2 (load l: .xy = kstep 2l, .zw = kstep 2l+1; 2 x 8 bytes)
-//   uint4b8  : UNITK = 128, LOADS = 1 (dword s = kstep s),     one dwordx4 = 4 x 8 nibbles
+//   uint4b8 / E2M1 (MXFP4, NVFP4) : UNITK = 128, LOADS = 1 (dword s = kstep s), one dwordx4 = 4 x 8 nibbles
 // internal kernel-format code: fp8 weights consumed by the native fp8 MFMA against dynamically
 // quantised fp8 activations (W8A8, the in-tree operator's block-fp8 semantics); same HBM layout as
 // LKM_W_FP8_E4M3.
@@ -155,7 +155,17 @@ struct WGeom<LKM_W_INT4_B8> {
     static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
 };
 
+template <>
+struct WGeom<LKM_W_MXFP4> {   // 4-bit formats share the uint4b8 geometry (dword s = kstep s)
+    static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
+};
+template <>
+struct WGeom<LKM_W_NVFP4> {
+    static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
+};
+
+inline bool wf_is_4bit(int wf) { return wf == LKM_W_INT4_B8 || wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4; }
 inline int wf_unitk(int wf) { return (wf == LKM_W_BF16 || wf == LKM_W_F16) ? 64 : 128; }
-inline int wf_loads(int wf) { return wf == LKM_W_INT4_B8 ? 1 : 2; }
+inline int wf_loads(int wf) { return wf_is_4bit(wf) ? 1 : 2; }
 
 }  // namespace lkm

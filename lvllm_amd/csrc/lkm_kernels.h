@@ -17,6 +17,8 @@ int launch_repack_s_int4(hipStream_t st, const void* src, void* dst, const Repac
                          int spu);
 int launch_repack_s_fp8(hipStream_t st, const void* src, void* dst, const RepackDims& d, int gN,
                         int gK);
+int launch_repack_s_fp4(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group,
+                        int pad);
 
 // ---- dispatch.hip
 int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
@@ -38,6 +40,7 @@ struct GemmParams {
     const void* w;
     const void* s;
     int spu;     // int4: scales per 128-k unit (1,2,4)
+    const float* gs;   // NVFP4: per-expert f32 multiplier [E] (NULL = 1)
     int T_half;  // tiles per half (gate / up); w2: tiles total
     int halves;  // 2 gated w13, 1 otherwise
     int U;       // K units

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void repack_w_kernel(const uint8_t* __restrict
                 out[2 * q] = lo;
                 out[2 * q + 1] = hi;
             }
-        } else {  // INT4: bytes [E][N][K/2]; zero padding must decode to 0 => stored nibble 8
+        } else {  // 4-bit: bytes [E][N][K/2]; zero padding must decode to 0 => uint4b8 nibble 8, E2M1 nibble 0
+            constexpr unsigned PADB = WF == LKM_W_INT4_B8 ? 0x88u : 0x00u;
             const uint8_t* p = src + ((size_t)e * N + n) * (d.K / 2);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -73,13 +74,13 @@ __global__ __launch_bounds__(256) void repack_w_kernel(const uint8_t* __restrict
                 unsigned w = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    unsigned b = (k0 + 2 * j < d.K) ? p[(k0 >> 1) + j] : 0x88u;
+                    unsigned b = (k0 + 2 * j < d.K) ? p[(k0 >> 1) + j] : PADB;
                     w |= b << (8 * j);
                 }
                 out[s] = w;
             }
         }
-    } else if (WF == LKM_W_INT4_B8) {
+    } else if (WF == LKM_W_INT4_B8) {   // padded rows decode to 0 (E2M1: the zero fill already does)
         out[0] = out[1] = out[2] = out[3] = 0x88888888u;
     }
     u32x4 o;
@@ -111,6 +112,34 @@ __global__ __launch_bounds__(256) void repack_s_int4_kernel(const unsigned short
     const int n = d.interleaved ? idx * d.halves + half : half * d.n_half + idx;
     const int k = u * 128 + j * (128 / spu);
     unsigned short s = 0;
+    if (idx < d.n_half && k < d.K) s = src[((size_t)e * N + n) * (d.K / group) + k / group];
+    dst[v] = s;
+}
+
+// 4-bit float block scales (one byte each): src [E][N][K/g] (MXFP4: E8M0, g=32; NVFP4: e4m3fn, g=16)
+//   -> dst [E][tile][unit][16 rows][128/g bytes]: the 4 (8) scales of a row for one 128-k unit are
+//   one dword (two) per lane.  Padding rows/units get `pad` (their weights are zero anyway).
+__global__ __launch_bounds__(256) void repack_s_fp4_kernel(const uint8_t* __restrict__ src,
+                                                           uint8_t* __restrict__ dst, RepackDims d,
+                                                           int group, int pad) {
+    const int spu = 128 / group;
+    const size_t n_out = (size_t)d.E * d.halves * d.T_half * d.U * 16 * spu;
+    size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_out) return;
+    const int j = (int)(v % spu);
+    size_t t = v / spu;
+    const int i = (int)(t & 15);
+    t >>= 4;
+    const int u = (int)(t % d.U);
+    t /= d.U;
+    const int tile = (int)(t % (d.halves * d.T_half));
+    const int e = (int)(t / (d.halves * d.T_half));
+    const int half = tile / d.T_half;
+    const int idx = (tile % d.T_half) * 16 + i;
+    const int N = d.n_half * d.halves;
+    const int n = d.interleaved ? idx * d.halves + half : half * d.n_half + idx;
+    const int k = u * 128 + j * group;
+    uint8_t s = (uint8_t)pad;
     if (idx < d.n_half && k < d.K) s = src[((size_t)e * N + n) * (d.K / group) + k / group];
     dst[v] = s;
 }
@@ -157,6 +186,10 @@ int launch_repack_w(hipStream_t st, int wf, const void* src, void* dst, const Re
     case LKM_W_INT4_B8:
         hipLaunchKernelGGL(repack_w_kernel<LKM_W_INT4_B8>, grid, block, 0, st, (const uint8_t*)src, (u32x4*)dst, d);
         break;
+    case LKM_W_MXFP4:
+    case LKM_W_NVFP4:
+        hipLaunchKernelGGL(repack_w_kernel<LKM_W_MXFP4>, grid, block, 0, st, (const uint8_t*)src, (u32x4*)dst, d);
+        break;
     default:
         set_error("repack: unsupported weight format %d", wf);
         return LKM_E_UNSUPPORTED;
@@ -171,6 +204,15 @@ int launch_repack_s_int4(hipStream_t st, const void* src, void* dst, const Repac
     hipLaunchKernelGGL(repack_s_int4_kernel, dim3((unsigned)ceil_div64((int64_t)n_out, 256)),
                        dim3(256), 0, st, (const unsigned short*)src, (unsigned short*)dst, d, group,
                        spu);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+int launch_repack_s_fp4(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group,
+                        int pad) {
+    const size_t n_out = (size_t)d.E * d.halves * d.T_half * d.U * 16 * (128 / group);
+    hipLaunchKernelGGL(repack_s_fp4_kernel, dim3((unsigned)ceil_div64((int64_t)n_out, 256)),
+                       dim3(256), 0, st, (const uint8_t*)src, (uint8_t*)dst, d, group, pad);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

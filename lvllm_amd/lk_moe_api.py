@@ -143,12 +143,13 @@ MOE_FP8 = _mk("MOE_FP8", _clib.W_FP8_E4M3, _clib.DT_BF16, "e4m3fn block-scaled w
 MOE_FP8_FP16 = _mk("MOE_FP8_FP16", _clib.W_FP8_E4M3, _clib.DT_F16, "e4m3fn weights, fp16 activations")
 MOE_WNA16 = _mk("MOE_WNA16", _clib.W_INT4_B8, _clib.DT_BF16, "uint4b8 group-scaled weights, bf16 activations")
 MOE_WNA16_FP16 = _mk("MOE_WNA16_FP16", _clib.W_INT4_B8, _clib.DT_F16, "uint4b8 weights, fp16 activations")
-# the four fp4 classes exist so that `import lk_moe` exposes the full name set;
-# constructing one raises LkmError(LKM_E_UNSUPPORTED) until those formats are built.
-MOE_NVFP4 = _mk("MOE_NVFP4", _clib.W_NVFP4, _clib.DT_BF16, "not built yet (raises)")
-MOE_NVFP4_FP16 = _mk("MOE_NVFP4_FP16", _clib.W_NVFP4, _clib.DT_F16, "not built yet (raises)")
-MOE_MXFP4 = _mk("MOE_MXFP4", _clib.W_MXFP4, _clib.DT_BF16, "not built yet (raises)")
-MOE_MXFP4_FP16 = _mk("MOE_MXFP4_FP16", _clib.W_MXFP4, _clib.DT_F16, "not built yet (raises)")
+# E2M1 formats (routed_experts.py:1673-1813).  NVFP4: fp8 e4m3fn scale per 16 k (linear
+# [E,N,K/16]) + per-expert f32 multipliers (the reference passes 1/global_scale when
+# need_reciprocal_global_scale); MXFP4: E8M0 scale per 32 k, no global scale (pass 0, 0).
+MOE_NVFP4 = _mk("MOE_NVFP4", _clib.W_NVFP4, _clib.DT_BF16, "NVFP4 weights (W4A16), bf16 activations")
+MOE_NVFP4_FP16 = _mk("MOE_NVFP4_FP16", _clib.W_NVFP4, _clib.DT_F16, "NVFP4 weights (W4A16), fp16 activations")
+MOE_MXFP4 = _mk("MOE_MXFP4", _clib.W_MXFP4, _clib.DT_BF16, "MXFP4 weights (W4A16), bf16 activations")
+MOE_MXFP4_FP16 = _mk("MOE_MXFP4_FP16", _clib.W_MXFP4, _clib.DT_F16, "MXFP4 weights (W4A16), fp16 activations")
 
 __all__ = ["MOEConfigV2", "MOE_BF16", "MOE_FP16", "MOE_FP8", "MOE_FP8_FP16", "MOE_WNA16",
            "MOE_WNA16_FP16", "MOE_NVFP4", "MOE_NVFP4_FP16", "MOE_MXFP4", "MOE_MXFP4_FP16"]

@@ -18,8 +18,8 @@ import ctypes as C
 import torch
 
 from . import _clib
-from .lk_moe_api import (MOE_BF16, MOE_FP16, MOE_FP8, MOE_FP8_FP16, MOE_WNA16, MOE_WNA16_FP16,
-                         MOEConfigV2)
+from .lk_moe_api import (MOE_BF16, MOE_FP16, MOE_FP8, MOE_FP8_FP16, MOE_MXFP4, MOE_MXFP4_FP16,
+                         MOE_NVFP4, MOE_NVFP4_FP16, MOE_WNA16, MOE_WNA16_FP16, MOEConfigV2)
 
 _DT = {torch.float32: _clib.DT_F32, torch.bfloat16: _clib.DT_BF16, torch.float16: _clib.DT_F16}
 _SCORING = {"softmax": 0, "sigmoid": 1}
@@ -175,7 +175,9 @@ def sort_slots(topk_ids: torch.Tensor, num_experts: int):
 _CLS = {("bf16", torch.bfloat16): MOE_BF16, ("bf16", torch.float16): MOE_FP16,
         ("fp16", torch.float16): MOE_FP16,
         ("fp8", torch.bfloat16): MOE_FP8, ("fp8", torch.float16): MOE_FP8_FP16,
-        ("int4", torch.bfloat16): MOE_WNA16, ("int4", torch.float16): MOE_WNA16_FP16}
+        ("int4", torch.bfloat16): MOE_WNA16, ("int4", torch.float16): MOE_WNA16_FP16,
+        ("mxfp4", torch.bfloat16): MOE_MXFP4, ("mxfp4", torch.float16): MOE_MXFP4_FP16,
+        ("nvfp4", torch.bfloat16): MOE_NVFP4, ("nvfp4", torch.float16): MOE_NVFP4_FP16}
 
 
 class RoutedExpertsEngine:
@@ -189,7 +191,9 @@ class RoutedExpertsEngine:
                  has_gate_proj: bool = True, activation_type: int = 0, swiglu_alpha: float = 1.702,
                  swiglu_limit: float = 7.0, max_num_seqs: int = 256, max_batch_size: int = 8192,
                  group_max_len: int = 0, num_processes: int = 1, process_id: int = 0,
-                 gpu_id: int | None = None, fp8_mode: int = _clib.FP8_W8A16):
+                 gpu_id: int | None = None, fp8_mode: int = _clib.FP8_W8A16,
+                 w13_global_scale: torch.Tensor | None = None,
+                 w2_global_scale: torch.Tensor | None = None):
         E = w13.shape[0]
         H = w2.shape[1]
         inter = w13.shape[1] // (2 if has_gate_proj else 1)
@@ -211,8 +215,11 @@ class RoutedExpertsEngine:
         w13c, w2c = w13.contiguous(), w2.contiguous()
         s13 = None if w13_scale is None else w13_scale.contiguous()
         s2 = None if w2_scale is None else w2_scale.contiguous()
+        g13 = None if w13_global_scale is None else w13_global_scale.to(torch.float32).contiguous()
+        g2 = None if w2_global_scale is None else w2_global_scale.to(torch.float32).contiguous()
         self.engine = cls(cfg, w13c.data_ptr(), w2c.data_ptr(), 0 if s13 is None else s13.data_ptr(),
-                          0 if s2 is None else s2.data_ptr(), 0, 0)
+                          0 if s2 is None else s2.data_ptr(), 0 if g13 is None else g13.data_ptr(),
+                          0 if g2 is None else g2.data_ptr())
         if w13c.is_cuda:
             torch.cuda.synchronize()
 

@@ -30,7 +30,7 @@
 /* dtype codes shared with include/lkm.h (kept numerically identical) */
 enum { OR_F32 = 0, OR_BF16 = 1, OR_F16 = 2 };
 /* weight formats */
-enum { OR_W_BF16 = 0, OR_W_F16 = 1, OR_W_FP8_E4M3 = 2, OR_W_INT4_B8 = 3 };
+enum { OR_W_BF16 = 0, OR_W_F16 = 1, OR_W_FP8_E4M3 = 2, OR_W_INT4_B8 = 3, OR_W_NVFP4 = 4, OR_W_MXFP4 = 5 };
 /* activation types: routed_experts.py:160-164 */
 enum { OR_ACT_SILU = 0, OR_ACT_SWIGLUOAI = 1, OR_ACT_RELU2 = 2 };
 
@@ -389,12 +389,45 @@ typedef struct {
                                    0: keep fp32 (CPU path, test_cpu_fused_moe.py:86-91) */
     int32_t w8a8;               /* fp8 only: 1 = dynamic 1xgroupK activation quant (W8A8,
                                    tests/kernels/moe/test_block_fp8.py:107-137) */
+    const float* gs13;          /* NVFP4 only: per-expert f32 multipliers [E] (the reference passes
+                                   1/global_scale when need_reciprocal_global_scale,            */
+    const float* gs2;           /*   routed_experts.py:1686-1688); NULL = 1.0 */
 } OrMoeDesc;
 
+/* FP4 E2M1 magnitudes (tests/kernels/quantization/nvfp4_utils.py:11-13 kE2M1ToFloat;
+   tests/quantization/reference_mxfp4.py:39-88): code = sign<<3 | index */
+static const float kE2M1[8] = {0.0f, 0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f};
+static inline float fp4_to_f32(unsigned c) { return (c & 8u) ? -kE2M1[c & 7u] : kE2M1[c & 7u]; }
+
 /* dequantise one weight row [K] to f32.  rows are [N][K] (K contiguous). */
-static void dequant_row(const OrMoeDesc* d, const void* w, const void* scale, int64_t e,
-                        int64_t N, int64_t K, int64_t n, float* out, int apply_scale) {
+static void dequant_row(const OrMoeDesc* d, const void* w, const void* scale, const float* gs,
+                        int64_t e, int64_t N, int64_t K, int64_t n, float* out, int apply_scale) {
     switch (d->wfmt) {
+    case OR_W_MXFP4: {
+        /* OCP MXFP4 (routed_experts.py:1747-1813; reference_mxfp4.py:91-117 dq_mxfp4_torch):
+           bytes [E,N,K/2] low nibble = even k, E2M1; scales uint8 E8M0 [E,N,K/32];
+           w = T(fp4) * T(2^(s-127)) computed in T -- exact unless the product leaves T's range */
+        const uint8_t* p = (const uint8_t*)w + ((size_t)e * N + n) * (K / 2);
+        const uint8_t* sc = (const uint8_t*)scale + ((size_t)e * N + n) * (K / 32);
+        for (int64_t k = 0; k < K; ++k) {
+            float v = fp4_to_f32((p[k >> 1] >> ((k & 1) * 4)) & 0xfu);
+            float sf = round_act(ldexpf(1.0f, (int)sc[k / 32] - 127), d->act_dtype);
+            out[k] = round_act(v * sf, d->act_dtype);
+        }
+    } break;
+    case OR_W_NVFP4: {
+        /* NVFP4 (routed_experts.py:1673-1745; nvfp4_utils.py:39-66 dequantize_nvfp4_to_dtype with
+           the scale factors in linear layout): bytes [E,N,K/2] E2M1, block scales fp8 e4m3fn
+           [E,N,K/16], per-expert f32 multiplier gs[e]:  w = T(fp4 * (f32(sf) * gs)) */
+        const uint8_t* p = (const uint8_t*)w + ((size_t)e * N + n) * (K / 2);
+        const uint8_t* sc = (const uint8_t*)scale + ((size_t)e * N + n) * (K / 16);
+        const float g = gs ? gs[e] : 1.0f;
+        for (int64_t k = 0; k < K; ++k) {
+            float v = fp4_to_f32((p[k >> 1] >> ((k & 1) * 4)) & 0xfu);
+            float sf = fp8e4m3_to_f32(sc[k / 16]) * g;
+            out[k] = round_act(v * sf, d->act_dtype);
+        }
+    } break;
     case OR_W_BF16: {
         const uint16_t* p = (const uint16_t*)w + ((size_t)e * N + n) * K;
         for (int64_t k = 0; k < K; ++k) out[k] = bf16_to_f32(p[k]);
@@ -547,7 +580,7 @@ LKM_OR_API int lkm_or_moe(const OrMoeDesc* d, const void* w13, const void* w2, c
             if (R == 0) continue;
             const float* xe = xs + (size_t)offs[e] * H;
             float* ge = g1 + (size_t)offs[e] * N1;
-            dequant_row(d, w13, s13, e, N1, H, n, wrow, !d->w8a8);
+            dequant_row(d, w13, s13, d->gs13, e, N1, H, n, wrow, !d->w8a8);
             for (int r0 = 0; r0 < R; r0 += 4096) {
                 int rr = R - r0 < 4096 ? R - r0 : 4096;
                 if (!d->w8a8) {
@@ -619,7 +652,7 @@ LKM_OR_API int lkm_or_moe(const OrMoeDesc* d, const void* w13, const void* w2, c
             int R = counts[e];
             if (R == 0) continue;
             const float* ae = act + (size_t)offs[e] * I;
-            dequant_row(d, w2, s2, e, H, I, h, wrow, !d->w8a8);
+            dequant_row(d, w2, s2, d->gs2, e, H, I, h, wrow, !d->w8a8);
             for (int r0 = 0; r0 < R; r0 += 4096) {
                 int rr = R - r0 < 4096 ? R - r0 : 4096;
                 if (!d->w8a8) {
@@ -749,6 +782,27 @@ LKM_OR_API void lkm_or_f32_to_fp8(const float* src, int64_t n, uint8_t* dst) {
 }
 
 /* threads > 0 sets the OpenMP team size; the GEMM task loops use schedule(runtime) = dynamic,64 */
+/* dequantise E x N rows of a packed 4-bit format to act-dtype bit patterns (golden pinning) */
+LKM_OR_API void lkm_or_dequant_rows(int wfmt, int act_dtype, const void* w, const void* scale,
+                                    const float* gs, int64_t E, int64_t N, int64_t K, int groupK,
+                                    uint16_t* out) {
+    OrMoeDesc d;
+    memset(&d, 0, sizeof d);
+    d.wfmt = wfmt;
+    d.act_dtype = act_dtype;
+    d.groupN = 1;
+    d.groupK = groupK;
+    float* row = (float*)malloc(sizeof(float) * (size_t)K);
+    for (int64_t e = 0; e < E; ++e)
+        for (int64_t n = 0; n < N; ++n) {
+            dequant_row(&d, w, scale, gs, e, N, K, n, row, 1);
+            uint16_t* o = out + ((size_t)e * N + n) * K;
+            for (int64_t k = 0; k < K; ++k)
+                o[k] = act_dtype == OR_BF16 ? f32_to_bf16(row[k]) : f32_to_f16(row[k]);
+        }
+    free(row);
+}
+
 LKM_OR_API void lkm_or_configure(int threads) {
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);

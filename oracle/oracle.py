@@ -20,7 +20,7 @@ HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "liblkm_oracle.so"
 
 F32, BF16, F16 = 0, 1, 2
-W_BF16, W_F16, W_FP8, W_INT4 = 0, 1, 2, 3
+W_BF16, W_F16, W_FP8, W_INT4, W_NVFP4, W_MXFP4 = 0, 1, 2, 3, 4, 5
 ACT_SILU, ACT_SWIGLUOAI, ACT_RELU2 = 0, 1, 2
 
 
@@ -165,7 +165,8 @@ class _Desc(C.Structure):
     _fields_ = [("E", C.c_int32), ("H", C.c_int32), ("I", C.c_int32), ("has_gate", C.c_int32),
                 ("activation", C.c_int32), ("swiglu_alpha", C.c_float), ("swiglu_limit", C.c_float),
                 ("act_dtype", C.c_int32), ("wfmt", C.c_int32), ("groupN", C.c_int32),
-                ("groupK", C.c_int32), ("round_gemm1", C.c_int32), ("w8a8", C.c_int32)]
+                ("groupK", C.c_int32), ("round_gemm1", C.c_int32), ("w8a8", C.c_int32),
+                ("gs13", C.c_void_p), ("gs2", C.c_void_p)]
 
 
 @dataclass
@@ -185,8 +186,9 @@ class MoeDesc:
     w8a8: bool = False
 
 
-def moe(d: MoeDesc, w13, w2, x, ids, tw, s13=None, s2=None) -> np.ndarray:
-    """Routed experts; returns fp32 [M,H].  Arrays: see lkm_or_moe."""
+def moe(d: MoeDesc, w13, w2, x, ids, tw, s13=None, s2=None, gs13=None, gs2=None) -> np.ndarray:
+    """Routed experts; returns fp32 [M,H].  Arrays: see lkm_or_moe.  gs13/gs2: NVFP4 per-expert
+    f32 multipliers [E]."""
     x = _c(x)
     ids = _c(ids, np.int32)
     tw = _c(tw, np.float32)
@@ -195,8 +197,11 @@ def moe(d: MoeDesc, w13, w2, x, ids, tw, s13=None, s2=None) -> np.ndarray:
     w13, w2 = _c(w13), _c(w2)
     s13 = None if s13 is None else _c(s13)
     s2 = None if s2 is None else _c(s2)
+    gs13 = None if gs13 is None else _c(gs13, np.float32)
+    gs2 = None if gs2 is None else _c(gs2, np.float32)
     cd = _Desc(d.E, d.H, d.I, int(d.has_gate), d.activation, d.swiglu_alpha, d.swiglu_limit,
-               d.act_dtype, d.wfmt, d.groupN, d.groupK, int(d.round_gemm1), int(d.w8a8))
+               d.act_dtype, d.wfmt, d.groupN, d.groupK, int(d.round_gemm1), int(d.w8a8),
+               None if gs13 is None else gs13.ctypes.data, None if gs2 is None else gs2.ctypes.data)
     out = np.empty((M, d.H), np.float32)
     rc = lib().lkm_or_moe(C.byref(cd), _p(w13), _p(w2), _p(s13), _p(s2), _p(x), _p(ids), _p(tw),
                           C.c_int(M), C.c_int(K), _p(out))
@@ -227,6 +232,19 @@ def quant_fp8_block(w: np.ndarray, gN: int, gK: int):
         lib().lkm_or_quant_fp8_block(_p(w[e]), C.c_int64(N), C.c_int64(K), C.c_int(gN), C.c_int(gK),
                                      _p(q[e]), _p(s[e]))
     return q, s
+
+
+def dequant_rows(wfmt: int, act_dtype: int, w: np.ndarray, scale: np.ndarray, K: int, groupK: int,
+                 gs=None) -> np.ndarray:
+    """packed 4-bit weights uint8 [E,N,K/2] (+ scales, + NVFP4 multipliers) -> act-dtype bits [E,N,K]"""
+    w = _c(w, np.uint8)
+    scale = _c(scale)
+    E, N = w.shape[0], w.shape[1]
+    gs = None if gs is None else _c(gs, np.float32)
+    out = np.empty((E, N, K), np.uint16)
+    lib().lkm_or_dequant_rows(C.c_int(wfmt), C.c_int(act_dtype), _p(w), _p(scale), _p(gs), C.c_int64(E),
+                              C.c_int64(N), C.c_int64(K), C.c_int(groupK), _p(out))
+    return out
 
 
 def set_threads(n: int) -> None:

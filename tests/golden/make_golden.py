@@ -20,6 +20,9 @@ Functions executed (paths relative to /root/reference):
   native_per_token_group_quant_fp8  tests/kernels/quant_utils.py:157-180
   native_w8a8_block_matmul          tests/kernels/quant_utils.py:91-154
   torch_w8a8_block_fp8_moe          tests/kernels/moe/test_block_fp8.py:107-137
+  dq_mxfp4_torch (+ e8m0_to_half, upcast_fp4_to_fp16_or_bf16)   tests/quantization/reference_mxfp4.py:28-117
+  dequantize_nvfp4_to_dtype (+ break_fp4_bytes, convert_swizzled_to_linear)
+                                    tests/kernels/quantization/nvfp4_utils.py:16-87
 
 Run here (needs /root/reference):   python tests/golden/make_golden.py
 The GPU box never runs this; it only reads the committed .npz files.
@@ -60,6 +63,20 @@ def extract(path: str, names: list[str], ns: dict, cls: str | None = None, strip
     missing = set(names) - set(found)
     if missing:
         raise RuntimeError(f"{path}: functions not found: {missing}")
+    return ns
+
+
+def extract_assigns(path: str, ns: dict, upto_line: int = 10**9):
+    """exec the top-level constant assignments of a reference file (module constants the extracted
+    functions look up)."""
+    tree = ast.parse((REF / path).read_text())
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and node.lineno < upto_line:
+            try:
+                exec(compile(ast.fix_missing_locations(ast.Module(body=[node], type_ignores=[])),
+                             str(REF / path), "exec"), ns)
+            except Exception:
+                pass   # assignments that need names we do not provide are not used by our functions
     return ns
 
 
@@ -357,17 +374,85 @@ def gen_moe_fp8(ns):
     print("moe_fp8_block.npz:", idx, "cases")
 
 
+def gen_moe_fp4(ns):
+    """MXFP4 / NVFP4 expert weights: the reference's own dequantisers produce the dense weights, the
+    reference's CPU MoE oracle (ref_fused_moe) the outputs."""
+    nm = dict(ns)
+    extract_assigns("tests/quantization/reference_mxfp4.py", nm)
+    extract("tests/quantization/reference_mxfp4.py",
+            ["e8m0_to_half", "upcast_fp4_to_fp16_or_bf16", "dq_mxfp4_torch"], nm)
+    nn_ = dict(ns)
+    nn_["kE2M1ToFloat"] = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], dtype=torch.float32)
+    extract("tests/kernels/quantization/nvfp4_utils.py",
+            ["convert_swizzled_to_linear", "convert_swizzled_8x4_layout_to_linear",
+             "dequantize_nvfp4_to_dtype", "break_fp4_bytes"], nn_)
+    extract("tests/kernels/moe/test_cpu_fused_moe.py", ["ref_fused_moe"], ns)
+    dq_mx, dq_nv, to_linear = nm["dq_mxfp4_torch"], nn_["dequantize_nvfp4_to_dtype"], nn_["convert_swizzled_to_linear"]
+    ref_fused_moe = ns["ref_fused_moe"]
+    cases = {}
+    idx = 0
+    for fmt in ("mxfp4", "nvfp4"):
+        for (m, n, k, e, topk) in ((1, 128, 128, 4, 2), (33, 256, 128, 4, 2), (20, 128, 256, 8, 2)):
+            for dtype in (torch.bfloat16, torch.float16):
+                if dtype == torch.float16 and m != 33:
+                    continue
+                g = torch.Generator().manual_seed(100 + idx)
+                a = (torch.randn((m, k), generator=g) / 10).to(dtype)
+                score = torch.randn((m, e), generator=g).to(dtype)
+                tw, ids = _route(score, topk)
+                q1 = torch.randint(0, 256, (e, 2 * n, k // 2), generator=g, dtype=torch.uint8)
+                q2 = torch.randint(0, 256, (e, k, n // 2), generator=g, dtype=torch.uint8)
+                key = f"c{idx}"
+                if fmt == "mxfp4":
+                    s1 = torch.randint(119, 125, (e, 2 * n, k // 32), generator=g, dtype=torch.uint8)
+                    s2 = torch.randint(119, 125, (e, k, n // 32), generator=g, dtype=torch.uint8)
+                    w1 = dq_mx(q1, s1, dtype)
+                    w2 = dq_mx(q2, s2, dtype)
+                    cases[key + "_s1"], cases[key + "_s2"] = s1.numpy(), s2.numpy()
+                else:
+                    # block scales: random fp8 e4m3fn bytes (finite, positive), generated in the reference's
+                    # 128x4-swizzled storage and un-swizzled with the reference's own helper
+                    def sf(rows, kk):
+                        mt, kt = (rows + 127) // 128, (kk // 16 + 3) // 4
+                        raw = torch.randint(0x28, 0x48, (mt * 128 * kt * 4,), generator=g, dtype=torch.uint8)
+                        return raw, mt, kt
+                    gs1 = torch.tensor([2.0 ** (3 + (i % 3)) for i in range(e)])      # global scales (powers of two:
+                    gs2 = torch.tensor([2.0 ** (2 + (i % 2)) for i in range(e)])      #  sf / g == sf * (1/g) exactly)
+                    w1l, w2l, s1l, s2l = [], [], [], []
+                    for i in range(e):
+                        for (q, rows, kk, gsc, wl, sl) in ((q1[i], 2 * n, k, gs1[i], w1l, s1l), (q2[i], k, n, gs2[i], w2l, s2l)):
+                            raw, mt, kt = sf(rows, kk)
+                            swz = raw.view(torch.float8_e4m3fn)
+                            wl.append(dq_nv(q, swz, gsc, dtype, "cpu", block_size=16, is_sf_128x4_layout=True))
+                            lin = to_linear(raw, rows, kk, 16)       # the same scales, linear [rows, kk/16]
+                            sl.append(lin.contiguous())
+                    w1, w2 = torch.stack(w1l), torch.stack(w2l)
+                    cases[key + "_s1"], cases[key + "_s2"] = torch.stack(s1l).numpy(), torch.stack(s2l).numpy()
+                    cases[key + "_gs1"], cases[key + "_gs2"] = (1.0 / gs1).numpy().astype(np.float32), (1.0 / gs2).numpy().astype(np.float32)
+                out = ref_fused_moe(a, w1, w2, None, None, tw, ids.long(), MoEActivation.SILU)
+                cases[key + "_meta"] = np.array([m, n, k, e, topk, 0 if fmt == "mxfp4" else 1,
+                                                 1 if dtype == torch.bfloat16 else 2], np.int32)
+                cases[key + "_a"] = bits(a)
+                cases[key + "_q1"], cases[key + "_q2"] = q1.numpy(), q2.numpy()
+                if m == 1 or dtype == torch.float16:   # the reference's dequantised weights (pins the dequant)
+                    cases[key + "_w1"], cases[key + "_w2"] = bits(w1), bits(w2)
+                cases[key + "_tw"], cases[key + "_ids"] = tw.numpy(), ids.numpy()
+                cases[key + "_out"] = bits(out)
+                idx += 1
+    cases["n"] = np.array(idx, np.int32)
+    np.savez_compressed(OUT / "moe_fp4.npz", **cases)
+    print("moe_fp4.npz:", idx, "cases")
+
+
 def main():
     if not REF.exists():
         sys.exit("needs /root/reference (run in the build container, not on the GPU box)")
     torch.set_num_threads(8)
     ns = base_ns()
-    gen_topk(dict(ns))
-    gen_grouped(dict(ns))
-    gen_expert_map(dict(ns))
-    gen_moe_bf16(dict(ns))
-    gen_moe_int4(dict(ns))
-    gen_moe_fp8(dict(ns))
+    gens = {"topk": gen_topk, "grouped": gen_grouped, "expert_map": gen_expert_map, "bf16": gen_moe_bf16,
+            "int4": gen_moe_int4, "fp8": gen_moe_fp8, "fp4": gen_moe_fp4}
+    for name in (sys.argv[1:] or list(gens)):    # `make_golden.py fp4` regenerates one file only
+        gens[name](dict(ns))
 
 
 if __name__ == "__main__":

@@ -224,7 +224,7 @@ def test_quantised_tiled_path(fmt):
 
 @pytest.mark.parametrize("fmt", ["bf16", "int4", "fp8", "fp8a8"])
 def test_tiled_prefetch_depth_is_bit_identical(fmt):
-    """the weight/token prefetch rings (pd = 2 / 4 / 8 register stages) only move loads earlier: the
+    """the weight/token prefetch rings (pd = 2 / 4 register stages) only move loads earlier: the
     arithmetic and its order are unchanged, so every depth must give the SAME bits -- also when the
     ring is deeper than the K loop (U < pd) and when U is not a multiple of pd."""
     from lvllm_amd import _clib
@@ -244,7 +244,7 @@ def test_tiled_prefetch_depth_is_bit_identical(fmt):
             eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
                        w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128,
                        fp8_mode=_clib.FP8_W8A8 if fmt == "fp8a8" else _clib.FP8_W8A16)
-        for tiled, waves, depths in ((64, 4, (4, 8)), (64, 8, (4, 8)), (128, 8, (4,))):
+        for tiled, waves, depths in ((64, 4, (4,)), (64, 8, (4,)), (128, 8, (4,))):
             eng.engine.set_tuning(tiled=tiled, waves=waves, pd1=2, pd2=2)
             base = _run_decode(eng, a, tw, ids)
             assert np.isfinite(base).all() and np.abs(base).max() > 0
@@ -252,6 +252,81 @@ def test_tiled_prefetch_depth_is_bit_identical(fmt):
                 eng.engine.set_tuning(tiled=tiled, waves=waves, pd1=pd, pd2=pd)
                 out = _run_decode(eng, a, tw, ids)
                 assert np.array_equal(out, base), f"{fmt} {eng.engine.describe()}"
+
+
+def _fp4_engine(c, fmt, dt, e, n, k, topk):
+    tdt = torch.bfloat16 if dt == orc.BF16 else torch.float16
+    kw = {}
+    if fmt == 1:
+        kw = dict(w13_global_scale=torch.from_numpy(c["gs1"]), w2_global_scale=torch.from_numpy(c["gs2"]))
+    return _eng(torch.from_numpy(c["q1"]), torch.from_numpy(c["q2"]), top_k=topk, act_dtype=tdt,
+                fmt="mxfp4" if fmt == 0 else "nvfp4", w13_scale=torch.from_numpy(c["s1"]),
+                w2_scale=torch.from_numpy(c["s2"]), group_n=1, group_k=32 if fmt == 0 else 16, **kw), tdt
+
+
+def test_fp4_golden_cases():
+    """MXFP4 / NVFP4 experts: vs the CPU oracle (whose dequantisation is pinned bit-exactly to
+    the reference's dq_mxfp4_torch / dequantize_nvfp4_to_dtype) and vs the reference's own MoE output."""
+    n_cases = 0
+    for i, c in load_golden("moe_fp4.npz"):
+        m, n, k, e, topk, fmt, dt = [int(v) for v in c["meta"]]
+        eng, tdt = _fp4_engine(c, fmt, dt, e, n, k, topk)
+        a = bits_to_torch(c["a"], dt)
+        wf, g = (orc.W_MXFP4, 32) if fmt == 0 else (orc.W_NVFP4, 16)
+        d = orc.MoeDesc(E=e, H=k, I=n, act_dtype=dt, wfmt=wf, groupN=1, groupK=g)
+        ref = orc.moe(d, c["q1"], c["q2"], c["a"], c["ids"], c["tw"], s13=c["s1"], s2=c["s2"],
+                      gs13=c.get("gs1"), gs2=c.get("gs2"))
+        scale = max(1.0, float(np.abs(ref).max()))
+        for tiled in (-1, 64):
+            eng.engine.set_tuning(tiled=tiled)
+            out = _run_decode(eng, a, c["tw"], c["ids"])
+            np.testing.assert_allclose(out, ref, atol=ATOL * scale, rtol=RTOL, err_msg=f"case {i} fmt={fmt} tiled={tiled}")
+        gold = orc.bits_to_f32(c["out"], dt)
+        np.testing.assert_allclose(orc.bits_to_f32(orc.f32_to_bits(out, dt), dt), gold, atol=1e-3 * scale,
+                                   rtol=1.6e-2 if dt == orc.BF16 else 1e-3, err_msg=f"case {i} vs reference")
+        n_cases += 1
+    assert n_cases == 8
+
+
+@pytest.mark.parametrize("fmt", ["mxfp4", "nvfp4"])
+def test_fp4_dequant_is_bit_exact_on_gpu(fmt):
+    """reads the dequantised weights back through the engine: with x = e_j (one-hot rows, exact in bf16),
+    a non-gated relu2 expert and w2 = identity the output is relu(W13[:, j])^2 -- every E2M1 code x
+    scale combination must match the oracle's (= the reference's) dequantisation exactly."""
+    E, H, I, K = 2, 128, 128, 1
+    rng = np.random.default_rng(5)
+    q13 = rng.integers(0, 256, (E, I, H // 2), dtype=np.uint8)
+    if fmt == "mxfp4":
+        s13 = rng.integers(121, 131, (E, I, H // 32), dtype=np.uint8)
+        g, wf, gs = 32, orc.W_MXFP4, None
+    else:
+        s13 = rng.integers(0x30, 0x40, (E, I, H // 16), dtype=np.uint8)
+        g, wf, gs = 16, orc.W_NVFP4, np.array([0.5, 1.75], np.float32)
+    wd = orc.bits_to_f32(orc.dequant_rows(wf, orc.BF16, q13, s13, H, g, gs=gs), orc.BF16)    # [E, I, H]
+    # w2 = identity in the same format: E2M1 code 2 (=1.0) on the diagonal, unit scales
+    q2 = np.zeros((E, H, I // 2), np.uint8)
+    for r in range(H):
+        q2[:, r, r // 2] = 0x02 << (4 * (r & 1))
+    s2 = np.full((E, H, I // g), 127 if fmt == "mxfp4" else 0x38, np.uint8)
+    kw = {} if gs is None else dict(w13_global_scale=torch.from_numpy(gs), w2_global_scale=torch.ones(E))
+    eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt=fmt,
+               w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=1, group_k=g,
+               has_gate_proj=False, activation_type=2, **kw)
+    x = torch.eye(H, dtype=torch.bfloat16)
+    for e in range(E):
+        ids = np.full((H, 1), e, np.int32)
+        tw = np.ones((H, 1), np.float32)
+        for tiled in (-1, 64):
+            eng.engine.set_tuning(tiled=tiled)
+            out = _run_decode(eng, x, tw, ids)                       # out[j, i] = bf16(relu(W[e,i,j])^2)
+            want = np.maximum(wd[e].T, 0.0) ** 2
+            want = orc.bits_to_f32(orc.f32_to_bits(want.astype(np.float32), orc.BF16), orc.BF16)
+            np.testing.assert_array_equal(out, want, err_msg=f"{fmt} expert {e} tiled={tiled}")
+            # negative weights: same with x = -e_j
+            out = _run_decode(eng, -x, tw, ids)
+            want = np.maximum(-wd[e].T, 0.0) ** 2
+            want = orc.bits_to_f32(orc.f32_to_bits(want.astype(np.float32), orc.BF16), orc.BF16)
+            np.testing.assert_array_equal(out, want, err_msg=f"{fmt} expert {e} tiled={tiled} (neg)")
 
 
 def test_relu2_non_gated():
@@ -334,8 +409,12 @@ def test_errors_are_loud():
     import lk_moe
     cfg = lk_moe.MOEConfigV2()
     cfg.expert_num, cfg.top_k, cfg.hidden_size, cfg.intermediate_size = 2, 1, 64, 64
+    cfg.groupN, cfg.groupK = 1, 64
     with pytest.raises(LkmError):
-        lk_moe.MOE_NVFP4(cfg, 1, 1, 1, 1, 1, 1)               # not built -> raises
+        lk_moe.MOE_MXFP4(cfg, 1, 1, 1, 1, 0, 0)               # MXFP4 block scales are 1 x 32
+    cfg.groupK = 32
+    with pytest.raises(LkmError):
+        lk_moe.MOE_MXFP4(cfg, 1, 1, 0, 0, 0, 0)               # missing scales
 
 
 @pytest.fixture(scope="module")

@@ -166,6 +166,27 @@ def test_int4_quantiser_and_moe_vs_reference():
             np.testing.assert_array_equal(out2, out)
 
 
+def test_fp4_dequant_and_moe_vs_reference():
+    """MXFP4 (dq_mxfp4_torch) and NVFP4 (dequantize_nvfp4_to_dtype) dequantisation bit-exact; MoE on
+    those weights vs the reference's CPU oracle with its own tolerance (allclose_default.py:8-9)."""
+    seen = set()
+    for i, c in load_golden("moe_fp4.npz"):
+        m, n, k, e, topk, fmt, dt = [int(v) for v in c["meta"]]
+        wf, g = (orc.W_MXFP4, 32) if fmt == 0 else (orc.W_NVFP4, 16)
+        gs1, gs2 = (c.get("gs1"), c.get("gs2")) if fmt == 1 else (None, None)
+        if "w1" in c:
+            np.testing.assert_array_equal(orc.dequant_rows(wf, dt, c["q1"], c["s1"], k, g, gs=gs1), c["w1"])
+            np.testing.assert_array_equal(orc.dequant_rows(wf, dt, c["q2"], c["s2"], n, g, gs=gs2), c["w2"])
+            seen.add((fmt, dt))
+        d = orc.MoeDesc(E=e, H=k, I=n, act_dtype=dt, wfmt=wf, groupN=1, groupK=g)
+        out = orc.moe(d, c["q1"], c["q2"], c["a"], c["ids"], c["tw"], s13=c["s1"], s2=c["s2"], gs13=gs1, gs2=gs2)
+        ref = orc.bits_to_f32(c["out"], dt)
+        rtol = 1.6e-2 if dt == orc.BF16 else 1e-3
+        np.testing.assert_allclose(orc.bits_to_f32(orc.f32_to_bits(out, dt), dt), ref,
+                                   atol=1e-3 * max(1.0, float(np.abs(ref).max())), rtol=rtol, err_msg=f"case {i}")
+    assert seen == {(0, orc.BF16), (0, orc.F16), (1, orc.BF16), (1, orc.F16)}
+
+
 def test_fp8_block_w8a8_vs_reference():
     """torch_w8a8_block_fp8_moe; tol 0.035: tests/kernels/moe/test_block_fp8.py:205-207."""
     for i, c in load_golden("moe_fp8_block.npz"):

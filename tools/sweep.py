@@ -13,7 +13,7 @@ import torch
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
-from bench import WORKLOADS, make_weights, quantize_fp8_block, quantize_int4  # noqa: E402
+from bench import WORKLOADS, build_engine, make_weights  # noqa: E402
 from lvllm_amd import ops  # noqa: E402
 
 
@@ -32,20 +32,7 @@ def main():
     E, K, H, I, M, fmt = wl["E"], wl["K"], wl["H"], wl["I"], wl["M"], wl["fmt"]
     dev = torch.device("cuda", 0)
     w13, w2 = make_weights(E, 0, H, I, dev, fmt)
-    if fmt == "int4":
-        q13, s13 = quantize_int4(w13, wl["g"]); q2, s2 = quantize_int4(w2, wl["g"])
-        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="int4", w13_scale=s13,
-                                      w2_scale=s2, group_n=1, group_k=wl["g"])
-        bpe = 0.5 + 2.0 / wl["g"]
-    elif fmt == "fp8":
-        q13, s13 = quantize_fp8_block(w13); q2, s2 = quantize_fp8_block(w2)
-        eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="fp8", w13_scale=s13,
-                                      w2_scale=s2, group_n=128, group_k=128, fp8_mode=wl.get("fp8_mode", 0),
-                                      max_num_seqs=max(256, M))
-        bpe = 1.0 + 4.0 / (128 * 128)
-    else:
-        eng = ops.RoutedExpertsEngine(w13, w2, top_k=K, act_dtype=torch.bfloat16, max_num_seqs=max(256, M))
-        bpe = 2.0
+    eng, bpe, _ = build_engine(ops, wl, w13, w2, max_num_seqs=max(256, M))
     del w13, w2
     gen = torch.Generator(device=dev).manual_seed(7)
     x = (torch.randn((M, H), generator=gen, device=dev) / 10).to(torch.bfloat16)

@@ -360,7 +360,8 @@ def main():
             "metric": "moe_layer_decode_tokens_per_s", "value": round(tokens_per_s, 1), "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act", "fp8": "fp8-w/" + ("fp8-act" if wl.get("fp8_mode") else "bf16-act")}[fmt], "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act", "mxfp4": "mxfp4-w/bf16-act", "nvfp4": "nvfp4-w/bf16-act",
+                              "fp8": "fp8-w/" + ("fp8-act" if wl.get("fp8_mode") else "bf16-act")}[fmt], "data": "synthetic",
             "config": {"workload": args.workload, "experts": E, "top_k": K, "hidden": H,
                        "intermediate": I, "batch_per_gpu": M, "routing": args.routing,
                        "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}",

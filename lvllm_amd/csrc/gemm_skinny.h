@@ -530,7 +530,9 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
                                 pk.y = ActT<ADT>::pack2(v[2], v[3]);
                                 *(u32x2*)o = pk;
                             } else {
-                                for (int r = 0; r < 4 && n + r < p.n_real; ++r) o[r] = ActT<ADT>::from_f32(v[r]);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)   // static r: a runtime index would spill acc
+                                    if (n + r < p.n_real) o[r] = ActT<ADT>::from_f32(v[r]);
                             }
                         }
                     }
@@ -601,7 +603,9 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
                     if (n + 4 <= p.n_real) {
                         *(f32x4*)o = acc[t][b];
                     } else {
-                        for (int r = 0; r < 4 && n + r < p.n_real; ++r) o[r] = acc[t][b][r];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < p.n_real) o[r] = acc[t][b][r];
                     }
                 }
             }

@@ -55,6 +55,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     static_assert(PIECES >= 1 && TM * SLOTS % THREADS == 0, "staging split");
     extern __shared__ __attribute__((aligned(16))) char xlds[];   // [2]{[TM][ROWB], A8: float[TM]}
 
+    // Measured and NOT used at 256-row tiles (GLM prefill, gemm1/gemm2 us): writing the next unit's token
+    // rows to LDS at the top of the iteration + double-buffered token-fragment chunks interleaved with
+    // the MFMAs by sched_group_barrier: 2123/1168 vs 1853/1048; 4 waves x 4 weight tiles x 256 tokens (one
+    // wave per SIMD, 512 registers): 2452/1233.  What this kernel lacks for the MFMA roof is the
+    // weight operand through LDS (glds) with a counted-vmcnt multi-phase schedule -- see DESIGN.md 6.
     // Work mapping: blockIdx.x = row group (fastest), blockIdx.y = (expert, token tile) item, default
     // round-robin XCD placement.  Measured and NOT used: (1) a "contiguous run of items per XCD" remap
     // (GLM prefill 4.54 ms vs 4.12 ms, Mixtral M=512 1.31 ms vs 0.93 ms: the XCDs then stream different
@@ -355,59 +360,66 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
         }
     }
 
-    // epilogue: D layout lane (g,j): rows tile*16 + g*4 + r, token column j of block b
+    // epilogue: D layout lane (g,j): rows tile*16 + g*4 + r, token column j of block b.  Blocks and
+    // tiles are compile-time indices (static_for): a runtime index into acc[][] would move the whole
+    // accumulator array to scratch memory.
     if (!wave_on) return;
-#pragma unroll
-    for (int b = 0; b < TBW; ++b) {
+    static_for<TBW>([&](auto BC) __attribute__((always_inline)) {
+        constexpr int b = decltype(BC)::v;
         const int r_tok = r0 + b * 16 + j;
         if (r_tok < m_e) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            static_for<NT>([&](auto TC) __attribute__((always_inline)) {
+                constexpr int t = decltype(TC)::v;
                 const int n = (tile0 + t) * 16 + g * 4;
-                if (n >= p.n_real) continue;
-                if (IS_G1) {
-                    float v[4];
+                if (n < p.n_real) {
+                    if constexpr (IS_G1) {
+                        float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float a = acc[t][b][r];
-                        if (p.round_gemm1) a = ActT<ADT>::to_f32(ActT<ADT>::from_f32(a));
-                        if (GATED) {
-                            float up = acc[NTT - NT + t][b][r];
-                            if (p.round_gemm1) up = ActT<ADT>::to_f32(ActT<ADT>::from_f32(up));
-                            if (p.act_type == LKM_ACT_SWIGLUOAI) {
-                                const float gg = fminf(a, p.limit);
-                                const float uu = fmaxf(fminf(up, p.limit), -p.limit);
-                                v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
-                            } else if (p.round_gemm1) {
-                                v[r] = ActT<ADT>::to_f32(ActT<ADT>::from_f32(act_silu(a))) * up;
+                        for (int r = 0; r < 4; ++r) {
+                            float a = acc[t][b][r];
+                            if (p.round_gemm1) a = ActT<ADT>::to_f32(ActT<ADT>::from_f32(a));
+                            if constexpr (GATED) {
+                                float up = acc[NTT - NT + t][b][r];
+                                if (p.round_gemm1) up = ActT<ADT>::to_f32(ActT<ADT>::from_f32(up));
+                                if (p.act_type == LKM_ACT_SWIGLUOAI) {
+                                    const float gg = fminf(a, p.limit);
+                                    const float uu = fmaxf(fminf(up, p.limit), -p.limit);
+                                    v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
+                                } else if (p.round_gemm1) {
+                                    v[r] = ActT<ADT>::to_f32(ActT<ADT>::from_f32(act_silu(a))) * up;
+                                } else {
+                                    v[r] = act_silu(a) * up;
+                                }
                             } else {
-                                v[r] = act_silu(a) * up;
+                                const float tt = a > 0.0f ? a : 0.0f;
+                                v[r] = tt * tt;
                             }
+                        }
+                        unsigned short* o = (unsigned short*)p.out + (size_t)(off_e + r_tok) * p.ldo + n;
+                        if (n + 4 <= p.n_real) {
+                            u32x2 pk;
+                            pk.x = ActT<ADT>::pack2(v[0], v[1]);
+                            pk.y = ActT<ADT>::pack2(v[2], v[3]);
+                            *(u32x2*)o = pk;
                         } else {
-                            const float tt = a > 0.0f ? a : 0.0f;
-                            v[r] = tt * tt;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (n + r < p.n_real) o[r] = ActT<ADT>::from_f32(v[r]);
+                        }
+                    } else {
+                        float* o = (float*)p.out + (size_t)(off_e + r_tok) * p.ldo + n;
+                        if (n + 4 <= p.n_real) {
+                            *(f32x4*)o = acc[t][b];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (n + r < p.n_real) o[r] = acc[t][b][r];
                         }
                     }
-                    unsigned short* o = (unsigned short*)p.out + (size_t)(off_e + r_tok) * p.ldo + n;
-                    if (n + 4 <= p.n_real) {
-                        u32x2 pk;
-                        pk.x = ActT<ADT>::pack2(v[0], v[1]);
-                        pk.y = ActT<ADT>::pack2(v[2], v[3]);
-                        *(u32x2*)o = pk;
-                    } else {
-                        for (int r = 0; r < 4 && n + r < p.n_real; ++r) o[r] = ActT<ADT>::from_f32(v[r]);
-                    }
-                } else {
-                    float* o = (float*)p.out + (size_t)(off_e + r_tok) * p.ldo + n;
-                    if (n + 4 <= p.n_real) {
-                        *(f32x4*)o = acc[t][b];
-                    } else {
-                        for (int r = 0; r < 4 && n + r < p.n_real; ++r) o[r] = acc[t][b][r];
-                    }
                 }
-            }
+            });
         }
-    }
+    });
 }
 
 template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1, int PD>

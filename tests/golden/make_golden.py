@@ -21,6 +21,8 @@ Functions executed (paths relative to /root/reference):
   native_w8a8_block_matmul          tests/kernels/quant_utils.py:91-154
   torch_w8a8_block_fp8_moe          tests/kernels/moe/test_block_fp8.py:107-137
   dq_mxfp4_torch (+ e8m0_to_half, upcast_fp4_to_fp16_or_bf16)   tests/quantization/reference_mxfp4.py:28-117
+  RoutedExperts._load_w13 / _load_w2 / _load_model_weight_or_group_weight_scale /
+    _narrow_expert_data_for_padding / _get_hidden_dim   vllm/model_executor/layers/fused_moe/routed_experts.py:383-612
   dequantize_nvfp4_to_dtype (+ break_fp4_bytes, convert_swizzled_to_linear)
                                     tests/kernels/quantization/nvfp4_utils.py:16-87
 
@@ -444,13 +446,128 @@ def gen_moe_fp4(ns):
     print("moe_fp4.npz:", idx, "cases")
 
 
+def gen_ingest(ns):
+    """SURVEY 8(f1) weight ingest: a tiny synthetic checkpoint (per-expert gate/up/down tensors) is loaded
+    with the reference's own RoutedExperts loader helpers (_load_w13, _load_w2,
+    _load_model_weight_or_group_weight_scale, _narrow_expert_data_for_padding, _get_hidden_dim;
+    routed_experts.py:383-612) for every (tp_rank, ep_rank), then put through the _process_* hand-off
+    (routed_experts.py:1457-1466: the compressed-tensors int4 parameters are stored transposed and are
+    transposed back + viewed as uint8).  Saved: the checkpoint tensors and, per rank, the tensors the
+    reference would pass to lk_moe."""
+    import functools
+    import types
+    fns = {}
+    extract("vllm/model_executor/layers/fused_moe/routed_experts.py",
+            ["_load_w13", "_load_w2", "_load_model_weight_or_group_weight_scale", "_narrow_expert_data_for_padding",
+             "_get_hidden_dim"], fns, cls="RoutedExperts")
+    extract("vllm/model_executor/layers/fused_moe/expert_map_manager.py", ["determine_expert_map"],
+            ns_em := dict(ns, get_compute_capability=None, logger=types.SimpleNamespace(info=lambda *a, **k: None,
+                                                                                       warning=lambda *a, **k: None)))
+
+    def make_self(tp_size, tp_rank):
+        me = types.SimpleNamespace()
+        me.moe_config = types.SimpleNamespace(is_act_and_mul=True, tp_rank=tp_rank, tp_size=tp_size,
+                                              moe_parallel_config=types.SimpleNamespace(tp_size=tp_size))
+        me._get_hidden_dim = fns["_get_hidden_dim"]
+        me._narrow_expert_data_for_padding = fns["_narrow_expert_data_for_padding"]
+        me._load_w13 = functools.partial(fns["_load_w13"], me)
+        me._load_w2 = functools.partial(fns["_load_w2"], me)
+        me.load = functools.partial(fns["_load_model_weight_or_group_weight_scale"], me)
+        return me
+
+    g = torch.Generator().manual_seed(4242)
+    cases = {}
+    idx = 0
+    for quant in ("none", "fp8_block", "int4", "mxfp4"):
+        E, H, I = (2, 128, 256) if quant == "fp8_block" else (4, 64, 64)
+        # ---- the checkpoint: per expert, w1/w3 [I, K=H], w2 [H, K=I] in the checkpoint's own packing
+        ck = {}
+        for e in range(E):
+            for sid, (n, k) in (("w1", (I, H)), ("w3", (I, H)), ("w2", (H, I))):
+                if quant == "none":
+                    ck[(e, sid, "weight")] = torch.randn((n, k), generator=g).to(torch.bfloat16)
+                elif quant == "fp8_block":
+                    ck[(e, sid, "weight")] = torch.randint(0, 256, (n, k), generator=g, dtype=torch.uint8)
+                    ck[(e, sid, "weight_scale_inv")] = torch.rand((n // 128, k // 128), generator=g) + 0.5
+                elif quant == "int4":      # compressed-tensors pack-quantized: int32 [N, K/8], scales [N, K/g]
+                    ck[(e, sid, "weight_packed")] = torch.randint(-2**31, 2**31 - 1, (n, k // 8), generator=g, dtype=torch.int32)
+                    ck[(e, sid, "weight_scale")] = (torch.rand((n, k // 32), generator=g) / 8).to(torch.bfloat16)
+                else:                      # mxfp4: uint8 [N, K/2], E8M0 [N, K/32]
+                    ck[(e, sid, "weight_packed")] = torch.randint(0, 256, (n, k // 2), generator=g, dtype=torch.uint8)
+                    ck[(e, sid, "weight_scale")] = torch.randint(118, 130, (n, k // 32), generator=g, dtype=torch.uint8)
+        key = f"c{idx}"
+        for (e, sid, kind), t in ck.items():
+            cases[f"{key}_ck_{e}_{sid}_{kind}"] = bits(t) if t.dtype == torch.bfloat16 else t.numpy()
+        ranks = []
+        for (tp, ep) in ((1, 1), (2, 1), (1, 2), (2, 2)):
+            for tp_rank in range(tp):
+                for ep_rank in range(ep):
+                    n_local, emap, _ = ns_em["determine_expert_map"](ep, ep_rank, E) if ep > 1 else (E, None, None)
+                    Ip = I // tp
+                    me = make_self(tp, tp_rank)
+                    transposed = quant == "int4"     # CompressedTensorsWNA16MoEMethod: is_transposed params
+                    P = {}
+                    if quant == "none":
+                        P["w13_weight"] = torch.zeros((n_local, 2 * Ip, H), dtype=torch.bfloat16)
+                        P["w2_weight"] = torch.zeros((n_local, H, Ip), dtype=torch.bfloat16)
+                    elif quant == "fp8_block":
+                        P["w13_weight"] = torch.zeros((n_local, 2 * Ip, H), dtype=torch.uint8)
+                        P["w2_weight"] = torch.zeros((n_local, H, Ip), dtype=torch.uint8)
+                        P["w13_weight_scale_inv"] = torch.zeros((n_local, 2 * Ip // 128, H // 128))
+                        P["w2_weight_scale_inv"] = torch.zeros((n_local, H // 128, max(1, Ip // 128)))
+                    elif quant == "int4":
+                        P["w13_weight_packed"] = torch.zeros((n_local, H // 8, 2 * Ip), dtype=torch.int32)
+                        P["w2_weight_packed"] = torch.zeros((n_local, Ip // 8, H), dtype=torch.int32)
+                        P["w13_weight_scale"] = torch.zeros((n_local, H // 32, 2 * Ip), dtype=torch.bfloat16)
+                        P["w2_weight_scale"] = torch.zeros((n_local, Ip // 32, H), dtype=torch.bfloat16)
+                    else:
+                        P["w13_weight_packed"] = torch.zeros((n_local, 2 * Ip, H // 2), dtype=torch.uint8)
+                        P["w2_weight_packed"] = torch.zeros((n_local, H, Ip // 2), dtype=torch.uint8)
+                        P["w13_weight_scale"] = torch.zeros((n_local, 2 * Ip, H // 32), dtype=torch.uint8)
+                        P["w2_weight_scale"] = torch.zeros((n_local, H, Ip // 32), dtype=torch.uint8)
+                    for (e, sid, kind), t in ck.items():
+                        le = e if emap is None else int(emap[e])
+                        if le < 0:
+                            continue
+                        pname = ("w13_" if sid in ("w1", "w3") else "w2_") + kind
+                        lw = t.t().contiguous() if transposed else t                      # weight_loader :707-716
+                        shard_dim = {"w1": 0, "w2": 1, "w3": 0}[sid]
+                        if transposed:
+                            shard_dim = int(not shard_dim)                                 # :763-765
+                        me.load(shard_dim=shard_dim, expert_data=P[pname][le], shard_id=sid, loaded_weight=lw,
+                                tp_rank=tp_rank)
+                    if quant == "int4":                                                    # _process_wna16 :1457-1461
+                        out = {"w13": P["w13_weight_packed"].transpose(1, 2).contiguous().view(torch.uint8),
+                               "w2": P["w2_weight_packed"].transpose(1, 2).contiguous().view(torch.uint8),
+                               "s13": P["w13_weight_scale"].transpose(1, 2).contiguous(),
+                               "s2": P["w2_weight_scale"].transpose(1, 2).contiguous()}
+                    elif quant == "none":
+                        out = {"w13": P["w13_weight"], "w2": P["w2_weight"]}
+                    elif quant == "fp8_block":
+                        out = {"w13": P["w13_weight"], "w2": P["w2_weight"], "s13": P["w13_weight_scale_inv"],
+                               "s2": P["w2_weight_scale_inv"]}
+                    else:
+                        out = {"w13": P["w13_weight_packed"], "w2": P["w2_weight_packed"],
+                               "s13": P["w13_weight_scale"], "s2": P["w2_weight_scale"]}
+                    tag = f"{key}_r{len(ranks)}"
+                    ranks.append((tp, tp_rank, ep, ep_rank))
+                    for nm, t in out.items():
+                        cases[f"{tag}_{nm}"] = bits(t) if t.dtype == torch.bfloat16 else t.numpy()
+        cases[key + "_ranks"] = np.array(ranks, np.int32)
+        cases[key + "_meta"] = np.array([E, H, I, {"none": 0, "fp8_block": 1, "int4": 2, "mxfp4": 3}[quant]], np.int32)
+        idx += 1
+    cases["n"] = np.array(idx, np.int32)
+    np.savez_compressed(OUT / "ingest.npz", **cases)
+    print("ingest.npz:", idx, "cases")
+
+
 def main():
     if not REF.exists():
         sys.exit("needs /root/reference (run in the build container, not on the GPU box)")
     torch.set_num_threads(8)
     ns = base_ns()
     gens = {"topk": gen_topk, "grouped": gen_grouped, "expert_map": gen_expert_map, "bf16": gen_moe_bf16,
-            "int4": gen_moe_int4, "fp8": gen_moe_fp8, "fp4": gen_moe_fp4}
+            "int4": gen_moe_int4, "fp8": gen_moe_fp8, "fp4": gen_moe_fp4, "ingest": gen_ingest}
     for name in (sys.argv[1:] or list(gens)):    # `make_golden.py fp4` regenerates one file only
         gens[name](dict(ns))
 

@@ -153,6 +153,27 @@ int lkm_grouped_topk(void* stream, const void* logits, int32_t logits_dtype, con
                      float* out_weights, int32_t* out_ids);
 
 /*
+ * Router GEMM + routing in one call: logits = hidden . gate_w^T (+ gate_bias), then the
+ * routing of lkm_topk_softmax (n_group == 0) or lkm_grouped_topk (n_group > 0) on those logits.
+ * Replaces the gate projection + router of moe_runner.py:903-908 / router/gate_linear.py:17-34
+ * (F.linear or the small-M router GEMMs; numerical reference tests/kernels/test_fp32_router_gemm.py:
+ * F.linear in fp32) followed by fused_topk / grouped_topk.
+ *   hidden [M,H] bf16|fp16 (x_dtype); gate_w [E,H] in x_dtype or fp32 (w_dtype); gate_bias [E] fp32 or
+ *   NULL; score_bias = e_score_correction_bias [E] or NULL; logits_dtype: LKM_DT_F32 keeps the fp32
+ *   logits (router GEMMs with fp32 output), x_dtype rounds them first (F.linear in the gate's dtype);
+ *   workspace: >= lkm_router_workspace_bytes(M,H,E) bytes of device memory (split-K partials);
+ *   logits_out [M,E] fp32 or NULL.  H must be a multiple of 32 (16 with fp32 gate weights).
+ * Two launches, stream-ordered, graph-capturable.
+ */
+int64_t lkm_router_workspace_bytes(int32_t M, int32_t H, int32_t E);
+int lkm_router_gemm_topk(void* stream, const void* hidden, int32_t x_dtype, const void* gate_w,
+                         int32_t w_dtype, const float* gate_bias, const float* score_bias, int32_t M,
+                         int32_t H, int32_t E, int32_t K, int32_t scoring, int32_t renormalize,
+                         float routed_scaling, int32_t n_group, int32_t topk_group,
+                         int32_t logits_dtype, void* workspace, int64_t workspace_bytes,
+                         float* logits_out, float* out_weights, int32_t* out_ids);
+
+/*
  * Replaces RoutedExperts.global_to_local_expert_ids (routed_experts.py:1332-1342):
  * out[i] = ids[i] < 0 ? -1 : expert_map[clamp(ids[i], 0, E-1)].  DEVICE pointers.
  */

@@ -57,6 +57,11 @@ _SIGS = {
     "lkm_grouped_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "lkm_router_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "lkm_router_gemm_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lkm_map_expert_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                      C.c_void_p]),
     "lkm_ep_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

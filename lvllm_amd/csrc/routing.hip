@@ -21,15 +21,47 @@ __device__ __forceinline__ float load_logit(const void* p, int dt, size_t i) {
     return dt == LKM_DT_BF16 ? bf16_bits_to_f32(h) : f16_bits_to_f32(h);
 }
 
+// Where a row's logits come from: a tensor in any of the three dtypes, or -- behind the router GEMM
+// (router_gemm.hip) -- n_slabs f32 split-K partials that are summed in ascending slab order, plus the
+// gate bias, optionally rounded to the gate's output dtype (F.linear in bf16/f16), optionally copied out.
+struct LogitSrc {
+    const void* p;
+    int dt;
+    int n_slabs;
+    long long slab_stride;   // floats between slabs
+    const float* gate_bias;  // [E] or null
+    int round_dt;            // LKM_DT_F32 = keep fp32
+    float* logits_out;       // [M,E] fp32 or null
+    __device__ __forceinline__ float load(int row, int E, int e) const {
+#pragma clang fp contract(off)
+        const size_t i = (size_t)row * E + e;
+        if (n_slabs <= 1 && !gate_bias && round_dt == LKM_DT_F32 && !logits_out) return load_logit(p, dt, i);
+        float v = load_logit(p, dt, i);
+        for (int s0 = 1; s0 < n_slabs; s0 += 8) {   // up to 8 independent loads in flight, summed in slab order
+            float part[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                part[q] = s0 + q < n_slabs ? ((const float*)p)[(size_t)(s0 + q) * slab_stride + i] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v = v + part[q];
+        }
+        if (gate_bias) v = v + gate_bias[e];
+        if (round_dt == LKM_DT_BF16) v = bf16_bits_to_f32(f32_to_bf16_bits(v));
+        if (round_dt == LKM_DT_F16) v = f16_bits_to_f32(f32_to_f16_bits(v));
+        if (logits_out) logits_out[i] = v;
+        return v;
+    }
+};
+
 // scores for one row, in registers: sc[s] = score of expert s*64+lane (0 for e >= E)
-__device__ __forceinline__ void row_scores(const void* logits, int dt, int row, int E, int lane,
+__device__ __forceinline__ void row_scores(const LogitSrc& src, int row, int E, int lane,
                                            int scoring, float (&sc)[kMaxSlots]) {
 #pragma clang fp contract(off)
     float v[kMaxSlots];
 #pragma unroll
     for (int s = 0; s < kMaxSlots; ++s) {
         int e = s * 64 + lane;
-        v[s] = (e < E) ? load_logit(logits, dt, (size_t)row * E + e) : -__builtin_inff();
+        v[s] = (e < E) ? src.load(row, E, e) : -__builtin_inff();
     }
     if (scoring == 0) {
         float mx = v[0];
@@ -78,14 +110,14 @@ __device__ __forceinline__ void wave_argmax(float& bv, int& be, float& bp) {
 }
 
 __global__ __launch_bounds__(256) void topk_softmax_kernel(
-    const void* __restrict__ logits, int dt, const float* __restrict__ bias, int M, int E, int K,
+    LogitSrc src, const float* __restrict__ bias, int M, int E, int K,
     int scoring, int renorm, float rsf, float* __restrict__ out_w, int32_t* __restrict__ out_ids) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     float sc[kMaxSlots], ch[kMaxSlots];
-    row_scores(logits, dt, row, E, lane, scoring, sc);
+    row_scores(src, row, E, lane, scoring, sc);
 #pragma unroll
     for (int s = 0; s < kMaxSlots; ++s) {
         int e = s * 64 + lane;
@@ -125,7 +157,7 @@ __global__ __launch_bounds__(256) void topk_softmax_kernel(
 }
 
 __global__ __launch_bounds__(256) void grouped_topk_kernel(
-    const void* __restrict__ logits, int dt, const float* __restrict__ bias, int M, int E, int K,
+    LogitSrc src, const float* __restrict__ bias, int M, int E, int K,
     int n_group, int topk_group, int scoring, int renorm, float rsf, float* __restrict__ out_w,
     int32_t* __restrict__ out_ids) {
 #pragma clang fp contract(off)
@@ -137,7 +169,7 @@ __global__ __launch_bounds__(256) void grouped_topk_kernel(
     const int gsz = E / n_group;
     float sc[kMaxSlots], ch[kMaxSlots];
     if (active) {
-        row_scores(logits, dt, row, E, lane, scoring, sc);
+        row_scores(src, row, E, lane, scoring, sc);
 #pragma unroll
         for (int s = 0; s < kMaxSlots; ++s) {
             int e = s * 64 + lane;
@@ -283,9 +315,9 @@ extern "C" int lkm_topk_softmax(void* stream, const void* logits, int32_t logits
     LKM_REQUIRE(logits_dtype >= LKM_DT_F32 && logits_dtype <= LKM_DT_F16, "topk_softmax: bad dtype");
     LKM_REQUIRE(scoring == 0 || scoring == 1, "topk_softmax: scoring must be 0 (softmax) or 1 (sigmoid)");
     if (M == 0) return LKM_OK;
+    const LogitSrc src{logits, logits_dtype, 1, 0, nullptr, LKM_DT_F32, nullptr};
     hipLaunchKernelGGL(topk_softmax_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, (hipStream_t)stream,
-                       logits, logits_dtype, bias, M, E, K, scoring, renormalize, routed_scaling,
-                       out_weights, out_ids);
+                       src, bias, M, E, K, scoring, renormalize, routed_scaling, out_weights, out_ids);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }
@@ -303,9 +335,198 @@ extern "C" int lkm_grouped_topk(void* stream, const void* logits, int32_t logits
     LKM_REQUIRE(logits_dtype >= LKM_DT_F32 && logits_dtype <= LKM_DT_F16, "grouped_topk: bad dtype");
     LKM_REQUIRE(scoring == 0 || scoring == 1, "grouped_topk: scoring must be 0 or 1");
     if (M == 0) return LKM_OK;
+    const LogitSrc src{logits, logits_dtype, 1, 0, nullptr, LKM_DT_F32, nullptr};
     hipLaunchKernelGGL(grouped_topk_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, (hipStream_t)stream,
-                       logits, logits_dtype, bias, M, E, K, n_group, topk_group, scoring,
-                       renormalize, routed_scaling, out_weights, out_ids);
+                       src, bias, M, E, K, n_group, topk_group, scoring, renormalize, routed_scaling,
+                       out_weights, out_ids);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+
+// ------------------------------------------------------------------ router GEMM
+// logits[M,E] = x[M,H] . Wg[E,H]^T, fp32 accumulate: the gate projection the reference runs as F.linear /
+// its specialised small-M router GEMMs (moe_runner.py:903-908, router/gate_linear.py:17-34;
+// tests/kernels/test_fp32_router_gemm.py:35-37 is the numerical reference: F.linear in fp32).
+// The problem is tiny and latency-bound (DSv3: 3.7 MB of gate weights, M <= a few hundred), so it is
+// cut into (16-expert tile) x (K slice) x (16-token block) work items, one wavefront each, spread over
+// the whole chip; every item writes its f32 partial tile to slab[kslice] and the top-k kernel that
+// follows sums the slabs in ascending order while it loads the row (LogitSrc) -- deterministic, no
+// atomics, no third launch.  Gate weights = MFMA A operand straight from their [E,H] row-major home
+// (16-byte loads), tokens = B operand.
+//   16-bit gate weights (dtype of x): v_mfma_f32_16x16x32_{bf16,f16}
+//   fp32 gate weights (force_fp32_compute): v_mfma_f32_16x16x4_f32, x widened exactly; one 16-byte
+//   weight load feeds 4 MFMAs (MFMA s takes element s of every lane's float4: any k assignment that is
+//   the same for A and B is a valid dot product).
+constexpr int kRouterSteps = 8;   // MFMA k-steps per wave: the whole K sub-slice is loaded up front
+
+template <int XDT, bool W32, int NT>
+__global__ __launch_bounds__(256) void router_gemm_kernel(const unsigned short* __restrict__ x,
+                                                          const void* __restrict__ w,
+                                                          float* __restrict__ partial, int M, int H, int E,
+                                                          int ETG, int KG, int kslice) {
+    // workgroup = (group of NT expert tiles, token block, K group); its 4 waves take consecutive K
+    // sub-slices of `kslice` elements and are reduced through LDS in wave order -> slab[K group]
+    constexpr int Q = W32 ? 16 : 32;                 // k elements one wave-wide MFMA step covers
+    __shared__ f32x4 red[3][NT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    const int tg = blockIdx.x % ETG, kg = (blockIdx.x / ETG) % KG, mb = blockIdx.x / (ETG * KG);
+    const int k0 = (kg * 4 + wave) * kslice;
+    const int nsteps = k0 < H ? min(kslice, H - k0) / Q : 0;      // wave-uniform
+    const int trow = mb * 16 + i;
+    const size_t xrow = (size_t)(trow < M ? trow : M - 1) * H;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!W32) {
+        u32x4 a[NT][kRouterSteps], b[kRouterSteps];
+#pragma unroll
+        for (int s = 0; s < kRouterSteps; ++s) {
+            const int k = k0 + s * 32 + g * 8;
+            const bool on = s < nsteps;
+            b[s] = on ? *(const u32x4*)(x + xrow + k) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int erow = (tg * NT + t) * 16 + i;
+                a[t][s] = (on && erow < E) ? *(const u32x4*)((const unsigned short*)w + (size_t)erow * H + k)
+                                           : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < kRouterSteps; ++s)
+            if (s < nsteps) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = ActT<XDT>::mfma(a[t][s], b[s], acc[t]);
+            }
+    } else {
+        f32x4 a[NT][kRouterSteps];
+        u32x2 b[kRouterSteps];
+#pragma unroll
+        for (int s = 0; s < kRouterSteps; ++s) {
+            const int k = k0 + s * 16 + g * 4;
+            const bool on = s < nsteps;
+            b[s] = on ? *(const u32x2*)(x + xrow + k) : u32x2{0u, 0u};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int erow = (tg * NT + t) * 16 + i;
+                a[t][s] = (on && erow < E) ? *(const f32x4*)((const float*)w + (size_t)erow * H + k)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < kRouterSteps; ++s)
+            if (s < nsteps) {
+                float xf[4];
+                xf[0] = ActT<XDT>::to_f32((unsigned short)(b[s].x & 0xffffu));
+                xf[1] = ActT<XDT>::to_f32((unsigned short)(b[s].x >> 16));
+                xf[2] = ActT<XDT>::to_f32((unsigned short)(b[s].y & 0xffffu));
+                xf[3] = ActT<XDT>::to_f32((unsigned short)(b[s].y >> 16));
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s][q], xf[q], acc[t], 0, 0, 0);
+            }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) red[wave - 1][t][lane] = acc[t];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // D layout: lane (g, j=i): experts tile*16 + g*4 + r, token mb*16 + j
+    const int tok = mb * 16 + i;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x4 v = acc[t];
+#pragma unroll
+        for (int wv = 0; wv < 3; ++wv) v = v + red[wv][t][lane];
+        const int e0 = (tg * NT + t) * 16 + g * 4;
+        if (tok < M) {
+            float* o = partial + (size_t)kg * M * E + (size_t)tok * E + e0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (e0 + r < E) o[r] = v[r];
+        }
+    }
+}
+
+struct RouterPlan {
+    int NT, ETG, KG, kslice, MB;
+};
+static RouterPlan router_plan(int M, int H, int E, bool w32) {
+    RouterPlan p;
+    const int q = w32 ? 16 : 32;
+    const int ET = ceil_div(E, 16);
+    p.MB = ceil_div(M, 16);
+    p.NT = (p.MB >= 64 && ET >= 4) ? 4 : 1;           // many token blocks: reuse the token fragments
+    p.ETG = ceil_div(ET, p.NT);
+    // K sub-slice per wave: as short as it takes to put >= 256 workgroups on the chip, at most
+    // kRouterSteps MFMA steps, and never more than 8 slabs for the routing kernel to sum
+    int want_kg = ceil_div(256, p.ETG * p.MB);
+    if (want_kg < 1) want_kg = 1;
+    if (want_kg > 8) want_kg = 8;
+    int ks = ceil_div(ceil_div(H, 4 * want_kg), q) * q;
+    const int max_ks = kRouterSteps * q;
+    if (ks > max_ks) ks = max_ks;
+    if (ks < q) ks = q;
+    p.kslice = ks;
+    p.KG = ceil_div(H, 4 * ks);
+    return p;
+}
+
+extern "C" int64_t lkm_router_workspace_bytes(int32_t M, int32_t H, int32_t E) {
+    if (M <= 0 || H <= 0 || E <= 0) return 0;
+    const RouterPlan a = router_plan(M, H, E, false), b = router_plan(M, H, E, true);
+    return (int64_t)(a.KG > b.KG ? a.KG : b.KG) * M * E * 4;
+}
+
+extern "C" int lkm_router_gemm_topk(void* stream, const void* x, int32_t x_dtype, const void* gate_w,
+                                    int32_t w_dtype, const float* gate_bias, const float* score_bias,
+                                    int32_t M, int32_t H, int32_t E, int32_t K, int32_t scoring,
+                                    int32_t renormalize, float routed_scaling, int32_t n_group,
+                                    int32_t topk_group, int32_t logits_dtype, void* workspace,
+                                    int64_t workspace_bytes, float* logits_out, float* out_weights,
+                                    int32_t* out_ids) {
+    LKM_REQUIRE(M >= 0 && E > 0 && K > 0 && K <= E && H > 0, "router: bad shape M=%d H=%d E=%d K=%d", M, H, E, K);
+    LKM_REQUIRE(E <= kMaxSlots * 64, "router: E=%d > %d unsupported", E, kMaxSlots * 64);
+    LKM_REQUIRE(x_dtype == LKM_DT_BF16 || x_dtype == LKM_DT_F16, "router: hidden states must be bf16 or fp16");
+    LKM_REQUIRE(w_dtype == x_dtype || w_dtype == LKM_DT_F32, "router: gate weights must have the activation dtype or be fp32 (got %d)", w_dtype);
+    const bool w32 = w_dtype == LKM_DT_F32;
+    LKM_REQUIRE(H % (w32 ? 16 : 32) == 0, "router: hidden_size=%d must be a multiple of %d", H, w32 ? 16 : 32);
+    LKM_REQUIRE(logits_dtype == LKM_DT_F32 || logits_dtype == x_dtype, "router: logits_dtype must be fp32 or the activation dtype");
+    LKM_REQUIRE(scoring == 0 || scoring == 1, "router: scoring must be 0 (softmax) or 1 (sigmoid)");
+    if (n_group > 0) {
+        LKM_REQUIRE(n_group <= 64 && E % n_group == 0, "router: n_group=%d must divide E=%d and be <= 64", n_group, E);
+        LKM_REQUIRE(topk_group > 0 && topk_group <= n_group, "router: bad topk_group=%d", topk_group);
+        LKM_REQUIRE(K <= topk_group * (E / n_group), "router: K=%d exceeds kept experts", K);
+    }
+    if (M == 0) return LKM_OK;
+    const RouterPlan pl = router_plan(M, H, E, w32);
+    const int KS = pl.KG;
+    LKM_REQUIRE(workspace && workspace_bytes >= (int64_t)KS * M * E * 4, "router: workspace too small (%lld < %lld bytes; lkm_router_workspace_bytes)", (long long)workspace_bytes, (long long)KS * M * E * 4);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(pl.ETG * pl.KG * pl.MB), block(256);
+    float* part = (float*)workspace;
+    const unsigned short* xp = (const unsigned short*)x;
+#define LKM_ROUTER_LAUNCH(XDT, W32, NT) \
+    hipLaunchKernelGGL((router_gemm_kernel<XDT, W32, NT>), grid, block, 0, st, xp, gate_w, part, M, H, E, pl.ETG, pl.KG, pl.kslice)
+    if (x_dtype == LKM_DT_BF16) {
+        if (w32) { if (pl.NT == 4) LKM_ROUTER_LAUNCH(LKM_DT_BF16, true, 4); else LKM_ROUTER_LAUNCH(LKM_DT_BF16, true, 1); }
+        else     { if (pl.NT == 4) LKM_ROUTER_LAUNCH(LKM_DT_BF16, false, 4); else LKM_ROUTER_LAUNCH(LKM_DT_BF16, false, 1); }
+    } else {
+        if (w32) { if (pl.NT == 4) LKM_ROUTER_LAUNCH(LKM_DT_F16, true, 4); else LKM_ROUTER_LAUNCH(LKM_DT_F16, true, 1); }
+        else     { if (pl.NT == 4) LKM_ROUTER_LAUNCH(LKM_DT_F16, false, 4); else LKM_ROUTER_LAUNCH(LKM_DT_F16, false, 1); }
+    }
+#undef LKM_ROUTER_LAUNCH
+    LKM_HIP_CHECK(hipGetLastError());
+    const LogitSrc src{part, LKM_DT_F32, KS, (long long)M * E, gate_bias, logits_dtype, logits_out};
+    if (n_group > 0)
+        hipLaunchKernelGGL(grouped_topk_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, src, score_bias, M, E,
+                           K, n_group, topk_group, scoring, renormalize, routed_scaling, out_weights, out_ids);
+    else
+        hipLaunchKernelGGL(topk_softmax_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, src, score_bias, M, E,
+                           K, scoring, renormalize, routed_scaling, out_weights, out_ids);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

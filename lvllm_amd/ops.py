@@ -107,6 +107,43 @@ def grouped_topk(hidden_states: torch.Tensor, gating_output: torch.Tensor, topk:
     return w, ids
 
 
+_router_ws: dict = {}
+
+
+def router_topk(hidden_states: torch.Tensor, gate_weight: torch.Tensor, topk: int, renormalize: bool, *,
+                gate_bias: torch.Tensor | None = None, scoring_func: str = "softmax",
+                num_expert_group: int = 0, topk_group: int = 0, routed_scaling_factor: float = 1.0,
+                e_score_correction_bias: torch.Tensor | None = None,
+                logits_dtype: torch.dtype = torch.float32, return_logits: bool = False):
+    """Gate projection + routing in one call: what moe_runner.py:903-908 + fused_topk /
+    grouped_topk do in two operators.  gate_weight [E,H] in the activation dtype or fp32 (GateLinear
+    force_fp32_compute); logits_dtype fp32 (router GEMMs with fp32 output) or the activation dtype
+    (F.linear in the gate's dtype).  -> (topk_weights fp32, topk_ids int32[, router_logits fp32])."""
+    _need_cuda(hidden_states, gate_weight, gate_bias, e_score_correction_bias)
+    if scoring_func not in _SCORING:
+        raise ValueError(f"Unsupported scoring function: {scoring_func}")
+    x, gw = hidden_states.contiguous(), gate_weight.contiguous()
+    M, H = x.shape
+    E = gw.shape[0]
+    assert gw.shape[1] == H, "gate weight / hidden size mismatch"
+    dev = x.device
+    gb = None if gate_bias is None else gate_bias.to(torch.float32).contiguous()
+    sb = None if e_score_correction_bias is None else e_score_correction_bias.to(torch.float32).contiguous()
+    need = int(_clib.lib().lkm_router_workspace_bytes(M, H, E))
+    ws = _router_ws.get(dev)
+    if ws is None or ws.numel() < need:           # grow-only per-device scratch (split-K partials)
+        ws = torch.empty((max(need, 1 << 20),), dtype=torch.uint8, device=dev)
+        _router_ws[dev] = ws
+    w = torch.empty((M, topk), dtype=torch.float32, device=dev)
+    ids = torch.empty((M, topk), dtype=torch.int32, device=dev)
+    logits = torch.empty((M, E), dtype=torch.float32, device=dev) if return_logits else None
+    _clib.check(_clib.lib().lkm_router_gemm_topk(
+        _stream(x), _ptr(x), _DT[x.dtype], _ptr(gw), _DT[gw.dtype], _ptr(gb), _ptr(sb), M, H, E, topk,
+        _SCORING[scoring_func], int(renormalize), float(routed_scaling_factor), num_expert_group, topk_group,
+        _DT[logits_dtype], _ptr(ws), ws.numel(), _ptr(logits), _ptr(w), _ptr(ids)))
+    return (w, ids, logits) if return_logits else (w, ids)
+
+
 def determine_expert_map(ep_size: int, ep_rank: int, global_num_experts: int,
                          expert_placement_strategy: str = "linear"):
     """expert_map_manager.py:22-92 -> (local_num_experts, expert_map int32 [E] | None).  Host logic."""

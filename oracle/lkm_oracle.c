@@ -782,6 +782,25 @@ LKM_OR_API void lkm_or_f32_to_fp8(const float* src, int64_t n, uint8_t* dst) {
 }
 
 /* threads > 0 sets the OpenMP team size; the GEMM task loops use schedule(runtime) = dynamic,64 */
+/* router GEMM: logits[M,E] = x[M,H] . w[E,H]^T (+ bias), the reference's F.linear in fp32
+   (tests/kernels/test_fp32_router_gemm.py:35-37); accumulated in double so that the oracle is the
+   exact value rounded once; optional rounding to the gate's output dtype. */
+LKM_OR_API void lkm_or_router_logits(const void* x, int x_dtype, const void* w, int w_dtype,
+                                     const float* bias, int M, int H, int E, int round_dtype,
+                                     float* out) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m)
+        for (int e = 0; e < E; ++e) {
+            double acc = 0.0;
+            for (int k = 0; k < H; ++k)
+                acc += (double)load_act(x, x_dtype, (size_t)m * H + k) * (double)load_act(w, w_dtype, (size_t)e * H + k);
+            float v = (float)acc;
+            if (bias) v = v + bias[e];
+            if (round_dtype != OR_F32) v = round_act(v, round_dtype);
+            out[(size_t)m * E + e] = v;
+        }
+}
+
 /* dequantise E x N rows of a packed 4-bit format to act-dtype bit patterns (golden pinning) */
 LKM_OR_API void lkm_or_dequant_rows(int wfmt, int act_dtype, const void* w, const void* scale,
                                     const float* gs, int64_t E, int64_t N, int64_t K, int groupK,

@@ -247,6 +247,18 @@ def dequant_rows(wfmt: int, act_dtype: int, w: np.ndarray, scale: np.ndarray, K:
     return out
 
 
+def router_logits(x: np.ndarray, x_dt: int, w: np.ndarray, w_dt: int, bias=None, round_dt: int = F32) -> np.ndarray:
+    """x [M,H] (uint16 bits of x_dt), w [E,H] (uint16 bits or float32) -> fp32 logits [M,E]"""
+    x, w = _c(x), _c(w)
+    M, H = x.shape
+    E = w.shape[0]
+    bias = None if bias is None else _c(bias, np.float32)
+    out = np.empty((M, E), np.float32)
+    lib().lkm_or_router_logits(_p(x), C.c_int(x_dt), _p(w), C.c_int(w_dt), _p(bias), C.c_int(M), C.c_int(H),
+                               C.c_int(E), C.c_int(round_dt), _p(out))
+    return out
+
+
 def set_threads(n: int) -> None:
     lib().lkm_or_configure(C.c_int(int(n)))
 

@@ -200,3 +200,20 @@ def test_fp8_block_w8a8_vs_reference():
         d16 = orc.MoeDesc(E=e, H=k, I=n, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128)
         out16 = orc.moe(d16, c["w1"], c["w2"], c["a"], c["ids"], c["tw"], s13=c["w1s"], s2=c["w2s"])
         np.testing.assert_allclose(out16, ref, atol=0.035, rtol=0.035)
+
+
+def test_router_logits_vs_f_linear_fp32():
+    """the router-GEMM oracle vs the reference's own baseline `F.linear(a.float(), b.float())`
+    (tests/kernels/test_fp32_router_gemm.py:35-37), tolerance ATOL_FP32 = 2e-4 (:24)."""
+    import torch
+    for (M, H, E, xdt, wdt) in ((5, 3072, 256, torch.bfloat16, torch.float32), (32, 6144, 128, torch.bfloat16, torch.bfloat16),
+                                (3, 1024, 8, torch.float16, torch.float16)):
+        g = torch.Generator().manual_seed(M)
+        a = (torch.randn((M, H), generator=g) / 4).to(xdt)
+        b = (torch.randn((E, H), generator=g) / 8).to(wdt)
+        ref = torch.nn.functional.linear(a.float(), b.float()).numpy()
+        xd = orc.BF16 if xdt == torch.bfloat16 else orc.F16
+        ab = a.view(torch.int16).numpy().view(np.uint16)
+        bb, wd = (b.numpy(), orc.F32) if wdt == torch.float32 else (b.view(torch.int16).numpy().view(np.uint16), xd)
+        out = orc.router_logits(ab, xd, bb, wd)
+        np.testing.assert_allclose(out, ref, atol=2e-4, rtol=0)

@@ -561,13 +561,40 @@ def gen_ingest(ns):
     print("ingest.npz:", idx, "cases")
 
 
+def gen_residency(ns):
+    """the reference's layer-tier predicates (vllm/envs.py:2356-2407) evaluated over a grid of
+    LVLLM_GPU_RESIDENT_MOE_LAYERS specs, thresholds and layer names."""
+    import json
+    env_state = {}
+    nr = {"environment_variables": {"LVLLM_GPU_RESIDENT_MOE_LAYERS": lambda: env_state["spec"],
+                                    "LVLLM_MOE_NUMA_ENABLED": lambda: env_state["on"],
+                                    "LVLLM_GPU_PREFILL_MIN_BATCH_SIZE": lambda: env_state["thr"]}}
+    extract("vllm/model_executor/models/utils.py", ["extract_layer_index"], nr)
+    extract("vllm/envs.py", ["is_lk_moe_feature_enabled", "is_lk_moe_use_gpu_prefill", "is_lk_moe_mtp_layer",
+                             "is_lk_moe_gpu_prefill_layer", "is_lk_moe_cpu_layer", "is_lk_moe_gpu_resident_layer"], nr)
+    rows = []
+    names = ["model.layers.0.mlp.experts", "model.layers.5.mlp.experts", "model.layers.7.block_sparse_moe",
+             "model.layers.12.mlp.experts", "mtp.layers.0.mlp.experts", "model.layers.61.mlp.experts"]
+    for spec in ["", "0-5,7", " 3 , 9-8, x, 12-12,", "0-100", "5", "a-b,7-", "61,0"]:
+        for on in (True, False):
+            for thr in (0, 256):
+                env_state.update(spec=spec, on=on, thr=thr)
+                for nm in names:
+                    rows.append(dict(spec=spec, on=on, thr=thr, name=nm,
+                                     resident=bool(nr["is_lk_moe_gpu_resident_layer"](nm)),
+                                     prefill=bool(nr["is_lk_moe_gpu_prefill_layer"](nm)),
+                                     cpu=bool(nr["is_lk_moe_cpu_layer"](nm))))
+    (OUT / "residency.json").write_text(json.dumps(rows))
+    print("residency.json:", len(rows), "rows")
+
+
 def main():
     if not REF.exists():
         sys.exit("needs /root/reference (run in the build container, not on the GPU box)")
     torch.set_num_threads(8)
     ns = base_ns()
     gens = {"topk": gen_topk, "grouped": gen_grouped, "expert_map": gen_expert_map, "bf16": gen_moe_bf16,
-            "int4": gen_moe_int4, "fp8": gen_moe_fp8, "fp4": gen_moe_fp4, "ingest": gen_ingest}
+            "int4": gen_moe_int4, "fp8": gen_moe_fp8, "fp4": gen_moe_fp4, "ingest": gen_ingest, "residency": gen_residency}
     for name in (sys.argv[1:] or list(gens)):    # `make_golden.py fp4` regenerates one file only
         gens[name](dict(ns))
 

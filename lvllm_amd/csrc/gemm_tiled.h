@@ -355,6 +355,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
         } else if constexpr (TBW == 4 && GRAN == 2) {
             if (nb <= 2) run(IC<2>{});
             else run(IC<4>{});
+        } else if constexpr (TBW >= 8 && (TBW / 4) % GRAN == 0) {
+            // prefill tiles in quarters: the ragged last tile of an expert (GLM: 512 +- 22 rows over
+            // 256-row tiles) costs what it holds, not a full tile
+            constexpr int Q = TBW / 4;
+            if (nb <= Q) run(IC<Q>{});
+            else if (nb <= 2 * Q) run(IC<2 * Q>{});
+            else if (nb <= 3 * Q) run(IC<3 * Q>{});
+            else run(IC<TBW>{});
         } else {
             run(IC<TBW>{});
         }

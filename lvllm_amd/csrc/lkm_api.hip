@@ -498,13 +498,16 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
     // 714 us vs tiled64 585 us; 64-row tiles beat 128-row tiles up to M=512, 4 waves beat 8.
     int tiled = 0, split = 0;
     {
-        // 128-row tiles only for 16-bit weights at prefill sizes (GLM, 512 rows/expert: 4.1 ms vs
-        // 5.3-5.7 ms with 64-row tiles); the fp8/int4 decoders run out of registers there.
+        // Tile rows by rows per expert (profiles/r01_tile_thresholds.log, Mixtral shapes, 8 experts):
+        // 16-bit weights 48 rows/expert: 64 (507 us vs 604 at 128); 64: 128 (602 vs 746); 96: 128 (628 vs
+        // 655 at 256); 128: 256 (735 vs 862); 256: 256 (973 vs 1149).  MXFP4: 128 from 64 rows/expert
+        // (325 vs 354 us).  fp8 / int4 stay at 64 (fp8-W8A8 M=256: 491 vs 574 us; the 128-row variants
+        // of the decoding formats run out of registers).
         const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
         if (M > 32 && avg_rows > 24) {
             tiled = 64;
-            if (w16 && avg_rows >= 192) tiled = 128;
-            if (w16 && avg_rows >= 384) tiled = 256;   // GLM: 3.6 ms vs 4.1 ms (128) vs 5.3 ms (64)
+            if (w16 && avg_rows > 56) tiled = avg_rows >= 112 ? 256 : 128;
+            if (h->wf == LKM_W_MXFP4 && avg_rows >= 64) tiled = 128;
         } else if (M > 16 * tb && h->t_hybrid >= 0) {
             tiled = 64;
             split = 16 * tb;

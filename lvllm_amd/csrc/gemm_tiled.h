@@ -66,13 +66,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     // experts and shared operands are re-fetched later instead of concurrently); (2) skipping the
     // empty 16-token blocks of a partially filled tile with wave-uniform branches (GLM 4.63 ms vs
     // 4.12 ms: the branches break the ds_read / MFMA interleave).
-    const int ti = blockIdx.y;
+    int ti = blockIdx.y, bx = blockIdx.x;
+    if (p.xcd_map) {
+        // 1-D grid; hardware places workgroup L on XCD L % 8.  XCD c takes a contiguous run of items
+        // (tiles of the same expert are adjacent in the list) and, inside it, row group fastest: the
+        // workgroups that share a token tile or a weight panel run on ONE L2 at the same time.
+        const int RG = p.xcd_map, n_items = p.meta[3];
+        const int ipx = (n_items + 7) >> 3;
+        const int L = blockIdx.x, c = L & 7, sidx = L >> 3;
+        ti = c * ipx + sidx / RG;
+        bx = sidx % RG;
+        if (sidx / RG >= ipx || ti >= n_items) return;
+    }
     if (ti >= p.meta[3]) return;
     const int e = p.tile_e[ti], r0 = p.tile_r0[ti];
     const int m_e = p.counts[e], off_e = p.offsets[e];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
-    const int tile0 = (blockIdx.x * WAVES + wave) * NT;
+    const int tile0 = (bx * WAVES + wave) * NT;
     const bool wave_on = tile0 < p.T_half;            // tail group of a padded tile count
     const int T_all = p.T_half * p.halves;
     const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
@@ -434,13 +445,19 @@ template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1, i
 static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr int ROWB = Dec<WF, ADT>::UNITK * (Dec<WF, ADT>::A8 ? 1 : 2);
     constexpr size_t lds = (size_t)2 * (TBW * 16 * ROWB + (Dec<WF, ADT>::A8 ? TBW * 16 * 4 : 0));
-    dim3 grid(ceil_div(p.T_half, WAVES * NT), max_tiles), block(WAVES * 64);
+    const int RG = ceil_div(p.T_half, WAVES * NT);
+    dim3 grid(RG, max_tiles), block(WAVES * 64);
+    GemmParams pp = p;
+    if (p.xcd_map) {     // 1-D launch, see the kernel's work mapping
+        pp.xcd_map = RG;
+        grid = dim3(8 * ceil_div(max_tiles, 8) * RG, 1);
+    }
     auto kern = p.stream_nt ? gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1, PD, true>
                             : gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1, PD, false>;
     if (lds > 64 * 1024) {
         LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kern, grid, block, lds, st, p);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, pp);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

@@ -156,7 +156,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -608,6 +608,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.s = h->s13;
     p1.spu = h->spu;
     p1.gs = h->gs13;
+    p1.xcd_map = h->t_xcd > 0 ? 1 : 0;
     p1.T_half = h->T1_half;
     p1.halves = h->gated ? 2 : 1;
     p1.U = h->U1;
@@ -651,6 +652,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.s = h->s2;
     p2.spu = h->spu;
     p2.gs = h->gs2;
+    p2.xcd_map = h->t_xcd > 0 ? 1 : 0;
     p2.T_half = h->T2;
     p2.halves = 1;
     p2.U = h->U2;
@@ -860,6 +862,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "waves")) h->t_waves = value;
     else if (!strcmp(key, "pd1")) h->t_pd1 = value;
     else if (!strcmp(key, "pd2")) h->t_pd2 = value;
+    else if (!strcmp(key, "xcd")) h->t_xcd = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else {
         set_error("lkm_set_tuning: unknown key '%s'", key);

@@ -71,6 +71,7 @@ struct GemmParams {
     size_t sk_stride;  // GEMM2: elements between split-K slabs
     int SK;            // GEMM2: number of K splits
     int groups;        // tile groups per expert = T_half / NT
+    int xcd_map;       // tiled kernels: != 0 -> XCD-aware 1-D work mapping (holds the row-group count in the kernel)
     // activation
     int act_type;
     float alpha, limit;

@@ -61,11 +61,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     // wave per SIMD, 512 registers): 2452/1233.  What this kernel lacks for the MFMA roof is the
     // weight operand through LDS (glds) with a counted-vmcnt multi-phase schedule -- see DESIGN.md 6.
     // Work mapping: blockIdx.x = row group (fastest), blockIdx.y = (expert, token tile) item, default
-    // round-robin XCD placement.  Measured and NOT used: (1) a "contiguous run of items per XCD" remap
-    // (GLM prefill 4.54 ms vs 4.12 ms, Mixtral M=512 1.31 ms vs 0.93 ms: the XCDs then stream different
-    // experts and shared operands are re-fetched later instead of concurrently); (2) skipping the
-    // empty 16-token blocks of a partially filled tile with wave-uniform branches (GLM 4.63 ms vs
-    // 4.12 ms: the branches break the ds_read / MFMA interleave).
+    // round-robin XCD placement (all XCDs work on the same one or two items at a time).  Measured:
+    // (1) the XCD-aware mapping below (`xcd` tuning knob, off by default) cuts GLM-prefill GEMM1 HBM
+    // traffic 11.4 -> 7.6 GB per launch but the time only 5 % (GEMM2 +6 %), and loses 40 % on Mixtral
+    // M=1024 where every expert has a single tile (profiles/r01_prefill_pmc.md); (2) skipping the
+    // empty 16-token blocks of a partially filled tile with wave-uniform branches INSIDE the K loop
+    // loses 10 % -- the block count is a template parameter of the loop instead (run<NB>).
     int ti = blockIdx.y, bx = blockIdx.x;
     if (p.xcd_map) {
         // 1-D grid; hardware places workgroup L on XCD L % 8.  XCD c takes a contiguous run of items

@@ -463,6 +463,12 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     return LKM_OK;
 }
 
+// 16-bit weights, 256-row tiles: the LDS-DMA prefill kernel (gemm_prefill.h) when the plan asks for it
+// and the shape qualifies; returns false to fall through to gemm_tiled_kernel
+template <typename ADTC>
+static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
+                              int max_tiles, int* rc, ADTC);
+
 // tiled variants built per format: (TM, WAVES, NT) = (64,4,1) (64,8,1) (128,8,1) (128,8,2 non-gated)
 // and, for 16-bit weights only, (256,8,1): the prefill tile (weights re-read once per 256 tokens)
 template <int WF>
@@ -486,6 +492,10 @@ struct W16Only {
     int launch_gemm1_tiled_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
                                     bool gated, int max_tiles) {                                      \
         constexpr int WF_ = WF, ADT_ = ADT;                                                           \
+        if constexpr (W16Only<WF_>::value) {                                                          \
+            int rc = LKM_OK;                                                                          \
+            if (launch_prefill_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc;    \
+        }                                                                                             \
         if (gated) {                                                                                  \
             LKM_TILED_CASE(4, 4, 1, true, true)                                                       \
             LKM_TILED_CASE(4, 8, 1, true, true)                                                       \
@@ -505,6 +515,10 @@ struct W16Only {
     int launch_gemm2_tiled_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
                                     int max_tiles) {                                                  \
         constexpr int WF_ = WF, ADT_ = ADT;                                                           \
+        if constexpr (W16Only<WF_>::value) {                                                          \
+            int rc = LKM_OK;                                                                          \
+            if (launch_prefill_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;   \
+        }                                                                                             \
         LKM_TILED_CASE(4, 4, 1, false, false)                                                         \
         LKM_TILED_CASE(4, 8, 1, false, false)                                                         \
         LKM_TILED_CASE(4, 4, 2, false, false)                                                         \

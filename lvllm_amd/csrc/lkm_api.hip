@@ -156,7 +156,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -516,8 +516,8 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
         if (h->t_tiled < 0) { tiled = 0; split = 0; }
     }
     pl->split_rows = split;
-    pl->t1 = pl->t2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0};
-    pl->s1 = pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0};
+    pl->t1 = pl->t2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
+    pl->s1 = pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
     if (tiled) {
         const int waves = h->t_waves > 0 ? h->t_waves : (tiled >= 128 ? 8 : 4);
         const int nt1 = (h->t_nt1 > 0 && !split) ? h->t_nt1 : 1;
@@ -532,10 +532,11 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
             pd1 = w16 ? 4 : 2;
             pd2 = 4;
         }
+        const int pf = (tiled == 256 && h->t_pf > 0) ? h->t_pf : 0;
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;
-        pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves, pd1};
-        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, 1, tiled, waves, pd2};
+        pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves, pd1, pf};
+        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, 1, tiled, waves, pd2, pf};
         if (!split) return;
     }
     // ---- skinny geometry (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4;
@@ -552,7 +553,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
         while (kw < 8 && waves * kw < kMinWaves && h->U1 / (kw * 2) >= 2) kw *= 2;
     }
     if (h->t_kw1 > 0) kw = h->t_kw1;
-    pl->s1 = LaunchCfg{nt1, tb, kw, 1, 0, 0, 0};
+    pl->s1 = LaunchCfg{nt1, tb, kw, 1, 0, 0, 0, 0};
     // sub-16-bit weights: two tiles per wave halve the token-operand loads per weight byte
     // (int4 M=32: gemm2 120 us -> 85 us)
     int nt2 = (wf_is_4bit(h->wf) || h->wf == LKM_W_FP8_E4M3) && tb >= 2 ? 2 : 1;
@@ -568,7 +569,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
     // split-K slabs must fit the partial buffer
     const size_t y_rows = h->arena->y_elems / h->H;
     while (sk > 1 && (size_t)sk * n_slots > y_rows) sk /= 2;
-    pl->s2 = LaunchCfg{nt2, tb, 1, sk, 0, 0, 0};
+    pl->s2 = LaunchCfg{nt2, tb, 1, sk, 0, 0, 0, 0};
 }
 
 // one chunk: rows [0,M) of the given pointers
@@ -609,6 +610,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.spu = h->spu;
     p1.gs = h->gs13;
     p1.xcd_map = h->t_xcd > 0 ? 1 : 0;
+    p1.x_rows = M;
     p1.T_half = h->T1_half;
     p1.halves = h->gated ? 2 : 1;
     p1.U = h->U1;
@@ -653,6 +655,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.spu = h->spu;
     p2.gs = h->gs2;
     p2.xcd_map = h->t_xcd > 0 ? 1 : 0;
+    p2.x_rows = (long long)n_slots;
     p2.T_half = h->T2;
     p2.halves = 1;
     p2.U = h->U2;
@@ -863,6 +866,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "pd1")) h->t_pd1 = value;
     else if (!strcmp(key, "pd2")) h->t_pd2 = value;
     else if (!strcmp(key, "xcd")) h->t_xcd = value;
+    else if (!strcmp(key, "pf")) h->t_pf = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else {
         set_error("lkm_set_tuning: unknown key '%s'", key);

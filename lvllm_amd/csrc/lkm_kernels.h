@@ -71,6 +71,7 @@ struct GemmParams {
     size_t sk_stride;  // GEMM2: elements between split-K slabs
     int SK;            // GEMM2: number of K splits
     int groups;        // tile groups per expert = T_half / NT
+    long long x_rows;  // rows of the activation matrix behind `x` (bounds of the LDS-DMA buffer window)
     int xcd_map;       // tiled kernels: != 0 -> XCD-aware 1-D work mapping (holds the row-group count in the kernel)
     // activation
     int act_type;
@@ -81,7 +82,8 @@ struct LaunchCfg {
     int tiled;   // 0: skinny streamer (token operand straight from L2);
                  // else token-tile rows (64 / 128): token operand staged through LDS
     int waves;   // tiled: waves per workgroup (4 / 8)
-    int pd;      // tiled: weight register stages (2 / 4 / 8; prefetch distance pd-1 K units)
+    int pd;      // tiled: weight register stages (2 / 4; prefetch distance pd-1 K units)
+    int pf;      // 256-row tiles, 16-bit weights: 8 / 4 = LDS-DMA prefill kernel with that many waves (gemm_prefill.h)
 };
 int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                  bool gated, int max_active);

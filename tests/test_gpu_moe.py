@@ -329,6 +329,33 @@ def test_fp4_dequant_is_bit_exact_on_gpu(fmt):
             np.testing.assert_array_equal(out, want, err_msg=f"{fmt} expert {e} tiled={tiled} (neg)")
 
 
+@pytest.mark.parametrize("pf", [8, 4])
+@pytest.mark.parametrize("gated", [True, False])
+def test_prefill_kernel_ragged_multi_tile(pf, gated):
+    """gemm_prefill.h vs the oracle: experts with 0, a few, ~300 and ~700 rows (1-3 token tiles, ragged last
+    tile, empty wave quarters), weight rows not a multiple of the 128/256-row workgroup tile."""
+    M, E, K, H, I = 520, 5, 2, 512, 384
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=91, gated=gated)
+    rng = np.random.default_rng(3)
+    pool = np.array([0, 1, 3, 4], np.int32)                     # expert 2 stays empty
+    prob = np.array([0.02, 0.28, 0.62, 0.08])                   # ~20, ~290, ~640, ~90 rows
+    first = rng.choice(4, size=M, p=prob)
+    second = (first + rng.integers(1, 4, size=M)) % 4           # a different expert of the pool
+    ids = np.ascontiguousarray(np.stack([pool[first], pool[second]], axis=1).astype(np.int32))
+    kw = dict(has_gate_proj=False, activation_type=2) if not gated else {}
+    eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16, **kw)
+    eng.engine.set_tuning(tiled=256, waves=8, pf=pf)
+    out = _run_decode(eng, a, tw, ids)
+    assert "tm=256" in eng.engine.describe()
+    d = orc.MoeDesc(E=E, H=H, I=I, has_gate=gated, activation=orc.ACT_SILU if gated else orc.ACT_RELU2,
+                    act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+    np.testing.assert_allclose(out, ref, atol=ATOL * max(1.0, float(np.abs(ref).max())), rtol=RTOL)
+    eng.engine.set_tuning(pf=0)
+    base = _run_decode(eng, a, tw, ids)                         # same tiles through gemm_tiled_kernel
+    np.testing.assert_allclose(out, base, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4)
+
+
 def test_relu2_non_gated():
     M, E, K, H, I = 19, 8, 2, 256, 128
     a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=5, gated=False)
@@ -352,6 +379,12 @@ def test_all_launch_geometries_agree():
             eng.engine.set_tuning(tiled=-1, nt1=nt1, tbmax=tb, kw1=kw, nt2=nt2, sk2=sk)
             out = _run_decode(eng, a, tw, ids)
             np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())
+    # LDS-DMA prefill kernels (gemm_prefill.h): 256-row tiles, 8 or 4 waves
+    for pf in (8, 4):
+        eng.engine.set_tuning(tiled=256, waves=8, nt1=1, nt2=1, pf=pf, tbmax=0, kw1=0, sk2=0)
+        out = _run_decode(eng, a, tw, ids)
+        np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=f"pf={pf} " + eng.engine.describe())
+    eng.engine.set_tuning(pf=0)
     # LDS-staged tiled kernels (gemm_tiled.h)
     for tiled, waves, nt1, nt2 in ((64, 4, 1, 1), (64, 8, 1, 1), (64, 4, 1, 2), (128, 8, 1, 1), (128, 8, 1, 2),
                                    (256, 8, 1, 1), (256, 8, 1, 2)):

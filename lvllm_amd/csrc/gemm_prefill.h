@@ -31,9 +31,10 @@ constexpr int kPfTiles = 16;            // weight tiles per workgroup (gated: 8 
 constexpr int kPfABytes = kPfTiles * 2 * 1024;                       // 16 tiles x 2 k-steps x 1 KiB
 constexpr int kPfBufBytes = kPfABytes + kPfTokens * 128;             // + token rows, one unit
 
-// WAVES = 8: 2 x 4 waves, 8 tiles x 4 token blocks each, two waves per SIMD (256 registers per lane);
-// WAVES = 4: 2 x 2 waves, 8 tiles x 8 token blocks each, ONE wave per SIMD with 256 accumulator
-//            registers (AGPRs) + 256 VGPRs: the fragment streaming below is what keeps a lone wave busy.
+// WAVES = 8: 2 x 4 waves, 8 tiles x 4 token blocks each, two waves per SIMD (256 registers per lane).
+// Measured and dropped (profiles/r01_prefill_pmc.md): WAVES = 4 (2 x 2 waves, one per SIMD, 256 AGPR
+// accumulators): 2551 vs 1793 us on GLM prefill GEMM1; a variant with the tokens in a 3-buffer DMA ring and
+// the weights in a 3-stage register ring (128 KiB in flight per CU instead of 64): 1769 us, no gain.
 template <int ADT, bool GATED, bool IS_G1, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemm_prefill_kernel(GemmParams p) {
     static_assert(!GATED || IS_G1, "only GEMM1 is gated");
@@ -286,14 +287,10 @@ template <typename ADTC>
 static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
                               int max_tiles, int* rc, ADTC) {
     constexpr int ADT = ADTC::v;
-    if (cfg.tiled != 256 || (cfg.pf != 8 && cfg.pf != 4)) return false;
+    if (cfg.tiled != 256 || cfg.pf != 8) return false;
     if (!prefill_kernel_ok(p, p.x_rows)) return false;
-    if (is_g1) {
-        if (gated) *rc = cfg.pf == 8 ? launch_prefill_t<ADT, true, true, 8>(st, p, max_tiles) : launch_prefill_t<ADT, true, true, 4>(st, p, max_tiles);
-        else *rc = cfg.pf == 8 ? launch_prefill_t<ADT, false, true, 8>(st, p, max_tiles) : launch_prefill_t<ADT, false, true, 4>(st, p, max_tiles);
-    } else {
-        *rc = cfg.pf == 8 ? launch_prefill_t<ADT, false, false, 8>(st, p, max_tiles) : launch_prefill_t<ADT, false, false, 4>(st, p, max_tiles);
-    }
+    if (is_g1) *rc = gated ? launch_prefill_t<ADT, true, true, 8>(st, p, max_tiles) : launch_prefill_t<ADT, false, true, 8>(st, p, max_tiles);
+    else *rc = launch_prefill_t<ADT, false, false, 8>(st, p, max_tiles);
     return true;
 }
 

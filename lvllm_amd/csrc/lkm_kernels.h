@@ -83,7 +83,7 @@ struct LaunchCfg {
                  // else token-tile rows (64 / 128): token operand staged through LDS
     int waves;   // tiled: waves per workgroup (4 / 8)
     int pd;      // tiled: weight register stages (2 / 4; prefetch distance pd-1 K units)
-    int pf;      // 256-row tiles, 16-bit weights: 8 / 4 = LDS-DMA prefill kernel with that many waves (gemm_prefill.h)
+    int pf;      // 256-row tiles, 16-bit weights: 8 = the LDS-DMA prefill kernel (gemm_prefill.h, opt-in)
 };
 int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                  bool gated, int max_active);

@@ -314,29 +314,6 @@ __global__ __launch_bounds__(kChunk) void sort_scatter_kernel(const int32_t* __r
 
 // out[m][h] = sum_k w[m,k] * sum_s y[s][pos(m,k)][h]   (fp32; s ascending, then k ascending)
 template <typename OutT>
-__device__ __forceinline__ void store4(OutT* p, f32x4 v);
-template <>
-__device__ __forceinline__ void store4<float>(float* p, f32x4 v) {
-    *(f32x4*)p = v;
-}
-struct bf16_out { unsigned short v; };
-struct f16_out { unsigned short v; };
-template <>
-__device__ __forceinline__ void store4<bf16_out>(bf16_out* p, f32x4 v) {
-    u32x2 o;
-    o.x = ActT<LKM_DT_BF16>::pack2(v.x, v.y);
-    o.y = ActT<LKM_DT_BF16>::pack2(v.z, v.w);
-    *(u32x2*)p = o;
-}
-template <>
-__device__ __forceinline__ void store4<f16_out>(f16_out* p, f32x4 v) {
-    u32x2 o;
-    o.x = ActT<LKM_DT_F16>::pack2(v.x, v.y);
-    o.y = ActT<LKM_DT_F16>::pack2(v.z, v.w);
-    *(u32x2*)p = o;
-}
-
-template <typename OutT>
 __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ y, int SK,
                                                       size_t sk_stride,
                                                       const int32_t* __restrict__ pos_of_slot,

@@ -4,6 +4,7 @@ namespace lkm {
 #define LKM_DECL(SUFFIX)                                                                            \
     int launch_gemm1_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);         \
     int launch_gemm2_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, int);               \
+    int launch_gemm2_direct_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, int);        \
     int launch_gemm1_tiled_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);   \
     int launch_gemm2_tiled_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 LKM_DECL(bf16) LKM_DECL(f16) LKM_DECL(int4_bf16) LKM_DECL(int4_f16) LKM_DECL(fp8_bf16) LKM_DECL(fp8_f16)
@@ -11,6 +12,8 @@ LKM_DECL(mxfp4_bf16) LKM_DECL(mxfp4_f16) LKM_DECL(nvfp4_bf16) LKM_DECL(nvfp4_f16
 #undef LKM_DECL
 int launch_gemm1_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
 int launch_gemm2_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
+int launch_gemm2_direct_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
+int launch_gemm2_direct_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 int launch_gemm1_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
 int launch_gemm2_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 int launch_gemm1_tiled_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
@@ -53,6 +56,24 @@ int launch_gemm2(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const Ge
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm2_fp8a8_bf16(st, cfg, p, max_active);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm2_fp8a8_f16(st, cfg, p, max_active);
     set_error("gemm2: unsupported weight format %d with activation dtype %d", wf, adt);
+    return LKM_E_UNSUPPORTED;
+}
+
+int launch_gemm2_direct(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p, int K) {
+    if (K <= 0) return LKM_OK;
+    if (wf == LKM_W_BF16 && adt == LKM_DT_BF16) return launch_gemm2_direct_bf16(st, cfg, p, K);
+    if (wf == LKM_W_F16 && adt == LKM_DT_F16) return launch_gemm2_direct_f16(st, cfg, p, K);
+    if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_gemm2_direct_int4_bf16(st, cfg, p, K);
+    if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_gemm2_direct_int4_f16(st, cfg, p, K);
+    if (wf == LKM_W_MXFP4 && adt == LKM_DT_BF16) return launch_gemm2_direct_mxfp4_bf16(st, cfg, p, K);
+    if (wf == LKM_W_MXFP4 && adt == LKM_DT_F16) return launch_gemm2_direct_mxfp4_f16(st, cfg, p, K);
+    if (wf == LKM_W_NVFP4 && adt == LKM_DT_BF16) return launch_gemm2_direct_nvfp4_bf16(st, cfg, p, K);
+    if (wf == LKM_W_NVFP4 && adt == LKM_DT_F16) return launch_gemm2_direct_nvfp4_f16(st, cfg, p, K);
+    if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_BF16) return launch_gemm2_direct_fp8_bf16(st, cfg, p, K);
+    if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm2_direct_fp8_f16(st, cfg, p, K);
+    if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm2_direct_fp8a8_bf16(st, cfg, p, K);
+    if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm2_direct_fp8a8_f16(st, cfg, p, K);
+    set_error("gemm2 direct: unsupported weight format %d with activation dtype %d", wf, adt);
     return LKM_E_UNSUPPORTED;
 }
 

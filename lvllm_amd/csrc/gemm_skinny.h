@@ -414,16 +414,26 @@ __device__ __forceinline__ float act_silu(float g) { return g / (1.0f + lkm_expf
 // ------------------------------------------------------------------ GEMM1 + activation
 // grid = (groups, max_active_experts); block = 64*KW threads: the KW waves of a workgroup split K
 // and reduce through LDS (needed when an expert has too few tiles to fill the chip, e.g. M=1).
-template <int WF, int ADT, int NT, int TB, bool GATED>
+// DIRECT (single-token decode): blockIdx.y is the slot; expert = direct_ids[slot], one row, no sort output.
+template <int WF, int ADT, int NT, int TB, bool GATED, bool DIRECT = false>
 __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
     typedef Dec<WF, ADT> D;
     constexpr int NTT = GATED ? 2 * NT : NT;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [NTT*TB][64] f32x4
     const int ai = blockIdx.y;
-    if (ai >= p.meta[0]) return;
-    const int e = p.active[ai];
-    const int m_e = p.counts[e], off_e = p.offsets[e];
-    if (p.max_rows > 0 && m_e > p.max_rows) return;   // workgroup-uniform: the tiled kernel owns this expert
+    int e, m_e, off_e;
+    if constexpr (DIRECT) {
+        e = p.direct_ids[ai];
+        if (e < 0) return;
+        m_e = 1;
+        off_e = ai;
+    } else {
+        if (ai >= p.meta[0]) return;
+        e = p.active[ai];
+        m_e = p.counts[e];
+        off_e = p.offsets[e];
+        if (p.max_rows > 0 && m_e > p.max_rows) return;   // workgroup-uniform: the tiled kernel owns this expert
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, KW = blockDim.x >> 6;
     const int g = lane >> 4, j = lane & 15;
     const int tile0 = blockIdx.x * NT;
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
             const int r = sb + b * 16 + j;
-            const int slot = p.sorted_slot[off_e + (r < m_e ? r : 0)];
+            const int slot = DIRECT ? off_e : p.sorted_slot[off_e + (r < m_e ? r : 0)];
             const int tok = slot / p.top_k;
             xp[b] = (const unsigned char*)p.x + (size_t)tok * p.ldx * XB;
             xsp[b] = p.xscale + (size_t)tok * p.ld_xscale;
@@ -613,6 +623,90 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------ GEMM2 + combine, single-token decode
+// grid = tile groups; block = K*SK waves: wave (k, s) streams slice s of expert ids[k]'s rows against the
+// slot's intermediate row; the workgroup then forms  out[h] = sum_k w[k] * sum_s partial[k][s][h]  through
+// LDS in exactly the order of combine_kernel (s ascending, then k ascending).
+template <int WF, int ADT, int NT, typename OutT>
+__global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K) {
+#pragma clang fp contract(off)
+    typedef Dec<WF, ADT> D;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [K*SK][NT][64] f32x4
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int SK = p.SK;
+    const int k = wave / SK, sk = wave % SK;
+    const int e = p.direct_ids[k];
+    const int tile0 = blockIdx.x * NT;
+    f32x4 acc[NT][1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (e >= 0) {
+        const u32x4* wp[NT];
+        const char* auxp[NT];
+        const int aux_step = D::aux_step(p.spu);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const size_t tl = (size_t)e * p.T_half + tile0 + t;
+            wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
+            auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
+        }
+        const int u0 = (int)((long long)sk * p.U / SK), u1 = (int)((long long)(sk + 1) * p.U / SK);
+        const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
+        constexpr int XB = D::A8 ? 1 : 2;
+        const unsigned char* xp[1] = {(const unsigned char*)p.x + (size_t)k * p.ldx * XB};
+        const float* xsp[1] = {p.xscale + (size_t)k * p.ld_xscale};
+        Streamer<WF, ADT, NT, 1>::run(acc, wp, auxp, aux_step, dparam, xp, xsp, u0, u1, p.Kreal, lane, 1);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ((f32x4*)red)[(wave * NT + t) * 64 + lane] = acc[t][0];
+    __syncthreads();
+    // wave 0, lanes with token column j == 0 hold the row: D layout lane (g,0): rows tile*16 + g*4 + r
+    if (wave != 0 || j != 0) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = (tile0 + t) * 16 + g * 4;
+        if (n >= p.n_real) continue;
+        f32x4 out = {0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < K; ++kk) {
+            if (p.direct_ids[kk] < 0) continue;
+            f32x4 v = ((const f32x4*)red)[((kk * SK) * NT + t) * 64 + lane];
+            for (int s = 1; s < SK; ++s) v += ((const f32x4*)red)[((kk * SK + s) * NT + t) * 64 + lane];
+            out += p.direct_w[kk] * v;
+        }
+        OutT* o = (OutT*)p.out + n;
+        if (n + 4 <= p.n_real) {
+            store4<OutT>(o, out);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.n_real) store1<OutT>(o + r, out[r]);
+        }
+    }
+}
+
+template <int WF, int ADT>
+static int launch_g2_direct_t(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, int K) {
+    const int waves = K * p.SK;
+    LKM_REQUIRE(waves >= 1 && waves <= 16, "gemm2 direct: K*sk=%d waves do not fit one workgroup", waves);
+    dim3 grid(p.T_half / cfg.nt), block(64 * waves);
+    const size_t lds = (size_t)waves * cfg.nt * 64 * sizeof(f32x4);
+    typedef typename std::conditional<ADT == LKM_DT_BF16, bf16_out, f16_out>::type ActOut;
+#define LKM_G2D(NT)                                                                                       \
+    if (p.direct_out_dt == LKM_DT_F32)                                                                    \
+        hipLaunchKernelGGL((gemm2_direct_kernel<WF, ADT, NT, float>), grid, block, lds, st, p, K);        \
+    else                                                                                                  \
+        hipLaunchKernelGGL((gemm2_direct_kernel<WF, ADT, NT, ActOut>), grid, block, lds, st, p, K);
+    if (cfg.nt == 2) {
+        LKM_G2D(2)
+    } else {
+        LKM_G2D(1)
+    }
+#undef LKM_G2D
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
 // ------------------------------------------------------------------ launchers (per format TU)
 template <int WF, int ADT, int NT, int TB>
 static int launch_g1_t(hipStream_t st, const GemmParams& p, bool gated, int kw, int max_active) {
@@ -620,6 +714,14 @@ static int launch_g1_t(hipStream_t st, const GemmParams& p, bool gated, int kw, 
     const int ntt = gated ? 2 * NT : NT;
     const size_t lds = kw > 1 ? (size_t)ntt * TB * 64 * sizeof(f32x4) : 0;
     // only register-resident variants are built (see -Rpass-analysis=kernel-resource-usage)
+    if constexpr (TB == 1 && NT == 1) {
+        if (p.direct_ids) {
+            if (gated) hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, 1, 1, true, true>), grid, block, lds, st, p);
+            else hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, 1, 1, false, true>), grid, block, lds, st, p);
+            LKM_HIP_CHECK(hipGetLastError());
+            return LKM_OK;
+        }
+    }
     if (gated) {
         if constexpr (NT <= 2 && NT * TB <= 4) {
             hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, true>), grid, block, lds, st, p);
@@ -676,6 +778,10 @@ static int launch_g2_t(hipStream_t st, const GemmParams& p, int max_active) {
     int launch_gemm2_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
                               int max_active) {                                                 \
         LKM_DISPATCH_NT(launch_g2_t, WF, ADT, st, p, max_active)                                \
+    }                                                                                           \
+    int launch_gemm2_direct_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, \
+                                     int K) {                                                   \
+        return launch_g2_direct_t<WF, ADT>(st, cfg, p, K);                                      \
     }
 
 }  // namespace lkm

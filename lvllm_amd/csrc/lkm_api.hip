@@ -156,7 +156,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -592,10 +592,22 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         if (rc != LKM_OK) return rc;
     }
     const int tile_rows = pl.t1.tiled ? pl.t1.tiled : pl.t2.tiled;
-    rc = launch_sort(st, ids, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
-                     a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, a->hist,
-                     a->hist_cap);
-    if (rc != LKM_OK) return rc;
+    // Single-token decode: the K slots of the one token are K distinct experts, so the scatter is the
+    // identity: GEMM1 reads the router's ids itself (one workgroup row per slot) and GEMM2 multiplies all K
+    // slots and forms the weighted sum in one workgroup -- two launches instead of four (Qwen3-30B-A3B
+    // M=1: 38 -> 2x us is launch latency, not bandwidth).
+    int sk_direct = 1;
+    if (M == 1 && K <= 16) {
+        const long long waves = (long long)K * (h->T2 / 1);
+        while (sk_direct * 2 * K <= 16 && waves * sk_direct < 2048 && h->U2 / (sk_direct * 2) >= 2) sk_direct *= 2;
+    }
+    const bool direct = M == 1 && K <= 16 && pl.s1.tb == 1 && pl.s1.nt == 1 && !pl.t1.tiled && h->t_direct >= 0;
+    if (!direct) {
+        rc = launch_sort(st, ids, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
+                         a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, a->hist,
+                         a->hist_cap);
+        if (rc != LKM_OK) return rc;
+    }
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[1], st));
     const int max_active = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
     const int max_tiles = tile_rows ? (int)(n_slots / tile_rows) + max_active : 0;
@@ -638,9 +650,13 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.act_type = h->cfg.activation_type;
     p1.alpha = h->cfg.swiglu_alpha;
     p1.limit = h->cfg.swiglu_limit;
+    if (direct) {
+        p1.direct_ids = ids;
+        p1.direct_w = tw;
+    }
     if (pl.s1.tb) {
         p1.groups = h->T1_half / pl.s1.nt;
-        rc = launch_gemm1(st, h->wfk, h->adt, pl.s1, p1, h->gated, max_active);
+        rc = launch_gemm1(st, h->wfk, h->adt, pl.s1, p1, h->gated, direct ? K : max_active);
         if (rc != LKM_OK) return rc;
     }
     if (pl.t1.tiled) {
@@ -684,6 +700,26 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.sk_stride = n_slots * (size_t)h->H;
     const int sk = pl.s2.tb ? pl.s2.sk : 1;
     p2.SK = sk;
+    if (direct) {
+        p2.direct_ids = ids;
+        p2.direct_w = tw;
+        p2.direct_out_dt = out_dt;
+        p2.out = out;
+        p2.SK = sk_direct;
+        LaunchCfg dc = pl.s2;
+        dc.nt = 1;
+        rc = launch_gemm2_direct(st, h->wfk, h->adt, dc, p2, K);
+        if (rc != LKM_OK) return rc;
+        if (prof) {
+            LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
+            LKM_HIP_CHECK(hipEventRecord(h->ev[4], st));
+            h->prof_valid = true;
+        }
+        snprintf(h->last_desc, sizeof(h->last_desc),
+                 "M=1 K=%d | direct (no sort / combine launch) | skinny g1 nt=1 tb=1 kw=%d, g2+combine nt=1 sk=%d | nt_loads=1",
+                 K, pl.s1.kw, sk_direct);
+        return LKM_OK;
+    }
     if (pl.s2.tb) {
         p2.groups = h->T2 / pl.s2.nt;
         rc = launch_gemm2(st, h->wfk, h->adt, pl.s2, p2, max_active);
@@ -867,6 +903,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "pd2")) h->t_pd2 = value;
     else if (!strcmp(key, "xcd")) h->t_xcd = value;
     else if (!strcmp(key, "pf")) h->t_pf = value;
+    else if (!strcmp(key, "direct")) h->t_direct = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else {
         set_error("lkm_set_tuning: unknown key '%s'", key);

@@ -118,6 +118,45 @@ struct ActT<LKM_DT_F16> {
 __host__ __device__ constexpr inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ constexpr inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ------------------------------------------------------------------ typed output stores (fp32 / act dtype)
+template <typename OutT>
+__device__ __forceinline__ void store4(OutT* p, f32x4 v);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, f32x4 v) {
+    *(f32x4*)p = v;
+}
+struct bf16_out { unsigned short v; };
+struct f16_out { unsigned short v; };
+template <>
+__device__ __forceinline__ void store4<bf16_out>(bf16_out* p, f32x4 v) {
+    u32x2 o;
+    o.x = ActT<LKM_DT_BF16>::pack2(v.x, v.y);
+    o.y = ActT<LKM_DT_BF16>::pack2(v.z, v.w);
+    *(u32x2*)p = o;
+}
+template <>
+__device__ __forceinline__ void store4<f16_out>(f16_out* p, f32x4 v) {
+    u32x2 o;
+    o.x = ActT<LKM_DT_F16>::pack2(v.x, v.y);
+    o.y = ActT<LKM_DT_F16>::pack2(v.z, v.w);
+    *(u32x2*)p = o;
+}
+
+template <typename OutT>
+__device__ __forceinline__ void store1(OutT* p, float v);
+template <>
+__device__ __forceinline__ void store1<float>(float* p, float v) {
+    *p = v;
+}
+template <>
+__device__ __forceinline__ void store1<bf16_out>(bf16_out* p, float v) {
+    p->v = f32_to_bf16_bits(v);
+}
+template <>
+__device__ __forceinline__ void store1<f16_out>(f16_out* p, float v) {
+    p->v = f32_to_f16_bits(v);
+}
+
 // ------------------------------------------------------------------ pre-shuffled weight geometry
 // A weight matrix [N rows][K] (K contiguous, "B^T" form) is stored per expert as
 //   [tile = n/16][unit = k/UNITK][load][lane 0..63][16 bytes]

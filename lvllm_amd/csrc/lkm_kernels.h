@@ -71,6 +71,11 @@ struct GemmParams {
     size_t sk_stride;  // GEMM2: elements between split-K slabs
     int SK;            // GEMM2: number of K splits
     int groups;        // tile groups per expert = T_half / NT
+    // single-token decode (M == 1): the K slots are K distinct experts, so the scatter is the identity --
+    // the GEMM kernels read the router's ids / weights themselves and the sort + combine launches go away
+    const int32_t* direct_ids;   // [K] (non-null: direct mode; id < 0 = not local)
+    const float* direct_w;       // [K]
+    int direct_out_dt;           // LKM_DT_* of `out` in the direct GEMM2
     long long x_rows;  // rows of the activation matrix behind `x` (bounds of the LDS-DMA buffer window)
     int xcd_map;       // tiled kernels: != 0 -> XCD-aware 1-D work mapping (holds the row-group count in the kernel)
     // activation
@@ -89,6 +94,8 @@ int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const Ge
                  bool gated, int max_active);
 int launch_gemm2(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                  int max_active);
+// single-token decode: GEMM2 of all K slots + weighted sum in one launch (cfg.nt, cfg.sk; K*sk <= 16)
+int launch_gemm2_direct(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p, int K);
 // tiled variants: grid.y = max_tiles (upper bound of the device-side work list)
 int launch_gemm1_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                        bool gated, int max_tiles);

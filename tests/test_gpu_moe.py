@@ -356,6 +356,53 @@ def test_prefill_kernel_ragged_multi_tile(pf, gated):
     np.testing.assert_allclose(out, base, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4)
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "f16", "int4", "fp8", "fp8a8", "mxfp4"])
+def test_single_token_direct_path(fmt):
+    """M == 1 takes the two-launch path (GEMM1 by slot, GEMM2 + weighted sum in one workgroup): same result
+    as the sort -> GEMM -> combine path (fp32 reorder tolerance) and as the oracle, with non-local (-1)
+    slots, through decode (fp32 out) and gpu_prefill (act-dtype out)."""
+    from lvllm_amd import _clib
+    E, K, H, I = 16, 8, 512, 384
+    dt = torch.float16 if fmt == "f16" else torch.bfloat16
+    a, w13, w2, tw, ids = _rand_case(1, E, K, H, I, dt, seed=123)
+    ids[0, 2] = -1                                             # an expert of another EP rank
+    if fmt in ("bf16", "f16"):
+        eng = _eng(w13, w2, top_k=K, act_dtype=dt)
+    elif fmt == "int4":
+        q13, s13 = orc.quant_int4(torch_to_bits(w13), orc.BF16, 128)
+        q2, s2 = orc.quant_int4(torch_to_bits(w2), orc.BF16, 128)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="int4",
+                   w13_scale=bits_to_torch(s13, orc.BF16), w2_scale=bits_to_torch(s2, orc.BF16), group_n=1, group_k=128)
+    elif fmt == "mxfp4":
+        rng = np.random.default_rng(9)
+        q13 = rng.integers(0, 256, (E, 2 * I, H // 2), dtype=np.uint8)
+        q2 = rng.integers(0, 256, (E, H, I // 2), dtype=np.uint8)
+        s13 = rng.integers(118, 122, (E, 2 * I, H // 32), dtype=np.uint8)
+        s2 = rng.integers(118, 122, (E, H, I // 32), dtype=np.uint8)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="mxfp4",
+                   w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=1, group_k=32)
+    else:
+        q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+        q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="fp8",
+                   w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128,
+                   fp8_mode=_clib.FP8_W8A8 if fmt == "fp8a8" else _clib.FP8_W8A16)
+    out = _run_decode(eng, a, tw, ids)
+    assert "direct" in eng.engine.describe()
+    eng.engine.set_tuning(direct=-1)
+    base = _run_decode(eng, a, tw, ids)
+    assert "direct" not in eng.engine.describe()
+    scale = max(1.0, float(np.abs(base).max()))
+    np.testing.assert_allclose(out, base, atol=2e-5 * scale, rtol=1e-4)
+    eng.engine.set_tuning(direct=0)
+    pre = eng.prefill(a.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)).float().cpu().numpy()
+    np.testing.assert_allclose(pre, out, atol=1e-2 * scale, rtol=1e-2)      # act-dtype rounding of the output
+    if fmt == "bf16":
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+        ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+        np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL)
+
+
 def test_relu2_non_gated():
     M, E, K, H, I = 19, 8, 2, 256, 128
     a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=5, gated=False)

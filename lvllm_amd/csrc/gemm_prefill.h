@@ -205,50 +205,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_prefill_kernel(GemmParams p) 
                 const int tl = GATED ? wr * 4 + t : wr * 8 + t;          // tile index inside the half
                 const int n = (tbase + tl) * 16 + g * 4;
                 if (tbase + tl < p.T_half && n < p.n_real) {
-                    if constexpr (IS_G1) {
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float a = acc[t][b][r];
-                            if (p.round_gemm1) a = ActT<ADT>::to_f32(ActT<ADT>::from_f32(a));
-                            if constexpr (GATED) {
-                                float up = acc[4 + t][b][r];
-                                if (p.round_gemm1) up = ActT<ADT>::to_f32(ActT<ADT>::from_f32(up));
-                                if (p.act_type == LKM_ACT_SWIGLUOAI) {
-                                    const float gg = fminf(a, p.limit);
-                                    const float uu = fmaxf(fminf(up, p.limit), -p.limit);
-                                    v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
-                                } else if (p.round_gemm1) {
-                                    v[r] = ActT<ADT>::to_f32(ActT<ADT>::from_f32(act_silu(a))) * up;
-                                } else {
-                                    v[r] = act_silu(a) * up;
-                                }
-                            } else {
-                                const float tt = a > 0.0f ? a : 0.0f;
-                                v[r] = tt * tt;
-                            }
-                        }
-                        unsigned short* o = (unsigned short*)p.out + (size_t)(off_e + r_tok) * p.ldo + n;
-                        if (n + 4 <= p.n_real) {
-                            u32x2 pk;
-                            pk.x = ActT<ADT>::pack2(v[0], v[1]);
-                            pk.y = ActT<ADT>::pack2(v[2], v[3]);
-                            *(u32x2*)o = pk;
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (n + r < p.n_real) o[r] = ActT<ADT>::from_f32(v[r]);
-                        }
-                    } else {
-                        float* o = (float*)p.out + (size_t)(off_e + r_tok) * p.ldo + n;
-                        if (n + 4 <= p.n_real) {
-                            *(f32x4*)o = acc[t][b];
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (n + r < p.n_real) o[r] = acc[t][b][r];
-                        }
-                    }
+                    if constexpr (IS_G1) store_gemm1_frag<ADT, GATED>(p, acc[t][b], acc[GATED ? 4 + t : t][b], (size_t)(off_e + r_tok), n);
+                    else store_gemm2_frag(p, acc[t][b], 0, (size_t)(off_e + r_tok), n);
                 }
             });
         }

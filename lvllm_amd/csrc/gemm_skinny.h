@@ -411,6 +411,60 @@ struct Streamer {
 
 __device__ __forceinline__ float act_silu(float g) { return g / (1.0f + lkm_expf(-g)); }
 
+// ------------------------------------------------------------------ epilogues shared by all GEMM kernels
+// One D fragment = 4 consecutive output features n..n+3 of one routed row.
+// GEMM1: activation (SiLU-mul / swigluoai / relu2; rounding points per GemmParams::round_gemm1) and ONE
+// rounding to the activation dtype; the row is `out_row` of the expert-sorted intermediate.
+template <int ADT, bool GATED>
+__device__ __forceinline__ void store_gemm1_frag(const GemmParams& p, const f32x4& gate, const f32x4& upv,
+                                                 size_t out_row, int n) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = gate[r];
+        if (p.round_gemm1) a = ActT<ADT>::to_f32(ActT<ADT>::from_f32(a));
+        if constexpr (GATED) {
+            float up = upv[r];
+            if (p.round_gemm1) up = ActT<ADT>::to_f32(ActT<ADT>::from_f32(up));
+            if (p.act_type == LKM_ACT_SWIGLUOAI) {
+                const float gg = fminf(a, p.limit);
+                const float uu = fmaxf(fminf(up, p.limit), -p.limit);
+                v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
+            } else if (p.round_gemm1) {
+                // T(silu_f32(g)) * u  (activation_kernels.cu:57-75,157-160)
+                v[r] = ActT<ADT>::to_f32(ActT<ADT>::from_f32(act_silu(a))) * up;
+            } else {
+                v[r] = act_silu(a) * up;
+            }
+        } else {
+            const float tt = a > 0.0f ? a : 0.0f;
+            v[r] = tt * tt;
+        }
+    }
+    unsigned short* o = (unsigned short*)p.out + out_row * p.ldo + n;
+    if (n + 4 <= p.n_real) {
+        u32x2 pk;
+        pk.x = ActT<ADT>::pack2(v[0], v[1]);
+        pk.y = ActT<ADT>::pack2(v[2], v[3]);
+        *(u32x2*)o = pk;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)   // static r: a runtime index would spill the accumulators
+            if (n + r < p.n_real) o[r] = ActT<ADT>::from_f32(v[r]);
+    }
+}
+// GEMM2: fp32 partial of split-K slab `slab`
+__device__ __forceinline__ void store_gemm2_frag(const GemmParams& p, const f32x4& v, int slab, size_t out_row, int n) {
+    float* o = (float*)p.out + (size_t)slab * p.sk_stride + out_row * p.ldo + n;
+    if (n + 4 <= p.n_real) {
+        *(f32x4*)o = v;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < p.n_real) o[r] = v[r];
+    }
+}
+
 // ------------------------------------------------------------------ GEMM1 + activation
 // grid = (groups, max_active_experts); block = 64*KW threads: the KW waves of a workgroup split K
 // and reduce through LDS (needed when an expert has too few tiles to fill the chip, e.g. M=1).
@@ -509,42 +563,8 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int n = (tile0 + t) * 16 + g * 4;
-                        if (n < p.n_real) {
-                            float v[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                float a = acc[t][b][r];
-                                if (p.round_gemm1) a = ActT<ADT>::to_f32(ActT<ADT>::from_f32(a));
-                                if (GATED) {
-                                    float up = acc[NT + t][b][r];
-                                    if (p.round_gemm1) up = ActT<ADT>::to_f32(ActT<ADT>::from_f32(up));
-                                    if (p.act_type == LKM_ACT_SWIGLUOAI) {
-                                        const float gg = fminf(a, p.limit);
-                                        const float uu = fmaxf(fminf(up, p.limit), -p.limit);
-                                        v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
-                                    } else if (p.round_gemm1) {
-                                        // T(silu_f32(g)) * u  (activation_kernels.cu:57-75,157-160)
-                                        v[r] = ActT<ADT>::to_f32(ActT<ADT>::from_f32(act_silu(a))) * up;
-                                    } else {
-                                        v[r] = act_silu(a) * up;
-                                    }
-                                } else {
-                                    const float tt = a > 0.0f ? a : 0.0f;
-                                    v[r] = tt * tt;
-                                }
-                            }
-                            unsigned short* o = (unsigned short*)p.out + (size_t)(off_e + r_tok) * p.ldo + n;
-                            if (n + 4 <= p.n_real) {
-                                u32x2 pk;
-                                pk.x = ActT<ADT>::pack2(v[0], v[1]);
-                                pk.y = ActT<ADT>::pack2(v[2], v[3]);
-                                *(u32x2*)o = pk;
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)   // static r: a runtime index would spill acc
-                                    if (n + r < p.n_real) o[r] = ActT<ADT>::from_f32(v[r]);
-                            }
-                        }
+                        if (n < p.n_real)
+                            store_gemm1_frag<ADT, GATED>(p, acc[t][b], acc[GATED ? NT + t : t][b], (size_t)(off_e + r_tok), n);
                     }
                 }
             }
@@ -609,14 +629,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int n = (tile0 + t) * 16 + g * 4;
-                    float* o = (float*)p.out + (size_t)sk * p.sk_stride + (size_t)(off_e + r_tok) * p.ldo + n;
-                    if (n + 4 <= p.n_real) {
-                        *(f32x4*)o = acc[t][b];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (n + r < p.n_real) o[r] = acc[t][b][r];
-                    }
+                    store_gemm2_frag(p, acc[t][b], sk, (size_t)(off_e + r_tok), n);
                 }
             }
         }

@@ -403,6 +403,65 @@ def test_single_token_direct_path(fmt):
         np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL)
 
 
+def test_randomised_shapes_and_formats_vs_oracle():
+    """seeded random sweep over (M, E, K, H, I, format, gating, routing skew, dropped slots): every case
+    against the CPU oracle with the stated tolerances; whatever kernel path the planner picks."""
+    rng = np.random.default_rng(20260925)
+    n_done = 0
+    for case in range(28):
+        fmt = ["bf16", "f16", "int4", "fp8", "mxfp4", "bf16", "int4"][case % 7]
+        gated = bool(rng.integers(0, 4))                       # 3 in 4 gated
+        E = int(rng.integers(2, 41))
+        K = int(rng.integers(1, min(E, 8) + 1))
+        M = int(rng.choice([1, 2, 5, 17, 33, 64, 130, 300]))
+        g = int(rng.choice([32, 64, 128])) if fmt == "int4" else (128 if fmt == "fp8" else 32)
+        H = int(rng.integers(1, 9)) * 128
+        I = int(rng.integers(1, 7)) * 128
+        dt = torch.float16 if fmt == "f16" else torch.bfloat16
+        odt = orc.F16 if fmt == "f16" else orc.BF16
+        a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, dt, seed=1000 + case, gated=gated,
+                                         drop=float(rng.choice([0.0, 0.2])), skew=float(rng.choice([0.0, 1.5])))
+        kw = dict(has_gate_proj=False, activation_type=2) if not gated else {}
+        act = orc.ACT_SILU if gated else orc.ACT_RELU2
+        if fmt in ("bf16", "f16"):
+            eng = _eng(w13, w2, top_k=K, act_dtype=dt, **kw)
+            d = orc.MoeDesc(E=E, H=H, I=I, has_gate=gated, activation=act, act_dtype=odt,
+                            wfmt=orc.W_F16 if fmt == "f16" else orc.W_BF16)
+            ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+        elif fmt == "int4":
+            q13, s13 = orc.quant_int4(torch_to_bits(w13), odt, g)
+            q2, s2 = orc.quant_int4(torch_to_bits(w2), odt, g)
+            eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="int4",
+                       w13_scale=bits_to_torch(s13, odt), w2_scale=bits_to_torch(s2, odt), group_n=1, group_k=g, **kw)
+            d = orc.MoeDesc(E=E, H=H, I=I, has_gate=gated, activation=act, act_dtype=odt, wfmt=orc.W_INT4, groupN=1, groupK=g)
+            ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+        elif fmt == "fp8":
+            q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+            q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+            eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="fp8",
+                       w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128, **kw)
+            d = orc.MoeDesc(E=E, H=H, I=I, has_gate=gated, activation=act, act_dtype=odt, wfmt=orc.W_FP8, groupN=128, groupK=128)
+            ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+        else:
+            r2 = np.random.default_rng(case)
+            q13 = r2.integers(0, 256, w13.shape[:2] + (H // 2,), dtype=np.uint8)
+            q2 = r2.integers(0, 256, (E, H, I // 2), dtype=np.uint8)
+            s13 = r2.integers(117, 121, w13.shape[:2] + (H // 32,), dtype=np.uint8)
+            s2 = r2.integers(117, 121, (E, H, I // 32), dtype=np.uint8)
+            eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="mxfp4",
+                       w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=1, group_k=32, **kw)
+            d = orc.MoeDesc(E=E, H=H, I=I, has_gate=gated, activation=act, act_dtype=odt, wfmt=orc.W_MXFP4, groupN=1, groupK=32)
+            ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+        out = _run_decode(eng, a, tw, ids)
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(out, ref, atol=ATOL * scale, rtol=RTOL,
+                                   err_msg=f"case {case}: {fmt} gated={gated} M={M} E={E} K={K} H={H} I={I} | {eng.engine.describe()}")
+        dead = (ids < 0).all(axis=1)
+        assert not out[dead].any()
+        n_done += 1
+    assert n_done == 28
+
+
 def test_relu2_non_gated():
     M, E, K, H, I = 19, 8, 2, 256, 128
     a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=5, gated=False)

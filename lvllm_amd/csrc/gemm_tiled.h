@@ -89,6 +89,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     const int T_all = p.T_half * p.halves;
     const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
 
+    // split-K (GEMM2 only, blockIdx.z = slab): this workgroup multiplies units [u0, u0 + U_loc) and writes
+    // its fp32 partial to slab `sk`; combine_kernel sums the slabs.  Used when an EP rank holds so few
+    // experts that the (tile group x token tile) grid alone leaves most of the chip idle.
+    const int sk = IS_G1 ? 0 : blockIdx.z;
+    const int u0 = IS_G1 ? 0 : (int)((long long)sk * p.U / p.SK);
+    const int U_loc = IS_G1 ? p.U : (int)((long long)(sk + 1) * p.U / p.SK) - u0;
+    const int k_base = u0 * D::UNITK;                 // element offset of the slice
+    const int Kreal_loc = p.Kreal - k_base;           // for the ragged-tail test of the last unit
     // a wave past the padded tile count (wave_on == false) streams tile 0 of the expert and drops the
     // result: every load of the K loop is unconditional (see the loop comment)
     const u32x4* wp[NTT];
@@ -98,8 +106,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     for (int t = 0; t < NTT; ++t) {
         const int tile = (IS_G1 && GATED && t >= NT) ? p.T_half + tile0 + (t - NT) : tile0 + t;
         const size_t tl = (size_t)e * T_all + (wave_on ? tile : 0);
-        wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
-        auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
+        wp[t] = (const u32x4*)p.w + (tl * p.U + u0) * D::LOADS * 64 + lane;
+        auxp[t] = D::aux_ptr(p.s, tl * p.U + u0, lane, p.spu);
     }
 
     // staging assignment of this thread: PIECES 16-byte pieces per unit
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
             const int slot = p.sorted_slot[off_e + rr];
             xrow[q] = (const unsigned char*)p.x + (size_t)(slot / p.top_k) * p.ldx * XB;
         } else {
-            xrow[q] = (const unsigned char*)p.x + (size_t)(off_e + rr) * p.ldx * XB;
+            xrow[q] = (const unsigned char*)p.x + ((size_t)(off_e + rr) * p.ldx + k_base) * XB;
         }
         // 16-bit: slot ks*4+g holds k = ks*32 + g*8 .. +7;  fp8: slot i*4+g holds k = i*64 + g*16 .. +15
         xsrc_off[q] = lslot * (16 / XB);
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
         const int r = r0 + (tid < TM ? tid : TM - 1);
         const int rr = r < m_e ? r : r0;
         const size_t rowidx = IS_G1 ? (size_t)(p.sorted_slot[off_e + rr] / p.top_k) : (size_t)(off_e + rr);
-        xsrow = p.xscale + rowidx * p.ld_xscale;
+        xsrow = p.xscale + rowidx * p.ld_xscale + u0;      // one activation scale per 128-k unit
     }
     float xsv[XD] = {};
 
@@ -159,15 +167,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
         // are unconditional; only a ragged K tail (never for the model shapes) is zero-filled.
         // STEADY: the unit is not the last one, so it cannot be a ragged K tail -> no branch at all
         auto load_x = [&](u32x4 (&xs)[PIECES], float& xsv, int u, auto STEADY) __attribute__((always_inline)) {
-            const bool tail = !decltype(STEADY)::value && (u + 1) * D::UNITK > p.Kreal;   // workgroup-uniform
+            const bool tail = !decltype(STEADY)::value && (u + 1) * D::UNITK > Kreal_loc;   // workgroup-uniform
     #pragma unroll
             for (int q = 0; q < PCS; ++q) {
-                const int k = u * D::UNITK + xsrc_off[q];
+                const int k = u * D::UNITK + xsrc_off[q];          // relative to the slice (xrow is shifted)
                 if (!tail) {
                     xs[q] = *(const u32x4*)(xrow[q] + (size_t)k * XB);
                 } else {
                     u32x4 v = {0u, 0u, 0u, 0u};
-                    if (k + 16 / XB <= p.Kreal) v = *(const u32x4*)(xrow[q] + (size_t)k * XB);
+                    if (k + 16 / XB <= Kreal_loc) v = *(const u32x4*)(xrow[q] + (size_t)k * XB);
                     xs[q] = v;
                 }
             }
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
         // loop below was made branch-free).  Hence: steady loop = units whose look-ahead stays inside the
         // K range and away from the (possibly ragged) last unit, all loads unconditional; the last few
         // units run in the drain loop with the bounds checks.
-        const int U = p.U;
+        const int U = U_loc;
         typedef std::true_type Steady;
         typedef std::false_type Drain;
         load_x(xs[0], xsv[0], 0, Drain{});
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
                 const int n = (tile0 + t) * 16 + g * 4;
                 if (n < p.n_real) {
                     if constexpr (IS_G1) store_gemm1_frag<ADT, GATED>(p, acc[t][b], acc[NTT - NT + t][b], (size_t)(off_e + r_tok), n);
-                    else store_gemm2_frag(p, acc[t][b], 0, (size_t)(off_e + r_tok), n);
+                    else store_gemm2_frag(p, acc[t][b], sk, (size_t)(off_e + r_tok), n);
                 }
             });
         }
@@ -405,11 +413,11 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr int ROWB = Dec<WF, ADT>::UNITK * (Dec<WF, ADT>::A8 ? 1 : 2);
     constexpr size_t lds = (size_t)2 * (TBW * 16 * ROWB + (Dec<WF, ADT>::A8 ? TBW * 16 * 4 : 0));
     const int RG = ceil_div(p.T_half, WAVES * NT);
-    dim3 grid(RG, max_tiles), block(WAVES * 64);
+    dim3 grid(RG, max_tiles, IS_G1 ? 1 : p.SK), block(WAVES * 64);
     GemmParams pp = p;
     if (p.xcd_map) {     // 1-D launch, see the kernel's work mapping
         pp.xcd_map = RG;
-        grid = dim3(8 * ceil_div(max_tiles, 8) * RG, 1);
+        grid = dim3(8 * ceil_div(max_tiles, 8) * RG, 1, IS_G1 ? 1 : p.SK);
     }
     auto kern = p.stream_nt ? gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1, PD, true>
                             : gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1, PD, false>;
@@ -458,12 +466,14 @@ struct W16Only {
             LKM_TILED_CASE(4, 4, 1, true, true)                                                       \
             LKM_TILED_CASE(4, 8, 1, true, true)                                                       \
             LKM_TILED_CASE(8, 8, 1, true, true)                                                       \
+            LKM_TILED_CASE_W16(8, 4, 1, true, true)                                                   \
             LKM_TILED_CASE_W16(16, 8, 1, true, true)                                                  \
         } else {                                                                                      \
             LKM_TILED_CASE(4, 4, 1, false, true)                                                      \
             LKM_TILED_CASE(4, 8, 1, false, true)                                                      \
             LKM_TILED_CASE(8, 8, 1, false, true)                                                      \
             LKM_TILED_CASE(8, 8, 2, false, true)                                                      \
+            LKM_TILED_CASE_W16(8, 4, 1, false, true)                                                  \
             LKM_TILED_CASE_W16(16, 8, 1, false, true)                                                 \
         }                                                                                             \
         set_error("gemm1 tiled: variant tm=%d waves=%d nt=%d gated=%d not built", cfg.tiled,          \
@@ -482,6 +492,7 @@ struct W16Only {
         LKM_TILED_CASE(4, 4, 2, false, false)                                                         \
         LKM_TILED_CASE(8, 8, 1, false, false)                                                         \
         LKM_TILED_CASE(8, 8, 2, false, false)                                                         \
+        LKM_TILED_CASE_W16(8, 4, 1, false, false)                                                     \
         LKM_TILED_CASE_W16(16, 8, 1, false, false)                                                    \
         LKM_TILED_CASE_W16(16, 8, 2, false, false)                                                    \
         set_error("gemm2 tiled: variant tm=%d waves=%d nt=%d not built", cfg.tiled, cfg.waves,        \

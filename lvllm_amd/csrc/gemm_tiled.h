@@ -229,9 +229,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
                 }
     #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const float xsc = *(const float*)(xb + TM * ROWB + (b * 16 + j) * 4);
+                    const f32x2 xsp = splat2_opaque(*(const float*)(xb + TM * ROWB + (b * 16 + j) * 4));
     #pragma unroll
-                    for (int t = 0; t < NTT; ++t) acc[t][b] += (s.aux[t].s * xsc) * part[t][b];
+                    for (int t = 0; t < NTT; ++t) acc[t][b] += scale4(s.aux[t].s, xsp) * part[t][b];
                 }
             } else if constexpr (D::UNIT_SCALE) {
                 f32x4 part[NTT][NB];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     #pragma unroll
                     for (int b = 0; b < NB; ++b) acc[t][b] += s.aux[t].s * part[t][b];
             } else if constexpr (WF == LKM_W_INT4_B8) {
-                // in-register decode costs ~21 VALU per fragment against 4 x TBW/4 MFMAs: decode k-step
+                // in-register decode costs ~19 VALU per fragment against 4 x TBW/4 MFMAs: decode k-step
                 // ks+1 while the MFMAs of k-step ks occupy the matrix pipe (one MFMA : DEC_PER VALU)
                 static_assert(TBW <= 8, "int4 tiles: 64 or 128 rows");
                 u32x4 a[2][NTT];
@@ -282,7 +282,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
     #pragma unroll
                         for (int b = 0; b < NB; ++b) acc[t][b] = ActT<ADT>::mfma(a[ks & 1][t], bf[b], acc[t][b]);
                     if (ks + 1 < D::KSTEPS) {
+                        #ifdef LKM_I4_OLD
                         constexpr int DEC_PER = (21 * NTT + NTT * NB - 1) / (NTT * NB);
+#else
+                        constexpr int DEC_PER = (19 * NTT + NTT * NB - 1) / (NTT * NB);
+#endif
     #pragma unroll
                         for (int i = 0; i < NTT * NB; ++i) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA

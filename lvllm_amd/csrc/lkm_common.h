@@ -83,6 +83,23 @@ __device__ __forceinline__ unsigned short f32_to_f16_bits(float f) {
 }
 
 // Activation-dtype traits: the MFMA flavour and the scalar conversions.
+// {v, v} in a register pair the compiler cannot see through, and a 4-vector scaled by it.  Packed fp32
+// instructions (v_pk_mul/fma/add_f32) then read the pair with the default op_sel.  MEASURED on MI355X
+// (tools/probe_hazard.hip): a packed instruction whose LOW lane takes the HIGH dword of a VGPR pair
+// (op_sel = 1) returns 0 for that operand in lanes 48..63, in ~0.05 % of the executions, when the same
+// pair is also read through another swizzle (same instruction or one nearby) while MFMAs are in flight --
+// which is what the compiler emits for `vec * scalar` when two scalars share a pair.  Wait states do not
+// help; one swizzle per pair is always right.  tools/scan_pk_swizzle.py checks the generated assembly.
+static __device__ __forceinline__ f32x2 splat2_opaque(float v) {
+    f32x2 p = {v, v};
+    asm("" : "+v"(p));
+    return p;
+}
+static __device__ __forceinline__ f32x4 scale4(f32x4 a, f32x2 b) {
+    const f32x2 lo = f32x2{a.x, a.y} * b, hi = f32x2{a.z, a.w} * b;
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
 template <int DT>
 struct ActT;
 template <>

@@ -30,6 +30,25 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert _clib.lib().lkm_abi_version() == _clib.LKM_ABI_VERSION
 
 
+def test_generated_code_has_no_mixed_swizzle_packed_fp32():
+    """MI355X returns a wrong low lane now and then for a v_pk_{fma,mul,add}_f32 that takes the HIGH dword of a
+    VGPR pair for its LOW lane while the pair is also read through another swizzle (measured:
+    tools/probe_hazard.hip; the int4 decoder and the W8A8 scale product hit it until their operands were
+    made opaque pairs, lkm_common.h splat2_opaque).  The compiler emits that form on its own for
+    `vector * scalar`, so the disassembly of every kernel in the built library is checked."""
+    import importlib.util
+    from lvllm_amd import build
+    lib_path = build.build()
+    spec = importlib.util.spec_from_file_location("scan_pk_swizzle", ROOT / "tools" / "scan_pk_swizzle.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        strict, mixed, seen = mod.scan(mod.disassemble_lib(str(lib_path), td), verbose=False)
+    assert seen > 10000, "disassembly found no packed fp32 instructions: scanner broken?"
+    assert strict == 0 and mixed == 0, (strict, mixed)
+
+
 def test_config_struct_layout_matches_header():
     from lvllm_amd import _clib
     text = (ROOT / "include" / "lkm.h").read_text()

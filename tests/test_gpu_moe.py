@@ -329,6 +329,40 @@ def test_fp4_dequant_is_bit_exact_on_gpu(fmt):
             np.testing.assert_array_equal(out, want, err_msg=f"{fmt} expert {e} tiled={tiled} (neg)")
 
 
+@pytest.mark.parametrize("g", [32, 64, 128])
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_int4_dequant_is_bit_exact_on_gpu(g, dt):
+    """uint4b8: every nibble x scale product must come out of the in-register decode (e4m3-subnormal
+    conversion + packed fma, gemm_skinny.h Dec<LKM_W_INT4_B8>) with the bits of the reference's
+    T((q - 8) * s) -- read back through a relu2 expert with one-hot token rows, as for FP4 above."""
+    E, H, I, K = 2, 256, 128, 1
+    odt, tdt = (orc.BF16, torch.bfloat16) if dt == "bf16" else (orc.F16, torch.float16)
+    rng = np.random.default_rng(11 + g)
+    q13 = rng.integers(0, 256, (E, I, H // 2), dtype=np.uint8)
+    q13[0, 0, :8] = np.arange(0, 256, 32, dtype=np.uint8) + np.arange(8, dtype=np.uint8)   # all 16 codes
+    s13 = (rng.uniform(0.004, 0.03, (E, I, H // g)) * rng.choice([1.0, 37.0, 0.25], (E, I, H // g))).astype(np.float32)
+    s13b = orc.f32_to_bits(s13, odt)
+    wd = orc.bits_to_f32(orc.dequant_rows(orc.W_INT4, odt, q13, s13b, H, g), odt)      # [E, I, H]
+    q2 = np.full((E, H, I // 2), 0x88, np.uint8)                                       # zeros ...
+    for r in range(min(H, I)):
+        q2[:, r, r // 2] = 0x88 + (1 << (4 * (r & 1)))                                 # ... and 1.0 on the diagonal
+    s2b = orc.f32_to_bits(np.ones((E, H, max(1, I // g)), np.float32), odt)
+    eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=tdt, fmt="int4",
+               w13_scale=bits_to_torch(s13b, odt), w2_scale=bits_to_torch(s2b, odt), group_n=1, group_k=g,
+               has_gate_proj=False, activation_type=2)
+    x = torch.eye(H, dtype=tdt)
+    for e in range(E):
+        ids = np.full((H, 1), e, np.int32)
+        tw = np.ones((H, 1), np.float32)
+        for tiled in (-1, 64, 128):
+            eng.engine.set_tuning(tiled=tiled)
+            for sign in (1.0, -1.0):
+                out = _run_decode(eng, x * sign, tw, ids)[:, :I]                       # out[j, i] = T(relu(+-W[e,i,j])^2)
+                want = np.maximum(sign * wd[e].T, 0.0) ** 2
+                want = orc.bits_to_f32(orc.f32_to_bits(want.astype(np.float32), odt), odt)
+                np.testing.assert_array_equal(out, want, err_msg=f"g={g} expert {e} tiled={tiled} sign={sign}")
+
+
 @pytest.mark.parametrize("pf", [8])
 @pytest.mark.parametrize("gated", [True, False])
 def test_prefill_kernel_ragged_multi_tile(pf, gated):

@@ -221,9 +221,11 @@ int lkm_get_profile(LkmHandle h, float* ms /* [LKM_PROF_N] */);
 /* HBM bytes held by this engine (weights + scales), and its launch geometry as text. */
 int64_t lkm_weight_bytes(LkmHandle h);
 int lkm_describe(LkmHandle h, char* buf, int32_t buf_len);
-/* tuning knobs (bench / tests): key in {"nt1","nt2","kw1","sk2","tbmax","tiled","waves","hybrid"};
- * value 0 = auto ("tiled": -1 forces the skinny streamer, 64 / 128 force a token-tile size;
- * "hybrid": -1 disables the skinny+tiled split by rows-per-expert) */
+/* tuning knobs (bench / tests): key in {"nt1","nt2","kw1","sk2","tbmax","tiled","waves","hybrid","pd1",
+ * "pd2","xcd","pf","direct","valid_den","prof_rep"}; value 0 = auto ("tiled": -1 forces the skinny
+ * streamer, 64 / 128 / 256 force a token-tile size; "hybrid": -1 disables the skinny+tiled split by
+ * rows-per-expert; "prof_rep": N > 1 launches each GEMM N times between its two profiling events and
+ * lkm_get_profile divides the interval -- profiling mode only, results unchanged) */
 int lkm_set_tuning(LkmHandle h, const char* key, int32_t value);
 
 /* Measures the HBM *read* ceiling of the device with the access shape of the expert-weight stream

@@ -35,13 +35,24 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// resident workgroups per CU the register allocation must allow (second __launch_bounds__ argument)
+constexpr int tiled_min_blocks(int wf, int tbw, int waves, bool gated_g1, int pd) {
+    // 4-bit decode tiles are latency/issue bound with two waves per SIMD, and the gated 64-row kernel
+    // sits ~10 registers above the three-wave budget (168): forcing it there (60 B of scratch) measured
+    // GEMM1 -8 % int4, -5 % NVFP4, -2 % MXFP4 at Mixtral M=128
+    if ((wf == LKM_W_INT4_B8 || wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4) && tbw == 4 && waves == 4 && gated_g1 && pd == 2) return 3;
+    return 1;
+}
+
 template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1, int PD, bool NTL>
-__global__ __launch_bounds__(WAVES * 64) void gemm_tiled_kernel(GemmParams p) {
+__global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED && IS_G1, PD)) void gemm_tiled_kernel(GemmParams p) {
     typedef Dec<WF, ADT> D;
     // PD = weight register stages (prefetch distance PD-1 units), XD = token-row register stages
     // (prefetch distance XD units).  The products of (resident waves) x (bytes in flight per wave)
     // must cover HBM latency x bandwidth (~16 MB chip-wide): a sub-16-bit unit is only 1 KiB per
-    // tile, so those formats need the deeper ring.
+    // tile, so those formats need the deeper ring.  (Measured for the 4-bit formats at Mixtral M=128:
+    // eight stages are SLOWER than two -- GEMM1 int4 238 vs 141 us, MXFP4 119 vs 107 -- the registers
+    // cost a resident wave, and resident waves hide more latency than a deeper ring: tiled_min_blocks.)
     static_assert(PD >= 2 && PD % 2 == 0, "PD even: the LDS buffer parity is the unroll index parity");
     constexpr int XD = PD > 2 ? 2 : 1;
     constexpr int NTT = (IS_G1 && GATED) ? 2 * NT : NT;

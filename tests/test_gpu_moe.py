@@ -580,6 +580,26 @@ def test_decode_is_hip_graph_capturable():
     assert torch.equal(out, eng.decode(ad, twd, idd))
 
 
+def test_profiling_repeats_leave_results_unchanged():
+    """lkm_set_tuning("prof_rep", N): the profiled call launches each GEMM N times between its events (what
+    bench.py's roofline timing uses) -- same output bits, and a per-launch time no larger than the
+    single-launch interval."""
+    M, E, K, H, I = 48, 4, 2, 512, 256
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=5)
+    eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+    base = _run_decode(eng, a, tw, ids)
+    eng.engine.set_profiling(True)
+    one = _run_decode(eng, a, tw, ids)
+    p1 = eng.engine.get_profile()
+    eng.engine.set_tuning(prof_rep=8)
+    rep = _run_decode(eng, a, tw, ids)
+    p8 = eng.engine.get_profile()
+    eng.engine.set_tuning(prof_rep=0)
+    eng.engine.set_profiling(False)
+    assert np.array_equal(one, base) and np.array_equal(rep, base)
+    assert 0 < p8["gemm1"] <= p1["gemm1"] * 1.5 and 0 < p8["gemm2"] <= p1["gemm2"] * 1.5, (p1, p8)
+
+
 def test_errors_are_loud():
     from lvllm_amd._clib import LkmError
     w13 = torch.zeros((2, 64, 36), dtype=torch.bfloat16)     # hidden 36 not a multiple of 8

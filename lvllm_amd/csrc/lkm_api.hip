@@ -511,10 +511,21 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // (325 vs 354 us).  fp8 / int4 stay at 64 (fp8-W8A8 M=256: 491 vs 574 us; the 128-row variants
         // of the decoding formats run out of registers).
         const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
-        if (M > 32 && avg_rows > 24) {
+        if (M > 32 && avg_rows >= 16) {   // bf16 M=64: 497 (streamer) vs 466 us, M=96: 562 (hybrid) vs 467; M=48 stays hybrid
             tiled = 64;
             if (w16 && avg_rows > 56) tiled = avg_rows >= 112 ? 256 : 128;
             if (h->wf == LKM_W_MXFP4 && avg_rows >= 64) tiled = 128;
+        } else if (h->wf == LKM_W_FP8_E4M3 && M >= 48) {
+            // fp8 (both modes): tiles from 48 tokens on (profiles/r01_fp8_tile_threshold.log: Mixtral W8A8
+            // M=48 275 -> 265 us, M=64 356 -> 273, M=96 379 -> 281; DSv3 rank slice, 256 rows over 32
+            // experts, 280 -> 259; M=16/32 stay with the streamer, 248 vs 261 and 254 vs 260)
+            tiled = 64;
+        } else if (wf_is_4bit(h->wf) && M >= 8) {
+            // 4-bit weights: the tile kernel (token rows staged once per workgroup through LDS, 4 waves x
+            // 3 resident workgroups) beats the streamer at EVERY decode batch measured, Mixtral shapes
+            // (profiles/r01_4bit_tile_threshold.log): MXFP4 M=8 148 -> 124 us, M=32 166 -> 155, M=64 267 ->
+            // 170; int4 M=16 227 -> 196, M=64 300 -> 223; NVFP4 M=32 200 -> 186, M=64 296 -> 213.
+            tiled = 64;
         } else if (M > 16 * tb && h->t_hybrid >= 0) {
             tiled = 64;
             split = 16 * tb;

@@ -565,7 +565,12 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         int sk2 = 1;
         if (!split && !pf) {
             const long long wg = (long long)n_act * ((avg_rows + tiled - 1) / tiled) * ((h->T2 + waves * nt2 - 1) / (waves * nt2));
-            while (sk2 < 8 && wg * sk2 < 512 && h->U2 / (sk2 * 2) >= 4) sk2 *= 2;
+            // 4-bit weights: a workgroup's K loop is latency-bound, so more and shorter ones pay up to 4 slabs
+            // (Mixtral M=128, 512 workgroups at sk 1: GEMM2 int4 107 -> 95 us, NVFP4 100 -> 86, MXFP4 88 -> 75);
+            // 16-bit and fp8 lose with any split once the grid covers the chip (bf16 154 -> 163, fp8 90 -> 95)
+            const long long wg_target = wf_is_4bit(h->wf) ? 2048 : 512;
+            const int sk_cap = wf_is_4bit(h->wf) ? 4 : 8;
+            while (sk2 < sk_cap && wg * sk2 < wg_target && h->U2 / (sk2 * 2) >= 4) sk2 *= 2;
             const size_t y_rows = h->arena->y_elems / h->H;
             while (sk2 > 1 && (size_t)sk2 * n_slots > y_rows) sk2 /= 2;
             if (h->t_sk2 > 0) sk2 = h->t_sk2;
@@ -751,8 +756,10 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         p2.SK = sk_direct;
         LaunchCfg dc = pl.s2;
         dc.nt = 1;
-        rc = launch_gemm2_direct(st, h->wfk, h->adt, dc, p2, K);
-        if (rc != LKM_OK) return rc;
+        for (int r = 0; r < rep; ++r) {
+            rc = launch_gemm2_direct(st, h->wfk, h->adt, dc, p2, K);
+            if (rc != LKM_OK) return rc;
+        }
         if (prof) {
             LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
             LKM_HIP_CHECK(hipEventRecord(h->ev[4], st));

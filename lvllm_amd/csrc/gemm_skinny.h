@@ -79,28 +79,6 @@ struct Dec<LKM_W_INT4_B8, ADT> {
     static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux& a, int ks,
                                                  int spu) {
         const unsigned w = raw[0][ks];
-#ifdef LKM_I4_OLD
-        const int idx = (ks * spu) >> 2;   // 0 for g>=128, ks/2 for g=64, ks for g=32
-        const unsigned long long bits =
-            ((unsigned long long)a.raw.y << 32 | a.raw.x) >> (16 * idx);
-        const float s = ActT<ADT>::to_f32((unsigned short)(bits & 0xffffu));
-        const float m8 = -8.0f * s;
-        unsigned lo = w & 0x0f0f0f0fu, hi = (w >> 4) & 0x0f0f0f0fu;
-        // keep lo/hi opaque: the byte extracts below then select v_cvt_f32_ubyte0..3 directly
-        // (23 VALU per 8 weights instead of ~31 with per-nibble v_bfe_u32)
-        asm volatile("" : "+v"(lo), "+v"(hi));
-        u32x4 o;
-        // byte b of the dword holds k=2b (low nibble) and k=2b+1 (high nibble)
-        o.x = ActT<ADT>::pack2(__builtin_fmaf((float)(lo & 0xffu), s, m8),
-                               __builtin_fmaf((float)(hi & 0xffu), s, m8));
-        o.y = ActT<ADT>::pack2(__builtin_fmaf((float)((lo >> 8) & 0xffu), s, m8),
-                               __builtin_fmaf((float)((hi >> 8) & 0xffu), s, m8));
-        o.z = ActT<ADT>::pack2(__builtin_fmaf((float)((lo >> 16) & 0xffu), s, m8),
-                               __builtin_fmaf((float)((hi >> 16) & 0xffu), s, m8));
-        o.w = ActT<ADT>::pack2(__builtin_fmaf((float)(lo >> 24), s, m8),
-                               __builtin_fmaf((float)(hi >> 24), s, m8));
-        return o;
-#else
         const int idx = (ks * spu) >> 2;   // 0 for g>=128, ks/2 for g=64, ks for g=32 (wave-uniform)
         // scale `idx` of the 8 fetched bytes -> f32 with one v_perm_b32 (bf16: the half-word moved to
         // the upper half IS the float; f16: to the lower half, then v_cvt_f32_f16)
@@ -137,7 +115,6 @@ struct Dec<LKM_W_INT4_B8, ADT> {
         o.z = ActT<ADT>::pack2(e23.x, o23.x);
         o.w = ActT<ADT>::pack2(e23.y, o23.y);
         return o;
-#endif
     }
 };
 

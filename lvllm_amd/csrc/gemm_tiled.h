@@ -293,11 +293,7 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
     #pragma unroll
                         for (int b = 0; b < NB; ++b) acc[t][b] = ActT<ADT>::mfma(a[ks & 1][t], bf[b], acc[t][b]);
                     if (ks + 1 < D::KSTEPS) {
-                        #ifdef LKM_I4_OLD
-                        constexpr int DEC_PER = (21 * NTT + NTT * NB - 1) / (NTT * NB);
-#else
-                        constexpr int DEC_PER = (19 * NTT + NTT * NB - 1) / (NTT * NB);
-#endif
+                                                constexpr int DEC_PER = (19 * NTT + NTT * NB - 1) / (NTT * NB);
     #pragma unroll
                         for (int i = 0; i < NTT * NB; ++i) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA

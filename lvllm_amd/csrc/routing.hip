@@ -10,6 +10,7 @@
 // ascending e then butterfly 32..1, 1/sum, score*rinv) is restated verbatim in
 // oracle/lkm_oracle.c so ids AND weights are bit-reproducible; contraction is off for that reason.
 #include "lkm_common.h"
+#include "lkm_kernels.h"
 
 namespace lkm {
 
@@ -475,10 +476,57 @@ static RouterPlan router_plan(int M, int H, int E, bool w32) {
     return p;
 }
 
+// ---- prefill-size router GEMM: the gate projection is ONE more grouped GEMM -- a single "expert" whose
+// weight rows are the E router rows and whose token rows are all M tokens -- so at M >= kRouterBigM it runs
+// on gemm_tiled_kernel (GEMM2 flavour: tokens staged through LDS once per 128/256-row tile, fp32 split-K
+// slabs), which is exactly the slab format the routing kernels sum.  The work items of router_gemm_kernel
+// are one MFMA fragment deep and re-read both operands through L2 (655 MB at M=8192; 98 us against 45 us for
+// a library GEMM); this path reads x once.  16-bit gate weights only (the tiled kernels take the activation
+// dtype); fp32 gate weights keep router_gemm_kernel.
+static const int kRouterBigM = 1024;
+struct RouterBigPlan {
+    int tile_rows, waves, T, U, n_tiles, SK;
+    size_t slab_bytes, w_bytes, meta_ints;
+    size_t total() const { return slab_bytes + w_bytes + meta_ints * 4; }
+};
+static RouterBigPlan router_big_plan(int M, int H, int E) {
+    RouterBigPlan b;
+    b.T = ceil_div(E, 16);
+    b.waves = b.T >= 5 ? 8 : 4;
+    b.tile_rows = b.waves == 8 ? 256 : 128;
+    b.U = ceil_div(H, 64);
+    b.n_tiles = ceil_div(M, b.tile_rows);
+    const long long wg = (long long)b.n_tiles * ceil_div(b.T, b.waves);
+    b.SK = 1;
+    while (b.SK < 8 && wg * b.SK < 256 && b.U / (b.SK * 2) >= 4) b.SK *= 2;
+    b.slab_bytes = ((size_t)b.SK * M * E * 4 + 255) / 256 * 256;
+    b.w_bytes = (size_t)b.T * b.U * 2 * 64 * 16;
+    b.meta_ints = 16 + 2 * (size_t)b.n_tiles;
+    return b;
+}
+static bool router_big_ok(int M, int H, int E, bool w32) { return !w32 && M >= kRouterBigM && H % 64 == 0; }
+
+__global__ void router_meta_kernel(int32_t* meta, int M, int rows, int n_tiles) {
+    // layout: [0..3] meta (meta[3] = work items), [4] counts, [5..6] offsets, [16..] tile_e, then tile_r0
+    for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
+        meta[16 + i] = 0;
+        meta[16 + n_tiles + i] = i * rows;
+    }
+    if (threadIdx.x == 0) {
+        meta[0] = meta[1] = meta[2] = 0;
+        meta[3] = n_tiles;
+        meta[4] = M;
+        meta[5] = 0;
+        meta[6] = M;
+    }
+}
+
 extern "C" int64_t lkm_router_workspace_bytes(int32_t M, int32_t H, int32_t E) {
     if (M <= 0 || H <= 0 || E <= 0) return 0;
     const RouterPlan a = router_plan(M, H, E, false), b = router_plan(M, H, E, true);
-    return (int64_t)(a.KG > b.KG ? a.KG : b.KG) * M * E * 4;
+    const int64_t small = (int64_t)(a.KG > b.KG ? a.KG : b.KG) * M * E * 4;
+    const int64_t big = router_big_ok(M, H, E, false) ? (int64_t)router_big_plan(M, H, E).total() : 0;
+    return small > big ? small : big;
 }
 
 extern "C" int lkm_router_gemm_topk(void* stream, const void* x, int32_t x_dtype, const void* gate_w,
@@ -502,12 +550,49 @@ extern "C" int lkm_router_gemm_topk(void* stream, const void* x, int32_t x_dtype
         LKM_REQUIRE(K <= topk_group * (E / n_group), "router: K=%d exceeds kept experts", K);
     }
     if (M == 0) return LKM_OK;
-    const RouterPlan pl = router_plan(M, H, E, w32);
-    const int KS = pl.KG;
-    LKM_REQUIRE(workspace && workspace_bytes >= (int64_t)KS * M * E * 4, "router: workspace too small (%lld < %lld bytes; lkm_router_workspace_bytes)", (long long)workspace_bytes, (long long)KS * M * E * 4);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(pl.ETG * pl.KG * pl.MB), block(256);
     float* part = (float*)workspace;
+    int KS;
+    if (router_big_ok(M, H, E, w32)) {
+        const RouterBigPlan bp = router_big_plan(M, H, E);
+        LKM_REQUIRE(workspace && workspace_bytes >= (int64_t)bp.total(), "router: workspace too small (%lld < %lld bytes; lkm_router_workspace_bytes)", (long long)workspace_bytes, (long long)bp.total());
+        void* wrep = (char*)workspace + bp.slab_bytes;
+        int32_t* meta = (int32_t*)((char*)workspace + bp.slab_bytes + bp.w_bytes);
+        const int wf = x_dtype == LKM_DT_BF16 ? LKM_W_BF16 : LKM_W_F16;
+        const RepackDims rd{1, E, 1, 0, H, bp.T, bp.U, 0};
+        int rc = launch_repack_w(st, wf, gate_w, wrep, rd);
+        if (rc != LKM_OK) return rc;
+        hipLaunchKernelGGL(router_meta_kernel, dim3(1), dim3(256), 0, st, meta, M, bp.tile_rows, bp.n_tiles);
+        LKM_HIP_CHECK(hipGetLastError());
+        GemmParams gp{};
+        gp.w = wrep;
+        gp.T_half = bp.T;
+        gp.halves = 1;
+        gp.U = bp.U;
+        gp.Kreal = H;
+        gp.n_real = E;
+        gp.x = x;
+        gp.ldx = H;
+        gp.x_rows = M;
+        gp.top_k = 1;
+        gp.meta = meta;
+        gp.counts = meta + 4;
+        gp.offsets = meta + 5;
+        gp.tile_e = meta + 16;
+        gp.tile_r0 = meta + 16 + bp.n_tiles;
+        gp.out = part;
+        gp.ldo = E;
+        gp.sk_stride = (size_t)M * E;
+        gp.SK = bp.SK;
+        const LaunchCfg cfg{1, bp.tile_rows / 16, 1, bp.SK, bp.tile_rows, bp.waves, 2, 0};
+        rc = launch_gemm2_tiled(st, wf, x_dtype, cfg, gp, bp.n_tiles);
+        if (rc != LKM_OK) return rc;
+        KS = bp.SK;
+    } else {
+    const RouterPlan pl = router_plan(M, H, E, w32);
+    KS = pl.KG;
+    LKM_REQUIRE(workspace && workspace_bytes >= (int64_t)KS * M * E * 4, "router: workspace too small (%lld < %lld bytes; lkm_router_workspace_bytes)", (long long)workspace_bytes, (long long)KS * M * E * 4);
+    dim3 grid(pl.ETG * pl.KG * pl.MB), block(256);
     const unsigned short* xp = (const unsigned short*)x;
 #define LKM_ROUTER_LAUNCH(XDT, W32, NT) \
     hipLaunchKernelGGL((router_gemm_kernel<XDT, W32, NT>), grid, block, 0, st, xp, gate_w, part, M, H, E, pl.ETG, pl.KG, pl.kslice)
@@ -520,6 +605,7 @@ extern "C" int lkm_router_gemm_topk(void* stream, const void* x, int32_t x_dtype
     }
 #undef LKM_ROUTER_LAUNCH
     LKM_HIP_CHECK(hipGetLastError());
+    }
     const LogitSrc src{part, LKM_DT_F32, KS, (long long)M * E, gate_bias, logits_dtype, logits_out};
     if (n_group > 0)
         hipLaunchKernelGGL(grouped_topk_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, src, score_bias, M, E,

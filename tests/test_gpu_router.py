@@ -52,6 +52,27 @@ def test_router_logits_and_topk(M, H, E, K, xdt, wdt):
     np.testing.assert_array_equal(tw.cpu().numpy(), ow)
 
 
+@pytest.mark.parametrize("M,H,E,K", [(1500, 4096, 128, 8), (1024, 2048, 8, 2), (2100, 7168, 256, 8), (1300, 1024, 60, 6)])
+@pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float16])
+def test_router_prefill_sizes_run_on_the_tiled_grouped_gemm(M, H, E, K, xdt):
+    """M >= 1024 with 16-bit gate weights: the gate projection is one more grouped GEMM (a single expert of E
+    rows over all M tokens) on gemm_tiled_kernel, fp32 split-K slabs summed by the routing kernel.  Ragged last
+    token tile, E not a multiple of 16, one expert tile only (E = 8)."""
+    from lvllm_amd import ops
+    x, w, gb = _case(M, H, E, xdt, xdt, seed=M + E, bias=(E == 128))
+    tw, ids, logits = ops.router_topk(x.to(DEV), w.to(DEV), K, True, gate_bias=None if gb is None else gb.to(DEV),
+                                      return_logits=True)
+    ref = _oracle_logits(x, w, gb)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref, atol=2e-4 * max(1.0, float(np.abs(ref).max())), rtol=0)
+    ow, oi = orc.topk_softmax(logits.cpu().numpy(), K, renormalize=True)
+    np.testing.assert_array_equal(ids.cpu().numpy(), oi)
+    np.testing.assert_array_equal(tw.cpu().numpy(), ow)
+    # a second call on the same workspace (other inputs in between) gives the same bits
+    ops.router_topk(x[:64].to(DEV), w.to(DEV), K, True)
+    tw2, ids2 = ops.router_topk(x.to(DEV), w.to(DEV), K, True, gate_bias=None if gb is None else gb.to(DEV))
+    assert torch.equal(ids, ids2) and torch.equal(tw, tw2)
+
+
 def test_router_grouped_sigmoid_bias_and_rounded_logits():
     from lvllm_amd import ops
     M, H, E, K = 24, 7168, 256, 8

@@ -478,6 +478,7 @@ struct Plan {
     LaunchCfg s1, s2;   // skinny GEMM1 / GEMM2 (s1.tb == 0: not launched)
     LaunchCfg t1, t2;   // tiled  GEMM1 / GEMM2 (t1.tiled == 0: not launched)
     int split_rows;     // hybrid threshold (0: no split)
+    int xcd1;           // GEMM1: XCD-aware work mapping (gemm_tiled.h)
 };
 
 static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   // M, n_slots: as handed over (incl. -1 slots)
@@ -534,6 +535,13 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         if (h->t_tiled < 0) { tiled = 0; split = 0; }
     }
     pl->split_rows = split;
+    // 256-row tiles with two or more token tiles per expert: the workgroups that share a token tile or a
+    // weight panel run on ONE XCD at the same time.  Bytes that miss the L2 arrive at <= 7.6 TB/s chip-wide
+    // (14 B/clk/CU, tools/probe_l2.hip) against 32 TB/s from the L2, and that IS what the prefill GEMMs run
+    // at; GLM-4.5-Air GEMM1: L2 hits 19 -> 54 %, 1761 -> 1686 us.  Not GEMM2 (+6 %) and not single-tile
+    // experts (Mixtral M=1024: -40 %) and not with fewer experts than a few per XCD (Mixtral M=4096, 8
+    // experts of 4 tiles: 1957 -> 2490 us), profiles/r01_prefill_pmc.md.
+    pl->xcd1 = (tiled == 256 && avg_rows >= 384 && n_act >= 32 && h->t_xcd >= 0) ? 1 : 0;
     pl->t1 = pl->t2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
     pl->s1 = pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
     if (tiled) {
@@ -667,7 +675,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.s = h->s13;
     p1.spu = h->spu;
     p1.gs = h->gs13;
-    p1.xcd_map = h->t_xcd > 0 ? 1 : 0;
+    p1.xcd_map = (h->t_xcd > 0 || pl.xcd1) ? 1 : 0;
     p1.x_rows = M;
     p1.T_half = h->T1_half;
     p1.halves = h->gated ? 2 : 1;

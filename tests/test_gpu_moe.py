@@ -388,6 +388,14 @@ def test_prefill_kernel_ragged_multi_tile(pf, gated):
     eng.engine.set_tuning(pf=0)
     base = _run_decode(eng, a, tw, ids)                         # same tiles through gemm_tiled_kernel
     np.testing.assert_allclose(out, base, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4)
+    # XCD-aware work mapping (the planner turns it on for GEMM1 from two token tiles per expert): only WHERE a
+    # workgroup runs changes, so the bits must not -- on both kernels, forced on and forced off
+    for pf2 in (0, pf):
+        for xcd in (1, -1):
+            eng.engine.set_tuning(pf=pf2, xcd=xcd)
+            got = _run_decode(eng, a, tw, ids)
+            assert np.array_equal(got, base if pf2 == 0 else out), f"pf={pf2} xcd={xcd} " + eng.engine.describe()
+    eng.engine.set_tuning(pf=0, xcd=0)
 
 
 @pytest.mark.parametrize("fmt", ["bf16", "f16", "int4", "fp8", "fp8a8", "mxfp4"])

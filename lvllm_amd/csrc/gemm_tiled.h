@@ -212,37 +212,45 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
             if (!wave_on) return;
             const char* xb = xlds + buf * BUFB;
             if constexpr (D::A8) {
-                // fp8 x fp8: one ds_read_b128 = the token operand of a PAIR of k-steps
-                f32x4 part[NTT][NB];
+                // fp8 x fp8: one ds_read_b128 = the token operand of a PAIR of k-steps.  The unit's partial
+                // sums (they take the block scales before they join the accumulator) are formed four token
+                // blocks at a time: the weight fragment is a register select, so a second pass over the
+                // k-steps costs nothing and the 128/256-row tiles keep `part` at NTT x 4 fragments.
+                constexpr int BCH = NB > 4 ? 4 : NB;
+                static_assert(NB % BCH == 0, "token blocks in chunks of four");
     #pragma unroll
-                for (int t = 0; t < NTT; ++t)
+                for (int b0 = 0; b0 < NB; b0 += BCH) {
+                    f32x4 part[NTT][BCH];
     #pragma unroll
-                    for (int b = 0; b < NB; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int t = 0; t < NTT; ++t)
     #pragma unroll
-                for (int i = 0; i < D::KSTEPS / 2; ++i) {
-                    u32x4 bf[NB];
+                        for (int b = 0; b < BCH; ++b) part[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     #pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const int row = b * 16 + j;
-                        bf[b] = *(const u32x4*)(xb + row * ROWB + (((i * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
+                    for (int i = 0; i < D::KSTEPS / 2; ++i) {
+                        u32x4 bf[BCH];
+    #pragma unroll
+                        for (int b = 0; b < BCH; ++b) {
+                            const int row = (b0 + b) * 16 + j;
+                            bf[b] = *(const u32x4*)(xb + row * ROWB + (((i * 4 + g) ^ x_swizzle<ROWB>(row)) * 16));
+                        }
+    #pragma unroll
+                        for (int q = 0; q < 2; ++q)
+    #pragma unroll
+                            for (int t = 0; t < NTT; ++t) {
+                                const long a = D::frag8(s.w[t], 2 * i + q);
+    #pragma unroll
+                                for (int b = 0; b < BCH; ++b)
+                                    part[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                                        a, __builtin_bit_cast(long, u32x2{bf[b][q * 2], bf[b][q * 2 + 1]}),
+                                        part[t][b], 0, 0, 0);
+                            }
                     }
     #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                    for (int b = 0; b < BCH; ++b) {
+                        const f32x2 xsp = splat2_opaque(*(const float*)(xb + TM * ROWB + ((b0 + b) * 16 + j) * 4));
     #pragma unroll
-                        for (int t = 0; t < NTT; ++t) {
-                            const long a = D::frag8(s.w[t], 2 * i + q);
-    #pragma unroll
-                            for (int b = 0; b < NB; ++b)
-                                part[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                                    a, __builtin_bit_cast(long, u32x2{bf[b][q * 2], bf[b][q * 2 + 1]}), part[t][b],
-                                    0, 0, 0);
-                        }
-                }
-    #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const f32x2 xsp = splat2_opaque(*(const float*)(xb + TM * ROWB + (b * 16 + j) * 4));
-    #pragma unroll
-                    for (int t = 0; t < NTT; ++t) acc[t][b] += scale4(s.aux[t].s, xsp) * part[t][b];
+                        for (int t = 0; t < NTT; ++t) acc[t][b0 + b] += scale4(s.aux[t].s, xsp) * part[t][b];
+                    }
                 }
             } else if constexpr (D::UNIT_SCALE) {
                 f32x4 part[NTT][NB];

@@ -509,13 +509,17 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // Tile rows by rows per expert (profiles/r01_tile_thresholds.log, Mixtral shapes, 8 experts):
         // 16-bit weights 48 rows/expert: 64 (507 us vs 604 at 128); 64: 128 (602 vs 746); 96: 128 (628 vs
         // 655 at 256); 128: 256 (735 vs 862); 256: 256 (973 vs 1149).  MXFP4: 128 from 64 rows/expert
-        // (325 vs 354 us).  fp8 / int4 stay at 64 (fp8-W8A8 M=256: 491 vs 574 us; the 128-row variants
-        // of the decoding formats run out of registers).
+        // (325 vs 354 us).  fp8-W8A16 / int4 stay at 64 (the 128-row variants of the formats that decode
+        // in registers run out of them); fp8-W8A8: see below.
         const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
         if (M > 32 && avg_rows >= 16) {   // bf16 M=64: 497 (streamer) vs 466 us, M=96: 562 (hybrid) vs 467; M=48 stays hybrid
             tiled = 64;
             if (w16 && avg_rows > 56) tiled = avg_rows >= 112 ? 256 : 128;
             if (h->wf == LKM_W_MXFP4 && avg_rows >= 64) tiled = 128;
+            // fp8 x fp8 (W8A8): 128-row tiles from ~200 rows per expert, now that the per-unit partial sums
+            // are formed four token blocks at a time and the kernel fits its registers (GLM-4.5-Air prefill
+            // 3677 -> 3179 us with two GEMM2 tiles per wave; Mixtral M=2048 1996 -> 1820; M=512 equal)
+            if (h->a8 && avg_rows >= 192) tiled = 128;
         } else if (h->wf == LKM_W_FP8_E4M3 && M >= 48) {
             // fp8 (both modes): tiles from 48 tokens on (profiles/r01_fp8_tile_threshold.log: Mixtral W8A8
             // M=48 275 -> 265 us, M=64 356 -> 273, M=96 379 -> 281; DSv3 rank slice, 256 rows over 32
@@ -552,7 +556,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         if (tiled == 128 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && wg8 < 512) waves = 4;
         if (h->t_waves > 0) waves = h->t_waves;
         const int nt1 = (h->t_nt1 > 0 && !split) ? h->t_nt1 : 1;
-        const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : (tiled == 256 ? 2 : 1);   // GLM: 3.61 vs 3.81 ms
+        const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : ((tiled == 256 || (tiled == 128 && h->a8)) ? 2 : 1);   // GLM bf16: 3.61 vs 3.81 ms; fp8-W8A8 GEMM2 1343 -> 1141 us
         // weight/token register ring depth (64-row tiles; the larger tiles have no registers to spare).
         // Measured at M=128 (profiles/r01_prefetch_depth.log): bf16 4/4 (473 vs 525 us at 2/2); the
         // formats that decode in registers keep GEMM1 at 2 (occupancy): int4 2/4 260 us vs 4/4 291 us,

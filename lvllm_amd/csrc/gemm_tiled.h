@@ -41,6 +41,8 @@ constexpr int tiled_min_blocks(int wf, int tbw, int waves, bool gated_g1, int pd
     // sits ~10 registers above the three-wave budget (168): forcing it there (60 B of scratch) measured
     // GEMM1 -8 % int4, -5 % NVFP4, -2 % MXFP4 at Mixtral M=128
     if ((wf == LKM_W_INT4_B8 || wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4) && tbw == 4 && waves == 4 && gated_g1 && pd == 2) return 3;
+    // (the fp8 kernels sit 34 registers above that budget: forced there they spill 156-236 B and LOSE,
+    // DSv3 rank slice GEMM1 151 -> 178 us)
     return 1;
 }
 

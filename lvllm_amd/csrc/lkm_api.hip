@@ -566,6 +566,9 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
             pd1 = w16 ? 4 : 2;
             pd2 = 4;
+            // fp8 with a short K loop (DSv3: I = 2048 = 16 units): four resident waves beat the deeper ring,
+            // GEMM2 W8A16 91.3 -> 83.9 us, W8A8 90.8 -> 88.4
+            if (h->wf == LKM_W_FP8_E4M3 && h->U2 <= 32) pd2 = 2;
         }
         if (tiled == 128 && waves == 4) pd1 = pd2 = 4;   // EP=8 Mixtral rank: 154 vs 229 us at 2/2
         const int pf = (tiled == 256 && h->t_pf > 0) ? h->t_pf : 0;

@@ -539,13 +539,12 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         if (h->t_tiled < 0) { tiled = 0; split = 0; }
     }
     pl->split_rows = split;
-    // 256-row tiles with two or more token tiles per expert: the workgroups that share a token tile or a
-    // weight panel run on ONE XCD at the same time.  Bytes that miss the L2 arrive at <= 7.6 TB/s chip-wide
-    // (14 B/clk/CU, tools/probe_l2.hip) against 32 TB/s from the L2, and that IS what the prefill GEMMs run
-    // at; GLM-4.5-Air GEMM1: L2 hits 19 -> 54 %, 1761 -> 1686 us.  Not GEMM2 (+6 %) and not single-tile
-    // experts (Mixtral M=1024: -40 %) and not with fewer experts than a few per XCD (Mixtral M=4096, 8
-    // experts of 4 tiles: 1957 -> 2490 us), profiles/r01_prefill_pmc.md.
-    pl->xcd1 = (tiled == 256 && avg_rows >= 384 && n_act >= 32 && h->t_xcd >= 0) ? 1 : 0;
+    // XCD-aware work mapping (gemm_tiled.h; the workgroups that share a token tile or a weight panel run on
+    // ONE XCD at the same time) stays a knob ("xcd"): bytes that miss the L2 arrive at <= 7.6 TB/s chip-wide
+    // against 32 TB/s from the L2 (tools/probe_l2.hip), and the mapping lifts GLM-4.5-Air GEMM1's L2 hits
+    // from 19 to 54 % -- but the step gains 2 % with uniform routing and LOSES 7 % with Zipf routing (equal
+    // item counts per XCD are not equal work), GEMM2 +6 %, Mixtral M=4096 +27 %: profiles/r01_prefill_pmc.md.
+    pl->xcd1 = 0;
     pl->t1 = pl->t2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
     pl->s1 = pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
     if (tiled) {

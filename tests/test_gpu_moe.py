@@ -388,7 +388,7 @@ def test_prefill_kernel_ragged_multi_tile(pf, gated):
     eng.engine.set_tuning(pf=0)
     base = _run_decode(eng, a, tw, ids)                         # same tiles through gemm_tiled_kernel
     np.testing.assert_allclose(out, base, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4)
-    # XCD-aware work mapping (the planner turns it on for GEMM1 from two token tiles per expert): only WHERE a
+    # XCD-aware work mapping (opt-in knob "xcd"): only WHERE a
     # workgroup runs changes, so the bits must not -- on both kernels, forced on and forced off
     for pf2 in (0, pf):
         for xcd in (1, -1):

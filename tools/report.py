@@ -10,6 +10,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 OUT = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out"
+# optional second argument: comma list of workload names -- re-measure only those rows and merge them into the
+# report.md / report.jsonl already in OUT
+ONLY = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None
 RUNS = [
     ("1 Qwen3-30B-A3B bf16 M=1", "qwen3_30b_a3b_bf16_decode_m1", 300, 2.5e3, 2.0),
     ("2 Mixtral-8x7B bf16 M=32", "mixtral8x7b_bf16_decode_m32", 200, 2.5e3, 2.0),
@@ -39,6 +42,8 @@ def main():
     OUT.mkdir(parents=True, exist_ok=True)
     rows, raw = [], []
     for name, wl, steps, mfma_peak, _ in RUNS:
+        if ONLY is not None and wl not in ONLY:
+            continue
         for routing in ("uniform", "zipf"):
             try:
                 j = run(wl, steps, routing)
@@ -56,6 +61,15 @@ def main():
     hdr = ("| config | routing | step µs (graph, incl. router) | tokens/s | routed rows / experts hit | "
            "kernel µs sort / gemm1 / gemm2 / combine (HIP events) | GEMM1 GB/s (% of 8 TB/s) | layer weight GB/s over the whole step (%) | "
            "layer TFLOP/s (% of 2.5 PF bf16 MFMA) | geometry |\n|---|---|---|---|---|---|---|---|---|---|")
+    if ONLY is not None and (OUT / "report.md").exists():
+        key = lambda line: tuple(c.strip() for c in line.split("|")[1:3])
+        fresh = {key(r): r for r in rows}
+        rows = [fresh.pop(key(l), l) for l in (OUT / "report.md").read_text().splitlines()[2:] if l.strip()]
+        rows += list(fresh.values())
+        old = [json.loads(l) for l in (OUT / "report.jsonl").read_text().splitlines() if l.strip()]
+        jkey = lambda j: (j["config"]["workload"], j["config"]["routing"])
+        new = {jkey(j): j for j in raw}
+        raw = [new.pop(jkey(j), j) for j in old] + list(new.values())
     md = hdr + "\n" + "\n".join(rows) + "\n"
     (OUT / "report.md").write_text(md)
     (OUT / "report.jsonl").write_text("\n".join(json.dumps(x) for x in raw) + "\n")

@@ -61,7 +61,7 @@ __global__ void k(const unsigned* win, const float* sin_, f32x2* out, int iters)
             asm volatile("v_and_b32 %1, 0x0f0f0f0f, %2\n s_nop 4\n v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_1\n"
                          "v_pk_fma_f32 %0, %0, %3, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n"
                          : "=&v"(r), "=&v"(t) : "v"(w), "v"(sm));
-        } else if (MODE >= 9 && MODE <= 30) {
+        } else if (MODE >= 9 && MODE <= 32) {
             const f32x2 s512 = {sm.x, sm.x}, m8 = {sm.y, sm.y};
 #define PRE "v_and_b32 %[t], 0x0f0f0f0f, %[w]\n s_nop 4\n v_mfma_f32_16x16x32_bf16 %[acc], %[za], %[zb], %[acc]\n"
 #define OPS : [r] "=&v"(r), [t] "=&v"(t), [acc] "+v"(acc) : [sm] "v"(sm), [s512] "v"(s512), [m8] "v"(m8), [za] "v"(za), [zb] "v"(zb), [w] "v"(w)
@@ -97,12 +97,9 @@ __global__ void k(const unsigned* win, const float* sin_, f32x2* out, int iters)
                 if (MODE == 25) asm volatile(PRE CV MUL_LO U1 ADD_HI OPS3);
                 if (MODE == 26) asm volatile(PRE CV MUL_LO U1 U1 ADD_HI OPS3);
                 if (MODE == 27) asm volatile(PRE CV MUL_LO U1 U1 U1 U1 U1 ADD_HI OPS3);
-                if (MODE == 28) asm volatile(PRE CV MUL_LO "v_pk_mul_f32 %[s512], %[s512], %[s512]\n" ADD_HI
-                                             : [r] "=&v"(r), [t] "=&v"(t), [acc] "+v"(acc), [s512] "+v"(*(f32x2*)&d0) : [sm] "v"(sm), [za] "v"(za), [zb] "v"(zb), [w] "v"(w));
                 if (MODE == 29) asm volatile(PRE CV MUL_LO "s_nop 7\n" ADD_HI OPS3);
                 if (MODE == 31) asm volatile(PRE CV ADD_HI OPS3);                                   // hi-broadcast src1 alone: c + m8
                 if (MODE == 32) asm volatile(PRE CV "v_pk_mul_f32 %[r], %[r], %[sm] op_sel:[0,1] op_sel_hi:[1,1]\n" OPS3);   // c * m8
-                if (MODE == 30) asm volatile(PRE CV MUL_LO "v_pk_mul_f32 %[r], %[r], %[s512] op_sel_hi:[1,0]\n v_pk_mul_f32 %[r], %[r], %[s512] op_sel:[0,1]\n" ADD_HI OPS3);
                 if (d0 == 0x12345 && d1 == 0x777) out[1] = f32x2{1.f, 2.f};
             }
             if (MODE == 16) {   // conversion finished long before the MFMA: only pk_fma follows it

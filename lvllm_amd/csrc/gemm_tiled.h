@@ -41,6 +41,8 @@ constexpr int tiled_min_blocks(int wf, int tbw, int waves, bool gated_g1, int pd
     // sits ~10 registers above the three-wave budget (168): forcing it there (60 B of scratch) measured
     // GEMM1 -8 % int4, -5 % NVFP4, -2 % MXFP4 at Mixtral M=128
     if ((wf == LKM_W_INT4_B8 || wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4) && tbw == 4 && waves == 4 && gated_g1 && pd == 2) return 3;
+    // the 32-row tile of the same formats is two registers above FOUR waves per SIMD (int4: 130)
+    if ((wf == LKM_W_INT4_B8 || wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4) && tbw == 2 && waves == 4 && gated_g1 && pd == 2) return 4;
     // (the fp8 kernels sit 34 registers above that budget: forced there they spill 156-236 B and LOSE,
     // DSv3 rank slice GEMM1 151 -> 178 us)
     return 1;
@@ -397,6 +399,9 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
         } else if constexpr (TBW == 4 && GRAN == 2) {
             if (nb <= 2) run(IC<2>{});
             else run(IC<4>{});
+        } else if constexpr (TBW == 2 && GRAN == 1) {
+            if (nb <= 1) run(IC<1>{});
+            else run(IC<2>{});
         } else if constexpr (TBW >= 8 && (TBW / 4) % GRAN == 0) {
             // prefill tiles in quarters: the ragged last tile of an expert (GLM: 512 +- 22 rows over
             // 256-row tiles) costs what it holds, not a full tile
@@ -485,12 +490,14 @@ struct W16Only {
             if (launch_prefill_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc;    \
         }                                                                                             \
         if (gated) {                                                                                  \
+            LKM_TILED_CASE(2, 4, 1, true, true)                                                       \
             LKM_TILED_CASE(4, 4, 1, true, true)                                                       \
             LKM_TILED_CASE(4, 8, 1, true, true)                                                       \
             LKM_TILED_CASE(8, 8, 1, true, true)                                                       \
             LKM_TILED_CASE_W16(8, 4, 1, true, true)                                                   \
             LKM_TILED_CASE_W16(16, 8, 1, true, true)                                                  \
         } else {                                                                                      \
+            LKM_TILED_CASE(2, 4, 1, false, true)                                                      \
             LKM_TILED_CASE(4, 4, 1, false, true)                                                      \
             LKM_TILED_CASE(4, 8, 1, false, true)                                                      \
             LKM_TILED_CASE(8, 8, 1, false, true)                                                      \
@@ -509,6 +516,7 @@ struct W16Only {
             int rc = LKM_OK;                                                                          \
             if (launch_prefill_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;   \
         }                                                                                             \
+        LKM_TILED_CASE(2, 4, 1, false, false)                                                         \
         LKM_TILED_CASE(4, 4, 1, false, false)                                                         \
         LKM_TILED_CASE(4, 8, 1, false, false)                                                         \
         LKM_TILED_CASE(4, 4, 2, false, false)                                                         \

@@ -34,7 +34,7 @@ struct Arena {
     int E_cap = 0;
     int32_t *counts = nullptr, *offsets = nullptr, *active = nullptr, *meta = nullptr;
     int32_t *sorted_slot = nullptr, *pos_of_slot = nullptr;
-    int32_t *tile_e = nullptr, *tile_r0 = nullptr;   // [cap_slots/64 + E_cap + 8] each
+    int32_t *tile_e = nullptr, *tile_r0 = nullptr;   // [cap_slots/32 + E_cap + 8] each
     size_t tile_cap = 0;
     int32_t* hist = nullptr;                         // multi-workgroup sort: [chunks][E]
     size_t hist_cap = 0;
@@ -95,7 +95,7 @@ static int arena_reserve(int device, int E, size_t slots, size_t act_elems, size
         a.cap_slots = slots;
     }
     {
-        const size_t want = a.cap_slots / 64 + (size_t)a.E_cap + 8;
+        const size_t want = a.cap_slots / 32 + (size_t)a.E_cap + 8;   // smallest token tile: 32 rows
         if (want > a.tile_cap) {
             size_t h1 = 0, h2 = 0;
             int32_t *t1 = nullptr, *t2 = nullptr;
@@ -535,6 +535,11 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             tiled = 64;
             split = 16 * tb;
         }
+        // 4-bit decode batches in which an expert is unlikely to hold more than 32 rows: the 32-row tile keeps half
+        // the accumulators and two more waves per SIMD resident (profiles/r01_tile32.log: int4 M=16 196 -> 186 us,
+        // M=32 196 -> 190, MXFP4 M=32 158 -> 150).  fp8 stays at 64: the DSv3 rank slice loses in GEMM1 (147 ->
+        // 160 us) what it gains in GEMM2 (88 -> 85), Mixtral W8A8 M=48 is equal.
+        if (tiled == 64 && !split && wf_is_4bit(h->wf) && est_max <= 32) tiled = 32;
         if (h->t_tiled > 0) { tiled = h->t_tiled; split = 0; }
         if (h->t_tiled < 0) { tiled = 0; split = 0; }
     }
@@ -561,7 +566,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // formats that decode in registers keep GEMM1 at 2 (occupancy): int4 2/4 260 us vs 4/4 291 us,
         // MXFP4 205 vs 221 us, fp8 293 vs 298 us.
         int pd1 = 2, pd2 = 2;
-        if (tiled == 64) {
+        if (tiled <= 64) {
             const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
             pd1 = w16 ? 4 : 2;
             pd2 = 4;

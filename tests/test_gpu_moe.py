@@ -216,7 +216,7 @@ def test_quantised_tiled_path(fmt):
                    w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128)
         d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128)
     ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
-    for tiled in (64, 128, -1):
+    for tiled in (32, 64, 128, -1):
         eng.engine.set_tuning(tiled=tiled)
         out = _run_decode(eng, a, tw, ids)
         np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=f"{fmt} tiled={tiled}")
@@ -277,7 +277,7 @@ def test_fp4_golden_cases():
         ref = orc.moe(d, c["q1"], c["q2"], c["a"], c["ids"], c["tw"], s13=c["s1"], s2=c["s2"],
                       gs13=c.get("gs1"), gs2=c.get("gs2"))
         scale = max(1.0, float(np.abs(ref).max()))
-        for tiled in (-1, 64):
+        for tiled in (-1, 32, 64):
             eng.engine.set_tuning(tiled=tiled)
             out = _run_decode(eng, a, c["tw"], c["ids"])
             np.testing.assert_allclose(out, ref, atol=ATOL * scale, rtol=RTOL, err_msg=f"case {i} fmt={fmt} tiled={tiled}")
@@ -316,7 +316,7 @@ def test_fp4_dequant_is_bit_exact_on_gpu(fmt):
     for e in range(E):
         ids = np.full((H, 1), e, np.int32)
         tw = np.ones((H, 1), np.float32)
-        for tiled in (-1, 64):
+        for tiled in (-1, 32, 64):
             eng.engine.set_tuning(tiled=tiled)
             out = _run_decode(eng, x, tw, ids)                       # out[j, i] = bf16(relu(W[e,i,j])^2)
             want = np.maximum(wd[e].T, 0.0) ** 2
@@ -354,7 +354,7 @@ def test_int4_dequant_is_bit_exact_on_gpu(g, dt):
     for e in range(E):
         ids = np.full((H, 1), e, np.int32)
         tw = np.ones((H, 1), np.float32)
-        for tiled in (-1, 64, 128):
+        for tiled in (-1, 32, 64, 128):
             eng.engine.set_tuning(tiled=tiled)
             for sign in (1.0, -1.0):
                 out = _run_decode(eng, x * sign, tw, ids)[:, :I]                       # out[j, i] = T(relu(+-W[e,i,j])^2)
@@ -541,7 +541,7 @@ def test_all_launch_geometries_agree():
         np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=f"pf={pf} " + eng.engine.describe())
     eng.engine.set_tuning(pf=0)
     # LDS-staged tiled kernels (gemm_tiled.h)
-    for tiled, waves, nt1, nt2 in ((64, 4, 1, 1), (64, 8, 1, 1), (64, 4, 1, 2), (128, 8, 1, 1), (128, 8, 1, 2),
+    for tiled, waves, nt1, nt2 in ((32, 4, 1, 1), (64, 4, 1, 1), (64, 8, 1, 1), (64, 4, 1, 2), (128, 8, 1, 1), (128, 8, 1, 2),
                                    (256, 8, 1, 1), (256, 8, 1, 2)):
         eng.engine.set_tuning(tiled=tiled, waves=waves, nt1=nt1, nt2=nt2, tbmax=0, kw1=0, sk2=0)
         out = _run_decode(eng, a, tw, ids)

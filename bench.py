@@ -160,6 +160,39 @@ def build_engine(ops, wl, w13, w2, **kw):
     return eng, 2.0, dict(wfmt="W_BF16", groupN=0, groupK=0, w13=w13, w2=w2)
 
 
+def time_reference_kernel(w13, w2, x, tw, ids, thread_cands, seconds, gpu_out):
+    """cpu_baseline kind "reference": oracle/_ref (the reference's in-tree CPU fused-MoE kernel) on this host."""
+    from oracle import ref
+    if not ref.available():
+        return None
+    ref.load()
+    p13, p2 = ref.prepack(w13.cpu()), ref.prepack(w2.cpu())
+    xc, twc, idc = x.cpu(), tw.cpu(), ids.cpu()
+    ref.set_threads(thread_cands[0])
+    ref.fused_moe(xc, p13, p2, twc, idc)                            # untimed first pass
+    best_t, best_c = None, thread_cands[0]
+    for c in thread_cands:                                          # same team-size probe as for the port
+        ref.set_threads(c)
+        c0 = time.perf_counter()
+        ref.fused_moe(xc, p13, p2, twc, idc)
+        tc = time.perf_counter() - c0
+        if best_t is None or tc < best_t:
+            best_t, best_c = tc, c
+        if tc > 3 * best_t:
+            break
+    ref.set_threads(best_c)
+    n, t_cpu, out = 0, 0.0, None
+    while n < 2 or (t_cpu < seconds and n < 200):
+        c0 = time.perf_counter()
+        out = ref.fused_moe(xc, p13, p2, twc, idc)
+        t_cpu += time.perf_counter() - c0
+        n += 1
+    o = out.float().numpy()
+    err = float(np.abs(gpu_out - o).max() / max(1e-9, np.abs(o).max()))
+    return {"value": round(x.size(0) / (t_cpu / n), 2), "unit": "tokens/s", "cores": best_c, "kind": "reference",
+            "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err, "n": n, "t": t_cpu}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,7 +203,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--force-ep", action="store_true", help="run the expert-parallel data path even with one rank (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget (s) for each CPU baseline sample (reference kernel, port)")
     ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf"],
                     help="router logits: randn (uniform-ish) or randn + Zipf(s=1) expert popularity bias (SURVEY 8d)")
     ap.add_argument("--tune", default="", help="comma list key=value for lkm_set_tuning (nt1,nt2,kw1,sk2,tbmax)")
@@ -363,6 +396,21 @@ def main():
                "sample": f"{n} full {args.workload} layer passes (M={M}) through oracle/lkm_oracle.c, "
                          f"{t_cpu:.1f} s of CPU work; lk_moe itself is a closed binary absent from the reference tree",
                "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err}
+        # The reference's OWN in-tree CPU fused-MoE kernel (csrc/cpu/cpu_fused_moe.cpp, compiled into oracle/_ref
+        # where /root/reference exists; 16-bit experts only) on the same inputs and host cores: when it loads it
+        # IS the cpu_baseline ("reference") and the port's figure moves to cpu_baseline["port"].
+        if fmt == "bf16":
+            try:
+                cpu_ref = time_reference_kernel(w13, w2, x, tw, ids, cands, args.cpu_seconds, gpu_out)
+            except Exception as e:
+                print(f"[bench] oracle/_ref unavailable ({e}); cpu_baseline is the port", file=sys.stderr)
+                cpu_ref = None
+            if cpu_ref is not None:
+                cpu_ref["sample"] = (f"{cpu_ref.pop('n')} full {args.workload} layer passes (M={M}) through the reference's "
+                                     f"csrc/cpu/cpu_fused_moe.cpp (AVX-512 'vec' micro-kernels, oracle/_ref), "
+                                     f"{cpu_ref.pop('t'):.1f} s of CPU work")
+                cpu_ref["port"] = cpu
+                cpu = cpu_ref
 
     if rank == 0:
         line = {

@@ -11,7 +11,10 @@
  * IS pinned are the in-tree operators that sit at the same position
  * (moe_runner.py:602-654) and their torch oracles; this file restates those and
  * is checked against golden vectors produced by running the reference's own
- * python oracle functions (tests/golden/make_golden.py).
+ * python oracle functions (tests/golden/make_golden.py), AND against the
+ * reference's own in-tree CPU fused-MoE kernel (csrc/cpu/cpu_fused_moe.cpp) run
+ * here: oracle/_ref, built by `make ref` from the reference sources where they
+ * lie (tests/test_oracle_ref.py).
  *
  * Each function cites the reference file:line (relative to /root/reference) it
  * follows.  Plain C99 + OpenMP; fp32 arithmetic with the rounding points of the

@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE ONLY.  May be imported by tests/, bench.py's cpu_baseline leg and
 __graft_entry__.smoke() -- never by lvllm_amd/ or lk_moe/ (tests/test_boundary.py checks).
 Parity status: see the header of lkm_oracle.c ("lk_moe boundary unpinned"; in-tree operator
-pinned by tests/golden/).
+pinned by tests/golden/ and by oracle/_ref = the reference's own CPU kernel, see oracle/ref.py).
 
 Arrays are numpy; bf16/fp16 tensors travel as uint16 bit patterns.
 """

@@ -1,0 +1,92 @@
+"""oracle/_ref front-end -- TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline).
+
+Runs the reference's OWN in-tree CPU fused-MoE kernel (/root/reference/csrc/cpu/cpu_fused_moe.cpp:640-702),
+compiled by oracle/Makefile (`make ref`) from the sources where they lie into oracle/_ref/liblkm_ref.so.  The
+product path (lvllm_amd/, lk_moe/) never imports this module.  The Python wrappers below restate the two
+thin wrappers of vllm/_custom_ops.py:3917-3962 (allocate the output, call the op).
+
+The reference's real engine for the path is the closed lk_moe wheel (not in /root/reference); this kernel is
+the nearest thing the reference tree can actually run: bf16/fp16 experts, gated activations, fp32 accumulate,
+one rounding of the activation to the activation dtype, output in the activation dtype
+(csrc/cpu/cpu_fused_moe.cpp:229-635) -- the rounding convention the oracle and the HIP kernels follow.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import torch
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "_ref" / "liblkm_ref.so"
+REF_ROOT = Path("/root/reference")
+_loaded = False
+_omp = None
+
+
+def build(verbose: bool = False) -> Path | None:
+    """make ref, when the reference tree is present (this container); the GPU box only uses the prebuilt file."""
+    if not (REF_ROOT / "csrc" / "cpu" / "cpu_fused_moe.cpp").exists():
+        return LIB if LIB.exists() else None
+    r = subprocess.run(["make", "-C", str(HERE), "ref"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"oracle/_ref build failed:\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
+    if verbose:
+        print(r.stdout[-400:])
+    return LIB
+
+
+def available() -> bool:
+    return LIB.exists()
+
+
+def load() -> None:
+    global _loaded, _omp
+    if _loaded:
+        return
+    if not LIB.exists():
+        raise RuntimeError(f"{LIB} not built (run `make -C oracle ref` where /root/reference exists)")
+    torch.ops.load_library(str(LIB))
+    try:        # the kernel's OpenMP runtime is clang's libomp (see oracle/Makefile), not torch's libgomp
+        _omp = ctypes.CDLL("libomp.so")
+    except OSError:
+        _omp = None
+    _loaded = True
+    # libomp's default team is every logical CPU of the host; containers usually may run far fewer, and
+    # oversubscribed spinning teams are slow -- start from the CPUs this process may actually use, at most 32
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    set_threads(max(1, min(usable, 32)))
+
+
+def set_threads(n: int) -> None:
+    load()
+    if _omp is not None:
+        _omp.omp_set_num_threads(int(n))
+
+
+def num_threads() -> int:
+    load()
+    return int(_omp.omp_get_max_threads()) if _omp is not None else 1
+
+
+def prepack(weight: torch.Tensor, isa: str = "vec") -> torch.Tensor:
+    """[E, N, K] contiguous bf16/fp16 (N % 32 == 0) -> the kernel's packed layout (same shape/dtype)."""
+    load()
+    packed = torch.empty_like(weight)
+    torch.ops.lkm_ref.prepack_moe_weight(weight.contiguous(), packed, isa)
+    return packed
+
+
+def fused_moe(x: torch.Tensor, packed_w13: torch.Tensor, packed_w2: torch.Tensor, topk_weights: torch.Tensor,
+              topk_ids: torch.Tensor, act: str = "silu", isa: str = "vec") -> torch.Tensor:
+    """x [M, H] act dtype; topk_weights fp32 [M, K]; topk_ids int32 [M, K] (all valid) -> [M, H] act dtype."""
+    load()
+    out = torch.empty_like(x)
+    torch.ops.lkm_ref.cpu_fused_moe(out, x.contiguous(), packed_w13, packed_w2, None, None,
+                                    topk_weights.contiguous().float(), topk_ids.contiguous().int(), False, act, isa)
+    return out

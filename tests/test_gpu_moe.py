@@ -675,3 +675,45 @@ def test_mixtral_full_size_vs_oracle(mixtral):
     ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
     scale = float(np.abs(ref).max())
     np.testing.assert_allclose(out, ref, atol=2e-3 * scale, rtol=1e-2)
+
+
+# ---------------------------------------------------------------- vs the reference's own CPU kernel (oracle/_ref)
+def _ref_or_skip():
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    try:
+        ref.load()
+    except Exception as e:      # e.g. a host without AVX-512 BF16
+        pytest.skip(f"oracle/_ref does not load on this host: {e}")
+    return ref
+
+
+@pytest.mark.parametrize("act", ["silu", "swigluoai"])
+@pytest.mark.parametrize("batch,H,I", [(1, 128, 128), (64, 2880, 128), (64, 128, 2880), (256, 2880, 2880)])
+def test_gpu_vs_reference_cpu_kernel(batch, H, I, act):
+    """HIP path against the REFERENCE'S OWN in-tree CPU fused-MoE kernel (csrc/cpu/cpu_fused_moe.cpp, compiled
+    into oracle/_ref from where it lies) on the shapes, input recipe, seed and tolerances of the reference's test
+    of that kernel (tests/kernels/moe/test_cpu_fused_moe.py:200-262; bf16 atol 1e-3 rtol 1.6e-2).  gpu_prefill
+    returns the activation dtype like that kernel; cpu_decode's fp32 result is rounded for the comparison."""
+    ref = _ref_or_skip()
+    from tests.test_oracle_ref import reference_case
+    dtype = torch.bfloat16
+    x, w13, w2, tw, ids = reference_case(batch, 8, H, I, dtype)
+    want = ref.fused_moe(x, ref.prepack(w13), ref.prepack(w2), tw, ids, act=act).float()
+    eng = _eng(w13, w2, top_k=ids.shape[1], act_dtype=dtype, activation_type=0 if act == "silu" else 1,
+               max_num_seqs=256)
+    pre = eng.prefill(x.to(DEV), tw.to(DEV), ids.to(DEV)).float().cpu()
+    torch.testing.assert_close(pre, want, atol=1e-3, rtol=1.6e-2)
+    dec = eng.decode(x.to(DEV), tw.to(DEV), ids.to(DEV)).to(dtype).float().cpu()
+    torch.testing.assert_close(dec, want, atol=1e-3, rtol=1.6e-2)
+
+
+def test_gpu_vs_reference_cpu_kernel_fp16():
+    ref = _ref_or_skip()
+    from tests.test_oracle_ref import reference_case
+    x, w13, w2, tw, ids = reference_case(64, 8, 256, 384, torch.float16)
+    want = ref.fused_moe(x, ref.prepack(w13), ref.prepack(w2), tw, ids).float()
+    eng = _eng(w13, w2, top_k=ids.shape[1], act_dtype=torch.float16, fmt="fp16")
+    pre = eng.prefill(x.to(DEV), tw.to(DEV), ids.to(DEV)).float().cpu()
+    torch.testing.assert_close(pre, want, atol=1e-3, rtol=1e-3)

@@ -1,6 +1,7 @@
 """oracle/_ref front-end -- TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline).
 
-Runs the reference's OWN in-tree CPU fused-MoE kernel (/root/reference/csrc/cpu/cpu_fused_moe.cpp:640-702),
+Runs the reference's OWN in-tree CPU fused-MoE kernels -- 16-bit experts: /root/reference/csrc/cpu/cpu_fused_moe.cpp:640-702;
+quantised experts (fp8-W8A16 block scales, MXFP4): /root/reference/csrc/cpu/sgl-kernels/moe.cpp:874-1224 --
 compiled by oracle/Makefile (`make ref`) from the sources where they lie into oracle/_ref/liblkm_ref.so.  The
 product path (lvllm_amd/, lk_moe/) never imports this module.  The Python wrappers below restate the two
 thin wrappers of vllm/_custom_ops.py:3917-3962 (allocate the output, call the op).
@@ -90,3 +91,37 @@ def fused_moe(x: torch.Tensor, packed_w13: torch.Tensor, packed_w2: torch.Tensor
     torch.ops.lkm_ref.cpu_fused_moe(out, x.contiguous(), packed_w13, packed_w2, None, None,
                                     topk_weights.contiguous().float(), topk_ids.contiguous().int(), False, act, isa)
     return out
+
+
+# ------------------------------------------------------------------ quantised experts (sgl-kernels MoE)
+# csrc/cpu/sgl-kernels/gemm.h:92 -- enum class CPUQuantMethod
+BF16, INT8_W8A8, FP8_W8A16, INT4_W4A8, MXFP4 = 0, 1, 2, 3, 4
+
+
+def fused_experts_fp8_w8a16(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, w13_scale: torch.Tensor,
+                            w2_scale: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor,
+                            block=(128, 128)) -> torch.Tensor:
+    """The reference's fp8-W8A16 block-scaled CPU MoE (csrc/cpu/sgl-kernels/moe.cpp:874, FP8_W8A16; call site
+    vllm/model_executor/layers/fused_moe/experts/cpu_moe.py:167-185): w13 [E,2I,H] / w2 [E,H,I] float8_e4m3fn,
+    scales fp32 [E, rows/128, cols/128]; SiLU-gated; returns the activation dtype."""
+    load()
+    pw13 = torch.ops.lkm_ref.convert_weight_packed(w13.contiguous())
+    pw2 = torch.ops.lkm_ref.convert_weight_packed(w2.contiguous())
+    return torch.ops.lkm_ref.fused_experts_cpu(x.clone(), pw13, pw2, topk_weights.float().contiguous(),
+                                               topk_ids.int().contiguous(), False, FP8_W8A16,
+                                               w13_scale.float().contiguous(), w2_scale.float().contiguous(),
+                                               None, None, list(block), None, None, None, None, True)
+
+
+def fused_experts_mxfp4(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, w13_scale: torch.Tensor,
+                        w2_scale: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
+    """The reference's MXFP4 CPU MoE (same entry point, MXFP4; call site cpu_moe.py:321-339): w13 [E,2I,H/2] /
+    w2 [E,H,I/2] uint8 (two E2M1 codes per byte, low nibble first), scales uint8 E8M0 [E, rows, cols/32]."""
+    load()
+    pw13 = torch.ops.lkm_ref.convert_weight_packed(w13.contiguous())
+    pw2 = torch.ops.lkm_ref.convert_weight_packed(w2.contiguous())
+    ps13 = torch.ops.lkm_ref.convert_scale_packed(w13_scale.contiguous())
+    ps2 = torch.ops.lkm_ref.convert_scale_packed(w2_scale.contiguous())
+    return torch.ops.lkm_ref.fused_experts_cpu(x.clone(), pw13, pw2, topk_weights.float().contiguous(),
+                                               topk_ids.int().contiguous(), False, MXFP4, ps13, ps2,
+                                               None, None, None, None, None, None, None, True)

@@ -5,6 +5,7 @@
 // that file drags in the whole CPU backend (oneDNN, attention, ...), so the two declarations are restated here.
 #include <optional>
 #include <string>
+#include <vector>
 
 #include <torch/library.h>
 #include <ATen/ATen.h>
@@ -15,7 +16,25 @@ void cpu_fused_moe(at::Tensor& output, const at::Tensor& input, const at::Tensor
                    const at::Tensor& topk_weights, const at::Tensor& topk_id, const bool skip_weighted,
                    const std::string& act, const std::string& isa);
 
+// Quantised experts: the reference's second in-tree CPU MoE kernel (csrc/cpu/sgl-kernels/moe.cpp:874-1224 with
+// moe_fp8.cpp / gemm.cpp:616-727; registered by the reference at csrc/cpu/torch_bindings.cpp:476-492), used here
+// for FP8_W8A16 (128x128 block scales) and MXFP4 experts.
+at::Tensor convert_weight_packed(at::Tensor& weight);
+at::Tensor convert_scale_packed(at::Tensor& scale);
+at::Tensor fused_experts_cpu(at::Tensor& hidden_states, at::Tensor& w1, at::Tensor& w2, at::Tensor& topk_weights,
+                             at::Tensor& topk_ids, bool inplace, int64_t moe_comp_method,
+                             const std::optional<at::Tensor>& w1_scale, const std::optional<at::Tensor>& w2_scale,
+                             const std::optional<at::Tensor>& w1_zero, const std::optional<at::Tensor>& w2_zero,
+                             const std::optional<std::vector<int64_t>> block_size,
+                             const std::optional<at::Tensor>& w1_bias, const std::optional<at::Tensor>& w2_bias,
+                             const std::optional<double>& alpha, const std::optional<double>& limit, bool is_vnni);
+
 TORCH_LIBRARY(lkm_ref, m) {
+  m.def("convert_weight_packed(Tensor weight) -> Tensor");
+  m.def("convert_scale_packed(Tensor scale) -> Tensor");
+  m.def("fused_experts_cpu(Tensor hidden_states, Tensor w1, Tensor w2, Tensor topk_weights, Tensor topk_ids, "
+        "bool inplace, int moe_comp_method, Tensor? w1_scale, Tensor? w2_scale, Tensor? w1_zero, Tensor? w2_zero, "
+        "int[]? block_size, Tensor? w1_bias, Tensor? w2_bias, float? alpha, float? limit, bool is_vnni) -> Tensor");
   m.def("prepack_moe_weight(Tensor weight, Tensor(a1!) packed_weight, str isa) -> ()");
   m.def("cpu_fused_moe(Tensor(a0!) output, Tensor input, Tensor w13, Tensor w2, Tensor? w13_bias, "
         "Tensor? w2_bias, Tensor topk_weights, Tensor topk_id, bool skip_weighted, str act, str isa) -> ()");
@@ -23,4 +42,7 @@ TORCH_LIBRARY(lkm_ref, m) {
 TORCH_LIBRARY_IMPL(lkm_ref, CPU, m) {
   m.impl("prepack_moe_weight", &prepack_moe_weight);
   m.impl("cpu_fused_moe", &cpu_fused_moe);
+  m.impl("convert_weight_packed", &convert_weight_packed);
+  m.impl("convert_scale_packed", &convert_scale_packed);
+  m.impl("fused_experts_cpu", &fused_experts_cpu);
 }

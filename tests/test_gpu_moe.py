@@ -717,3 +717,38 @@ def test_gpu_vs_reference_cpu_kernel_fp16():
     eng = _eng(w13, w2, top_k=ids.shape[1], act_dtype=torch.float16, fmt="fp16")
     pre = eng.prefill(x.to(DEV), tw.to(DEV), ids.to(DEV)).float().cpu()
     torch.testing.assert_close(pre, want, atol=1e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("M", [1, 64, 121])
+@pytest.mark.parametrize("N,K,E,topk", [(256, 512, 8, 2), (512, 256, 8, 4), (768, 2048, 8, 2), (768, 2048, 128, 8)])
+def test_gpu_fp8_w8a16_vs_reference_cpu_kernel(M, N, K, E, topk):
+    """fp8 W8A16 experts with 128x128 block scales (MOE_FP8) against the reference's CPU kernel for that scheme
+    (csrc/cpu/sgl-kernels/moe.cpp, FP8_W8A16, in oracle/_ref); shapes, input recipe and tolerance
+    (atol = rtol = 1e-2) of tests/kernels/moe/test_cpu_quant_fused_moe.py:150-201."""
+    ref = _ref_or_skip()
+    from tests.test_oracle_ref import fp8_case
+    a, w1, w2, w1_s, w2_s, tw, ids = fp8_case(M, N, K, E, topk)
+    want = ref.fused_experts_fp8_w8a16(a, w1, w2, w1_s, w2_s, tw, ids)
+    eng = _eng(w1.view(torch.uint8), w2.view(torch.uint8), top_k=topk, act_dtype=torch.bfloat16, fmt="fp8",
+               w13_scale=w1_s, w2_scale=w2_s, group_n=128, group_k=128)
+    pre = eng.prefill(a.to(DEV), tw.to(DEV), ids.to(DEV)).cpu()
+    torch.testing.assert_close(pre, want, atol=1e-2, rtol=1e-2)
+    dec = eng.decode(a.to(DEV), tw.to(DEV), ids.to(DEV)).to(torch.bfloat16).cpu()
+    torch.testing.assert_close(dec, want, atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("M", [1, 32, 121])
+@pytest.mark.parametrize("N,K,E,topk", [(128, 128, 4, 2), (256, 256, 8, 4), (352, 256, 8, 4), (512, 320, 8, 4)])
+def test_gpu_mxfp4_vs_reference_cpu_kernel(M, N, K, E, topk):
+    """MXFP4 experts (MOE_MXFP4) against the reference's CPU kernel (same entry point, MXFP4); shapes, input recipe
+    and tolerance (atol = rtol = 1e-2) of tests/kernels/moe/test_cpu_quant_fused_moe.py:386-441."""
+    ref = _ref_or_skip()
+    from tests.test_oracle_ref import mxfp4_case
+    a, q1, q2, s1, s2, tw, ids = mxfp4_case(M, N, K, E, topk)
+    want = ref.fused_experts_mxfp4(a, q1, q2, s1, s2, tw, ids)
+    eng = _eng(q1, q2, top_k=topk, act_dtype=torch.bfloat16, fmt="mxfp4", w13_scale=s1, w2_scale=s2,
+               group_n=1, group_k=32)
+    pre = eng.prefill(a.to(DEV), tw.to(DEV), ids.to(DEV)).cpu()
+    torch.testing.assert_close(pre, want, atol=1e-2, rtol=1e-2)
+    dec = eng.decode(a.to(DEV), tw.to(DEV), ids.to(DEV)).to(torch.bfloat16).cpu()
+    torch.testing.assert_close(dec, want, atol=1e-2, rtol=1e-2)

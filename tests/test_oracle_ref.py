@@ -81,3 +81,81 @@ def test_reference_kernel_is_deterministic_and_thread_count_independent():
     b = ref.fused_moe(x, p13, p2, tw, ids)
     ref.set_threads(n0)
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ quantised experts (sgl-kernels CPU MoE)
+def fp8_case(M, N, K, E, topk, seed=0):
+    """tests/kernels/moe/test_cpu_quant_fused_moe.py:117-181: fp8 weights ~ randn * 448, block scales ~ randn * 1e-3
+    (either sign), activations ~ randn / sqrt(K), softmax + torch.topk routing."""
+    torch.manual_seed(seed)
+    a = torch.randn(M, K, dtype=torch.bfloat16) / K ** 0.5
+    w1 = (torch.randn(E, 2 * N, K) * 448.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    w2 = (torch.randn(E, K, N) * 448.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    w1_s = torch.randn(E, -(-2 * N // 128), -(-K // 128)) * 1e-3
+    w2_s = torch.randn(E, -(-K // 128), -(-N // 128)) * 1e-3
+    score = torch.softmax(torch.randn(M, E, dtype=torch.bfloat16), dim=-1, dtype=torch.float32)
+    tw, ids = torch.topk(score, topk)
+    return a, w1, w2, w1_s, w2_s, tw, ids.to(torch.int32)
+
+
+FP8_CONFIGS = [(256, 512, 8, 2), (512, 256, 8, 4), (512, 512, 8, 4), (768, 2048, 8, 2), (768, 2048, 128, 8)]
+
+
+@pytest.mark.parametrize("M", [1, 2, 64, 121])
+@pytest.mark.parametrize("N,K,E,topk", FP8_CONFIGS)
+def test_oracle_matches_reference_fp8_w8a16_cpu_kernel(M, N, K, E, topk):
+    """fp8 W8A16 with 128x128 block scales (the lk_moe MOE_FP8 semantics, routed_experts.py:1627-1668) against the
+    reference's CPU kernel for exactly that scheme; shapes and tolerance (atol = rtol = 1e-2) of
+    test_cpu_quant_fused_moe.py:150-201."""
+    a, w1, w2, w1_s, w2_s, tw, ids = fp8_case(M, N, K, E, topk)
+    got = ref.fused_experts_fp8_w8a16(a, w1, w2, w1_s, w2_s, tw, ids)
+    d = orc.MoeDesc(E=E, H=K, I=N, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128)
+    want = orc.moe(d, torch_to_bits(w1), torch_to_bits(w2), torch_to_bits(a), ids.numpy(), tw.numpy(),
+                   s13=w1_s.numpy(), s2=w2_s.numpy())
+    torch.testing.assert_close(torch.from_numpy(want).bfloat16(), got, atol=1e-2, rtol=1e-2)
+
+
+def mxfp4_quantize(w: torch.Tensor):
+    """OCP MXFP4 of a [.., K] tensor in blocks of 32 along K: shared E8M0 exponent ceil(log2(amax / 6)), E2M1 codes
+    by round-to-nearest on the magnitude grid {0, .5, 1, 1.5, 2, 3, 4, 6}, two codes per byte (even element in the
+    low nibble) -- the recipe of test_cpu_quant_fused_moe.py:226-262 (MXFP4QuantizeUtil.quantize)."""
+    shp = w.shape
+    blk = w.float().reshape(-1, 32)
+    amax = blk.abs().amax(dim=1, keepdim=True)
+    e = torch.ceil(torch.maximum(torch.log2(amax / 6.0), torch.tensor(-127.0)))
+    y = blk / torch.exp2(e)
+    bounds = torch.tensor([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0])
+    code = (y.abs().unsqueeze(-1) > bounds).sum(dim=-1).to(torch.uint8)
+    code = code | ((y < 0).to(torch.uint8) << 3)
+    code = code.reshape(shp)
+    packed = code[..., 0::2] | (code[..., 1::2] << 4)
+    scale = (e + 127).to(torch.uint8).reshape(*shp[:-1], shp[-1] // 32)
+    return packed.contiguous(), scale.contiguous()
+
+
+def mxfp4_case(M, N, K, E, topk, seed=0):
+    """test_cpu_quant_fused_moe.py:398-420: activations and master weights ~ randn / 10."""
+    torch.manual_seed(seed)
+    a = torch.randn(M, K, dtype=torch.bfloat16) / 10
+    q1, s1 = mxfp4_quantize(torch.randn(E, 2 * N, K, dtype=torch.bfloat16) / 10)
+    q2, s2 = mxfp4_quantize(torch.randn(E, K, N, dtype=torch.bfloat16) / 10)
+    score = torch.softmax(torch.randn(M, E, dtype=torch.bfloat16), dim=-1, dtype=torch.float32)
+    tw, ids = torch.topk(score, topk)
+    return a, q1, q2, s1, s2, tw, ids.to(torch.int32)
+
+
+MXFP4_CONFIGS = [(128, 128, 4, 2), (256, 256, 8, 4), (352, 256, 8, 4), (512, 320, 8, 4)]
+
+
+@pytest.mark.parametrize("M", [1, 2, 32, 121])
+@pytest.mark.parametrize("N,K,E,topk", MXFP4_CONFIGS)
+def test_oracle_matches_reference_mxfp4_cpu_kernel(M, N, K, E, topk):
+    """MXFP4 experts (lk_moe MOE_MXFP4, routed_experts.py:1770-1813) against the reference's CPU kernel; shapes and
+    tolerance (atol = rtol = 1e-2) of test_cpu_quant_fused_moe.py:386-441."""
+    a, q1, q2, s1, s2, tw, ids = mxfp4_case(M, N, K, E, topk)
+    got = ref.fused_experts_mxfp4(a, q1, q2, s1, s2, tw, ids)
+    d = orc.MoeDesc(E=E, H=K, I=N, act_dtype=orc.BF16, wfmt=orc.W_MXFP4, groupN=1, groupK=32)
+    want = orc.moe(d, q1.numpy(), q2.numpy(), torch_to_bits(a), ids.numpy(), tw.numpy(), s13=s1.numpy(), s2=s2.numpy())
+    torch.testing.assert_close(torch.from_numpy(want).bfloat16(), got, atol=1e-2, rtol=1e-2)
+    # our own tighter statement: both decode E2M1 x E8M0 exactly, so only summation order and the bf16 output differ
+    torch.testing.assert_close(torch.from_numpy(want), got.float(), atol=2e-3 * max(1.0, float(np.abs(want).max())), rtol=1e-2)

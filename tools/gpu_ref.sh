@@ -1,8 +1,12 @@
 #!/bin/bash
-# oracle/_ref on the GPU box: smoke (incl. the reference CPU kernel), the full GPU suite, the bench line with
-# cpu_baseline.kind = "reference"
+# oracle/_ref on the GPU box: smoke (incl. the reference CPU kernel), the GPU suite with durations, the bench line
+# with cpu_baseline.kind = "reference".  `bash tools/gpu_ref.sh quick` runs only the *_vs_reference_cpu_kernel tests.
 set -u
 mkdir -p gpurun_out
+if [ "${1:-}" = quick ]; then
+  timeout 600 python -m pytest tests -m gpu -q --timeout 300 -k "reference_cpu_kernel" 2>&1 | tail -25
+  exit 0
+fi
 echo "== host"; nproc; lscpu | grep -E "Model name|Socket|NUMA node\(s\)" | head -3
 echo "== smoke"; timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
 echo "== pytest gpu (durations)"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 --durations=8 2>&1 | tail -14

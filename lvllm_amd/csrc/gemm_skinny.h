@@ -76,9 +76,11 @@ struct Dec<LKM_W_INT4_B8, ADT> {
     static __device__ __forceinline__ void load_aux_at(Aux& a, const char* p) {
         a.raw = *(const u32x2_unaligned*)p;
     }
-    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux& a, int ks,
-                                                 int spu) {
-        const unsigned w = raw[0][ks];
+    // the two multipliers of a (row, scale group): {512 s, 512 s} and {-8 s, -8 s}
+    struct Mult {
+        f32x2 s512, m8;
+    };
+    static __device__ __forceinline__ Mult mult(const Aux& a, int ks, int spu) {
         const int idx = (ks * spu) >> 2;   // 0 for g>=128, ks/2 for g=64, ks for g=32 (wave-uniform)
         // scale `idx` of the 8 fetched bytes -> f32 with one v_perm_b32 (bf16: the half-word moved to
         // the upper half IS the float; f16: to the lower half, then v_cvt_f32_f16)
@@ -88,33 +90,43 @@ struct Dec<LKM_W_INT4_B8, ADT> {
         } else {
             s = ActT<ADT>::to_f32((unsigned short)__builtin_amdgcn_perm(a.raw.y, a.raw.x, 0x0c0c0100u + idx * 0x0202u));
         }
-        // A byte 0000vvvv read as OCP e4m3 is v * 2^-9 for EVERY v in 0..15 (subnormals and the first
-        // binade are equally spaced), so v_cvt_pk_f32_fp8 turns two masked nibbles into two floats in
-        // one instruction; fma(v * 2^-9, 512 s, -8 s) = (v - 8) s exactly (<= 15 significant bits),
-        // two at a time on v_pk_fma_f32, then one RNE to the act dtype: 15 VALU per 8 weights (+4 for
-        // the scale), where v_cvt_f32_ubyte + scalar fma took 23 (+5) and per-nibble v_bfe_u32 31.
-        // Same bits as the reference's T((q-8)*s).
-        //
         // The multiplier and the addend are two full pairs {512 s, 512 s} and {-8 s, -8 s} behind empty
         // asm statements: folded into ONE pair {512 s, -8 s} read through two op_sel swizzles (what the
         // compiler does by itself) the decode is wrong now and then -- see splat2_opaque, lkm_common.h.
         f32x2 sv = {s, s};
         asm("" : "+v"(sv));
-        f32x2 s512 = sv * f32x2{512.0f, 512.0f}, m8 = sv * f32x2{-8.0f, -8.0f};
-        asm("" : "+v"(s512));
-        asm("" : "+v"(m8));
+        Mult m;
+        m.s512 = sv * f32x2{512.0f, 512.0f};
+        m.m8 = sv * f32x2{-8.0f, -8.0f};
+        asm("" : "+v"(m.s512));
+        asm("" : "+v"(m.m8));
+        return m;
+    }
+    // A byte 0000vvvv read as OCP e4m3 is v * 2^-9 for EVERY v in 0..15 (subnormals and the first
+    // binade are equally spaced), so v_cvt_pk_f32_fp8 turns two masked nibbles into two floats in
+    // one instruction; fma(v * 2^-9, 512 s, -8 s) = (v - 8) s exactly (<= 15 significant bits),
+    // two at a time on v_pk_fma_f32, then one RNE to the act dtype: 15 VALU per 8 weights (+4 for
+    // the scale, which the tiled kernels pay once per 128-k unit when the group is >= 128), where
+    // v_cvt_f32_ubyte + scalar fma took 23 (+5) and per-nibble v_bfe_u32 31.
+    // Same bits as the reference's T((q-8)*s).
+    static __device__ __forceinline__ u32x4 frag_m(const u32x4 (&raw)[LOADS], int ks, const Mult& m) {
+        const unsigned w = raw[0][ks];
         const unsigned lo = w & 0x0f0f0f0fu, hi = (w >> 4) & 0x0f0f0f0fu;
         // byte b of the dword holds k=2b (low nibble) and k=2b+1 (high nibble)
-        const f32x2 e01 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(lo, false), s512, m8);  // k = 0, 2
-        const f32x2 e23 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(lo, true), s512, m8);   // k = 4, 6
-        const f32x2 o01 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(hi, false), s512, m8);  // k = 1, 3
-        const f32x2 o23 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(hi, true), s512, m8);   // k = 5, 7
+        const f32x2 e01 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(lo, false), m.s512, m.m8);  // k = 0, 2
+        const f32x2 e23 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(lo, true), m.s512, m.m8);   // k = 4, 6
+        const f32x2 o01 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(hi, false), m.s512, m.m8);  // k = 1, 3
+        const f32x2 o23 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8(hi, true), m.s512, m.m8);   // k = 5, 7
         u32x4 o;
         o.x = ActT<ADT>::pack2(e01.x, o01.x);
         o.y = ActT<ADT>::pack2(e01.y, o01.y);
         o.z = ActT<ADT>::pack2(e23.x, o23.x);
         o.w = ActT<ADT>::pack2(e23.y, o23.y);
         return o;
+    }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux& a, int ks,
+                                                 int spu) {
+        return frag_m(raw, ks, mult(a, ks, spu));
     }
 };
 

@@ -167,8 +167,12 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
     // multiplies only those blocks.  The choice is workgroup-uniform and made once, so every variant
     // keeps a branch-free steady loop (a runtime "skip empty blocks" test inside the loop measured
     // slower, see above).  Staging piece q of a thread covers rows [q*RPP, (q+1)*RPP).
-    auto run = [&](auto NBC) __attribute__((always_inline)) {
+    auto run_h = [&](auto NBC, auto HC) __attribute__((always_inline)) {
         constexpr int NB = decltype(NBC)::v;
+        // int4 with one scale group per 128-k unit (g >= 128: the usual AWQ / GPTQ checkpoints): the two scale
+        // multipliers of a weight row are formed once per unit instead of once per k-step (3 of 19 VALU per
+        // fragment; the kernel is VALU-bound: 10 VALU per MFMA at 32 rows per expert).  Workgroup-uniform.
+        constexpr bool HOIST = decltype(HC)::v != 0;
         constexpr int PCS = NB * 16 * SLOTS / THREADS;
         static_assert(PCS >= 1 && PCS <= PIECES && (NB * 16 * SLOTS) % THREADS == 0, "block granularity");
         struct WStage {
@@ -287,8 +291,17 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
                 // ks+1 while the MFMAs of k-step ks occupy the matrix pipe (one MFMA : DEC_PER VALU)
                 static_assert(TBW <= 8, "int4 tiles: 64 or 128 rows");
                 u32x4 a[2][NTT];
+                typename D::Mult mu[NTT];
+                auto dec = [&](int t, int ks) __attribute__((always_inline)) {
+                    if constexpr (HOIST) return D::frag_m(s.w[t], ks, mu[t]);
+                    else return D::frag(s.w[t], s.aux[t], ks, dparam);
+                };
+                if constexpr (HOIST) {
     #pragma unroll
-                for (int t = 0; t < NTT; ++t) a[0][t] = D::frag(s.w[t], s.aux[t], 0, dparam);
+                    for (int t = 0; t < NTT; ++t) mu[t] = D::mult(s.aux[t], 0, 0);
+                }
+    #pragma unroll
+                for (int t = 0; t < NTT; ++t) a[0][t] = dec(t, 0);
     #pragma unroll
                 for (int ks = 0; ks < D::KSTEPS; ++ks) {
                     u32x4 bf[NB];
@@ -299,14 +312,14 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
                     }
                     if (ks + 1 < D::KSTEPS) {
     #pragma unroll
-                        for (int t = 0; t < NTT; ++t) a[(ks + 1) & 1][t] = D::frag(s.w[t], s.aux[t], ks + 1, dparam);
+                        for (int t = 0; t < NTT; ++t) a[(ks + 1) & 1][t] = dec(t, ks + 1);
                     }
     #pragma unroll
                     for (int t = 0; t < NTT; ++t)
     #pragma unroll
                         for (int b = 0; b < NB; ++b) acc[t][b] = ActT<ADT>::mfma(a[ks & 1][t], bf[b], acc[t][b]);
                     if (ks + 1 < D::KSTEPS) {
-                                                constexpr int DEC_PER = (19 * NTT + NTT * NB - 1) / (NTT * NB);
+                                                constexpr int DEC_PER = ((HOIST ? 16 : 19) * NTT + NTT * NB - 1) / (NTT * NB);
     #pragma unroll
                         for (int i = 0; i < NTT * NB; ++i) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
@@ -386,6 +399,12 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
             });
         }
 
+    };
+    auto run = [&](auto NBC) __attribute__((always_inline)) {
+        if constexpr (WF == LKM_W_INT4_B8) {
+            if (p.spu <= 1) return run_h(NBC, IC<1>{});
+        }
+        run_h(NBC, IC<0>{});
     };
     {
         constexpr int GRAN = THREADS / (16 * SLOTS) > 1 ? THREADS / (16 * SLOTS) : 1;   // blocks per staging piece

@@ -560,7 +560,12 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         if (tiled == 128 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && wg8 < 512) waves = 4;
         if (h->t_waves > 0) waves = h->t_waves;
         const int nt1 = (h->t_nt1 > 0 && !split) ? h->t_nt1 : 1;
-        const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : ((tiled == 256 || (tiled == 128 && h->a8)) ? 2 : 1);   // GLM bf16: 3.61 vs 3.81 ms; fp8-W8A8 GEMM2 1343 -> 1141 us
+        // two weight tiles per wave in GEMM2: 256-row tiles (GLM bf16: 3.61 vs 3.81 ms), fp8-W8A8 128-row tiles
+        // (GEMM2 1343 -> 1141 us) and the 4-bit formats at 64-row tiles (half the token-fragment LDS reads per
+        // weight byte; Mixtral M=128 GEMM2 int4 95 -> 92 us, NVFP4 85.6 -> 80.4, MXFP4 74.2 -> 67.5:
+        // profiles/r01_int4_hoist_nt2.log)
+        const bool w4_64 = wf_is_4bit(h->wf) && tiled == 64 && !split;
+        const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : ((tiled == 256 || (tiled == 128 && h->a8) || w4_64) ? 2 : 1);
         // weight/token register ring depth (64-row tiles; the larger tiles have no registers to spare).
         // Measured at M=128 (profiles/r01_prefetch_depth.log): bf16 4/4 (473 vs 525 us at 2/2); the
         // formats that decode in registers keep GEMM1 at 2 (occupancy): int4 2/4 260 us vs 4/4 291 us,
@@ -573,6 +578,9 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // fp8 with a short K loop (DSv3: I = 2048 = 16 units): four resident waves beat the deeper ring,
             // GEMM2 W8A16 91.3 -> 83.9 us, W8A8 90.8 -> 88.4
             if (h->wf == LKM_W_FP8_E4M3 && h->U2 <= 32) pd2 = 2;
+            // int4 / NVFP4 with two GEMM2 tiles per wave: the decoders are VALU-heavy, the resident wave is worth
+            // more than the deeper ring (int4 GEMM2 92 -> 84.5 us, NVFP4 80.4 -> 78.6; MXFP4 LOSES: 67.5 -> 72.7)
+            if (w4_64 && h->wf != LKM_W_MXFP4) pd2 = 2;
         }
         if (tiled == 128 && waves == 4) pd1 = pd2 = 4;   // EP=8 Mixtral rank: 154 vs 229 us at 2/2
         const int pf = (tiled == 256 && h->t_pf > 0) ? h->t_pf : 0;

@@ -564,7 +564,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // (GEMM2 1343 -> 1141 us) and the 4-bit formats at 64-row tiles (half the token-fragment LDS reads per
         // weight byte; Mixtral M=128 GEMM2 int4 95 -> 92 us, NVFP4 85.6 -> 80.4, MXFP4 74.2 -> 67.5:
         // profiles/r01_int4_hoist_nt2.log)
-        const bool w4_64 = wf_is_4bit(h->wf) && tiled == 64 && !split;
+        const bool w4_64 = wf_is_4bit(h->wf) && tiled == 64 && waves == 4 && !split;   // (the 8-wave variant exists with one tile only)
         const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : ((tiled == 256 || (tiled == 128 && h->a8) || w4_64) ? 2 : 1);
         // weight/token register ring depth (64-row tiles; the larger tiles have no registers to spare).
         // Measured at M=128 (profiles/r01_prefetch_depth.log): bf16 4/4 (473 vs 525 us at 2/2); the

@@ -125,3 +125,26 @@ def fused_experts_mxfp4(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, w1
     return torch.ops.lkm_ref.fused_experts_cpu(x.clone(), pw13, pw2, topk_weights.float().contiguous(),
                                                topk_ids.int().contiguous(), False, MXFP4, ps13, ps2,
                                                None, None, None, None, None, None, None, True)
+
+
+GPTQ = 1    # csrc/cpu/sgl-kernels/gemm.h:102 -- enum class CPUQuantAlgo { AWQ = 0, GPTQ = 1 }
+
+
+def fused_experts_int4_gptq(x: torch.Tensor, w13_packed: torch.Tensor, w2_packed: torch.Tensor, w13_scale: torch.Tensor,
+                            w2_scale: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
+    """The reference's int4 CPU MoE on the CHECKPOINT layout LvLLM hands to lk_moe before its transposition
+    (routed_experts.py:1461-1479): w13_packed int32 [E, H/8, 2I] / w2_packed int32 [E, I/8, H], nibble j of a word
+    = input channel 8*row + j, value + 8 (uint4b8, i.e. zero point 8); scales act dtype [E, groups, out].
+    Weight preparation as vllm/model_executor/layers/fused_moe/experts/cpu_moe.py:347-405 (symmetric checkpoints get
+    the synthetic zero points 0x77777777: the unpack adds 1).  NB the kernel computes W4A8 -- it quantises the
+    activations to int8 per token -- so it pins the FORMAT (nibble order, zero point, group-scale layout), not the
+    last bits of a W4A16 result."""
+    load()
+    E = w13_packed.size(0)
+    z13 = torch.full((E, w13_scale.size(1), w13_scale.size(2) // 8), 0x77777777, dtype=torch.int32)
+    z2 = torch.full((E, w2_scale.size(1), w2_scale.size(2) // 8), 0x77777777, dtype=torch.int32)
+    bw13, bz13, bs13 = torch.ops.lkm_ref.convert_weight_packed_scale_zp(w13_packed.contiguous(), z13, w13_scale.contiguous(), GPTQ)
+    bw2, bz2, bs2 = torch.ops.lkm_ref.convert_weight_packed_scale_zp(w2_packed.contiguous(), z2, w2_scale.contiguous(), GPTQ)
+    return torch.ops.lkm_ref.fused_experts_cpu(x.clone(), bw13, bw2, topk_weights.float().contiguous(),
+                                               topk_ids.int().contiguous(), False, INT4_W4A8, bs13, bs2, bz13, bz2,
+                                               None, None, None, None, None, True)

@@ -752,3 +752,23 @@ def test_gpu_mxfp4_vs_reference_cpu_kernel(M, N, K, E, topk):
     torch.testing.assert_close(pre, want, atol=1e-2, rtol=1e-2)
     dec = eng.decode(a.to(DEV), tw.to(DEV), ids.to(DEV)).to(torch.bfloat16).cpu()
     torch.testing.assert_close(dec, want, atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("M", [1, 64, 121])
+@pytest.mark.parametrize("N,K,E,topk", [(256, 512, 8, 2), (512, 512, 8, 4), (768, 2048, 8, 2)])
+def test_gpu_int4_format_vs_reference_cpu_kernel(M, N, K, E, topk):
+    """int4 experts handed over exactly as RoutedExperts._process_wna16 does (checkpoint words transposed and viewed
+    as bytes, routed_experts.py:1461-1479) against the reference's CPU int4 MoE kernel fed the SAME checkpoint words
+    (oracle/_ref; shapes and recipe of tests/kernels/moe/test_cpu_quant_fused_moe.py:591-690).  That kernel computes
+    W4A8, so this pins the format -- nibble order, zero point 8, group-scale layout -- within its int8 activation
+    noise; the last bits of the W4A16 result are pinned by test_int4_golden_cases / test_int4_dequant_is_bit_exact_on_gpu."""
+    ref = _ref_or_skip()
+    from tests.test_oracle_ref import assert_close_to_w4a8_kernel, int4_case, lk_moe_int4_layout
+    a, p1, p2, s1, s2, tw, ids = int4_case(M, N, K, E, topk)
+    kern = ref.fused_experts_int4_gptq(a, p1, p2, s1, s2, tw, ids)
+    q13, sc13 = lk_moe_int4_layout(p1, s1)
+    q2, sc2 = lk_moe_int4_layout(p2, s2)
+    eng = _eng(q13, q2, top_k=topk, act_dtype=torch.bfloat16, fmt="int4", w13_scale=sc13, w2_scale=sc2,
+               group_n=1, group_k=128)
+    pre = eng.prefill(a.to(DEV), tw.to(DEV), ids.to(DEV)).cpu()
+    assert_close_to_w4a8_kernel(pre, kern)

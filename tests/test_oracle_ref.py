@@ -159,3 +159,74 @@ def test_oracle_matches_reference_mxfp4_cpu_kernel(M, N, K, E, topk):
     torch.testing.assert_close(torch.from_numpy(want).bfloat16(), got, atol=1e-2, rtol=1e-2)
     # our own tighter statement: both decode E2M1 x E8M0 exactly, so only summation order and the bf16 output differ
     torch.testing.assert_close(torch.from_numpy(want), got.float(), atol=2e-3 * max(1.0, float(np.abs(want).max())), rtol=1e-2)
+
+
+# ------------------------------------------------------------------ int4 (GPTQ / compressed-tensors packing)
+def int4_case(M, N, K, E, topk, g=128, seed=0):
+    """tests/kernels/moe/test_cpu_quant_fused_moe.py:591-614, 686-690: random nibbles, scales |randn * 0.01| + 0.001,
+    activations randn / (0.5 sqrt(K)); packed along the input dim into int32 words (nibble j = channel 8*row + j),
+    i.e. the checkpoint layout w13_packed [E, H/8, 2I] that LvLLM's _process_wna16 receives."""
+    torch.manual_seed(seed)
+    a = torch.randn(M, K, dtype=torch.bfloat16) / (0.5 * K ** 0.5)
+    w1 = torch.randint(0, 16, (E, K, 2 * N), dtype=torch.int32)
+    w2 = torch.randint(0, 16, (E, N, K), dtype=torch.int32)
+    s1 = (torch.randn(E, K // g, 2 * N, dtype=torch.bfloat16) * 0.01).abs() + 0.001
+    s2 = (torch.randn(E, N // g, K, dtype=torch.bfloat16) * 0.01).abs() + 0.001
+
+    def pack(w):
+        e, kin, nout = w.shape
+        v = w.view(e, kin // 8, 8, nout)
+        out = torch.zeros(e, kin // 8, nout, dtype=torch.int32)
+        for j in range(8):
+            out |= (v[:, :, j, :] & 0xF) << (4 * j)
+        return out
+
+    score = torch.softmax(torch.randn(M, E, dtype=torch.bfloat16), dim=-1, dtype=torch.float32)
+    tw, ids = torch.topk(score, topk)
+    return a, pack(w1), pack(w2), s1, s2, tw, ids.to(torch.int32)
+
+
+def lk_moe_int4_layout(packed: torch.Tensor, scale: torch.Tensor):
+    """what RoutedExperts._process_wna16 passes to lk_moe (routed_experts.py:1461-1479): packed.transpose(1, 2)
+    .contiguous().view(uint8) = [E, out, in/2] (low nibble = even input channel), scales [E, out, groups]."""
+    return packed.transpose(1, 2).contiguous().view(torch.uint8), scale.transpose(1, 2).contiguous()
+
+
+def assert_close_to_w4a8_kernel(got: torch.Tensor, kernel_out: torch.Tensor):
+    """The reference kernel quantises activations to int8 (W4A8); a W4A16 result differs from it by that noise.
+    Measured on these cases: max <= 3 %, mean <= 0.7 % of max|out| (worst at a single token).  A wrong nibble order,
+    zero point or scale layout gives O(100 %): test_int4_format_criterion_rejects_a_wrong_nibble_order."""
+    ref_max = float(kernel_out.float().abs().max())
+    diff = (got.float() - kernel_out.float()).abs()
+    assert float(diff.max()) <= 0.06 * ref_max, (float(diff.max()), ref_max)
+    assert float(diff.mean()) <= 0.015 * ref_max, (float(diff.mean()), ref_max)
+
+
+@pytest.mark.parametrize("M", [1, 64, 121])
+@pytest.mark.parametrize("N,K,E,topk", [(256, 512, 8, 2), (512, 256, 8, 2), (512, 512, 8, 4), (768, 2048, 8, 2)])
+def test_oracle_int4_format_matches_reference_cpu_kernel(M, N, K, E, topk):
+    a, p1, p2, s1, s2, tw, ids = int4_case(M, N, K, E, topk)
+    kern = ref.fused_experts_int4_gptq(a, p1, p2, s1, s2, tw, ids)
+    q13, sc13 = lk_moe_int4_layout(p1, s1)
+    q2, sc2 = lk_moe_int4_layout(p2, s2)
+    d = orc.MoeDesc(E=E, H=K, I=N, act_dtype=orc.BF16, wfmt=orc.W_INT4, groupN=1, groupK=128)
+    want = orc.moe(d, q13.numpy(), q2.numpy(), torch_to_bits(a), ids.numpy(), tw.numpy(),
+                   s13=torch_to_bits(sc13), s2=torch_to_bits(sc2))
+    assert_close_to_w4a8_kernel(torch.from_numpy(want), kern)
+
+
+def test_int4_format_criterion_rejects_a_wrong_nibble_order():
+    """negative control: the same weights with the two nibbles of every byte swapped (or the zero point off by one)
+    must be far outside the acceptance band used above."""
+    a, p1, p2, s1, s2, tw, ids = int4_case(64, 256, 512, 8, 2)
+    kern = ref.fused_experts_int4_gptq(a, p1, p2, s1, s2, tw, ids)
+    q13, sc13 = lk_moe_int4_layout(p1, s1)
+    q2, sc2 = lk_moe_int4_layout(p2, s2)
+    d = orc.MoeDesc(E=8, H=512, I=256, act_dtype=orc.BF16, wfmt=orc.W_INT4, groupN=1, groupK=128)
+    swap = lambda q: ((q >> 4) | (q << 4)).to(torch.uint8)
+    bad = orc.moe(d, swap(q13).numpy(), q2.numpy(), torch_to_bits(a), ids.numpy(), tw.numpy(),
+                  s13=torch_to_bits(sc13), s2=torch_to_bits(sc2))
+    with pytest.raises(AssertionError):
+        assert_close_to_w4a8_kernel(torch.from_numpy(bad), kern)
+    ref_max = float(kern.float().abs().max())
+    assert float((torch.from_numpy(bad) - kern.float()).abs().max()) > 0.3 * ref_max

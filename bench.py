@@ -427,6 +427,10 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if use_ep:
+        # rank 0 spent a few ms more (kernel profiling, the JSON line): tear the communicator down with every rank
+        # still alive and idle
+        dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -1,0 +1,251 @@
+"""The reference's in-tree expert-operator surface over the MI355X engine (secondary boundary).
+
+GPU-resident MoE layers of LvLLM do not go through `lk_moe`; they run a `FusedMoEExpertsModular`
+(vllm/model_executor/layers/fused_moe/modular_kernel.py:762-975) between a prepare/finalize pair.  `LkmExperts`
+has that class's method surface -- same names, argument order and meaning -- so that it can stand where
+`AiterExperts` (experts/rocm_aiter_moe.py:422-572, the reference's own ROCm implementation and the model for the
+choices below) stands today:
+
+  * activation format Standard; inputs arrive unquantised (`expects_unquantized_inputs`), the engine quantises
+    activations itself for fp8-W8A8;
+  * workspaces are managed inside the engine: `workspace_shapes` -> ((0,), (0,), (M, K))  (rocm_aiter_moe.py:501-516);
+  * routing weights are applied and the top-k slots reduced inside `apply`, so
+    `finalize_weight_and_reduce_impl()` is the no-op reducer (topk_weight_and_reduce.py:44-77);
+  * `expert_map` (global -> local id, -1 = not on this rank) is applied on the device
+    (routed_experts.py:1332-1342) -- the expert-parallel form of the same operator.
+
+vLLM is not importable next to this repository's tests (zmq, msgspec, ... are absent), so the class is
+duck-typed; `bind_vllm_base()` returns a real `mk.FusedMoEExpertsModular` subclass when vLLM is present.
+No CPU path: CPU tensors raise, a missing liblkm.so raises at import of `lvllm_amd.ops`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any
+
+import torch
+
+from . import _clib, ops
+
+# vllm/model_executor/layers/fused_moe/activation.py:16-35 (MoEActivation values) -> MOEConfigV2.activation_type
+# (routed_experts.py:160-164: 0 silu-gated, 1 swigluoai, 2 relu2 without gate)
+_ACTIVATIONS = {"silu": (0, True), "swigluoai": (1, True), "relu2_no_mul": (2, False)}
+
+
+def _act_name(activation: Any) -> str:
+    """MoEActivation member or its string value"""
+    return str(getattr(activation, "value", activation))
+
+
+@dataclass
+class LkmQuant:
+    """What the engine needs of a FusedMoEQuantConfig (fused_moe/config.py): the weight format, its scales and
+    group / block shape.  `from_vllm` reads the same facts off the reference's object."""
+    fmt: str = "bf16"                    # bf16 | fp16 | int4 | fp8 | mxfp4 | nvfp4
+    w1_scale: torch.Tensor | None = None
+    w2_scale: torch.Tensor | None = None
+    group_n: int = 0
+    group_k: int = 0
+    w1_global_scale: torch.Tensor | None = None
+    w2_global_scale: torch.Tensor | None = None
+    fp8_mode: int = _clib.FP8_W8A16      # FP8_W8A8: activations quantised 1x128 on the fly (in-tree block-fp8)
+
+    @staticmethod
+    def from_vllm(qc: Any, act_dtype: torch.dtype) -> "LkmQuant":
+        if qc is None or getattr(qc, "w1_scale", None) is None:
+            return LkmQuant(fmt="bf16" if act_dtype == torch.bfloat16 else "fp16")
+        block = getattr(qc, "block_shape", None)
+        if getattr(qc, "use_fp8_w8a8", False) or getattr(qc, "use_fp8_w8a16", False):
+            if not block or list(block) != [128, 128]:
+                raise ValueError(f"fp8 experts: only 128x128 block scales are supported, got {block}")
+            return LkmQuant("fp8", qc.w1_scale, qc.w2_scale, 128, 128,
+                            fp8_mode=_clib.FP8_W8A8 if getattr(qc, "use_fp8_w8a8", False) else _clib.FP8_W8A16)
+        if getattr(qc, "use_int4_w4a16", False):
+            return LkmQuant("int4", qc.w1_scale, qc.w2_scale, 1, int(block[1]) if block else 128)
+        if getattr(qc, "use_mxfp4_w4a16", False):
+            return LkmQuant("mxfp4", qc.w1_scale, qc.w2_scale, 1, 32)
+        raise ValueError("quantisation scheme of this FusedMoEQuantConfig is not supported by the MI355X engine")
+
+
+class _NoOpReduce:
+    """`TopKWeightAndReduceNoOP` (topk_weight_and_reduce.py:44-77): apply() already weighted and reduced."""
+
+    def __eq__(self, other):
+        return type(other).__name__ in ("_NoOpReduce", "TopKWeightAndReduceNoOP")
+
+    def apply(self, output, fused_expert_output, topk_weights, topk_ids, apply_router_weight_on_input):
+        if output is None or output is fused_expert_output:
+            return fused_expert_output
+        assert output.size() == fused_expert_output.size(), (output.size(), fused_expert_output.size())
+        output.copy_(fused_expert_output, non_blocking=True)
+        return output
+
+
+class LkmExperts:
+    """`FusedMoEExpertsModular`-shaped operator; one instance per MoE layer (it owns that layer's pre-shuffled
+    weights in HBM, created from w1 / w2 on the first `apply`, like the engine behind `lk_moe.MOE_*`)."""
+
+    def __init__(self, moe_config: Any = None, quant_config: Any = None, *, quant: LkmQuant | None = None,
+                 max_num_tokens: int = 8192, max_num_seqs: int = 256):
+        self.moe_config, self.quant_config = moe_config, quant_config
+        self._quant = quant
+        self._max_num_tokens, self._max_num_seqs = max_num_tokens, max_num_seqs
+        self._engine: ops.RoutedExpertsEngine | None = None
+        self._engine_key: tuple | None = None
+
+    # ------------------------------------------------------------------ class-level facts (modular_kernel.py:508-664)
+    @staticmethod
+    def is_monolithic() -> bool:
+        return False
+
+    @staticmethod
+    def activation_format():
+        try:
+            from vllm.model_executor.layers.fused_moe import modular_kernel as mk
+            return mk.FusedMoEActivationFormat.Standard
+        except Exception:
+            return "standard"
+
+    @property
+    def expects_unquantized_inputs(self) -> bool:
+        return True
+
+    @staticmethod
+    def _supports_current_device() -> bool:
+        try:
+            n, arch = _clib.device_info()
+        except Exception:
+            return False
+        return n >= 1 and arch.startswith("gfx950")
+
+    @staticmethod
+    def _supports_no_act_and_mul() -> bool:
+        return True                       # relu2_no_mul (non-gated experts)
+
+    @staticmethod
+    def _supports_activation(activation: Any) -> bool:
+        return _act_name(activation) in _ACTIVATIONS
+
+    @staticmethod
+    def _supports_quant_scheme(weight_key: Any, activation_key: Any) -> bool:
+        """keys are the reference's QuantKey objects (quant_utils.py) or None; matched by name so that this module
+        imports without vLLM"""
+        w = "none" if weight_key is None else str(weight_key).lower()
+        a = "none" if activation_key is None else str(activation_key).lower()
+        if w == "none":
+            return a == "none"
+        if "fp8" in w and "128" in w:                       # kFp8Static128BlockSym x (None | kFp8Dynamic128Sym)
+            return a == "none" or ("fp8" in a and "128" in a)
+        if "mxfp4" in w or "nvfp4" in w or "int4" in w or "uint4" in w:
+            return a == "none"                              # W4A16
+        return False
+
+    @staticmethod
+    def _supports_parallel_config(moe_parallel_config: Any) -> bool:
+        return True                       # TP splits the intermediate size, EP arrives as expert_map
+
+    @staticmethod
+    def _supports_batch_invariance() -> bool:
+        return True                       # fixed-order reductions throughout
+
+    # ------------------------------------------------------------------ shapes (modular_kernel.py:772-870)
+    def moe_problem_size(self, a1: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, topk_ids: torch.Tensor):
+        assert w1.dim() == 3 and w2.dim() == 3
+        E, N, _ = w1.shape
+        K = a1.size(-1)
+        assert a1.dim() == 2 and topk_ids.size(0) == a1.size(0), f"{topk_ids.size(0)} != {a1.size(0)}"
+        assert topk_ids.dim() == 2
+        return E, a1.size(0), N, K, topk_ids.size(1)
+
+    def workspace_dtype(self, act_dtype: torch.dtype) -> torch.dtype:
+        return act_dtype
+
+    def workspace_shapes(self, M: int, N: int, K: int, topk: int, global_num_experts: int, local_num_experts: int,
+                         expert_tokens_meta: Any, activation: Any):
+        # scratch lives in the engine's per-device arena
+        return (0,), (0,), (M, K)
+
+    @staticmethod
+    def adjust_N_for_activation(N: int, activation: Any) -> int:
+        name = _act_name(activation)
+        gated = _ACTIVATIONS[name][1] if name in _ACTIVATIONS else not name.endswith("_no_mul")
+        return N // 2 if gated else N
+
+    def finalize_weight_and_reduce_impl(self):
+        try:
+            from vllm.model_executor.layers.fused_moe.topk_weight_and_reduce import TopKWeightAndReduceNoOP
+            return TopKWeightAndReduceNoOP()
+        except Exception:
+            return _NoOpReduce()
+
+    # ------------------------------------------------------------------ the operator (modular_kernel.py:922-975)
+    def _engine_for(self, w1: torch.Tensor, w2: torch.Tensor, topk: int, act_dtype: torch.dtype, activation: Any):
+        name = _act_name(activation)
+        if name not in _ACTIVATIONS:
+            raise ValueError(f"activation {name!r} is not supported by the MI355X expert engine "
+                             f"(supported: {sorted(_ACTIVATIONS)})")
+        key = (w1.data_ptr(), w2.data_ptr(), tuple(w1.shape), tuple(w2.shape), topk, act_dtype, name)
+        if self._engine is None or self._engine_key != key:
+            q = self._quant or LkmQuant.from_vllm(self.quant_config, act_dtype)
+            act_type, gated = _ACTIVATIONS[name]
+            fmt = q.fmt if q.fmt not in ("bf16", "fp16") else ("bf16" if act_dtype == torch.bfloat16 else "fp16")
+            w1u = w1.view(torch.uint8) if w1.dtype == torch.float8_e4m3fn else w1
+            w2u = w2.view(torch.uint8) if w2.dtype == torch.float8_e4m3fn else w2
+            self._engine = ops.RoutedExpertsEngine(
+                w1u, w2u, top_k=topk, act_dtype=act_dtype, fmt=fmt, w13_scale=q.w1_scale, w2_scale=q.w2_scale,
+                group_n=q.group_n, group_k=q.group_k, has_gate_proj=gated, activation_type=act_type,
+                max_num_seqs=self._max_num_seqs, max_batch_size=self._max_num_tokens, fp8_mode=q.fp8_mode,
+                w13_global_scale=q.w1_global_scale, w2_global_scale=q.w2_global_scale)
+            self._engine_key = key
+        return self._engine
+
+    def apply(self, output: torch.Tensor, hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor,
+              topk_weights: torch.Tensor, topk_ids: torch.Tensor, activation: Any, global_num_experts: int,
+              expert_map: torch.Tensor | None, a1q_scale: torch.Tensor | None, a2_scale: torch.Tensor | None,
+              workspace13: torch.Tensor | None, workspace2: torch.Tensor | None, expert_tokens_meta: Any,
+              apply_router_weight_on_input: bool) -> None:
+        """output [M, K] <- sum_k w[m,k] * W2[e] act(W13[e] x_m), weighted and reduced (fp32 output: the
+        `cpu_decode` arithmetic; activation-dtype output: `gpu_prefill`)."""
+        if not hidden_states.is_cuda:
+            raise RuntimeError("LkmExperts.apply needs tensors on an MI355X (no CPU path)")
+        if a1q_scale is not None:
+            raise ValueError("LkmExperts expects unquantised activations (expects_unquantized_inputs); "
+                             "got a1q_scale")
+        if hidden_states.dim() != 2 or output.shape != hidden_states.shape:
+            raise ValueError(f"standard activation format: hidden [M, K] and output [M, K], got "
+                             f"{tuple(hidden_states.shape)} / {tuple(output.shape)}")
+        M, topk = topk_ids.shape
+        if apply_router_weight_on_input:
+            # the caller already multiplied the inputs by the routing weight (only defined for top-1,
+            # fused_moe.py:1700-1704)
+            if topk != 1:
+                raise ValueError("apply_router_weight_on_input is only supported for topk=1")
+            topk_weights = torch.ones_like(topk_weights, dtype=torch.float32)
+        eng = self._engine_for(w1, w2, topk, hidden_states.dtype, activation)
+        ids = topk_ids if topk_ids.dtype == torch.int32 else topk_ids.to(torch.int32)
+        if expert_map is not None:
+            ids = ops.global_to_local_expert_ids(ids.contiguous(), expert_map.to(device=ids.device, dtype=torch.int32))
+        tw = topk_weights.to(torch.float32).contiguous()
+        x = hidden_states.contiguous()
+        if M == 0:
+            return
+        if output.dtype == torch.float32 and output.is_contiguous():
+            eng.decode(x, tw, ids.contiguous(), out=output)
+        elif output.dtype == torch.float32:
+            output.copy_(eng.decode(x, tw, ids.contiguous()))
+        else:
+            output.copy_(eng.prefill(x, tw, ids.contiguous()))
+
+
+def bind_vllm_base():
+    """`class LkmExpertsModular(LkmExperts, mk.FusedMoEExpertsModular)` for registration inside LvLLM
+    (e.g. through the kernel-selection table of the fused-MoE layer, or @PluggableLayer.register_oot around RoutedExperts, custom_op.py:47-101).
+    Raises ImportError where vLLM is not importable."""
+    from vllm.model_executor.layers.fused_moe import modular_kernel as mk
+
+    class LkmExpertsModular(LkmExperts, mk.FusedMoEExpertsModular):  # type: ignore[misc]
+        def __init__(self, moe_config, quant_config, max_num_tokens=None, num_dispatchers=None, **kw):
+            mk.FusedMoEExpertsModular.__init__(self, moe_config, quant_config, max_num_tokens, num_dispatchers)
+            LkmExperts.__init__(self, moe_config, quant_config, max_num_tokens=max_num_tokens or 8192, **kw)
+
+    return LkmExpertsModular

@@ -772,3 +772,71 @@ def test_gpu_int4_format_vs_reference_cpu_kernel(M, N, K, E, topk):
                group_n=1, group_k=128)
     pre = eng.prefill(a.to(DEV), tw.to(DEV), ids.to(DEV)).cpu()
     assert_close_to_w4a8_kernel(pre, kern)
+
+
+# ---------------------------------------------------------------- in-tree operator surface (lvllm_amd/modular.py)
+def test_modular_experts_apply_with_expert_map():
+    """`LkmExperts.apply` (FusedMoEExpertsModular surface) on one expert-parallel rank: global ids + expert_map,
+    weighted and reduced output (TopKWeightAndReduceNoOP), fp32 and activation-dtype outputs, vs the oracle."""
+    from lvllm_amd.modular import LkmExperts
+    from lvllm_amd.ops import determine_expert_map
+    M, E, K, H, I = 45, 8, 2, 256, 128
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=31)
+    for ep_rank in (0, 1):
+        n_loc, emap = determine_expert_map(2, ep_rank, E, "linear")
+        lo = ep_rank * n_loc
+        w13_l, w2_l = w13[lo:lo + n_loc].contiguous().to(DEV), w2[lo:lo + n_loc].contiguous().to(DEV)
+        ex = LkmExperts()
+        ws13, ws2, oshape = ex.workspace_shapes(M, 2 * I, H, K, E, n_loc, None, "silu")
+        assert oshape == (M, H) and ws13 == (0,) and ws2 == (0,)
+        lids = np.where((ids >= lo) & (ids < lo + n_loc), ids - lo, -1).astype(np.int32)
+        d = orc.MoeDesc(E=n_loc, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+        want = orc.moe(d, torch_to_bits(w13[lo:lo + n_loc]), torch_to_bits(w2[lo:lo + n_loc]), torch_to_bits(a), lids, tw)
+        for odt in (torch.float32, torch.bfloat16):
+            out = torch.full(oshape, float("nan"), dtype=odt, device=DEV)
+            ex.apply(out, a.to(DEV), w13_l, w2_l, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV), "silu",
+                     E, emap.to(DEV), None, None, None, None, None, False)
+            got = out.float().cpu().numpy()
+            tol = dict(atol=ATOL, rtol=RTOL) if odt == torch.float32 else dict(atol=1e-2, rtol=1.6e-2)
+            np.testing.assert_allclose(got, want, **tol)
+        red = ex.finalize_weight_and_reduce_impl()
+        assert red.apply(None, out, None, None, False) is out
+        with pytest.raises(ValueError):
+            ex.apply(out, a.to(DEV), w13_l, w2_l, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV), "gelu",
+                     E, emap.to(DEV), None, None, None, None, None, False)
+
+
+def test_modular_experts_top1_preweighted_and_fp8_quant_config():
+    from lvllm_amd import _clib
+    from lvllm_amd.modular import LkmExperts, LkmQuant
+    # top-1 with the routing weight already applied to the input (apply_router_weight_on_input)
+    M, E, K, H, I = 20, 4, 1, 256, 128
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=33)
+    a_w = (a.float() * torch.from_numpy(tw)).to(torch.bfloat16)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    want = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a_w), ids, np.ones_like(tw))
+    ex = LkmExperts()
+    out = torch.empty((M, H), dtype=torch.float32, device=DEV)
+    ex.apply(out, a_w.to(DEV), w13.to(DEV), w2.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV),
+             "silu", E, None, None, None, None, None, None, True)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=ATOL, rtol=RTOL)
+    # fp8 block-quantised experts described the way FusedMoEQuantConfig does (w1_scale, w2_scale, block_shape)
+    M, E, K, H, I = 40, 4, 2, 256, 256
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=34)
+    q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+    q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+
+    class QC:
+        w1_scale, w2_scale = torch.from_numpy(s13).to(DEV), torch.from_numpy(s2).to(DEV)
+        block_shape = [128, 128]
+        use_fp8_w8a16 = True
+    ex = LkmExperts(None, QC())
+    w1 = torch.from_numpy(q13).to(DEV).view(torch.float8_e4m3fn)
+    w2q = torch.from_numpy(q2).to(DEV).view(torch.float8_e4m3fn)
+    out = torch.empty((M, H), dtype=torch.float32, device=DEV)
+    ex.apply(out, a.to(DEV), w1, w2q, torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV), "silu", E, None,
+             None, None, None, None, None, False)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128)
+    want = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=ATOL, rtol=RTOL)
+    assert LkmQuant.from_vllm(QC(), torch.bfloat16).fp8_mode == _clib.FP8_W8A16

@@ -71,22 +71,32 @@ class ExpertParallelExperts:
         self.first_expert = [r * base + min(r, rem) for r in range(self.ep)]
 
     # -------------------------------------------------------------------------------- a2a, fixed
-    def _forward_a2a_fixed(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-        M, K = ids.shape
-        n = M * K
-        ep, dev = self.ep, hidden.device
-        send_x, send_ids, send_w = self.pack(hidden, tw, ids, self.E, ep)
+    def dispatch_fixed(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor):
+        """tokens -> owners: (rows [ep*M*K, H], local ids int32 [ep*M*K] (-1 = empty slot), weights fp32 [ep*M*K]).
+        Equal splits: no split-size exchange and no host sync."""
+        send_x, send_ids, send_w = self.pack(hidden, tw, ids, self.E, self.ep)
         recv_x = torch.empty_like(send_x)
         recv_ids = torch.empty_like(send_ids)
         recv_w = torch.empty_like(send_w)
-        dist.all_to_all_single(recv_x, send_x, group=self.group)        # equal splits: no host sync
+        dist.all_to_all_single(recv_x, send_x, group=self.group)
         dist.all_to_all_single(recv_ids, send_ids, group=self.group)
         dist.all_to_all_single(recv_w, send_w, group=self.group)
-        y = self.local_compute(recv_x.view(ep * n, self.H), recv_ids.view(ep * n, 1), recv_w.view(ep * n, 1))
-        y_back = torch.empty((ep, n, self.H), dtype=torch.float32, device=dev)
-        dist.all_to_all_single(y_back, y.view(ep, n, self.H), group=self.group)
+        n = ids.numel()
+        return recv_x.view(self.ep * n, self.H), recv_ids.view(self.ep * n), recv_w.view(self.ep * n)
+
+    def combine_fixed(self, y: torch.Tensor, M: int, K: int) -> torch.Tensor:
+        """owners -> tokens: y fp32 [ep*M*K, H] (weighted rows, zeros in empty slots) -> fp32 [M, H]"""
+        n = M * K
+        y_back = torch.empty((self.ep, n, self.H), dtype=torch.float32, device=y.device)
+        dist.all_to_all_single(y_back, y.view(self.ep, n, self.H).contiguous(), group=self.group)
         # every slot was computed by exactly one rank (rows of the others are zero): fixed-order fp32 sum
-        return y_back.view(ep, M, K, self.H).sum(dim=(0, 2))
+        return y_back.view(self.ep, M, K, self.H).sum(dim=(0, 2))
+
+    def _forward_a2a_fixed(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+        M, K = ids.shape
+        rows, lids, ws = self.dispatch_fixed(hidden, tw, ids)
+        y = self.local_compute(rows, lids.view(-1, 1), ws.view(-1, 1))
+        return self.combine_fixed(y, M, K)
 
     # -------------------------------------------------------------------------------- a2a, ragged
     def _forward_a2a(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:

@@ -237,6 +237,86 @@ class LkmExperts:
             output.copy_(eng.prefill(x, tw, ids.contiguous()))
 
 
+class LkmPrepareAndFinalize:
+    """`FusedMoEPrepareAndFinalizeModular`-shaped pair (modular_kernel.py:180-418) for expert parallelism over the
+    8 GPUs of one node: `prepare` is the fixed-capacity RCCL all-to-all of lvllm_amd/ep.py (tokens -> owning ranks,
+    no host sync), `finalize` the reverse all-to-all and the fixed-order fp32 sum.  Together with `LkmExperts`:
+
+        a1q, a1q_scale, meta, ids_d, w_d = pf.prepare(a1, topk_weights, topk_ids, E, expert_map, False, None, True)
+        experts.apply(fused, a1q, w1, w2, w_d, ids_d, activation, E, expert_map, None, None, None, None, None, False)
+        pf.finalize(output, fused, topk_weights, topk_ids, False, experts.finalize_weight_and_reduce_impl())
+
+    which is the call sequence of the reference's modular kernel (modular_kernel.py:1219-1420).  The dispatched ids
+    are GLOBAL ids (-1 = empty slot) because the experts apply `expert_map` themselves, as with the reference's
+    all-to-all backends (deepep_ht_prepare_finalize.py:196-215)."""
+
+    def __init__(self, num_experts: int, hidden_size: int, group=None, pack=None):
+        from .ep import ExpertParallelExperts
+        self._ep = ExpertParallelExperts(lambda *a: None, num_experts, hidden_size, group=group, mode="a2a", pack=pack)
+        self._shape: tuple[int, int] | None = None
+
+    # ---- facts (modular_kernel.py:201-246)
+    @property
+    def activation_format(self):
+        return LkmExperts.activation_format()
+
+    def topk_indices_dtype(self):
+        return torch.int32
+
+    def max_num_tokens_per_rank(self):
+        return None
+
+    def num_dispatchers(self) -> int:
+        return self._ep.ep
+
+    def output_is_reduced(self) -> bool:
+        return True                       # finalize returns the complete sum for this rank's tokens
+
+    def supports_async(self) -> bool:
+        return False
+
+    def post_init_setup(self, fused_experts) -> None:
+        pass
+
+    def on_commit(self) -> None:
+        pass
+
+    # ---- modular_kernel.py:264-299
+    def prepare(self, a1: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor, num_experts: int,
+                expert_map: torch.Tensor | None, apply_router_weight_on_input: bool, quant_config: Any,
+                defer_input_quant: bool = False):
+        if num_experts != self._ep.E:
+            raise ValueError(f"prepare: {num_experts} experts, constructed for {self._ep.E}")
+        if not defer_input_quant and quant_config is not None and getattr(quant_config, "quant_dtype", None) is not None:
+            raise ValueError("LkmPrepareAndFinalize dispatches unquantised rows (the experts quantise); "
+                             "call with defer_input_quant=True")
+        M, K = topk_ids.shape
+        tw = topk_weights.to(torch.float32)
+        if apply_router_weight_on_input:
+            if K != 1:
+                raise ValueError("apply_router_weight_on_input is only supported for topk=1")
+            a1 = (a1.to(torch.float32) * tw).to(a1.dtype)
+            tw = torch.ones_like(tw)
+        rows, lids, ws = self._ep.dispatch_fixed(a1.contiguous(), tw.contiguous(), topk_ids.to(torch.int32).contiguous())
+        first = self._ep.first_expert[self._ep.rank]
+        gids = torch.where(lids >= 0, lids + first, lids)             # back to global ids; -1 stays -1
+        self._shape = (M, K)
+        return rows, None, None, gids.view(-1, 1), ws.view(-1, 1)
+
+    # ---- modular_kernel.py:354-376
+    def finalize(self, output: torch.Tensor, fused_expert_output: torch.Tensor, topk_weights: torch.Tensor,
+                 topk_ids: torch.Tensor, apply_router_weight_on_input: bool, weight_and_reduce_impl: Any) -> None:
+        if weight_and_reduce_impl is not None and type(weight_and_reduce_impl).__name__ not in (
+                "_NoOpReduce", "TopKWeightAndReduceNoOP", "TopKWeightAndReduceDelegate"):
+            raise ValueError("LkmPrepareAndFinalize.finalize expects rows that are already weighted "
+                             "(TopKWeightAndReduceNoOP), as LkmExperts produces them")
+        M, K = topk_ids.shape
+        if self._shape != (M, K):
+            raise RuntimeError(f"finalize for [{M}, {K}] slots without the matching prepare ({self._shape})")
+        y = fused_expert_output if fused_expert_output.dtype == torch.float32 else fused_expert_output.to(torch.float32)
+        output.copy_(self._ep.combine_fixed(y.contiguous(), M, K))
+
+
 def bind_vllm_base():
     """`class LkmExpertsModular(LkmExperts, mk.FusedMoEExpertsModular)` for registration inside LvLLM
     (e.g. through the kernel-selection table of the fused-MoE layer, or @PluggableLayer.register_oot around RoutedExperts, custom_op.py:47-101).

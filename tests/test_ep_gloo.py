@@ -74,6 +74,55 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
+def _pf_worker(rank, world, port, q):
+    """the reference's modular call sequence (modular_kernel.py:1219-1420): prepare -> experts.apply -> finalize"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lvllm_amd.modular import LkmPrepareAndFinalize, _NoOpReduce
+        from lvllm_amd.ops import determine_expert_map
+        w13, w2 = _weights()
+        pf = LkmPrepareAndFinalize(E, H, pack=_torch_pack)
+        assert pf.num_dispatchers() == world and pf.output_is_reduced() and pf.topk_indices_dtype() == torch.int32
+        n_loc, emap = determine_expert_map(world, rank, E, "linear")
+        lo = pf._ep.first_expert[rank]
+        d = orc.MoeDesc(E=n_loc, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+        a, tw, ids = _tokens(rank)
+        a1q, a1q_scale, meta, ids_d, w_d = pf.prepare(a, tw, ids, E, emap, False, None, True)
+        assert a1q_scale is None and meta is None and ids_d.shape == (world * M * K, 1)
+        # what LkmExperts.apply does with them: expert_map, then the weighted expert rows (the oracle stands in)
+        g = ids_d.view(-1).to(torch.int64)
+        lids = torch.where(g >= 0, emap[g.clamp(min=0)].to(torch.int64), torch.full_like(g, -1)).to(torch.int32)
+        assert ((lids >= 0) == (g >= 0)).all(), "a dispatched row reached a rank that does not own its expert"
+        fused = torch.from_numpy(orc.moe(d, torch_to_bits(w13[lo:lo + n_loc]), torch_to_bits(w2[lo:lo + n_loc]),
+                                         torch_to_bits(a1q), lids.view(-1, 1).numpy(), w_d.numpy()))
+        out = torch.empty((M, H), dtype=torch.float32)
+        pf.finalize(out, fused, tw, ids, False, _NoOpReduce())
+        q.put((rank, out.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_prepare_finalize_pair_matches_single_rank_oracle(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pf_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w13, w2 = _weights()
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    for r in range(world):
+        a, tw, ids = _tokens(r)
+        ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids.numpy(), tw.numpy())
+        np.testing.assert_allclose(results[r], ref, atol=1e-5, rtol=1e-5)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

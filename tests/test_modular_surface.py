@@ -103,3 +103,25 @@ def test_errors_are_loud_on_the_host_side():
     w1, w2 = torch.zeros(2, 64, 64, dtype=torch.bfloat16), torch.zeros(2, 64, 32, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ex.apply(torch.empty_like(x), x, w1, w2, tw, ids, "silu", 2, None, None, None, None, None, None, False)
+
+
+def test_prepare_finalize_surface_matches_the_reference_interface():
+    """FusedMoEPrepareAndFinalizeModular (modular_kernel.py:257-418): prepare / finalize parameter names; the
+    abstract facts of its base (:201-239).  Behaviour over 2 and 4 ranks: tests/test_ep_gloo.py."""
+    from lvllm_amd.modular import LkmPrepareAndFinalize
+    assert _params(LkmPrepareAndFinalize.prepare) == ["self", "a1", "topk_weights", "topk_ids", "num_experts",
+                                                      "expert_map", "apply_router_weight_on_input", "quant_config",
+                                                      "defer_input_quant"]
+    assert _params(LkmPrepareAndFinalize.finalize) == ["self", "output", "fused_expert_output", "topk_weights",
+                                                       "topk_ids", "apply_router_weight_on_input",
+                                                       "weight_and_reduce_impl"]
+    if REF.exists():
+        tree = ast.parse(REF.read_text())
+        cls = {n.name: n for n in ast.walk(tree) if isinstance(n, ast.ClassDef)}
+        for cname in ("FusedMoEPrepareAndFinalize", "FusedMoEPrepareAndFinalizeModular"):
+            for f in cls[cname].body:
+                if isinstance(f, ast.FunctionDef) and any(
+                        getattr(d, "id", getattr(d, "attr", "")) == "abstractmethod" for d in f.decorator_list):
+                    assert hasattr(LkmPrepareAndFinalize, f.name), f.name
+                    if f.name in ("prepare", "finalize"):
+                        assert _params(getattr(LkmPrepareAndFinalize, f.name)) == [a.arg for a in f.args.args]

@@ -78,6 +78,13 @@ _SIGS = {
     "lkm_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "lkm_hbm_read_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(C.c_float)]),
+    # include/lkm_eplb.h
+    "lkm_eplb_map_record": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "lkm_expert_bytes": (C.c_int64, [C.c_void_p]),
+    "lkm_export_expert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "lkm_import_expert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

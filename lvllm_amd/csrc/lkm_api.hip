@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "lkm_kernels.h"
+#include "../../include/lkm_eplb.h"
 
 namespace lkm {
 
@@ -995,4 +996,81 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
         return LKM_E_INVALID;
     }
     return LKM_OK;
+}
+
+// ------------------------------------------------------------------ expert images (include/lkm_eplb.h)
+// One expert's slabs of the six HBM buffers, in image order: w13, w2, s13, s2, gs13, gs2.  The per-expert
+// sizes are the allocation formulas of lkm_create divided by E (every buffer is [E][...] with the expert
+// outermost); in the image each slab is padded to 16 bytes.
+namespace {
+struct ExpertSlabs {
+    char* ptr[6];
+    size_t bytes[6];
+    size_t offset[6];
+    size_t total;
+};
+}  // namespace
+
+static void expert_slabs(const LkmEngine* h, int expert, ExpertSlabs* s) {
+    const size_t halves = h->gated ? 2 : 1, loads = wf_loads(h->wf);
+    const size_t t13 = halves * h->T1_half * h->U1;   // (16-row tile, k unit) pairs of one expert
+    const size_t t2 = (size_t)h->T2 * h->U2;
+    size_t sb13 = 0, sb2 = 0;                         // scale bytes of one expert
+    if (h->wf == LKM_W_INT4_B8) {
+        sb13 = t13 * 16 * h->spu * 2;
+        sb2 = t2 * 16 * h->spu * 2;
+    } else if (h->wf == LKM_W_MXFP4 || h->wf == LKM_W_NVFP4) {
+        const size_t spu = 128 / h->cfg.groupK;
+        sb13 = t13 * 16 * spu;
+        sb2 = t2 * 16 * spu;
+    } else if (h->wf == LKM_W_FP8_E4M3) {
+        sb13 = t13 * 16 * 4;
+        sb2 = t2 * 16 * 4;
+    }
+    void* const base[6] = {h->w13, h->w2, h->s13, h->s2, h->gs13, h->gs2};
+    const size_t bytes[6] = {t13 * loads * 64 * 16, t2 * loads * 64 * 16, sb13, sb2, 4, 4};
+    size_t off = 0;
+    for (int i = 0; i < 6; ++i) {
+        s->bytes[i] = base[i] ? bytes[i] : 0;
+        s->ptr[i] = base[i] ? (char*)base[i] + (size_t)expert * bytes[i] : nullptr;
+        s->offset[i] = off;
+        off += (s->bytes[i] + 15) / 16 * 16;
+    }
+    s->total = off;
+}
+
+extern "C" int64_t lkm_expert_bytes(LkmHandle h) {
+    if (!h) {
+        set_error("lkm_expert_bytes: null engine handle");
+        return LKM_E_INVALID;
+    }
+    ExpertSlabs s;
+    expert_slabs(h, 0, &s);
+    return (int64_t)s.total;
+}
+
+static int copy_expert(LkmHandle h, void* stream, int32_t expert, char* image, bool to_image) {
+    LKM_REQUIRE(h, "null engine handle");
+    LKM_REQUIRE(image, "null expert image pointer");
+    LKM_REQUIRE(expert >= 0 && expert < h->E, "expert %d out of range (engine holds %d local experts)", expert, h->E);
+    LKM_HIP_CHECK(hipSetDevice(h->device));
+    ExpertSlabs s;
+    expert_slabs(h, expert, &s);
+    for (int i = 0; i < 6; ++i) {
+        if (!s.bytes[i]) continue;
+        char* img = image + s.offset[i];
+        const size_t pad = (16 - s.bytes[i] % 16) % 16;   // images are deterministic: padding is written as zeros
+        if (to_image && pad) LKM_HIP_CHECK(hipMemsetAsync(img + s.bytes[i], 0, pad, (hipStream_t)stream));
+        LKM_HIP_CHECK(hipMemcpyAsync(to_image ? (void*)img : (void*)s.ptr[i], to_image ? (const void*)s.ptr[i] : (const void*)img,
+                                     s.bytes[i], hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return LKM_OK;
+}
+
+extern "C" int lkm_export_expert(LkmHandle h, void* stream, int32_t expert, void* dst) {
+    return copy_expert(h, stream, expert, (char*)dst, true);
+}
+
+extern "C" int lkm_import_expert(LkmHandle h, void* stream, int32_t expert, const void* src) {
+    return copy_expert(h, stream, expert, (char*)src, false);
 }

@@ -121,6 +121,19 @@ class _MOE:
         for k, v in kv.items():
             _clib.check(self._lib.lkm_set_tuning(self._h, k.encode(), int(v)))
 
+    # ---- expert images for placement changes (include/lkm_eplb.h; used by lvllm_amd/eplb.py) --------
+    def expert_bytes(self) -> int:
+        n = int(self._lib.lkm_expert_bytes(self._h))
+        if n < 0:
+            _clib.check(n)
+        return n
+
+    def export_expert(self, stream: int, expert: int, dst_ptr: int) -> None:
+        _clib.check(self._lib.lkm_export_expert(self._h, _vp(stream), int(expert), _vp(dst_ptr)))
+
+    def import_expert(self, stream: int, expert: int, src_ptr: int) -> None:
+        _clib.check(self._lib.lkm_import_expert(self._h, _vp(stream), int(expert), _vp(src_ptr)))
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.lkm_destroy(self._h)

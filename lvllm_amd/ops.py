@@ -10,6 +10,7 @@ Reference interfaces mirrored (relative to the reference tree):
   grouped_topk      vllm/model_executor/layers/fused_moe/router/grouped_topk_router.py:80-161
   global_to_local_expert_ids   vllm/model_executor/layers/fused_moe/routed_experts.py:1332-1342
   determine_expert_map         vllm/model_executor/layers/fused_moe/expert_map_manager.py:22-92
+  eplb_map_to_physical_and_record   vllm/model_executor/layers/fused_moe/router/base_router.py:24-146
 """
 from __future__ import annotations
 
@@ -173,6 +174,41 @@ def global_to_local_expert_ids(topk_ids: torch.Tensor, expert_map: torch.Tensor)
     _clib.check(_clib.lib().lkm_map_expert_ids(_stream(ids), _ptr(ids), ids.numel(), _ptr(emap),
                                                emap.numel(), _ptr(out)))
     return out
+
+
+def eplb_map_to_physical_and_record(topk_ids: torch.Tensor, expert_load_view: torch.Tensor | None,
+                                    logical_to_physical_map: torch.Tensor, logical_replica_count: torch.Tensor,
+                                    record_enabled: torch.Tensor | None = None,
+                                    num_unpadded_tokens: torch.Tensor | None = None) -> torch.Tensor:
+    """Logical -> physical expert ids (replica picked by a hash of the token index) and, when recording
+    is on, expert_load_view[physical] += 1 per routed slot of an unpadded token; base_router.py:129-146
+    (same argument names and order).  Maps / counters / switches are used as they are when they already are
+    contiguous int32 tensors on the device (what lvllm_amd.eplb.EplbState keeps; required for the load view,
+    which is updated in place, and for switches that must stay live inside a captured graph); other integer
+    dtypes (the reference keeps int64 maps and a bool switch) are converted per call."""
+    _need_cuda(topk_ids, expert_load_view, logical_to_physical_map, logical_replica_count, record_enabled,
+               num_unpadded_tokens)
+    if topk_ids.numel() == 0:
+        return topk_ids
+    if topk_ids.dim() != 2:
+        raise ValueError("topk_ids must be [tokens, top_k]")
+    dev = topk_ids.device
+    ids = topk_ids.to(torch.int32).contiguous()
+
+    def i32(t):
+        return None if t is None else t.to(device=dev, dtype=torch.int32).contiguous()
+    l2p, cnt = i32(logical_to_physical_map), i32(logical_replica_count)
+    if l2p.dim() != 2 or cnt.dim() != 1 or l2p.size(0) != cnt.size(0):
+        raise ValueError("expected logical_to_physical_map [logical, slots] and logical_replica_count [logical]")
+    if expert_load_view is not None and (expert_load_view.dtype != torch.int32 or not expert_load_view.is_contiguous()):
+        raise ValueError("expert_load_view must be a contiguous int32 tensor (it is updated in place)")
+    rec, unpadded = i32(record_enabled), i32(num_unpadded_tokens)     # converted copies stay referenced until the launch
+    out = torch.empty_like(ids)
+    _clib.check(_clib.lib().lkm_eplb_map_record(
+        _stream(ids), _ptr(ids), ids.numel(), ids.size(1), _ptr(l2p), _ptr(cnt), l2p.size(0), l2p.size(1),
+        _ptr(expert_load_view), 0 if expert_load_view is None else expert_load_view.numel(),
+        _ptr(rec), _ptr(unpadded), _ptr(out)))
+    return out.to(topk_ids.dtype)
 
 
 def ep_pack(hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor, num_experts: int,

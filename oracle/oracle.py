@@ -265,3 +265,38 @@ def set_threads(n: int) -> None:
 
 def num_threads() -> int:
     return int(lib().lkm_or_num_threads())
+
+
+# ------------------------------------------------------------------ EPLB id map + load recording
+def eplb_map_record(topk_ids: np.ndarray, log2phy: np.ndarray, logcnt: np.ndarray, load: np.ndarray | None = None,
+                    record_enabled: bool = True, num_unpadded: int | None = None):
+    """Restates the reference's logical -> physical map + load recording kernel
+    (vllm/model_executor/layers/fused_moe/router/base_router.py:24-97, `_eplb_map_and_record_i32_kernel`):
+      slot i of token t = i // top_k;  valid = 0 <= id < num_logical
+      replica = ((t * 2654435769) & 0xFFFFFFFF) % max(logcnt[id], 1)             (:48-54)
+      phys    = log2phy[id, replica] if valid else -1                             (:55-60)
+      load[phys] += 1 if record_enabled and i < num_unpadded * top_k and 0 <= phys < len(load)   (:76-93)
+    topk_ids [M, K] int; log2phy [E, R]; logcnt [E]; load [P] int32 (a copy is updated and returned).
+    Parity: the Triton kernel itself cannot run here (no Triton, no GPU); the reference's only test of it
+    (tests/kernels/moe/test_routing.py:155-188, identity map, one replica: ids unchanged) is reproduced in
+    tests/test_eplb.py.  Deviation, unreachable with consistent maps: a replica count above the map width
+    is clamped to it (the reference would read out of bounds).  Returns (physical ids int32 [M, K], load)."""
+    ids = np.asarray(topk_ids, dtype=np.int64)
+    M, K = ids.shape
+    l2p = np.asarray(log2phy, dtype=np.int64)
+    cnt = np.asarray(logcnt, dtype=np.int64)
+    E, R = l2p.shape
+    flat = ids.reshape(-1)
+    valid = (flat >= 0) & (flat < E)
+    safe = np.where(valid, flat, 0)
+    c = np.clip(cnt[safe], 1, R)
+    tok = np.arange(flat.size, dtype=np.int64) // K
+    hashed = (tok * 2654435769) & 0xFFFFFFFF
+    phys = np.where(valid, l2p[safe, hashed % c], -1)
+    out_load = None if load is None else np.array(load, dtype=np.int32, copy=True)
+    if out_load is not None and record_enabled:
+        sel = (phys >= 0) & (phys < out_load.size)
+        if num_unpadded is not None:
+            sel &= np.arange(flat.size) < int(num_unpadded) * K
+        np.add.at(out_load, phys[sel], 1)
+    return phys.reshape(M, K).astype(np.int32), out_load

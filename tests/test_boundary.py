@@ -1,5 +1,5 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
-include/lkm.h declares, the lk_moe module has the reference's surface, and the product path never
+include/*.h (lkm.h and its extension lkm_eplb.h) declare, the lk_moe module has the reference's surface, and the product path never
 touches the oracle."""
 import ctypes
 import re
@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def _declared():
-    text = (ROOT / "include" / "lkm.h").read_text()
+    text = "".join(p.read_text() for p in sorted((ROOT / "include").glob("*.h")))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(lkm_[a-z0-9_]+)\s*\(", text)))
 
@@ -25,7 +25,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     names = _declared()
     assert len(names) >= 15
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/lkm.h but not exported by liblkm.so"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported by liblkm.so"
     assert sorted(_clib.EXPORTS) == names, "ctypes binding and header disagree"
     assert _clib.lib().lkm_abi_version() == _clib.LKM_ABI_VERSION
 

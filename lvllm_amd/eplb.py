@@ -43,6 +43,7 @@ __all__ = [
     "DefaultEplbPolicy", "rebalance_experts", "compute_logical_maps",
     "build_initial_global_physical_to_logical_map", "plan_layer_transfers", "LayerPlan",
     "ExpertStore", "TensorExpertStore", "EngineExpertStore", "rearrange_expert_weights_inplace",
+    "plan_rearrangement", "begin_expert_exchange", "finish_expert_exchange", "PendingExchange",
     "EplbLayerState", "EplbState",
 ]
 
@@ -380,14 +381,128 @@ class EngineExpertStore:
         self.moe.import_expert(torch.cuda.current_stream(src.device).cuda_stream, slot, src.data_ptr())
 
 
-def _exchange(sends: list[tuple[torch.Tensor, int]], recvs: list[tuple[torch.Tensor, int]], group) -> None:
-    ops = [dist.P2POp(dist.isend, t, dist.get_global_rank(group, peer) if group is not None else peer, group)
-           for t, peer in sends]
-    ops += [dist.P2POp(dist.irecv, t, dist.get_global_rank(group, peer) if group is not None else peer, group)
-            for t, peer in recvs]
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+def _post(sends: list[tuple[torch.Tensor, int]], recvs: list[tuple[torch.Tensor, int]], group) -> list:
+    """post the point-to-point transfers of one batch; returns the outstanding works (not waited)"""
+    def peer_of(r: int) -> int:
+        return dist.get_global_rank(group, r) if group is not None else r
+    ops = [dist.P2POp(dist.isend, t, peer_of(r), group) for t, r in sends]
+    ops += [dist.P2POp(dist.irecv, t, peer_of(r), group) for t, r in recvs]
+    return list(dist.batch_isend_irecv(ops)) if ops else []
+
+
+@dataclass
+class PendingExchange:
+    """One batch of layers in flight: images exported and transfers posted, nothing imported yet.  The engine's
+    weights are untouched until `finish_expert_exchange`, so forwards may keep running on the old placement."""
+    layers: range
+    works: list
+    commits: list            # (layer, dst_slot, image)        images that arrived by p2p or by a local move
+    fanout: list             # (layer, image, dst_slot)        further local slots of an image that arrived by p2p
+    keepalive: list          # send images: must outlive the transfers
+
+    def is_completed(self) -> bool:
+        """NB gloo's send/recv works only report completion after wait(); meaningful with RCCL"""
+        return all(w.is_completed() for w in self.works)
+
+
+def _layer_batches(plans: list[LayerPlan], stores: Sequence[ExpertStore], world: int, budget: int) -> list[range]:
+    """consecutive layers whose staged images (outgoing + incoming) fit `budget` bytes; at least one layer per
+    batch.  Every rank must cut the SAME batches (a batch is one collective batch_isend_irecv), so the budget is
+    compared against the busiest rank's need, which every rank computes from the global plans."""
+
+    def need(l: int) -> int:
+        pl, worst = plans[l], 0
+        for r in range(world):
+            out_slots = {s for sr, s, *_ in pl.p2p if sr == r}
+            inc = sum(1 for _, _, dr, *_ in pl.p2p if dr == r) + sum(1 for rr, *_ in pl.local if rr == r)
+            worst = max(worst, len(out_slots) + inc)
+        return worst * stores[l].expert_nbytes
+    out, l0, L = [], 0, len(plans)
+    while l0 < L:
+        l1, used = l0, 0
+        while l1 < L:
+            n = need(l1)
+            if l1 > l0 and used + n > budget:
+                break
+            used += n
+            l1 += 1
+        out.append(range(l0, l1))
+        l0 = l1
+    return out
+
+
+def begin_expert_exchange(plans: list[LayerPlan], layers: range, expert_stores: Sequence[ExpertStore], rank: int,
+                          ep_group=None) -> PendingExchange:
+    """Export the outgoing experts of `layers` (once per slot) and post ALL their transfers in one
+    batch_isend_irecv.  Every incoming image (remote or local move) is staged; no slot is overwritten here."""
+    sends: list[tuple[torch.Tensor, int]] = []
+    recvs: list[tuple[torch.Tensor, int]] = []
+    commits, fan, keep = [], [], []
+    for l in layers:
+        st, pl = expert_stores[l], plans[l]
+        nb = st.expert_nbytes
+        packed: dict[int, torch.Tensor] = {}
+
+        def image_of(slot: int, st=st, nb=nb, packed=packed) -> torch.Tensor:
+            if slot not in packed:
+                buf = torch.empty(nb, dtype=torch.uint8, device=st.device)
+                st.export_expert(slot, buf)
+                packed[slot] = buf
+            return packed[slot]
+        arrived: dict[int, torch.Tensor] = {}                  # primary dst slot -> staged image
+        for sr, ss, dr, ds, _e in pl.p2p:                      # the plan's order: identical on sender and receiver
+            if sr == rank:
+                sends.append((image_of(ss), dr))
+            if dr == rank:
+                buf = torch.empty(nb, dtype=torch.uint8, device=st.device)
+                recvs.append((buf, sr))
+                arrived[ds] = buf
+                commits.append((l, ds, buf))
+        for r, ss, ds, _e in pl.local:
+            if r == rank:
+                commits.append((l, ds, image_of(ss)))
+        for r, prim, ds, _e in pl.fanout:
+            if r == rank:
+                fan.append((l, arrived[prim], ds))
+        keep.extend(packed.values())
+    if sends or recvs:
+        dev = (sends or recvs)[0][0].device
+        if dev.type == "cuda":                                 # the exports ran on the current stream
+            torch.cuda.current_stream(dev).synchronize()
+    return PendingExchange(layers, _post(sends, recvs, ep_group), commits, fan, keep)
+
+
+def finish_expert_exchange(pending: PendingExchange, expert_stores: Sequence[ExpertStore]) -> None:
+    """wait for the batch's transfers, then import the staged images into their slots"""
+    for w in pending.works:
+        w.wait()
+    for l, ds, img in pending.commits:
+        expert_stores[l].import_expert(ds, img)
+    for l, img, ds in pending.fanout:
+        expert_stores[l].import_expert(ds, img)
+    pending.works, pending.commits, pending.fanout, pending.keepalive = [], [], [], []
+
+
+def _np_maps(old_global_expert_indices, new_global_expert_indices, n_layers: int):
+    old = np.asarray(old_global_expert_indices.cpu() if isinstance(old_global_expert_indices, torch.Tensor)
+                     else old_global_expert_indices, dtype=np.int64)
+    new = np.asarray(new_global_expert_indices.cpu() if isinstance(new_global_expert_indices, torch.Tensor)
+                     else new_global_expert_indices, dtype=np.int64)
+    if old.shape != new.shape or old.ndim != 2 or old.shape[0] != n_layers:
+        raise ValueError("old/new must be [layers, physical] with one expert store per layer")
+    return old, new
+
+
+def plan_rearrangement(old_global_expert_indices, new_global_expert_indices, expert_stores: Sequence[ExpertStore],
+                       world: int) -> list[LayerPlan]:
+    old, new = _np_maps(old_global_expert_indices, new_global_expert_indices, len(expert_stores))
+    L, P = old.shape
+    if P % world:
+        raise ValueError(f"{P} physical experts do not divide over {world} ranks")
+    for l, st in enumerate(expert_stores):
+        if st.num_local != P // world:
+            raise ValueError(f"layer {l}: store holds {st.num_local} experts, placement has {P // world} per rank")
+    return [plan_layer_transfers(old[l], new[l], world) for l in range(L)]
 
 
 def rearrange_expert_weights_inplace(old_global_expert_indices, new_global_expert_indices,
@@ -398,85 +513,17 @@ def rearrange_expert_weights_inplace(old_global_expert_indices, new_global_exper
     (rebalance_execute.py:511-616).  old/new: [layers, P] logical ids; expert_stores[l]: this rank's
     experts of layer l.  Collective over ep_group (every rank calls it with the same maps).
 
-    Per batch of layers (as many as fit `max_staging_bytes` of staging): pack outgoing experts once per
-    (slot) -> ONE batch_isend_irecv for the whole batch -> import staged images into their slots.  All
-    incoming images (remote and local moves) are staged before any slot is overwritten, so a slot can be
-    both a source and a destination.  Returns the per-layer plans (for logging / tests)."""
-    old = np.asarray(old_global_expert_indices.cpu() if isinstance(old_global_expert_indices, torch.Tensor)
-                     else old_global_expert_indices, dtype=np.int64)
-    new = np.asarray(new_global_expert_indices.cpu() if isinstance(new_global_expert_indices, torch.Tensor)
-                     else new_global_expert_indices, dtype=np.int64)
-    if old.shape != new.shape or old.ndim != 2 or old.shape[0] != len(expert_stores):
-        raise ValueError("old/new must be [layers, physical] with one expert store per layer")
+    Per batch of layers (as many as fit `max_staging_bytes` of staging on the busiest rank): pack outgoing
+    experts once per slot -> ONE batch_isend_irecv for the whole batch -> import staged images into their
+    slots.  All incoming images (remote and local moves) are staged before any slot is overwritten, so a slot can
+    be both a source and a destination.  Returns the per-layer plans (for logging / tests)."""
     if world is None:
         world = dist.get_world_size(ep_group) if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank(ep_group) if dist.is_initialized() else 0
-    L, P = old.shape
-    if P % world:
-        raise ValueError(f"{P} physical experts do not divide over {world} ranks")
-    per = P // world
-    plans = [plan_layer_transfers(old[l], new[l], world) for l in range(L)]
-    for l, st in enumerate(expert_stores):
-        if st.num_local != per:
-            raise ValueError(f"layer {l}: store holds {st.num_local} experts, placement has {per} per rank")
-
-    def staged_images(l: int) -> int:          # images this rank stages for layer l (outgoing + incoming)
-        pl = plans[l]
-        out_slots = {s for sr, s, *_ in pl.p2p if sr == rank}
-        inc = sum(1 for _, _, dr, *_ in pl.p2p if dr == rank) + sum(1 for r, *_ in pl.local if r == rank)
-        return len(out_slots) + inc
-
-    l0 = 0
-    while l0 < L:
-        # ---- batch of layers under the staging budget (at least one layer)
-        l1, used = l0, 0
-        while l1 < L:
-            need = staged_images(l1) * expert_stores[l1].expert_nbytes
-            if l1 > l0 and used + need > max_staging_bytes:
-                break
-            used += need
-            l1 += 1
-        sends: list[tuple[torch.Tensor, int]] = []
-        recvs: list[tuple[torch.Tensor, int]] = []
-        commits = []                                           # (layer, dst_slot, image)
-        fan = []                                               # (layer, primary image lookup key, dst_slot)
-        for l in range(l0, l1):
-            st, pl = expert_stores[l], plans[l]
-            nb = st.expert_nbytes
-            packed: dict[int, torch.Tensor] = {}
-            def image_of(slot: int) -> torch.Tensor:
-                if slot not in packed:
-                    buf = torch.empty(nb, dtype=torch.uint8, device=st.device)
-                    st.export_expert(slot, buf)
-                    packed[slot] = buf
-                return packed[slot]
-            arrived: dict[int, torch.Tensor] = {}              # primary dst slot -> staged image
-            # deterministic global order: the plan's order, identical on sender and receiver
-            for sr, ss, dr, ds, _e in pl.p2p:
-                if sr == rank:
-                    sends.append((image_of(ss), dr))
-                if dr == rank:
-                    buf = torch.empty(nb, dtype=torch.uint8, device=st.device)
-                    recvs.append((buf, sr))
-                    arrived[ds] = buf
-                    commits.append((l, ds, buf))
-            for r, ss, ds, _e in pl.local:
-                if r == rank:
-                    commits.append((l, ds, image_of(ss)))
-            for r, prim, ds, _e in pl.fanout:
-                if r == rank:
-                    fan.append((l, arrived[prim], ds))
-        if sends or recvs:
-            dev = (sends or recvs)[0][0].device
-            if dev.type == "cuda":                             # the exports above ran on the current stream
-                torch.cuda.current_stream(dev).synchronize()
-        _exchange(sends, recvs, ep_group)
-        for l, ds, img in commits:
-            expert_stores[l].import_expert(ds, img)
-        for l, img, ds in fan:
-            expert_stores[l].import_expert(ds, img)
-        l0 = l1
+    plans = plan_rearrangement(old_global_expert_indices, new_global_expert_indices, expert_stores, world)
+    for layers in _layer_batches(plans, expert_stores, world, max_staging_bytes):
+        finish_expert_exchange(begin_expert_exchange(plans, layers, expert_stores, rank, ep_group), expert_stores)
     for st in expert_stores:
         if st.device.type == "cuda":
             torch.cuda.current_stream(st.device).synchronize()
@@ -503,9 +550,24 @@ class EplbState:
     def __init__(self, num_layers: int, num_logical_experts: int, num_redundant_experts: int, *,
                  num_groups: int = 1, num_nodes: int = 1, window_size: int = 1000, step_interval: int = 3000,
                  device: torch.device | str = "cpu", ep_group=None, policy=DefaultEplbPolicy,
-                 expert_stores: Sequence[ExpertStore] | None = None):
+                 expert_stores: Sequence[ExpertStore] | None = None, overlap: bool = False,
+                 commit_after_steps: int = 1, max_staging_bytes: int = 8 << 30):
         self.group = ep_group
         self.expert_stores = expert_stores                   # one per layer; may be attached later
+        # overlap: the exchange of a batch of layers is only POSTED at the step that is due; forwards keep running
+        # on the old placement (weights and maps untouched) while the images travel; `commit_after_steps` steps
+        # later the batch is imported and its layers' maps are switched, and the next batch is posted (the
+        # reference's async mode, eplb_state.py:624-650 / async_worker.py, without a worker thread: RCCL p2p runs
+        # on the communicator's own stream).  Give EPLB its own process group then (dist.new_group): its p2p
+        # traffic must not interleave with the forward's all-to-all on one communicator.
+        self.overlap = overlap
+        self.commit_after_steps = max(1, commit_after_steps)
+        self._pending_age = 0
+        self.max_staging_bytes = max_staging_bytes
+        self._pending: PendingExchange | None = None
+        self._todo: list[range] = []
+        self._plans: list[LayerPlan] = []
+        self._new_p2l: torch.Tensor | None = None
         self.world = dist.get_world_size(ep_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(ep_group) if dist.is_initialized() else 0
         self.L, self.E = num_layers, num_logical_experts
@@ -538,12 +600,18 @@ class EplbState:
         per = self.P // self.world
         return self.physical_to_logical_map[layer, self.rank * per:(self.rank + 1) * per].tolist()
 
-    def _commit(self, p2l: torch.Tensor) -> None:
-        """new placement -> the device maps, IN PLACE (captured graphs keep reading the same buffers)."""
-        l2p, cnt = compute_logical_maps(p2l, self.E, max_slots=self.R)
-        self.logical_to_physical_map.copy_(l2p.to(torch.int32))
-        self.logical_replica_count.copy_(cnt.to(torch.int32))
-        self.physical_to_logical_map = p2l.clone()
+    def _commit(self, p2l: torch.Tensor, layers: range | None = None) -> None:
+        """new placement (of all layers, or of `layers` only) -> the device maps, IN PLACE (captured graphs keep
+        reading the same buffers; cf. _commit_eplb_maps_for_layer, eplb_state.py:1245-1280)."""
+        if layers is None:
+            layers = range(self.L)
+            self.physical_to_logical_map = p2l.clone()
+        else:
+            self.physical_to_logical_map[layers.start:layers.stop] = p2l[layers.start:layers.stop]
+        sel = slice(layers.start, layers.stop)
+        l2p, cnt = compute_logical_maps(p2l[sel], self.E, max_slots=self.R)
+        self.logical_to_physical_map[sel].copy_(l2p.to(torch.int32))
+        self.logical_replica_count[sel].copy_(cnt.to(torch.int32))
 
     # ---- per forward
     def step(self, is_dummy: bool = False) -> bool:
@@ -557,11 +625,59 @@ class EplbState:
             self.expert_load_pass.zero_()
             self.window_step = (self.window_step + 1) % self.window_size
         self.rearrangement_step += 1
+        changed = self._advance_overlapped() if self.in_flight else False
         if self.rearrangement_step >= self.step_interval:
+            if self.in_flight:                       # still moving the previous round: keep the counter (eplb_state.py:641-650)
+                return changed
             self.rearrangement_step = 0
-            self.rearrange()
-            return True
-        return False
+            if self.overlap:
+                self._begin_overlapped()
+            else:
+                self.rearrange()
+                changed = True
+        return changed
+
+    # ---- overlapped rearrangement
+    @property
+    def in_flight(self) -> bool:
+        return self._pending is not None
+
+    def _begin_overlapped(self) -> None:
+        stores = self._stores()
+        load = self.global_logical_load()
+        self._new_p2l = self.policy.rebalance_experts(load, self.P, self.num_groups, self.num_nodes, self.world,
+                                                      self.physical_to_logical_map)
+        self._plans = plan_rearrangement(self.physical_to_logical_map, self._new_p2l, stores, self.world)
+        self._todo = _layer_batches(self._plans, stores, self.world, self.max_staging_bytes)
+        self._pending = begin_expert_exchange(self._plans, self._todo.pop(0), stores, self.rank, self.group)
+        self._pending_age = 0
+
+    def _advance_overlapped(self, force: bool = False) -> bool:
+        """`commit_after_steps` steps after a batch was posted: wait for its transfers (with RCCL that is a stream
+        dependency, not a host stall), import it, switch ITS layers' maps, post the next batch.  Every rank does this
+        at the same step by construction, so -- unlike the reference, which all-reduces a "transfers done" flag every
+        step while a layer is in flight (eplb_state.py:984-1003) -- no agreement collective and no host
+        synchronisation are needed; a transfer that is not finished by then delays that step instead."""
+        self._pending_age += 1
+        if not force and self._pending_age < self.commit_after_steps:
+            return False
+        stores = self._stores()
+        finish_expert_exchange(self._pending, stores)
+        self._commit(self._new_p2l, self._pending.layers)
+        self._pending_age = 0
+        self._pending = (begin_expert_exchange(self._plans, self._todo.pop(0), stores, self.rank, self.group)
+                         if self._todo else None)
+        return True
+
+    def drain(self) -> None:
+        """finish an overlapped rearrangement now (collective; e.g. before shutdown or a checkpoint)"""
+        while self._pending is not None:
+            self._advance_overlapped(force=True)
+
+    def _stores(self) -> Sequence[ExpertStore]:
+        if self.expert_stores is None or len(self.expert_stores) != self.L:
+            raise RuntimeError("EplbState needs one expert store per MoE layer (expert_stores) to rearrange")
+        return self.expert_stores
 
     def global_logical_load(self) -> torch.Tensor:
         """window summed over steps, physical -> logical, summed over ranks: float32 [L, E] on CPU
@@ -574,16 +690,17 @@ class EplbState:
             dist.all_reduce(logical, group=self.group)
         return logical.float().cpu()
 
-    def rearrange(self, max_staging_bytes: int = 8 << 30) -> list[LayerPlan]:
+    def rearrange(self, max_staging_bytes: int | None = None) -> list[LayerPlan]:
         """load statistics -> policy -> weight exchange -> commit maps (eplb_state.py:722-930)."""
-        expert_stores = self.expert_stores
-        if expert_stores is None or len(expert_stores) != self.L:
-            raise RuntimeError("EplbState.rearrange needs one expert store per MoE layer (expert_stores)")
+        expert_stores = self._stores()
+        if self.in_flight:
+            raise RuntimeError("an overlapped rearrangement is in flight: drain() first")
         load = self.global_logical_load()
         new_p2l = self.policy.rebalance_experts(load, self.P, self.num_groups, self.num_nodes, self.world,
                                                 self.physical_to_logical_map)
         plans = rearrange_expert_weights_inplace(self.physical_to_logical_map, new_p2l, expert_stores, self.group,
-                                                 max_staging_bytes, rank=self.rank, world=self.world)
+                                                 max_staging_bytes or self.max_staging_bytes, rank=self.rank,
+                                                 world=self.world)
         self._commit(new_p2l)
         return plans
 

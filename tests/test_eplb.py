@@ -434,3 +434,115 @@ def test_map_restatement_against_a_slot_loop():
     hot = int(np.argmax(cnt))
     phys, _ = orc.eplb_map_record(np.full((9, 3), hot), l2p, cnt)
     assert (phys == phys[:, :1]).all() and len(set(phys[:, 0].tolist())) > 1
+
+
+# ------------------------------------------------------------------------------------------ EP + EPLB end to end
+def _e2e_worker(rank, world, port, q):
+    """route logical ids -> physical ids (CPU restatement as the test double of the HIP kernel) -> expert-parallel
+    all-to-all over the PHYSICAL experts (lvllm_amd/ep.py, linear placement of P slots) -> local experts from the
+    tensors the EPLB exchange maintains; before and after a rearrangement the result equals the single-rank
+    oracle on the logical ids."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lvllm_amd.ep import ExpertParallelExperts
+        from tests.helpers import make_routing, torch_to_bits
+        from tests.test_ep_gloo import _torch_pack
+        E, red, K, H, I, M = 8, 4, 2, 64, 32, 24
+        P, per = E + red, (E + red) // world
+        g = torch.Generator().manual_seed(5)
+        w13 = (torch.randn((E, 2 * I, H), generator=g) / 4).to(torch.bfloat16)
+        w2 = (torch.randn((E, H, I), generator=g) / 4).to(torch.bfloat16)
+        st = eplb.EplbState(1, E, red, window_size=2, step_interval=1)
+        mine = torch.tensor(st.local_logical_ids(0))
+        local13, local2 = w13[mine].contiguous(), w2[mine].contiguous()          # this rank's physical slots
+        st.expert_stores = [eplb.TensorExpertStore([local13, local2])]
+        d_loc = orc.MoeDesc(E=per, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+
+        def local_compute(x, lids, ws):
+            if x.shape[0] == 0:
+                return torch.zeros((0, H), dtype=torch.float32)
+            return torch.from_numpy(orc.moe(d_loc, torch_to_bits(local13), torch_to_bits(local2), torch_to_bits(x),
+                                            lids.numpy(), ws.numpy()))
+        ep = ExpertParallelExperts(local_compute, P, H, mode="a2a", pack=_torch_pack)
+        gx = torch.Generator().manual_seed(100 + rank)
+        x = (torch.randn((M, H), generator=gx) / 2).to(torch.bfloat16)
+        tw, ids = make_routing(M, E, K, seed=200 + rank, skew=2.0)                 # skewed: expert 0 is hot
+        d_all = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+        want = orc.moe(d_all, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(x), ids, tw)
+
+        def forward():
+            ls = st.layer_state(0)
+            phys, load = orc.eplb_map_record(ids, ls.logical_to_physical_map.numpy(), ls.logical_replica_count.numpy(),
+                                             ls.expert_load_view.numpy())
+            ls.expert_load_view.copy_(torch.from_numpy(load))
+            return ep.forward(x, torch.from_numpy(tw), torch.from_numpy(phys)).numpy()
+        ok = bool(np.allclose(forward(), want, atol=1e-5, rtol=1e-5))
+        before = st.physical_to_logical_map.clone()
+        ok = ok and st.step()                                                     # interval 1: rearrangement
+        moved = not torch.equal(before, st.physical_to_logical_map)
+        ok = ok and bool(np.allclose(forward(), want, atol=1e-5, rtol=1e-5))
+        hot = int(torch.bincount(torch.from_numpy(ids).reshape(-1).long(), minlength=E).argmax())
+        q.put((rank, (ok, moved, int(st.logical_replica_count[0, hot]), int(st.logical_replica_count.max()))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ep_all_to_all_over_rebalanced_physical_experts():
+    res = _spawn(_e2e_worker, 2)
+    assert all(ok for ok, *_ in res.values()), res
+    assert all(moved for _, moved, *_ in res.values()), "the rearrangement changed nothing: weak test"
+    assert all(c_hot == c_max >= 2 for _, _, c_hot, c_max in res.values()), res
+
+
+# ------------------------------------------------------------------------------------------ overlapped rearrangement
+def _overlap_worker(rank, world, port, q):
+    """overlap=True: a due step only posts the first batch; `commit_after_steps` steps later the batch is imported,
+    ITS layers' maps are switched and the next batch is posted.  Invariant checked after every step: each layer's
+    weights match the placement its maps describe."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, E, red = 3, 8, 4
+        st = eplb.EplbState(L, E, red, window_size=4, step_interval=2, overlap=True, commit_after_steps=2,
+                            max_staging_bytes=1)                                    # one layer per batch
+        st.expert_stores = [_make_store(l, st.local_logical_ids(l)) for l in range(L)]
+        init = st.physical_to_logical_map.clone()
+        P = E + red
+
+        def consistent():
+            l2p, cnt = eplb.compute_logical_maps(st.physical_to_logical_map, E, max_slots=red + 1)
+            return (torch.equal(st.logical_to_physical_map.long(), l2p) and torch.equal(st.logical_replica_count.long(), cnt)
+                    and all(_store_matches(st.expert_stores[l], l, st.local_logical_ids(l)) for l in range(L)))
+        ok, switched_at, commits = True, [], 0
+        for step in range(40):
+            for l in range(L):
+                view = st.layer_state(l).expert_load_view
+                for p_ in range(P):
+                    view[p_] += 50 * (l + 1) if int(init[l, p_]) == (2 * l + 1) % E else 1 + (p_ % 3)
+            changed = st.step()
+            commits += int(changed)
+            ok = ok and consistent()
+            n_switched = sum(int(not torch.equal(init[l], st.physical_to_logical_map[l])) for l in range(L))
+            switched_at.append(n_switched)
+            if step == 0:
+                ok = ok and not st.in_flight and not changed
+            if step == 1:
+                ok = ok and st.in_flight and not changed and n_switched == 0      # posted, nothing switched yet
+            if commits == L:
+                break
+        # posted at step 1; batches land every 2 steps: steps 3, 5, 7
+        ok = ok and commits == L and len(switched_at) == 8 and switched_at[-1] >= 1 and switched_at == sorted(switched_at)
+        st.drain()                                                                 # a second round may have been posted
+        ok = ok and consistent() and not st.in_flight
+        hot_ok = all(int(st.logical_replica_count[l, (2 * l + 1) % E]) >= 2 for l in range(L))
+        q.put((rank, (ok, hot_ok, st.physical_to_logical_map.tolist())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_rearrangement_over_gloo():
+    res = _spawn(_overlap_worker, 2)
+    assert all(ok for ok, _, _ in res.values()), res
+    assert all(hot for _, hot, _ in res.values()), res
+    assert res[0][2] == res[1][2], "ranks disagree on the placement"

@@ -17,7 +17,9 @@ This replaces the reference's CPU-NUMA offload tier: instead of parking experts 
          its local experts (other ids -> -1), and the [M,H] partial outputs are summed with
          reduce_scatter (= the reference's all-reduce, kept sharded).
 
-Placement is the reference's linear map (expert_map_manager.py:62-79).  `torch.distributed` with
+Placement is the reference's linear map (expert_map_manager.py:62-79).  With EPLB (lvllm_amd/eplb.py) the ids
+handed to forward() are PHYSICAL expert ids and `num_experts` is the number of physical slots: the linear map over
+the slots is exactly the EPLB placement (slot p lives on rank p // (P / ep)); tests/test_eplb.py runs that end to end.  `torch.distributed` with
 backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests (tests/test_ep_gloo.py),
 where the local expert computation is injected.
 """

@@ -259,12 +259,14 @@ class LayerPlan:
         return out
 
 
-def plan_layer_transfers(old_indices, new_indices, num_ranks: int) -> LayerPlan:
+def plan_layer_transfers(old_indices, new_indices, num_ranks: int, egress: list[int] | None = None) -> LayerPlan:
     """Transfers that turn the placement `old_indices` [P] into `new_indices` [P] (logical id per global
     physical slot, -1 = empty).  Result state == rebalance_execute.py:172-425 (every slot p ends up holding
     the weights of logical expert new[p]); the choice of sender differs: the reference deals a replicated
     expert's receivers to its holders in equal runs, here each receive goes to the holder with the least
-    egress so far (ties: the holder that comes first), which spreads the exchange over the xGMI mesh."""
+    egress so far (ties: the holder that comes first), which spreads the exchange over the xGMI mesh.
+    `egress` (images sent per rank so far, updated in place) carries the balance across the layers of one
+    rearrangement, which travel together."""
     old = np.asarray(old_indices, dtype=np.int64).reshape(-1)
     new = np.asarray(new_indices, dtype=np.int64).reshape(-1)
     if old.shape != new.shape:
@@ -283,7 +285,8 @@ def plan_layer_transfers(old_indices, new_indices, num_ranks: int) -> LayerPlan:
         if not hs or hs[-1][0] != r:
             hs.append((r, p - r * per))
     plan = LayerPlan()
-    egress = [0] * num_ranks
+    if egress is None:
+        egress = [0] * num_ranks
     for r in range(num_ranks):
         primary: dict[int, int] = {}                          # logical -> local slot that receives it
         local_src = {int(old[r * per + s]): s for s in range(per - 1, -1, -1) if old[r * per + s] >= 0}
@@ -502,7 +505,8 @@ def plan_rearrangement(old_global_expert_indices, new_global_expert_indices, exp
     for l, st in enumerate(expert_stores):
         if st.num_local != P // world:
             raise ValueError(f"layer {l}: store holds {st.num_local} experts, placement has {P // world} per rank")
-    return [plan_layer_transfers(old[l], new[l], world) for l in range(L)]
+    egress = [0] * world                                  # balanced over the whole rearrangement, not per layer
+    return [plan_layer_transfers(old[l], new[l], world, egress) for l in range(L)]
 
 
 def rearrange_expert_weights_inplace(old_global_expert_indices, new_global_expert_indices,

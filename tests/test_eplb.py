@@ -230,6 +230,11 @@ def test_plan_reaches_the_new_placement_and_spreads_senders():
     plan = eplb.plan_layer_transfers(old, new, 6)
     assert sorted(sr for sr, *_ in plan.p2p) == [0, 1, 2]
     assert plan.egress(6) == [1, 1, 1, 0, 0, 0]
+    # the balance carries across the layers of one rearrangement: layer 1 starts with the least-loaded holder
+    eg = [0] * 6
+    eplb.plan_layer_transfers(old, np.array([0, 1, 0, 2, 0, 3, 0, 5, 6, 7, 8, 9]), 6, eg)      # rank 3 <- expert 0 from rank 0
+    nxt = eplb.plan_layer_transfers(old, np.array([0, 1, 0, 2, 0, 3, 4, 5, 0, 7, 8, 9]), 6, eg)  # rank 4 <- expert 0
+    assert eg == [1, 1, 0, 0, 0, 0] and nxt.p2p[0][0] == 1
     # no change, no traffic; an expert nobody holds is an error
     assert eplb.plan_layer_transfers(old, old, 6) == eplb.LayerPlan()
     with pytest.raises(ValueError):

@@ -331,7 +331,7 @@ def main():
         e_act = int(torch.unique(ids[ids >= 0]).numel())
         scale_bytes = 0.0                                           # bpe (build_engine) includes the scales
         g1_bytes = e_act * 2 * I * H * (bpe + scale_bytes)          # algorithmic weight bytes of GEMM1
-        achieved = g1_bytes / (prof_ms["gemm1"] * 1e-3) / 1e9
+        achieved = g1_bytes / (max(prof_ms["gemm1"], 1e-6) * 1e-3) / 1e9      # (a rank whose experts got no row: 0)
         traffic = None
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists():

@@ -551,3 +551,34 @@ def test_overlapped_rearrangement_over_gloo():
     assert all(ok for ok, _, _ in res.values()), res
     assert all(hot for _, hot, _ in res.values()), res
     assert res[0][2] == res[1][2], "ranks disagree on the placement"
+
+
+def test_plan_on_arbitrary_placements():
+    """placements that no policy produced: duplicates on a rank, empty slots, experts that vanish, many ranks"""
+    rng = np.random.default_rng(123)
+    for case in range(300):
+        ranks = int(rng.choice([1, 2, 3, 4, 8]))
+        per = int(rng.integers(1, 7))
+        E = int(rng.integers(1, 12))
+        P = ranks * per
+        old = rng.integers(-1, E, size=P)
+        present = sorted(set(old[old >= 0].tolist()))
+        if not present:
+            continue
+        new = rng.choice(np.array(present + [-1]), size=P)              # only experts somebody holds (or empty)
+        plan = eplb.plan_layer_transfers(old, new, ranks)
+        cur = _simulate(old, new, ranks, plan)
+        np.testing.assert_array_equal(cur[new >= 0], new[new >= 0], err_msg=f"case {case}")
+        np.testing.assert_array_equal(cur[new < 0], old[new < 0])      # slots that become empty are left alone
+        assert sum(plan.egress(ranks)) == len(plan.p2p)
+        # nothing is received that the rank already had
+        for sr, ss, dr, ds, e in plan.p2p:
+            assert e not in old[dr * per:(dr + 1) * per]
+
+
+def test_exchange_with_empty_slots_single_rank():
+    old = np.array([[0, -1, 2, 1]])
+    new = np.array([[2, 0, -1, 0]])
+    store = _make_store(0, old[0])
+    eplb.rearrange_expert_weights_inplace(old, new, [store], None, rank=0, world=1)
+    assert _store_matches(store, 0, new[0])

@@ -515,7 +515,8 @@ def rearrange_expert_weights_inplace(old_global_expert_indices, new_global_exper
                                      world: int | None = None) -> list[LayerPlan]:
     """Move expert weights so that layer l's physical slot p holds logical expert new[l, p]
     (rebalance_execute.py:511-616).  old/new: [layers, P] logical ids; expert_stores[l]: this rank's
-    experts of layer l.  Collective over ep_group (every rank calls it with the same maps).
+    experts of layer l -- an ExpertStore, or (the reference's `expert_weights[l]`) a sequence of parameter tensors
+    [num_local, ...], updated in place.  Collective over ep_group (every rank calls it with the same maps).
 
     Per batch of layers (as many as fit `max_staging_bytes` of staging on the busiest rank): pack outgoing
     experts once per slot -> ONE batch_isend_irecv for the whole batch -> import staged images into their
@@ -525,6 +526,8 @@ def rearrange_expert_weights_inplace(old_global_expert_indices, new_global_exper
         world = dist.get_world_size(ep_group) if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank(ep_group) if dist.is_initialized() else 0
+    # the reference passes `expert_weights`: per layer a sequence of parameter tensors [num_local, ...]
+    expert_stores = [st if hasattr(st, "export_expert") else TensorExpertStore(st) for st in expert_stores]
     plans = plan_rearrangement(old_global_expert_indices, new_global_expert_indices, expert_stores, world)
     for layers in _layer_batches(plans, expert_stores, world, max_staging_bytes):
         finish_expert_exchange(begin_expert_exchange(plans, layers, expert_stores, rank, ep_group), expert_stores)

@@ -576,6 +576,14 @@ def test_plan_on_arbitrary_placements():
             assert e not in old[dr * per:(dr + 1) * per]
 
 
+def test_exchange_accepts_the_reference_expert_weights_lists():
+    old = np.array([[0, 1, 2, 3]])
+    new = np.array([[3, 0, 1, 2]])
+    st = _make_store(0, old[0])
+    eplb.rearrange_expert_weights_inplace(old, new, [st.tensors], None, rank=0, world=1)      # raw tensor lists
+    assert _store_matches(st, 0, new[0])
+
+
 def test_exchange_with_empty_slots_single_rank():
     old = np.array([[0, -1, 2, 1]])
     new = np.array([[2, 0, -1, 0]])

@@ -10,7 +10,7 @@
 * the EplbState loop (load window -> policy -> exchange -> maps) over gloo;
 * the CPU restatement of the id-map / load-recording kernel (oracle.eplb_map_record) against the reference's
   own test of that kernel and against a slot-by-slot Python loop.  The HIP kernel itself is checked against the
-  restatement on the GPU (tests/test_zz_gpu_eplb.py).
+  restatement on the GPU (tests/test_zz3_gpu_eplb.py).
 """
 import os
 import socket

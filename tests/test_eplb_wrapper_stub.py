@@ -1,7 +1,7 @@
 """CPU check of the host-side marshalling of `ops.eplb_map_to_physical_and_record` (argument order, pointer /
 size / dtype conversions) and of the GPU test's own logic: liblkm's entry point is replaced by a stub that reads the
 raw pointers it is handed and computes the result with the CPU restatement, then the GPU parity test's body runs on
-CPU tensors.  (The HIP kernel itself is only exercised by tests/test_zz_gpu_eplb.py on an MI355X.)"""
+CPU tensors.  (The HIP kernel itself is only exercised by tests/test_zz3_gpu_eplb.py on an MI355X.)"""
 import ctypes as C
 
 import numpy as np
@@ -40,7 +40,7 @@ class _StubLib:
 @pytest.fixture
 def stubbed(monkeypatch):
     from lvllm_amd import _clib, ops
-    import tests.test_zz_gpu_eplb as gpu_tests
+    import tests.test_zz3_gpu_eplb as gpu_tests
     stub = _StubLib()
     monkeypatch.setattr(_clib, "lib", lambda: stub)
     monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)

@@ -1,7 +1,7 @@
 """Control logic of lvllm_amd/layer.py (SURVEY 8 rows a4 / a10 and the chaining of a1-a3, f2, f4) on the CPU: the
 operator namespace and the engine are replaced by doubles built on the CPU oracle (tests may do that), so what is under
 test is the ORDER and the plumbing -- routing -> EPLB map -> shared slots -> EP map -> decode / prefill -> post.
-The same composition on the real kernels: tests/test_zz_gpu_layer.py."""
+The same composition on the real kernels: tests/test_zz2_gpu_layer.py."""
 import types
 
 import numpy as np

@@ -6,7 +6,7 @@
 * expert images: export -> import moves an expert between slots and between engines bit for bit, for every
   weight format; a rearranged engine computes what the plain engine computes.
 
-(Named test_zz_* so that it runs after the parity suites of the hot path proper.)
+(Named test_zz3_* so that it runs after the parity suites of the hot path proper and after the less risky new suites.)
 """
 import ctypes as C
 

@@ -34,9 +34,10 @@ def _digest(src: Path, headers: list[Path]) -> str:
     h = hashlib.sha256()
     h.update(" ".join(FLAGS).encode())
     text = src.read_bytes()
-    # extension headers of the ABI (include/lkm_*.h) count only for the sources that include them, so
+    # extension headers of the ABI (include/lkm_*.h) and .inc fragments count only for the sources that include them, so
     # adding one does not recompile the 24 GEMM instantiation units
-    extra = [p for p in sorted((PKG.parent / "include").glob("lkm_*.h")) if p.name.encode() in text]
+    extra = [p for p in sorted((PKG.parent / "include").glob("lkm_*.h")) + sorted(CSRC.glob("*.inc"))
+             if p.name.encode() in text]
     for p in [src, *headers, *extra]:
         h.update(p.read_bytes())
     return h.hexdigest()[:16]

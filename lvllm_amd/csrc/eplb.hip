@@ -13,51 +13,7 @@
 #include "lkm_common.h"
 #include "../../include/lkm_eplb.h"
 
-namespace lkm {
-
-constexpr int kEplbBlock = 256;
-constexpr int kEplbHistMax = 2048;   // physical experts per layer that fit the LDS histogram (8 KiB)
-
-template <bool LDS_HIST>
-__global__ __launch_bounds__(kEplbBlock) void eplb_map_record_kernel(
-    const int32_t* ids, int64_t numel, int top_k, const int32_t* __restrict__ log2phy,
-    const int32_t* __restrict__ logcnt, int num_logical, int map_slots, int32_t* load, int load_size,
-    const int32_t* __restrict__ record_enabled, const int32_t* __restrict__ num_unpadded, int32_t* out) {
-    __shared__ int32_t hist[LDS_HIST ? kEplbHistMax : 1];
-    const int tid = threadIdx.x;
-    // workgroup-uniform: the switch is a device scalar so that a captured graph keeps honouring it
-    const bool rec = load != nullptr && (record_enabled == nullptr || *record_enabled != 0);
-    if (LDS_HIST && rec) {
-        for (int j = tid; j < load_size; j += kEplbBlock) hist[j] = 0;
-        __syncthreads();
-    }
-    const int64_t i = (int64_t)blockIdx.x * kEplbBlock + tid;
-    if (i < numel) {
-        const int32_t id = ids[i];
-        int32_t phys = -1;
-        if (id >= 0 && id < num_logical) {
-            int32_t cnt = logcnt[id];
-            cnt = cnt < 1 ? 1 : (cnt > map_slots ? map_slots : cnt);   // > map_slots only for inconsistent maps: stay in bounds
-            const uint32_t hashed = (uint32_t)(i / top_k) * 2654435769u;   // low 32 bits of t * floor(2^32 / phi)
-            phys = log2phy[(int64_t)id * map_slots + (int32_t)(hashed % (uint32_t)cnt)];
-        }
-        out[i] = phys;
-        if (rec && phys >= 0 && phys < load_size &&
-            (num_unpadded == nullptr || i < (int64_t)(*num_unpadded) * top_k)) {
-            if (LDS_HIST) atomicAdd(&hist[phys], 1);
-            else atomicAdd(&load[phys], 1);
-        }
-    }
-    if (LDS_HIST && rec) {
-        __syncthreads();
-        for (int j = tid; j < load_size; j += kEplbBlock) {
-            const int32_t v = hist[j];
-            if (v != 0) atomicAdd(&load[j], v);
-        }
-    }
-}
-
-}  // namespace lkm
+#include "eplb_kernel.inc"
 
 using namespace lkm;
 

@@ -101,4 +101,9 @@ def test_product_path_never_references_the_oracle():
                 bad.append(str(p))
             if re.search(r"^\s*(from|import)\s+oracle", t, re.M) or "liblkm_oracle" in t or "lkm_ref" in t:
                 bad.append(str(p) + " (imports it)")
+    # development scripts measure the product: they may not import the checker either (only tests/, bench.py's
+    # cpu_baseline leg and __graft_entry__.smoke() do)
+    for p in (ROOT / "tools").glob("*.py"):
+        if re.search(r"^\s*(from|import)\s+oracle", p.read_text(errors="ignore"), re.M):
+            bad.append(str(p) + " (tools/ imports the oracle)")
     assert not bad, bad

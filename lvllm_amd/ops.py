@@ -146,8 +146,12 @@ def router_topk(hidden_states: torch.Tensor, gate_weight: torch.Tensor, topk: in
 
 
 def determine_expert_map(ep_size: int, ep_rank: int, global_num_experts: int,
-                         expert_placement_strategy: str = "linear"):
-    """expert_map_manager.py:22-92 -> (local_num_experts, expert_map int32 [E] | None).  Host logic."""
+                         expert_placement_strategy: str = "linear", num_fused_shared_experts: int = 0):
+    """expert_map_manager.py:22-113 -> (local_num_experts, expert_map int32 | None).  Host logic.
+    With num_fused_shared_experts = n > 0 (shared experts folded into the engine behind this rank's routed
+    experts, lvllm_amd/shared_experts.py) the map is the reference's extended map [E + n] (ids E+i ->
+    local_num_experts + i, :100-110) plus ONE more entry -1 for the sentinel id E + n: the reference masks
+    that id with a separate expert_mask whose last entry is 0 (:94-99), here the id map itself drops it."""
     assert ep_size > 0
     if ep_size == 1:
         return global_num_experts, None
@@ -162,6 +166,9 @@ def determine_expert_map(ep_size: int, ep_rank: int, global_num_experts: int,
     else:
         raise ValueError(f"Unsupported expert placement strategy '{expert_placement_strategy}', "
                          "expected one of ('linear', 'round_robin')")
+    if num_fused_shared_experts > 0:
+        tail = [local + i for i in range(num_fused_shared_experts)] + [-1]
+        emap = torch.cat((emap, torch.tensor(tail, dtype=torch.int32)))
     return local, emap
 
 

@@ -10,6 +10,8 @@ Executed (paths relative to /root/reference):
     preserve_intragpu_slots, rebalance_experts)          vllm/distributed/eplb/policy/default.py:20-332
   compute_logical_maps                                    vllm/distributed/eplb/eplb_state.py:1159-1235
   EplbState.build_initial_global_physical_to_logical_map  vllm/distributed/eplb/eplb_state.py:297-314
+  determine_expert_map with num_fused_shared_experts / return_expert_mask
+                                                          vllm/model_executor/layers/fused_moe/expert_map_manager.py:22-113
 Also stored: the known-answer vectors of the reference's own test of the policy
 (tests/distributed/test_eplb_algo.py:12-72, the DeepSeek EPLB example), after checking that the
 reference code run here reproduces them.
@@ -146,6 +148,22 @@ def main():
     for ci, (e, r) in enumerate([(8, 8), (128, 16), (256, 32), (6, 0), (4, 9)]):
         out[f"init{ci}"] = np.array([e, r] + list(build_initial(e, r)), dtype=np.int64)
     out["n_init"] = np.array(5)
+
+    # ---- expert map with fused shared experts (map tail + mask; lvllm_amd/shared_experts.py, ops.determine_expert_map)
+    path = REF / "vllm/model_executor/layers/fused_moe/expert_map_manager.py"
+    ns = {"torch": torch, "ExpertPlacementStrategy": str}
+    for node in ast.parse(path.read_text()).body:
+        if isinstance(node, ast.FunctionDef) and node.name == "determine_expert_map":
+            exec(compile(ast.Module(body=[node], type_ignores=[]), str(path), "exec"), ns)
+    ci = 0
+    for E, ep, n_sh in [(8, 2, 1), (8, 4, 2), (10, 3, 1), (128, 8, 1), (256, 8, 2)]:
+        for strat in ("linear", "round_robin"):
+            for r in range(ep):
+                n_loc, emap, mask = ns["determine_expert_map"](ep, r, E, strat, n_sh, True)
+                out[f"sm{ci}_meta"] = np.array([E, ep, r, n_sh, 0 if strat == "linear" else 1, n_loc], np.int64)
+                out[f"sm{ci}_map"], out[f"sm{ci}_mask"] = emap.numpy(), mask.numpy()
+                ci += 1
+    out["n_sm"] = np.array(ci)
 
     np.savez_compressed(OUT / "eplb.npz", **out)
     print(f"wrote {OUT / 'eplb.npz'} ({(OUT / 'eplb.npz').stat().st_size} bytes, {len(out)} arrays)")

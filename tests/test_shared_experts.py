@@ -135,3 +135,20 @@ def test_slot_buffers_follow_the_reference_layout():
         s.inject(torch.zeros((2, 4)), torch.zeros((2, 4), dtype=torch.int32))
     with pytest.raises(ValueError):
         se.SharedExpertSlots(8, 0, 2)
+
+
+def test_expert_map_with_fused_shared_experts_equals_the_reference_run():
+    """ops.determine_expert_map(..., num_fused_shared_experts=n): the first E + n entries are the reference's
+    extended expert_map, and (map >= 0) is the reference's expert_mask, whose last entry masks the sentinel id
+    (goldens: tests/golden/make_golden_eplb.py runs expert_map_manager.py:22-113 with return_expert_mask=True)"""
+    import os
+    from lvllm_amd import ops
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "eplb.npz"))
+    assert int(gold["n_sm"]) >= 50
+    for ci in range(int(gold["n_sm"])):
+        E_, ep, r, n_sh, strat, n_loc = gold[f"sm{ci}_meta"].tolist()
+        local, emap = ops.determine_expert_map(ep, r, E_, "linear" if strat == 0 else "round_robin", n_sh)
+        assert local == n_loc and emap.dtype == torch.int32 and emap.numel() == E_ + n_sh + 1
+        np.testing.assert_array_equal(emap[:-1].numpy(), gold[f"sm{ci}_map"])
+        np.testing.assert_array_equal((emap >= 0).to(torch.int32).numpy(), gold[f"sm{ci}_mask"])
+        np.testing.assert_array_equal(emap[E_:].numpy(), se.shared_expert_map_tail(n_loc, n_sh).numpy())

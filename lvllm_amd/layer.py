@@ -47,13 +47,18 @@ class RoutedExpertsLayer:
     def __init__(self, engine, routing: RoutingConfig, *, gate_weight: torch.Tensor | None = None,
                  expert_map: torch.Tensor | None = None, eplb_state: EplbLayerState | None = None,
                  shared_slots: SharedExpertSlots | None = None, shared_gate_weight: torch.Tensor | None = None,
-                 check_nan_in_output: bool = False, max_num_seqs: int | None = None, ops=None):
+                 check_nan_in_output: bool = False, max_num_seqs: int | None = None, expert_parallel=None,
+                 ops=None):
         """engine: lvllm_amd.ops.RoutedExpertsEngine holding this rank's (physical, + shared) experts.
         gate_weight [E, H]: run the gate projection inside the router operator (f2); else forward() takes logits.
         expert_map int32 [P (+ shared + sentinel)]: global -> local ids of this EP rank, None without EP.
         eplb_state: logical -> physical maps + load counters of this layer (lvllm_amd.eplb.EplbState.layer_state).
         shared_slots: the shared experts' slot buffers when they are folded into the engine (shared_experts.py);
         shared_gate_weight [1, H]: Qwen2-MoE style sigmoid gate of the shared expert.
+        expert_parallel: an lvllm_amd.ep.ExpertParallelExperts whose local_compute runs `engine`; the routed rows
+        then travel by all-to-all (tokens stay on their rank) and forward() returns the COMPLETE routed output of
+        this rank's tokens -- no reduction is left to the caller.  Exclusive with expert_map (the replicated-token
+        form) and, for now, with folded shared experts.
         ops: the operator namespace (default lvllm_amd.ops, the HIP kernels); tests inject a CPU double."""
         if ops is None:
             from . import ops as _ops
@@ -72,6 +77,10 @@ class RoutedExpertsLayer:
             raise ValueError("grouped top-k needs num_expert_group and topk_group")
         if shared_gate_weight is not None and shared_slots is None:
             raise ValueError("a shared-expert gate needs shared_slots")
+        if expert_parallel is not None and (expert_map is not None or shared_slots is not None):
+            raise ValueError("expert_parallel dispatches global ids itself: no expert_map; folded shared experts "
+                             "are not dispatched (run them on the token's own rank)")
+        self.expert_parallel = expert_parallel
         self._decode_out: torch.Tensor | None = None          # the shared fp32 buffer of the cpu_decode contract
 
     # ---- a1 / a2 (+ gate projection, f2)
@@ -97,7 +106,8 @@ class RoutedExpertsLayer:
     # ---- the whole step
     def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor | None = None) -> torch.Tensor:
         """[M, H] activations (+ [M, E] logits unless the layer owns the gate) -> [M, H] in the activation dtype:
-        the routed (+ folded shared) experts' output of THIS rank, before the TP/EP reduction."""
+        the routed (+ folded shared) experts' output of THIS rank, before the TP/EP reduction (with
+        `expert_parallel`: the complete output for this rank's tokens)."""
         M = hidden_states.size(0)
         if M == 0:
             return torch.empty_like(hidden_states)
@@ -115,7 +125,12 @@ class RoutedExpertsLayer:
             topk_weights, topk_ids = self.shared_slots.inject(topk_weights, topk_ids, gate)
         if self.expert_map is not None:                       # routed_experts.py:1332-1342
             topk_ids = self.ops.global_to_local_expert_ids(topk_ids, self.expert_map)
-        if M <= self.max_num_seqs:                            # the cpu_decode contract: fp32 into the shared buffer
+        if self.expert_parallel is not None:                  # rows -> owners -> local experts -> back, fp32 [M, H]
+            out = self.expert_parallel.forward(hidden_states, topk_weights, topk_ids)
+            if self.check_nan_in_output:
+                torch.nan_to_num(out, nan=0.0, out=out)
+            out = out.to(hidden_states.dtype)
+        elif M <= self.max_num_seqs:                          # the cpu_decode contract: fp32 into the shared buffer
             buf = self._decode_out
             if buf is None or buf.device != hidden_states.device or buf.size(1) != hidden_states.size(1):
                 buf = torch.empty((self.max_num_seqs, hidden_states.size(1)), dtype=torch.float32,

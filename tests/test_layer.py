@@ -197,3 +197,57 @@ def test_eplb_shared_experts_and_ep_map_chain_in_the_reference_order():
     np.testing.assert_allclose(total.numpy(), want, atol=0.03 * np.abs(want).max(), rtol=2e-2)      # two bf16 roundings
     # both ranks recorded the same tokens: the load view counts every routed slot twice, shared slots never
     assert int(st.expert_load_pass.sum()) == 2 * 11 * K
+
+
+# ------------------------------------------------------------------------------------------ the layer over EP + EPLB
+def _ep_layer_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lvllm_amd.ep import ExpertParallelExperts
+        from tests.test_ep_gloo import _torch_pack
+        calls = []
+        red = 4
+        P, per = E + red, (E + red) // world
+        w13, w2 = _weights(E)
+        st = eplb.EplbState(1, E, red, window_size=2, step_interval=1)
+        mine = torch.tensor(st.local_logical_ids(0))
+        l13, l2 = w13[mine].contiguous(), w2[mine].contiguous()
+        st.expert_stores = [eplb.TensorExpertStore([l13, l2])]
+
+        class _Live:                                              # engine double over the tensors the exchange maintains
+            cfg = types.SimpleNamespace(max_num_seqs=64, expert_num=per)
+
+            def decode(self, x, tw, ids, out=None):
+                if x.shape[0] == 0:
+                    return torch.zeros((0, H))
+                d = orc.MoeDesc(E=per, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+                return torch.from_numpy(orc.moe(d, torch_to_bits(l13), torch_to_bits(l2), torch_to_bits(x), ids.numpy(),
+                                                tw.numpy()))
+        eng = _Live()
+        ep = ExpertParallelExperts(lambda rows, lids, ws: eng.decode(rows, ws, lids), P, H, mode="a2a", pack=_torch_pack)
+        layer = RoutedExpertsLayer(eng, RoutingConfig(K, E, routed_scaling_factor=2.0), eplb_state=st.layer_state(0),
+                                   expert_parallel=ep, ops=_oracle_ops(calls))
+        x, logits = _x(10, seed=30 + rank)
+        logits[:, 2] += 2.0                                        # a hot expert on every rank
+        want = _ref(w13, w2, x, logits, 2.0)
+        ok = bool(np.allclose(layer.forward(x, logits).float().numpy(), want, atol=0.02 * np.abs(want).max(), rtol=2e-2))
+        before = st.physical_to_logical_map.clone()
+        ok = ok and st.step() and not torch.equal(before, st.physical_to_logical_map)      # rearranged
+        ok = ok and bool(np.allclose(layer.forward(x, logits).float().numpy(), want, atol=0.02 * np.abs(want).max(), rtol=2e-2))
+        q.put((rank, (ok, calls[:2], int(st.logical_replica_count[0, 2]))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_layer_over_expert_parallel_all_to_all_and_eplb():
+    from tests.test_eplb import _spawn
+    res = _spawn(_ep_layer_worker, 2)
+    assert all(ok for ok, _, _ in res.values()), res
+    assert all(c == ["topk", "eplb"] for _, c, _ in res.values())
+    assert all(n >= 2 for _, _, n in res.values()), "the hot expert was not replicated"
+    with pytest.raises(ValueError):
+        RoutedExpertsLayer(_Engine(*_weights(E), []), RoutingConfig(K, E), expert_parallel=object(),
+                           expert_map=torch.zeros(E, dtype=torch.int32), ops=_oracle_ops([]))

@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf"],
                     help="router logits: randn (uniform-ish) or randn + Zipf(s=1) expert popularity bias (SURVEY 8d)")
     ap.add_argument("--tune", default="", help="comma list key=value for lkm_set_tuning (nt1,nt2,kw1,sk2,tbmax)")
+    ap.add_argument("--flush-cache", action="store_true",
+                    help="also report ms_per_step_cold: every step preceded by a 1 GiB write that evicts the L2s and the "
+                         "256 MB Infinity Cache (SURVEY 8d flush variant; the headline numbers are unaffected)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -302,6 +305,23 @@ def main():
     dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     tokens_per_s = M * world / (dt / args.steps)
+
+    # ---- optional: cold-cache variant.  Not part of the timed K steps above.
+    cold_ms = None
+    if args.flush_cache and rank == 0:
+        flush = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        n_cold = min(args.steps, 50)
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_cold)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_cold)]
+        if not use_ep:                                   # EP steps are collective: every rank would have to join
+            for i in range(n_cold):
+                flush.fill_(i & 0xFF)
+                starts[i].record()
+                run()
+                ends[i].record()
+            torch.cuda.synchronize()
+            cold_ms = sum(a.elapsed_time(b) for a, b in zip(starts, ends)) / n_cold
+        del flush
 
     # ---- dominant-kernel roofline: GEMM1 duration from HIP events on the launch stream
     roofline = None
@@ -425,6 +445,8 @@ def main():
                        "launch": launch, "geometry": eng.engine.describe()},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if cold_ms is not None:
+            line["ms_per_step_cold"] = round(cold_ms, 4)     # events around each step, caches evicted before it
         print(json.dumps(line), flush=True)
     if use_ep:
         # rank 0 spent a few ms more (kernel profiling, the JSON line): tear the communicator down with every rank

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import oracle as orc
-from tests.helpers import bits_to_torch, dt_of, load_golden, make_routing, torch_to_bits
+from tests.helpers import bits_to_torch, load_golden, make_routing, torch_to_bits
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

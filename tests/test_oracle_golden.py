@@ -3,7 +3,6 @@
 import math
 
 import numpy as np
-import pytest
 
 from oracle import oracle as orc
 from tests.helpers import load_golden

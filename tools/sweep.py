@@ -4,7 +4,6 @@ the decode path (lkm_set_tuning), printed as a table + JSON lines.  Development 
 from __future__ import annotations
 
 import argparse
-import itertools
 import json
 import sys
 from pathlib import Path

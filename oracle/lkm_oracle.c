@@ -395,6 +395,10 @@ typedef struct {
     const float* gs13;          /* NVFP4 only: per-expert f32 multipliers [E] (the reference passes
                                    1/global_scale when need_reciprocal_global_scale,            */
     const float* gs2;           /*   routed_experts.py:1686-1688); NULL = 1.0 */
+    int32_t int4_unrounded;     /* int4 only, 1 = weight (q-8)*s kept in fp32 (exact) instead of rounded to the act
+                                   dtype: the result of applying the group scale to fp32 partial sums -- NOT the
+                                   reference's semantics (0), a checker for a candidate kernel mode that stays
+                                   inside the reference's tolerance (tests/test_oracle_golden.py) */
 } OrMoeDesc;
 
 /* FP4 E2M1 magnitudes (tests/kernels/quantization/nvfp4_utils.py:11-13 kE2M1ToFloat;
@@ -462,7 +466,7 @@ static void dequant_row(const OrMoeDesc* d, const void* w, const void* scale, co
         for (int64_t k = 0; k < K; ++k) {
             int q = (p[k >> 1] >> ((k & 1) * 4)) & 0xf;
             float sf = d->act_dtype == OR_BF16 ? bf16_to_f32(s[k / gK]) : f16_to_f32(s[k / gK]);
-            out[k] = round_act((float)(q - 8) * sf, d->act_dtype);
+            out[k] = d->int4_unrounded ? (float)(q - 8) * sf : round_act((float)(q - 8) * sf, d->act_dtype);
         }
     } break;
     }

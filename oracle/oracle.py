@@ -166,7 +166,7 @@ class _Desc(C.Structure):
                 ("activation", C.c_int32), ("swiglu_alpha", C.c_float), ("swiglu_limit", C.c_float),
                 ("act_dtype", C.c_int32), ("wfmt", C.c_int32), ("groupN", C.c_int32),
                 ("groupK", C.c_int32), ("round_gemm1", C.c_int32), ("w8a8", C.c_int32),
-                ("gs13", C.c_void_p), ("gs2", C.c_void_p)]
+                ("gs13", C.c_void_p), ("gs2", C.c_void_p), ("int4_unrounded", C.c_int32)]
 
 
 @dataclass
@@ -184,6 +184,7 @@ class MoeDesc:
     groupK: int = 0
     round_gemm1: bool = False
     w8a8: bool = False
+    int4_unrounded: bool = False       # candidate int4 mode (scale on fp32 partial sums); not the reference's semantics
 
 
 def moe(d: MoeDesc, w13, w2, x, ids, tw, s13=None, s2=None, gs13=None, gs2=None) -> np.ndarray:
@@ -201,7 +202,8 @@ def moe(d: MoeDesc, w13, w2, x, ids, tw, s13=None, s2=None, gs13=None, gs2=None)
     gs2 = None if gs2 is None else _c(gs2, np.float32)
     cd = _Desc(d.E, d.H, d.I, int(d.has_gate), d.activation, d.swiglu_alpha, d.swiglu_limit,
                d.act_dtype, d.wfmt, d.groupN, d.groupK, int(d.round_gemm1), int(d.w8a8),
-               None if gs13 is None else gs13.ctypes.data, None if gs2 is None else gs2.ctypes.data)
+               None if gs13 is None else gs13.ctypes.data, None if gs2 is None else gs2.ctypes.data,
+               int(d.int4_unrounded))
     out = np.empty((M, d.H), np.float32)
     rc = lib().lkm_or_moe(C.byref(cd), _p(w13), _p(w2), _p(s13), _p(s2), _p(x), _p(ids), _p(tw),
                           C.c_int(M), C.c_int(K), _p(out))

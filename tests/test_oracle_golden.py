@@ -165,6 +165,25 @@ def test_int4_quantiser_and_moe_vs_reference():
             np.testing.assert_array_equal(out2, out)
 
 
+def test_int4_scale_on_partial_sums_stays_inside_the_reference_tolerance():
+    """Checker for a candidate kernel mode: group scale applied to fp32 partial sums = the weight (q-8)*s
+    kept unrounded.  Not the reference's semantics, but inside its int4 tolerance (atol 2e-2, test_moe.py:565-693)
+    against the reference's own golden outputs, and close to the rounded-weight result."""
+    n = 0
+    for i, c in load_golden("moe_int4.npz"):
+        m, nn, k, e, topk, g, dt = [int(v) for v in c["meta"]]
+        kw = dict(E=e, H=k, I=nn, act_dtype=dt, wfmt=orc.W_INT4, groupN=1, groupK=g)
+        a = orc.moe(orc.MoeDesc(**kw), c["q1"], c["q2"], c["a"], c["ids"], c["tw"], s13=c["s1"], s2=c["s2"])
+        b = orc.moe(orc.MoeDesc(int4_unrounded=True, **kw), c["q1"], c["q2"], c["a"], c["ids"], c["tw"], s13=c["s1"],
+                    s2=c["s2"])
+        ref = orc.bits_to_f32(c["out"], dt)
+        np.testing.assert_allclose(b, ref, atol=2e-2, rtol=0, err_msg=f"case {i}")
+        assert np.abs(a - b).max() <= 5e-3 * max(1.0, np.abs(a).max())
+        assert not np.array_equal(a, b)
+        n += 1
+    assert n > 0
+
+
 def test_fp4_dequant_and_moe_vs_reference():
     """MXFP4 (dq_mxfp4_torch) and NVFP4 (dequantize_nvfp4_to_dtype) dequantisation bit-exact; MoE on
     those weights vs the reference's CPU oracle with its own tolerance (allclose_default.py:8-9)."""

@@ -590,3 +590,47 @@ def test_exchange_with_empty_slots_single_rank():
     store = _make_store(0, old[0])
     eplb.rearrange_expert_weights_inplace(old, new, [store], None, rank=0, world=1)
     assert _store_matches(store, 0, new[0])
+
+
+def _grouped_state_worker(rank, world, port, q):
+    """4 ranks, 16 experts in 4 groups (group-limited routing models: DeepSeek-V3 / GLM), 8 redundant slots: the
+    hierarchical policy inside the loop; every rank ends with the same maps and the weights its slots name"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, E, red = 2, 16, 8
+        st = eplb.EplbState(L, E, red, num_groups=4, num_nodes=1, window_size=3, step_interval=3)
+        st.expert_stores = [_make_store(l, st.local_logical_ids(l)) for l in range(L)]
+        P = E + red
+        init = st.physical_to_logical_map.clone()
+        rng = np.random.default_rng(7)                       # the same loads on every rank (they are summed anyway)
+        per_logical = (rng.random((L, E)) ** 4 * 1000).astype(np.int64) + 1
+        for step in range(3):
+            for l in range(L):
+                view = st.layer_state(l).expert_load_view
+                cnt = torch.bincount(init[l], minlength=E)
+                view += torch.from_numpy(per_logical[l])[init[l]].div(cnt[init[l]], rounding_mode="floor").to(torch.int32)
+            ran = st.step()
+        p2l = st.physical_to_logical_map
+        ok = ran and not torch.equal(p2l, init)
+        ok = ok and all(sorted(set(p2l[l].tolist())) == list(range(E)) for l in range(L))
+        ok = ok and all(_store_matches(st.expert_stores[l], l, st.local_logical_ids(l)) for l in range(L))
+        # the load per rank after the rearrangement (per-replica loads) is flatter than before
+        def imbalance(m):
+            worst = 0.0
+            for l in range(L):
+                c = torch.bincount(m[l], minlength=E).double()
+                load = (torch.from_numpy(per_logical[l]).double() / c)[m[l]].view(world, -1).sum(1)
+                worst = max(worst, float(load.max() / load.mean()))
+            return worst
+        q.put((rank, (ok, p2l.tolist(), imbalance(init), imbalance(p2l))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_state_loop_with_expert_groups_over_four_ranks():
+    res = _spawn(_grouped_state_worker, 4)
+    assert all(ok for ok, *_ in res.values()), res
+    assert len({str(v[1]) for v in res.values()}) == 1, "ranks disagree on the placement"
+    before, after = res[0][2], res[0][3]
+    assert after < before and after < 1.25, (before, after)

@@ -558,7 +558,8 @@ class EplbState:
                  num_groups: int = 1, num_nodes: int = 1, window_size: int = 1000, step_interval: int = 3000,
                  device: torch.device | str = "cpu", ep_group=None, policy=DefaultEplbPolicy,
                  expert_stores: Sequence[ExpertStore] | None = None, overlap: bool = False,
-                 commit_after_steps: int = 1, max_staging_bytes: int = 8 << 30):
+                 commit_after_steps: int = 1, max_staging_bytes: int = 8 << 30,
+                 initial_physical_to_logical_map: torch.Tensor | None = None):
         self.group = ep_group
         self.expert_stores = expert_stores                   # one per layer; may be attached later
         # overlap: the exchange of a batch of layers is only POSTED at the step that is due; forwards keep running
@@ -586,8 +587,17 @@ class EplbState:
         self.window_size, self.step_interval = window_size, step_interval
         self.policy = policy
         self.device = torch.device(device)
-        init = build_initial_global_physical_to_logical_map(num_logical_experts, num_redundant_experts)
-        self.physical_to_logical_map = torch.tensor(init, dtype=torch.int64).repeat(num_layers, 1)   # CPU
+        if initial_physical_to_logical_map is not None:      # resume a saved placement (cf. EplbState.from_mapping, :1043-1085)
+            p2l0 = initial_physical_to_logical_map.detach().to("cpu", torch.int64).reshape(num_layers, -1).clone()
+            if p2l0.size(1) != self.P or int(p2l0.max()) >= self.E:
+                raise ValueError(f"initial placement must be [{num_layers}, {self.P}] with ids below {self.E}")
+            for row in p2l0:
+                if set(row[row >= 0].tolist()) != set(range(self.E)):
+                    raise ValueError("initial placement: every logical expert needs at least one physical slot")
+            self.physical_to_logical_map = p2l0
+        else:
+            init = build_initial_global_physical_to_logical_map(num_logical_experts, num_redundant_experts)
+            self.physical_to_logical_map = torch.tensor(init, dtype=torch.int64).repeat(num_layers, 1)   # CPU
         i32 = dict(dtype=torch.int32, device=self.device)
         self.logical_to_physical_map = torch.full((self.L, self.E, self.R), -1, **i32)
         self.logical_replica_count = torch.zeros((self.L, self.E), **i32)

@@ -399,6 +399,16 @@ def test_state_single_process_and_dummy_steps():
     assert st.global_logical_load().tolist() == [[1.0, 2.0, 3.0, 4.0]]
     with pytest.raises(RuntimeError):
         st.rearrange()                                                      # no expert stores attached
+    # resuming a saved placement
+    saved = torch.tensor([[2, 0, 1, 3, 0, 2], [3, 2, 1, 0, 1, 1]])
+    st2 = eplb.EplbState(2, 4, 2, initial_physical_to_logical_map=saved)
+    assert torch.equal(st2.physical_to_logical_map, saved)
+    assert st2.logical_replica_count.tolist() == [[2, 1, 2, 1], [1, 3, 1, 1]]
+    assert st2.logical_to_physical_map[0, 0].tolist() == [1, 4, -1] and st2.logical_to_physical_map[1, 1].tolist() == [2, 4, 5]
+    with pytest.raises(ValueError):
+        eplb.EplbState(1, 4, 2, initial_physical_to_logical_map=torch.tensor([[0, 1, 2, 2, 1, 0]]))     # expert 3 missing
+    with pytest.raises(ValueError):
+        eplb.EplbState(1, 4, 2, initial_physical_to_logical_map=torch.tensor([[0, 1, 2, 3]]))           # wrong width
 
 
 # ------------------------------------------------------------------------------------------ id map restatement

@@ -131,6 +131,21 @@ int lkm_prefill_host(LkmHandle h, int32_t num_tokens, int32_t top_k, const int32
 int lkm_prefill_device(LkmHandle h, const void* hidden, void* out, const int32_t* topk_ids,
                        const float* topk_weights, int32_t num_tokens, int32_t top_k, void* stream);
 
+/*
+ * The same operator on STRIDED inputs, output dtype chosen by the caller: what lkm_decode (out fp32) and
+ * lkm_prefill_device (out = activation dtype) are special cases of.  Exists for the expert-parallel
+ * exchange (lkm_ep_pack_tokens below): rows arrive as [token row | ids | weights] records and are consumed
+ * in place, with no unpack copy.  Strides are in ELEMENTS of the respective array (hidden_ld >= H and a
+ * multiple of 8; ids_ld, weights_ld >= top_k); `id_offset` is subtracted from every id >= 0 before use
+ * (ids that fall outside [0, expert_num) are skipped like -1): a receiver of GLOBAL ids passes its first
+ * expert here (the linear form of RoutedExperts.global_to_local_expert_ids, routed_experts.py:1332-1342).
+ * out [num_tokens,H] contiguous in out_dtype (LKM_DT_F32 or the activation dtype), every row written.
+ * DEVICE pointers, asynchronous on `stream`, graph-capturable.
+ */
+int lkm_forward_strided(LkmHandle h, void* stream, int32_t num_tokens, int32_t top_k, const void* hidden,
+                        int64_t hidden_ld, const int32_t* topk_ids, int64_t ids_ld, int32_t id_offset,
+                        const float* topk_weights, int64_t weights_ld, void* out, int32_t out_dtype);
+
 /* -------------------------------------------------------------------------------------------
  * Routing (runs just before the engine call, moe_runner.py:577-600).
  *
@@ -181,15 +196,35 @@ int lkm_map_expert_ids(void* stream, const int32_t* ids, int64_t n, const int32_
                        int32_t E, int32_t* out);
 
 /*
- * Expert-parallel dispatch pack (the MI355X replacement of the CPU-NUMA tier: experts sharded over
- * the GPUs of a node).  Fixed capacity M*K rows per destination rank, so the following
- * all-to-all needs no split-size exchange and no host synchronisation.  Placement = the reference's
- * linear map (expert_map_manager.py:62-79).  send_x [ep][M*K][H] (activation dtype, 16-bit),
- * send_ids int32 [ep][M*K] (local id at the destination, -1 = not routed there), send_w fp32.
+ * Expert-parallel exchange (the MI355X replacement of the CPU-NUMA tier: experts sharded over the GPUs of a
+ * node; stands where the reference's all-to-all prepare/finalize backends stand,
+ * vllm/model_executor/layers/fused_moe/all2all_utils.py + modular_kernel.py:257-418).  TOKEN-granular and
+ * fixed-capacity: a token travels to a rank at most ONCE, whatever number of its top-k experts live there, as
+ * one record  [ H x 16-bit activations | top_k x int32 ids | top_k x fp32 weights ]  padded to 16 bytes
+ * (lkm_ep_row_bytes); every destination gets `capacity` record slots, so the all-to-all that follows has
+ * equal splits: no split-size exchange, no host synchronisation, capturable in a hipGraph.  capacity =
+ * num_tokens is the exact worst case (no overflow possible); with a smaller capacity the tokens that do not
+ * fit are NOT sent and are counted in *overflow (the caller re-runs the step through its ragged path).
+ * Placement = the reference's linear map (expert_map_manager.py:62-79).
+ *   send    [ep][capacity][row_bytes]; ids of a record are LOCAL ids at the destination (global_ids = 0) or
+ *           GLOBAL ids (global_ids = 1, for receivers that apply expert_map themselves), -1 for the slots of
+ *           the token that live on other ranks; unused record slots carry ids = -1 (their activations are
+ *           not written and never read);
+ *   slot_of int32 [ep][num_tokens]: record index of token m in the block sent to rank p, -1 = not sent;
+ *   overflow int32 [1], incremented by the number of (token, rank) pairs dropped for lack of capacity.
  */
-int lkm_ep_pack(void* stream, const void* hidden, const int32_t* topk_ids, const float* topk_weights,
-                int32_t M, int32_t K, int32_t H, int32_t num_experts, int32_t ep_size, void* send_x,
-                int32_t* send_ids, float* send_w);
+int64_t lkm_ep_row_bytes(int32_t H, int32_t K);
+int lkm_ep_pack_tokens(void* stream, const void* hidden, const int32_t* topk_ids, const float* topk_weights,
+                       int32_t M, int32_t K, int32_t H, int32_t num_experts, int32_t ep_size, int32_t capacity,
+                       int32_t global_ids, void* send, int32_t* slot_of, int32_t* overflow);
+/*
+ * The return leg: back [ep][capacity][H] (back_dtype: fp32 or a 16-bit activation dtype) holds, from every
+ * rank p, the weighted sum over p's experts of the records this rank sent there;
+ * out[m] = sum_p back[p][slot_of[p][m]] in fp32, p ascending (fixed order), written in out_dtype.
+ * Every row of out [num_tokens,H] is written (zeros for a token no rank computed).
+ */
+int lkm_ep_combine(void* stream, const void* back, int32_t back_dtype, const int32_t* slot_of, int32_t M,
+                   int32_t H, int32_t ep_size, int32_t capacity, void* out, int32_t out_dtype);
 
 /*
  * Token->expert scatter metadata, exposed for tests and for the expert-parallel host code.

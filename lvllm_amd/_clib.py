@@ -64,8 +64,15 @@ _SIGS = {
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lkm_map_expert_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                      C.c_void_p]),
-    "lkm_ep_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lkm_forward_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                      C.c_int32]),
+    "lkm_ep_row_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "lkm_ep_pack_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "lkm_ep_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_int32, C.c_void_p, C.c_int32]),
     "lkm_sort_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "lkm_last_error": (C.c_char_p, []),

@@ -14,13 +14,26 @@ namespace lkm {
 
 constexpr int kMaxLocalExperts = 512;
 
+// Slot ids as the expert-parallel exchange hands them over: slot i = column i % K of token i / K in an
+// [M][ld] int32 array (ld == K: the plain [M*K] list), GLOBAL ids made local by subtracting `off`
+// (an id that lands outside [0, E) is not local: -1).
+struct SlotIds {
+    const int32_t* p;
+    int K, ld, off;
+    __device__ __forceinline__ int at(int i, int E) const {
+        int id = ld == K ? p[i] : p[(size_t)(i / K) * ld + (i % K)];
+        if (id >= 0) id -= off;
+        return (id < 0 || id >= E) ? -1 : id;
+    }
+};
+
 // meta[0] = number of active experts, meta[1] = total routed rows, meta[2] = max rows of one expert,
 // meta[3] = number of (expert, token-tile) work items when tile_rows > 0.
 // One workgroup of THREADS threads (64 / 256 / 1024 by problem size: the decode case M*K <= 64 runs as
 // a single wavefront, where barriers are free).
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
-    const int32_t* __restrict__ ids, int n_slots, int E, int32_t* __restrict__ counts,
+    const SlotIds ids, int n_slots, int E, int32_t* __restrict__ counts,
     int32_t* __restrict__ offsets, int32_t* __restrict__ sorted_slot,
     int32_t* __restrict__ pos_of_slot, int32_t* __restrict__ active, int32_t* __restrict__ meta,
     int tile_rows, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0) {
@@ -39,8 +52,8 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
     }
     __syncthreads();
     for (int i = tid; i < n_slots; i += THREADS) {
-        int id = ids[i];
-        if (id >= 0 && id < E) atomicAdd(&cnt[id], 1);
+        const int id = ids.at(i, E);
+        if (id >= 0) atomicAdd(&cnt[id], 1);
     }
     __syncthreads();
 
@@ -119,10 +132,7 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
         __syncthreads();
         const int i = base + tid;
         int id = -1;
-        if (i < n_slots) {
-            id = ids[i];
-            if (id < 0 || id >= E) id = -1;
-        }
+        if (i < n_slots) id = ids.at(i, E);
         // rank among equal ids inside this wave (lower lanes first)
         int rank = 0, wc = 0;
         bool done = id < 0;
@@ -165,15 +175,15 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
 // scatters.  hist is [n_chunks][E].
 constexpr int kChunk = 1024;
 
-__global__ __launch_bounds__(kChunk) void sort_hist_kernel(const int32_t* __restrict__ ids, int n_slots,
+__global__ __launch_bounds__(kChunk) void sort_hist_kernel(const SlotIds ids, int n_slots,
                                                           int E, int32_t* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     for (int e = threadIdx.x; e < E; e += kChunk) smem[e] = 0;
     __syncthreads();
     const int i = blockIdx.x * kChunk + threadIdx.x;
     if (i < n_slots) {
-        const int id = ids[i];
-        if (id >= 0 && id < E) atomicAdd(&smem[id], 1);
+        const int id = ids.at(i, E);
+        if (id >= 0) atomicAdd(&smem[id], 1);
     }
     __syncthreads();
     for (int e = threadIdx.x; e < E; e += kChunk) hist[(size_t)blockIdx.x * E + e] = smem[e];
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(1024) void sort_scan_kernel(int n_chunks, int E, in
     }
 }
 
-__global__ __launch_bounds__(kChunk) void sort_scatter_kernel(const int32_t* __restrict__ ids, int n_slots,
+__global__ __launch_bounds__(kChunk) void sort_scatter_kernel(const SlotIds ids, int n_slots,
                                                              int E, const int32_t* __restrict__ hist,
                                                              const int32_t* __restrict__ offsets,
                                                              int32_t* __restrict__ sorted_slot,
@@ -277,10 +287,7 @@ __global__ __launch_bounds__(kChunk) void sort_scatter_kernel(const int32_t* __r
     __syncthreads();
     const int i = blockIdx.x * kChunk + tid;
     int id = -1;
-    if (i < n_slots) {
-        id = ids[i];
-        if (id < 0 || id >= E) id = -1;
-    }
+    if (i < n_slots) id = ids.at(i, E);
     int rank = 0;
     bool done = id < 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -317,8 +324,8 @@ template <typename OutT>
 __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ y, int SK,
                                                       size_t sk_stride,
                                                       const int32_t* __restrict__ pos_of_slot,
-                                                      const float* __restrict__ tw, int M, int K,
-                                                      int H, OutT* __restrict__ out) {
+                                                      const float* __restrict__ tw, int tw_ld, int M,
+                                                      int K, int H, OutT* __restrict__ out) {
 #pragma clang fp contract(off)
     const int m = blockIdx.y;
     const int h = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
     for (int k = 0; k < K; ++k) {
         int p = pos_of_slot[m * K + k];
         if (p < 0) continue;
-        float w = tw[m * K + k];
+        float w = tw[(size_t)m * tw_ld + k];
         const float* yp = y + (size_t)p * H + h;
         f32x4 v = *(const f32x4*)yp;
         for (int s = 1; s < SK; ++s) v += *(const f32x4*)(yp + s * sk_stride);
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
 }
 
 template <int THREADS>
-static void launch_sort_t(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
+static void launch_sort_t(hipStream_t st, const SlotIds ids, int n_slots, int E, int32_t* counts,
                           int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot,
                           int32_t* active, int32_t* meta, int tile_rows, int tile_min,
                           int32_t* tile_e, int32_t* tile_r0) {
@@ -348,10 +355,11 @@ static void launch_sort_t(hipStream_t st, const int32_t* ids, int n_slots, int E
                        tile_r0);
 }
 
-int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
-                int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
+int launch_sort(hipStream_t st, const int32_t* ids_ptr, int top_k, int ids_ld, int id_offset, int n_slots, int E,
+                int32_t* counts, int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
                 int32_t* meta, int tile_rows, int tile_min, int32_t* tile_e, int32_t* tile_r0,
                 int32_t* hist, size_t hist_cap) {
+    const SlotIds ids{ids_ptr, top_k, ids_ld, id_offset};
     LKM_REQUIRE(E > 0 && E <= kMaxLocalExperts, "sort: local experts E=%d out of range (1..%d)", E, kMaxLocalExperts);
     LKM_REQUIRE(tile_rows == 0 || (tile_e && tile_r0), "sort: tile list requested without buffers");
     const int n_chunks = ceil_div(n_slots, kChunk);
@@ -482,19 +490,19 @@ int launch_read_probe(hipStream_t st, const void* src, size_t bytes, int n_block
 }
 
 int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
-                   const int32_t* pos_of_slot, const float* tw, int M, int K, int H, void* out,
+                   const int32_t* pos_of_slot, const float* tw, int tw_ld, int M, int K, int H, void* out,
                    int out_dt) {
     if (M == 0) return LKM_OK;
     dim3 grid(ceil_div(H, 1024), M), block(256);
     if (out_dt == LKM_DT_F32)
         hipLaunchKernelGGL(combine_kernel<float>, grid, block, 0, st, y, SK, sk_stride, pos_of_slot,
-                           tw, M, K, H, (float*)out);
+                           tw, tw_ld, M, K, H, (float*)out);
     else if (out_dt == LKM_DT_BF16)
         hipLaunchKernelGGL(combine_kernel<bf16_out>, grid, block, 0, st, y, SK, sk_stride,
-                           pos_of_slot, tw, M, K, H, (bf16_out*)out);
+                           pos_of_slot, tw, tw_ld, M, K, H, (bf16_out*)out);
     else
         hipLaunchKernelGGL(combine_kernel<f16_out>, grid, block, 0, st, y, SK, sk_stride,
-                           pos_of_slot, tw, M, K, H, (f16_out*)out);
+                           pos_of_slot, tw, tw_ld, M, K, H, (f16_out*)out);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

@@ -493,6 +493,14 @@ __device__ __forceinline__ void store_gemm2_frag(const GemmParams& p, const f32x
     }
 }
 
+// single-token decode: the local expert of slot k, -1 = skip (negative, or not one of this engine's experts --
+// the same rule as the scatter of the batched path, dispatch.hip SlotIds)
+__device__ __forceinline__ int direct_expert(const GemmParams& p, int k) {
+    int e = p.direct_ids[k];
+    if (e >= 0) e -= p.direct_id_off;
+    return (e < 0 || e >= p.direct_E) ? -1 : e;
+}
+
 // ------------------------------------------------------------------ GEMM1 + activation
 // grid = (groups, max_active_experts); block = 64*KW threads: the KW waves of a workgroup split K
 // and reduce through LDS (needed when an expert has too few tiles to fill the chip, e.g. M=1).
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
     const int ai = blockIdx.y;
     int e, m_e, off_e;
     if constexpr (DIRECT) {
-        e = p.direct_ids[ai];
+        e = direct_expert(p, ai);
         if (e < 0) return;
         m_e = 1;
         off_e = ai;
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K)
     const int g = lane >> 4, j = lane & 15;
     const int SK = p.SK;
     const int k = wave / SK, sk = wave % SK;
-    const int e = p.direct_ids[k];
+    const int e = direct_expert(p, k);
     const int tile0 = blockIdx.x * NT;
     f32x4 acc[NT][1];
 #pragma unroll
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K)
         if (n >= p.n_real) continue;
         f32x4 out = {0.f, 0.f, 0.f, 0.f};
         for (int kk = 0; kk < K; ++kk) {
-            if (p.direct_ids[kk] < 0) continue;
+            if (direct_expert(p, kk) < 0) continue;
             f32x4 v = ((const f32x4*)red)[((kk * SK) * NT + t) * 64 + lane];
             for (int s = 1; s < SK; ++s) v += ((const f32x4*)red)[((kk * SK + s) * NT + t) * 64 + lane];
             out += p.direct_w[kk] * v;

@@ -640,9 +640,15 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
     pl->s2 = LaunchCfg{nt2, tb, 1, sk, 0, 0, 0, 0};
 }
 
+// strides (elements) of the three input arrays and the id offset of lkm_forward_strided
+struct InLayout {
+    int64_t x_ld, ids_ld, tw_ld;
+    int id_off;
+};
+
 // one chunk: rows [0,M) of the given pointers
 static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, const int32_t* ids,
-                     const float* tw, void* out, int out_dt) {
+                     const float* tw, void* out, int out_dt, const InLayout& il) {
     Arena* a = h->arena;
     const size_t n_slots = (size_t)M * K;
     Plan pl;
@@ -662,7 +668,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     const int kb1 = ceil_div(h->H, 128), kb2 = ceil_div(h->I, 128);
     if (h->a8) {   // dynamic 1x128 fp8 quantisation of the token rows (once per token, not per slot)
         LKM_REQUIRE((size_t)M * h->H <= a->xq_n && n_slots * h->I <= a->aq_n, "fp8 activation scratch too small");
-        rc = launch_quant_fp8_rows(st, x, h->H, h->adt, M, h->H, a->xq, a->xqs);
+        rc = launch_quant_fp8_rows(st, x, (int)il.x_ld, h->adt, M, h->H, a->xq, a->xqs);
         if (rc != LKM_OK) return rc;
     }
     const int tile_rows = pl.t1.tiled ? pl.t1.tiled : pl.t2.tiled;
@@ -677,7 +683,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     }
     const bool direct = M == 1 && K <= 16 && pl.s1.tb == 1 && pl.s1.nt == 1 && !pl.t1.tiled && h->t_direct >= 0;
     if (!direct) {
-        rc = launch_sort(st, ids, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
+        rc = launch_sort(st, ids, K, (int)il.ids_ld, il.id_off, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
                          a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, a->hist,
                          a->hist_cap);
         if (rc != LKM_OK) return rc;
@@ -703,7 +709,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.Kreal = h->H;
     p1.n_real = h->I;
     p1.x = h->a8 ? (const void*)a->xq : x;
-    p1.ldx = h->H;
+    p1.ldx = h->a8 ? h->H : (int)il.x_ld;
     p1.xscale = a->xqs;
     p1.ld_xscale = kb1;
     p1.round_gemm1 = h->a8 ? 1 : 0;
@@ -727,6 +733,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     if (direct) {
         p1.direct_ids = ids;
         p1.direct_w = tw;
+        p1.direct_E = h->E;
+        p1.direct_id_off = il.id_off;
     }
     for (int r = 0; r < rep; ++r) {
         if (pl.s1.tb) {
@@ -779,6 +787,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     if (direct) {
         p2.direct_ids = ids;
         p2.direct_w = tw;
+        p2.direct_E = h->E;
+        p2.direct_id_off = il.id_off;
         p2.direct_out_dt = out_dt;
         p2.out = out;
         p2.SK = sk_direct;
@@ -811,7 +821,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     }
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
 
-    rc = launch_combine(st, a->y, sk, p2.sk_stride, a->pos_of_slot, tw, M, K, h->H, out, out_dt);
+    rc = launch_combine(st, a->y, sk, p2.sk_stride, a->pos_of_slot, tw, (int)il.tw_ld, M, K, h->H, out, out_dt);
     if (rc != LKM_OK) return rc;
     if (prof) {
         LKM_HIP_CHECK(hipEventRecord(h->ev[4], st));
@@ -826,7 +836,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
 }
 
 static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, const int32_t* ids,
-                      const float* tw, void* out, int out_dt) {
+                      const float* tw, void* out, int out_dt, const InLayout* layout = nullptr) {
     LKM_REQUIRE(h, "null engine handle");
     LKM_REQUIRE(M >= 0, "num_tokens=%d < 0", M);
     LKM_REQUIRE(K > 0 && K <= 64, "top_k=%d out of range", K);
@@ -834,6 +844,9 @@ static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, 
     LKM_REQUIRE(x && ids && tw && out, "null device pointer");
     LKM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, "hidden/out pointers must be 16-byte aligned");
     LKM_HIP_CHECK(hipSetDevice(h->device));
+    const InLayout il = layout ? *layout : InLayout{h->H, K, K, 0};
+    LKM_REQUIRE(il.x_ld >= h->H && il.x_ld % 8 == 0 && il.x_ld < ((int64_t)1 << 31), "hidden row stride %lld must be >= H, a multiple of 8 and < 2^31", (long long)il.x_ld);
+    LKM_REQUIRE(il.ids_ld >= K && il.tw_ld >= K && il.ids_ld < ((int64_t)1 << 31) && il.tw_ld < ((int64_t)1 << 31), "ids / weights row strides must be >= top_k");
     // the arena was sized with cfg.top_k; a different K only changes how many tokens fit a chunk
     size_t chunk = h->arena->cap_slots / (size_t)K;
     if (h->arena->act_elems / ((size_t)K * h->ld_act) < chunk) chunk = h->arena->act_elems / ((size_t)K * h->ld_act);
@@ -843,11 +856,11 @@ static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, 
         if (h->arena->aq_n / ((size_t)K * h->I) < chunk) chunk = h->arena->aq_n / ((size_t)K * h->I);
     }
     LKM_REQUIRE(chunk > 0, "scratch arena too small for top_k=%d", K);
-    const size_t xrow = (size_t)h->H * 2, orow = (size_t)h->H * (out_dt == LKM_DT_F32 ? 4 : 2);
+    const size_t xrow = (size_t)il.x_ld * 2, orow = (size_t)h->H * (out_dt == LKM_DT_F32 ? 4 : 2);
     for (size_t m0 = 0; m0 < (size_t)M; m0 += chunk) {
         const int mc = (int)((size_t)M - m0 < chunk ? (size_t)M - m0 : chunk);
-        int rc = run_chunk(h, st, mc, K, (const char*)x + m0 * xrow, ids + m0 * K, tw + m0 * K,
-                           (char*)out + m0 * orow, out_dt);
+        int rc = run_chunk(h, st, mc, K, (const char*)x + m0 * xrow, ids + m0 * il.ids_ld, tw + m0 * il.tw_ld,
+                           (char*)out + m0 * orow, out_dt, il);
         if (rc != LKM_OK) return rc;
     }
     return LKM_OK;
@@ -866,6 +879,17 @@ extern "C" int lkm_prefill_device(LkmHandle h, const void* hidden, void* out,
     LKM_REQUIRE(h, "null engine handle");
     return run_device(h, (hipStream_t)stream, num_tokens, top_k, hidden, topk_ids, topk_weights, out,
                       h->adt);
+}
+
+extern "C" int lkm_forward_strided(LkmHandle h, void* stream, int32_t num_tokens, int32_t top_k,
+                                   const void* hidden, int64_t hidden_ld, const int32_t* topk_ids,
+                                   int64_t ids_ld, int32_t id_offset, const float* topk_weights,
+                                   int64_t weights_ld, void* out, int32_t out_dtype) {
+    LKM_REQUIRE(h, "null engine handle");
+    LKM_REQUIRE(out_dtype == LKM_DT_F32 || out_dtype == h->adt, "forward_strided: out_dtype must be fp32 or the activation dtype");
+    LKM_REQUIRE(id_offset >= 0, "forward_strided: id_offset must be >= 0");
+    const InLayout il{hidden_ld, ids_ld, weights_ld, id_offset};
+    return run_device(h, (hipStream_t)stream, num_tokens, top_k, hidden, topk_ids, topk_weights, out, out_dtype, &il);
 }
 
 extern "C" int lkm_prefill_host(LkmHandle h, int32_t num_tokens, int32_t top_k,
@@ -910,7 +934,7 @@ extern "C" int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots,
     const size_t hist_cap = n_slots > 4096 ? ((size_t)n_slots / 1024 + 1) * E : 0;
     LKM_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(int32_t) * ((size_t)E + 8 + hist_cap)));
     int32_t* hist = hist_cap ? tmp + E + 8 : nullptr;
-    int rc = launch_sort((hipStream_t)stream, ids, n_slots, E, counts, offsets, sorted_slot,
+    int rc = launch_sort((hipStream_t)stream, ids, 1, 1, 0, n_slots, E, counts, offsets, sorted_slot,
                          pos_of_slot, tmp, tmp + E, 0, 0, nullptr, nullptr, hist, hist_cap);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(tmp);

@@ -21,14 +21,15 @@ int launch_repack_s_fp4(hipStream_t st, const void* src, void* dst, const Repack
                         int pad);
 
 // ---- dispatch.hip
-int launch_sort(hipStream_t st, const int32_t* ids, int n_slots, int E, int32_t* counts,
-                int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
+// slot i = column i % top_k of token i / top_k in an [M][ids_ld] array; id_offset is subtracted from ids >= 0
+int launch_sort(hipStream_t st, const int32_t* ids, int top_k, int ids_ld, int id_offset, int n_slots, int E,
+                int32_t* counts, int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
                 int32_t* meta, int tile_rows, int tile_min, int32_t* tile_e, int32_t* tile_r0,
                 int32_t* hist, size_t hist_cap);
 int launch_quant_fp8_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, void* dst,
                           float* scales);
 int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
-                   const int32_t* pos_of_slot, const float* tw, int M, int K, int H, void* out,
+                   const int32_t* pos_of_slot, const float* tw, int tw_ld, int M, int K, int H, void* out,
                    int out_dt);
 
 int launch_read_probe(hipStream_t st, const void* src, size_t bytes, int n_blocks, int unroll,
@@ -76,6 +77,8 @@ struct GemmParams {
     const int32_t* direct_ids;   // [K] (non-null: direct mode; id < 0 = not local)
     const float* direct_w;       // [K]
     int direct_out_dt;           // LKM_DT_* of `out` in the direct GEMM2
+    int direct_E, direct_id_off; // direct mode: local expert count and the offset subtracted from ids >= 0
+                                 // (an id outside [0, E) after that is not local, like -1)
     long long x_rows;  // rows of the activation matrix behind `x` (bounds of the LDS-DMA buffer window)
     int xcd_map;       // tiled kernels: != 0 -> XCD-aware 1-D work mapping (holds the row-group count in the kernel)
     // activation

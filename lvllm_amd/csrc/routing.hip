@@ -259,53 +259,9 @@ __global__ void map_ids_kernel(const int32_t* __restrict__ ids, int64_t n,
     out[i] = id < 0 ? -1 : map[c];
 }
 
-// Expert-parallel dispatch pack (fixed capacity, no host synchronisation): for every destination
-// rank r and every slot s = m*K+k, send_ids[r][s] = local expert id at r (or -1 if the slot is not
-// routed to r), send_w[r][s] = routing weight, send_x[r][s] = hidden[m] (copied only for routed
-// slots; unrouted rows are never read by the receiving engine).  Linear expert placement
-// (expert_map_manager.py:62-79): the first `rem` ranks own base+1 experts.
-__global__ __launch_bounds__(256) void ep_pack_kernel(const unsigned short* __restrict__ hidden,
-                                                      const int32_t* __restrict__ ids,
-                                                      const float* __restrict__ tw, int M, int K, int H,
-                                                      int E, int ep, unsigned short* __restrict__ send_x,
-                                                      int32_t* __restrict__ send_ids,
-                                                      float* __restrict__ send_w) {
-    const int s = blockIdx.x, r = blockIdx.y;
-    const int n_slots = M * K;
-    const int id = ids[s];
-    const int base = E / ep, rem = E % ep, cut = rem * (base + 1);
-    int owner = -1, first = 0;
-    if (id >= 0 && id < E) {
-        owner = id < cut ? id / (base + 1) : rem + (id - cut) / (base > 0 ? base : 1);
-        first = owner * base + (owner < rem ? owner : rem);
-    }
-    const bool mine = owner == r;
-    if (threadIdx.x == 0) {
-        send_ids[(size_t)r * n_slots + s] = mine ? id - first : -1;
-        send_w[(size_t)r * n_slots + s] = mine ? tw[s] : 0.0f;
-    }
-    if (!mine) return;
-    const u32x4* src = (const u32x4*)(hidden + (size_t)(s / K) * H);
-    u32x4* dst = (u32x4*)(send_x + ((size_t)r * n_slots + s) * H);
-    for (int i = threadIdx.x; i < H / 8; i += 256) dst[i] = src[i];
-}
-
 }  // namespace lkm
 
 using namespace lkm;
-
-extern "C" int lkm_ep_pack(void* stream, const void* hidden, const int32_t* topk_ids,
-                           const float* topk_weights, int32_t M, int32_t K, int32_t H,
-                           int32_t num_experts, int32_t ep_size, void* send_x, int32_t* send_ids,
-                           float* send_w) {
-    LKM_REQUIRE(M >= 0 && K > 0 && H > 0 && H % 8 == 0 && num_experts > 0 && ep_size > 0, "ep_pack: bad sizes");
-    if (M == 0) return LKM_OK;
-    hipLaunchKernelGGL(ep_pack_kernel, dim3(M * K, ep_size), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)hidden, topk_ids, topk_weights, M, K, H, num_experts,
-                       ep_size, (unsigned short*)send_x, send_ids, send_w);
-    LKM_HIP_CHECK(hipGetLastError());
-    return LKM_OK;
-}
 
 extern "C" int lkm_topk_softmax(void* stream, const void* logits, int32_t logits_dtype,
                                 const float* bias, int32_t M, int32_t E, int32_t K,

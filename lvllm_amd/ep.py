@@ -3,25 +3,38 @@
 This replaces the reference's CPU-NUMA offload tier: instead of parking experts in host DRAM
 (lk_moe) each rank keeps E/ep experts resident in its 288 GB of HBM.  Two data paths:
 
-  "a2a"  (default, BASELINE.json north_star)  tokens stay DP-sharded; routed rows + (local id,
-         weight) travel by all_to_all_single -> local grouped GEMMs -> reverse all_to_all -> local
-         sum.  On the 8-GPU xGMI full mesh all 7 links of a GPU carry traffic concurrently
-         (SURVEY 8e).  Two flavours, chosen by size:
-           fixed   (decode, M*K <= fixed_capacity_slots): every peer gets M*K row slots, unrouted
-                   slots carry id -1; equal splits => NO split-size exchange and NO host sync.  At
-                   decode sizes the step is latency-bound (0.5 MB per peer ~ 4 us of xGMI time),
-                   so padding is free and removing the synchronisation is what matters.
+  "a2a"  (default, BASELINE.json north_star)  tokens stay DP-sharded, each token visits the ranks that own
+         its experts and comes back as one partial row per visited rank.  Two flavours, chosen by size:
+           fixed   (decode): TOKEN-granular records [activations | top-k ids | top-k weights], one per
+                   (token, destination rank) -- a token travels to a rank at most once however many of its
+                   experts live there -- in `capacity` record slots per destination.  capacity = the token
+                   count is the exact worst case, so nothing can overflow: ONE equal-split all-to-all out,
+                   ONE back (the owner's engine already formed the weighted sum over its experts; the row
+                   returns in the activation dtype by default), no split-size exchange, no host sync -- the
+                   whole step (pack kernel, RCCL, grouped GEMMs, RCCL, combine kernel) is capturable in a
+                   hipGraph, which is the only way the reference ever calls its decode engine
+                   (moe_runner.py:609-614).  With DeepSeek-V3 routing (8 experts out of <= 4 groups = ranks
+                   at ep 8) the bytes on the wire are <= the routed-row bytes M*K*H*2 of the slot-granular
+                   exchanges the reference uses (all2all.py:101-150); `wire_bytes()` reports them.
            ragged  (prefill): exact split sizes are exchanged first, only routed rows travel.
   "ar"   reference-compatible mode (what LvLLM does today, moe_runner.py:600,494 and
          routed_experts.py:1332-1342): every rank sees ALL tokens (all_gather), computes only
          its local experts (other ids -> -1), and the [M,H] partial outputs are summed with
          reduce_scatter (= the reference's all-reduce, kept sharded).
 
+Contract on token counts: the fixed path and "ar" use equal-split collectives, so every rank of the group must
+pass the SAME capacity (fixed) / token count ("ar") in the same step -- what vLLM guarantees for captured decode
+steps by padding the DP ranks to a common count (num_tokens_across_dp).  `forward(..., capacity=C)` (or the
+constructor's `capacity_tokens`) names the common value explicitly; a rank may then hold any M <= C tokens,
+including none.  The fixed-vs-ragged decision is made from that capacity, never from the rank-local M.  The ragged
+path exchanges its sizes and takes any M.  `validate_uniform=True` checks the contract with an all-gather (eager
+debugging aid; it synchronises the host).
+
 Placement is the reference's linear map (expert_map_manager.py:62-79).  With EPLB (lvllm_amd/eplb.py) the ids
 handed to forward() are PHYSICAL expert ids and `num_experts` is the number of physical slots: the linear map over
-the slots is exactly the EPLB placement (slot p lives on rank p // (P / ep)); tests/test_eplb.py runs that end to end.  `torch.distributed` with
-backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests (tests/test_ep_gloo.py),
-where the local expert computation is injected.
+the slots is exactly the EPLB placement (slot p lives on rank p // (P / ep)); tests/test_eplb.py runs that end to
+end.  `torch.distributed` with backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests
+(tests/test_ep_gloo.py), where the local expert computation and the two exchange kernels are injected.
 """
 from __future__ import annotations
 
@@ -32,10 +45,11 @@ import torch.distributed as dist
 
 from .ops import determine_expert_map
 
-# local_compute(rows [R,H] act dtype, local_ids int32 [R,1], weights fp32 [R,1]) -> fp32 [R,H]
-LocalCompute = Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor]
-# pack(hidden [M,H], weights [M,K], ids [M,K], num_experts, ep) -> (send_x [ep,MK,H], send_ids [ep,MK], send_w [ep,MK])
-PackFn = Callable[[torch.Tensor, torch.Tensor, torch.Tensor, int, int], tuple]
+# local_compute(rows [R,H] act dtype (row-strided view), ids int32 [R,Kx], weights fp32 [R,Kx], out_dtype) ->
+# [R,H] contiguous in out_dtype: for every row the weighted sum over the LOCAL experts among its Kx ids (< 0 = skip)
+LocalCompute = Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.dtype], torch.Tensor]
+# transport(out, inp): equal-split all-to-all over the group on tensors of shape [ep, ...]
+Transport = Callable[[torch.Tensor, torch.Tensor], None]
 
 
 def owner_of(ids: torch.Tensor, num_experts: int, ep_size: int) -> torch.Tensor:
@@ -53,52 +67,118 @@ def owner_of(ids: torch.Tensor, num_experts: int, ep_size: int) -> torch.Tensor:
 
 class ExpertParallelExperts:
     def __init__(self, local_compute: LocalCompute, num_experts: int, hidden_size: int,
-                 group: dist.ProcessGroup | None = None, mode: str = "a2a",
-                 pack: PackFn | None = None, fixed_capacity_slots: int = 2048):
+                 group: dist.ProcessGroup | None = None, mode: str = "a2a", kernels=None,
+                 transport: Transport | None = None, fixed_max_tokens: int = 1024,
+                 capacity_tokens: int | None = None, return_dtype: torch.dtype | None = None,
+                 global_ids: bool = False, validate_uniform: bool = False):
+        """kernels: namespace with ep_row_bytes / ep_pack_tokens / ep_combine (default lvllm_amd.ops = the HIP
+        kernels, no CPU path; the gloo tests inject torch doubles).  transport: equal-split all-to-all (default
+        dist.all_to_all_single over `group`).  fixed_max_tokens: largest capacity served by the fixed path.
+        capacity_tokens: the group-wide record capacity per destination (default: this step's token count).
+        return_dtype: dtype of the partial rows on the way back (default: the activation dtype; torch.float32
+        keeps the single-rank fp32 sum exactly).  global_ids: records carry GLOBAL expert ids (for a receiver
+        that applies expert_map itself, modular.LkmPrepareAndFinalize) instead of ids local to the owner."""
         if mode not in ("a2a", "ar"):
             raise ValueError(f"unknown EP mode {mode!r} (expected 'a2a' or 'ar')")
         self.local_compute = local_compute
-        if pack is None:
-            from .ops import ep_pack as pack       # the HIP kernel (no CPU path)
-        self.pack = pack
-        self.fixed_capacity_slots = fixed_capacity_slots
+        if kernels is None:
+            from . import ops as kernels           # the HIP kernels (no CPU path)
+        self.kernels = kernels
+        self.fixed_max_tokens = fixed_max_tokens
+        self.capacity_tokens = capacity_tokens
+        self.return_dtype = return_dtype
+        self.global_ids = global_ids
+        self.validate_uniform = validate_uniform
         self.E, self.H = num_experts, hidden_size
         self.group = group
         self.ep = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.mode = mode
+        self.transport = transport if transport is not None else self._dist_a2a
         self.local_num, emap = determine_expert_map(self.ep, self.rank, num_experts, "linear")
         self.expert_map = emap if emap is not None else torch.arange(num_experts, dtype=torch.int32)
         base, rem = divmod(num_experts, self.ep)
         self.first_expert = [r * base + min(r, rem) for r in range(self.ep)]
+        self._bufs: dict = {}
+        self.last_wire: dict | None = None
+
+    def _dist_a2a(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        dist.all_to_all_single(out, inp, group=self.group)
 
     # -------------------------------------------------------------------------------- a2a, fixed
-    def dispatch_fixed(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor):
-        """tokens -> owners: (rows [ep*M*K, H], local ids int32 [ep*M*K] (-1 = empty slot), weights fp32 [ep*M*K]).
-        Equal splits: no split-size exchange and no host sync."""
-        send_x, send_ids, send_w = self.pack(hidden, tw, ids, self.E, self.ep)
-        recv_x = torch.empty_like(send_x)
-        recv_ids = torch.empty_like(send_ids)
-        recv_w = torch.empty_like(send_w)
-        dist.all_to_all_single(recv_x, send_x, group=self.group)
-        dist.all_to_all_single(recv_ids, send_ids, group=self.group)
-        dist.all_to_all_single(recv_w, send_w, group=self.group)
-        n = ids.numel()
-        return recv_x.view(self.ep * n, self.H), recv_ids.view(self.ep * n), recv_w.view(self.ep * n)
+    def capacity_for(self, M: int, capacity: int | None = None) -> int:
+        cap = capacity if capacity is not None else (self.capacity_tokens if self.capacity_tokens is not None else M)
+        if M > cap:
+            raise ValueError(f"{M} tokens exceed the group-wide record capacity {cap}")
+        return max(cap, 1)
 
-    def combine_fixed(self, y: torch.Tensor, M: int, K: int) -> torch.Tensor:
-        """owners -> tokens: y fp32 [ep*M*K, H] (weighted rows, zeros in empty slots) -> fp32 [M, H]"""
-        n = M * K
-        y_back = torch.empty((self.ep, n, self.H), dtype=torch.float32, device=y.device)
-        dist.all_to_all_single(y_back, y.view(self.ep, n, self.H).contiguous(), group=self.group)
-        # every slot was computed by exactly one rank (rows of the others are zero): fixed-order fp32 sum
-        return y_back.view(self.ep, M, K, self.H).sum(dim=(0, 2))
+    def _buffers(self, M: int, K: int, cap: int, act_dtype: torch.dtype, ret_dtype: torch.dtype, dev):
+        """persistent per-shape exchange buffers (a captured graph replays on these addresses)"""
+        key = (M, K, cap, act_dtype, ret_dtype, str(dev))
+        b = self._bufs.get(key)
+        if b is None:
+            rowb = self.kernels.ep_row_bytes(self.H, K)
+            b = dict(rowb=rowb,
+                     send=torch.empty((self.ep, cap, rowb), dtype=torch.uint8, device=dev),
+                     recv=torch.empty((self.ep, cap, rowb), dtype=torch.uint8, device=dev),
+                     slot_of=torch.empty((self.ep, M), dtype=torch.int32, device=dev),
+                     overflow=torch.zeros((1,), dtype=torch.int32, device=dev),
+                     back=torch.empty((self.ep, cap, self.H), dtype=ret_dtype, device=dev))
+            self._bufs[key] = b
+        return b
 
-    def _forward_a2a_fixed(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    def dispatch_fixed(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor, capacity: int | None = None):
+        """tokens -> owners, ONE collective: (rows [ep*cap, H] act dtype, ids int32 [ep*cap, K], weights fp32
+        [ep*cap, K]) -- row-strided views into the receive buffer; unused record slots carry ids -1."""
         M, K = ids.shape
-        rows, lids, ws = self.dispatch_fixed(hidden, tw, ids)
-        y = self.local_compute(rows, lids.view(-1, 1), ws.view(-1, 1))
-        return self.combine_fixed(y, M, K)
+        cap = self.capacity_for(M, capacity)
+        ret = self.return_dtype or hidden.dtype
+        b = self._buffers(M, K, cap, hidden.dtype, ret, hidden.device)
+        self.kernels.ep_pack_tokens(hidden, tw, ids, self.E, self.ep, cap, b["send"], b["slot_of"], b["overflow"],
+                                    self.global_ids)
+        self.transport(b["recv"], b["send"])
+        rec = b["recv"].view(self.ep * cap, b["rowb"])
+        H2 = self.H * 2
+        rows = rec[:, :H2].view(hidden.dtype)
+        rids = rec[:, H2:H2 + 4 * K].view(torch.int32)
+        rws = rec[:, H2 + 4 * K:H2 + 8 * K].view(torch.float32)
+        self._last = (b, M, K, cap)
+        return rows, rids, rws
+
+    def combine_fixed(self, y: torch.Tensor, M: int, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """owners -> tokens, ONE collective: y [ep*cap, H] (the owners' weighted partial rows, return dtype) ->
+        [M, H] out_dtype = fixed-order fp32 sum over the ranks a token visited"""
+        b, M_, K, cap = self._last
+        assert M_ == M and y.shape == (self.ep * cap, self.H) and y.dtype == b["back"].dtype, (y.shape, y.dtype)
+        self.transport(b["back"], y.view(self.ep, cap, self.H))
+        out = torch.empty((M, self.H), dtype=out_dtype, device=y.device)
+        return self.kernels.ep_combine(b["back"], b["slot_of"], out)
+
+    def _forward_a2a_fixed(self, hidden, tw, ids, cap: int, out_dtype: torch.dtype) -> torch.Tensor:
+        M, K = ids.shape
+        rows, rids, rws = self.dispatch_fixed(hidden, tw, ids, cap)
+        ret = self.return_dtype or hidden.dtype
+        y = self.local_compute(rows, rids, rws, ret)
+        return self.combine_fixed(y, M, out_dtype)
+
+    def overflow_count(self) -> int:
+        """tokens dropped so far for lack of record capacity (only possible with a capacity below the token
+        count); reading it synchronises the host."""
+        return int(sum(int(b["overflow"].item()) for b in self._bufs.values()))
+
+    def wire_bytes(self, M: int, K: int, capacity: int | None = None, act_bytes: int = 2,
+                   ret_bytes: int | None = None) -> dict:
+        """bytes one rank puts on xGMI per fixed-path step (the blocks for the other ep-1 ranks) next to the
+        routed-row bytes of a slot-granular exchange of the same step"""
+        cap = self.capacity_for(M, capacity)
+        rowb = self.kernels.ep_row_bytes(self.H, K)
+        rb = act_bytes if ret_bytes is None else ret_bytes
+        out_b, back_b = (self.ep - 1) * cap * rowb, (self.ep - 1) * cap * self.H * rb
+        routed = M * K * self.H * act_bytes
+        return {"dispatch_bytes": out_b, "return_bytes": back_b, "routed_row_bytes": routed,
+                "dispatch_over_routed": round(out_b / max(routed, 1), 3),
+                "return_over_routed": round(back_b / max(M * K * self.H * rb, 1), 3),
+                "collectives_per_step": 2, "capacity_tokens": cap}
 
     # -------------------------------------------------------------------------------- a2a, ragged
     def _forward_a2a(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
@@ -127,7 +207,7 @@ class ExpertParallelExperts:
         dist.all_to_all_single(lid_recv, lid_send, rc, sc, group=self.group)
         dist.all_to_all_single(w_recv, w_send, rc, sc, group=self.group)
         # local experts: each received row is one (token, slot) pair => top_k = 1
-        y_recv = self.local_compute(x_recv, lid_recv.view(-1, 1), w_recv.view(-1, 1))
+        y_recv = self.local_compute(x_recv, lid_recv.view(-1, 1), w_recv.view(-1, 1), torch.float32)
         y_back = torch.empty((n_send, self.H), dtype=torch.float32, device=dev)
         dist.all_to_all_single(y_back, y_recv.contiguous(), sc, rc, group=self.group)
         out = torch.zeros((M, self.H), dtype=torch.float32, device=dev)
@@ -148,19 +228,40 @@ class ExpertParallelExperts:
         emap = self.expert_map.to(dev)
         local = torch.where(ii < 0, torch.full_like(ii, -1),
                             emap[ii.clamp(0, self.E - 1).to(torch.int64)])    # routed_experts.py:1332-1342
-        part = self.local_compute(xs, local.contiguous(), ww)                   # [ep*M, H] fp32
+        part = self.local_compute(xs, local.contiguous(), ww, torch.float32)    # [ep*M, H] fp32
         out = torch.empty((M, self.H), dtype=torch.float32, device=dev)
         dist.reduce_scatter_tensor(out, part.contiguous(), group=self.group)
         return out
 
+    def _check_uniform(self, value: int, what: str) -> None:
+        t = torch.tensor([value], dtype=torch.int64)
+        if dist.is_initialized() and dist.get_backend(self.group) != "gloo":
+            t = t.cuda()
+        got = [torch.empty_like(t) for _ in range(self.ep)]
+        dist.all_gather(got, t, group=self.group)
+        vals = [int(g.item()) for g in got]
+        if len(set(vals)) != 1:
+            raise RuntimeError(f"expert-parallel step with different {what} across ranks: {vals}; pad the ranks to a "
+                               f"common count or pass a common capacity (see the module docstring)")
+
     def forward(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor,
-                force_collectives: bool = False) -> torch.Tensor:
-        """hidden [M,H] (this rank's tokens), GLOBAL expert ids int32 [M,K] -> fp32 [M,H].
-        force_collectives runs the collective data path even on a single rank (plumbing checks)."""
+                force_collectives: bool = False, capacity: int | None = None,
+                out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """hidden [M,H] (this rank's tokens), GLOBAL expert ids int32 [M,K] -> [M,H] (fp32 by default).
+        force_collectives runs the collective data path even on a single rank (plumbing checks).
+        capacity: see the module docstring (the token count every rank of the group agrees on)."""
         if self.ep == 1 and not force_collectives:
-            return self.local_compute(hidden, topk_ids, topk_weights)
+            return self.local_compute(hidden, topk_ids, topk_weights, out_dtype)
+        M = topk_ids.size(0)
         if self.mode == "a2a":
-            if topk_ids.numel() <= self.fixed_capacity_slots:
-                return self._forward_a2a_fixed(hidden, topk_weights, topk_ids)
-            return self._forward_a2a(hidden, topk_weights, topk_ids)
-        return self._forward_ar(hidden, topk_weights, topk_ids)
+            cap = self.capacity_for(M, capacity)
+            if self.validate_uniform:
+                self._check_uniform(cap, "record capacity")
+            if cap <= self.fixed_max_tokens:
+                return self._forward_a2a_fixed(hidden, topk_weights, topk_ids, cap, out_dtype)
+            out = self._forward_a2a(hidden, topk_weights, topk_ids)
+        else:
+            if self.validate_uniform:
+                self._check_uniform(M, "token count")
+            out = self._forward_ar(hidden, topk_weights, topk_ids)
+        return out if out.dtype == out_dtype else out.to(out_dtype)

@@ -118,10 +118,19 @@ class RoutedExpertsLayer:
                 topk_ids, s.expert_load_view, s.logical_to_physical_map, s.logical_replica_count,
                 s.should_record_tensor, s.num_unpadded_tokens)
         if self.shared_slots is not None:                     # inject_shared_expert_weights, rocm_aiter_moe.py:113-158
+            # The routed scaling factor applied to the OUTPUT below must not scale the shared expert: the
+            # reference gives the shared slots the weight 1/routed_scaling_factor in that case
+            # (fused_moe/layer.py:306-318), so that x * rsf leaves them at 1.
+            r_ = self.routing
+            comp = 1.0 / r_.routed_scaling_factor if (r_.routed_scaling_factor != 1.0
+                                                      and not r_.apply_routed_scaling_in_router) else 1.0
             gate = None
             if self.shared_gate_weight is not None:           # qwen2_moe.py: sigmoid(shared_expert_gate(x)) * shared(x)
                 g = torch.sigmoid(torch.nn.functional.linear(hidden_states, self.shared_gate_weight).float())
-                gate = g.expand(M, self.shared_slots.n_shared)
+                gate = (g * comp).expand(M, self.shared_slots.n_shared)
+            elif comp != 1.0:
+                s = self.shared_slots
+                gate = s.total_topk_weights.new_full((M, s.n_shared), s.shared_experts_score * comp)
             topk_weights, topk_ids = self.shared_slots.inject(topk_weights, topk_ids, gate)
         if self.expert_map is not None:                       # routed_experts.py:1332-1342
             topk_ids = self.ops.global_to_local_expert_ids(topk_ids, self.expert_map)

@@ -100,6 +100,15 @@ class _MOE:
                                                  _vp(topk_ids_ptr), _vp(topk_weights_ptr),
                                                  num_tokens, top_k, _vp(stream)))
 
+    # ---- extension: the same operator on strided records (expert-parallel exchange, include/lkm.h) ----
+    def forward_strided(self, stream: int, num_tokens: int, top_k: int, hidden_ptr: int, hidden_ld: int,
+                        topk_ids_ptr: int, ids_ld: int, id_offset: int, topk_weights_ptr: int, weights_ld: int,
+                        out_ptr: int, out_dtype: int) -> None:
+        _clib.check(self._lib.lkm_forward_strided(self._h, _vp(stream), num_tokens, top_k, _vp(hidden_ptr),
+                                                  int(hidden_ld), _vp(topk_ids_ptr), int(ids_ld), int(id_offset),
+                                                  _vp(topk_weights_ptr), int(weights_ld), _vp(out_ptr),
+                                                  int(out_dtype)))
+
     # ---- measurement / introspection (extensions) --------------------------------------
     def set_profiling(self, enable: bool) -> None:
         _clib.check(self._lib.lkm_set_profiling(self._h, int(enable)))

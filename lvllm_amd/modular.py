@@ -225,34 +225,44 @@ class LkmExperts:
         ids = topk_ids if topk_ids.dtype == torch.int32 else topk_ids.to(torch.int32)
         if expert_map is not None:
             ids = ops.global_to_local_expert_ids(ids.contiguous(), expert_map.to(device=ids.device, dtype=torch.int32))
-        tw = topk_weights.to(torch.float32).contiguous()
-        x = hidden_states.contiguous()
+        tw = topk_weights.to(torch.float32)
         if M == 0:
             return
-        if output.dtype == torch.float32 and output.is_contiguous():
-            eng.decode(x, tw, ids.contiguous(), out=output)
-        elif output.dtype == torch.float32:
-            output.copy_(eng.decode(x, tw, ids.contiguous()))
+
+        def rowwise(t_):      # rows of the token-granular EP exchange arrive as row-strided views: used in place
+            return t_ if t_.dim() == 2 and (t_.size(1) == 1 or t_.stride(1) == 1) and t_.stride(0) % 8 == 0 else t_.contiguous()
+        x, ids, tw = rowwise(hidden_states), rowwise(ids), rowwise(tw)
+        if output.is_contiguous() and output.dtype in (torch.float32, hidden_states.dtype):
+            eng.forward_rows(x, tw, ids, out=output)
         else:
-            output.copy_(eng.prefill(x, tw, ids.contiguous()))
+            output.copy_(eng.forward_rows(x, tw, ids, out_dtype=torch.float32 if output.dtype == torch.float32
+                                          else hidden_states.dtype))
 
 
 class LkmPrepareAndFinalize:
     """`FusedMoEPrepareAndFinalizeModular`-shaped pair (modular_kernel.py:180-418) for expert parallelism over the
-    8 GPUs of one node: `prepare` is the fixed-capacity RCCL all-to-all of lvllm_amd/ep.py (tokens -> owning ranks,
-    no host sync), `finalize` the reverse all-to-all and the fixed-order fp32 sum.  Together with `LkmExperts`:
+    8 GPUs of one node: `prepare` is the token-granular fixed-capacity RCCL all-to-all of lvllm_amd/ep.py (tokens ->
+    owning ranks, one collective, no host sync), `finalize` the reverse all-to-all and the fixed-order fp32 sum.
+    Together with `LkmExperts`:
 
         a1q, a1q_scale, meta, ids_d, w_d = pf.prepare(a1, topk_weights, topk_ids, E, expert_map, False, None, True)
         experts.apply(fused, a1q, w1, w2, w_d, ids_d, activation, E, expert_map, None, None, None, None, None, False)
         pf.finalize(output, fused, topk_weights, topk_ids, False, experts.finalize_weight_and_reduce_impl())
 
-    which is the call sequence of the reference's modular kernel (modular_kernel.py:1219-1420).  The dispatched ids
-    are GLOBAL ids (-1 = empty slot) because the experts apply `expert_map` themselves, as with the reference's
-    all-to-all backends (deepep_ht_prepare_finalize.py:196-215)."""
+    which is the call sequence of the reference's modular kernel (modular_kernel.py:1219-1420).  A dispatched row is
+    one TOKEN with its top-k ids and weights (ids of experts on other ranks and of empty record slots are -1); the
+    ids are GLOBAL because the experts apply `expert_map` themselves, as with the reference's all-to-all backends
+    (deepep_ht_prepare_finalize.py:196-215).  Every rank must pass the same token count (or construct with a common
+    `capacity_tokens`): see lvllm_amd/ep.py.  Above `fixed_max_tokens` tokens the equal-split exchange would pad
+    prefill-sized batches; use `ExpertParallelExperts.forward` (ragged path) there."""
 
-    def __init__(self, num_experts: int, hidden_size: int, group=None, pack=None):
+    def __init__(self, num_experts: int, hidden_size: int, group=None, kernels=None, transport=None,
+                 capacity_tokens: int | None = None, fixed_max_tokens: int = 1024):
         from .ep import ExpertParallelExperts
-        self._ep = ExpertParallelExperts(lambda *a: None, num_experts, hidden_size, group=group, mode="a2a", pack=pack)
+        self._ep = ExpertParallelExperts(lambda *a: None, num_experts, hidden_size, group=group, mode="a2a",
+                                         kernels=kernels, transport=transport, capacity_tokens=capacity_tokens,
+                                         fixed_max_tokens=fixed_max_tokens, global_ids=True,
+                                         return_dtype=torch.float32)   # the experts' rows return as they are
         self._shape: tuple[int, int] | None = None
 
     # ---- facts (modular_kernel.py:201-246)
@@ -264,7 +274,7 @@ class LkmPrepareAndFinalize:
         return torch.int32
 
     def max_num_tokens_per_rank(self):
-        return None
+        return self._ep.capacity_tokens
 
     def num_dispatchers(self) -> int:
         return self._ep.ep
@@ -291,17 +301,19 @@ class LkmPrepareAndFinalize:
             raise ValueError("LkmPrepareAndFinalize dispatches unquantised rows (the experts quantise); "
                              "call with defer_input_quant=True")
         M, K = topk_ids.shape
+        cap = self._ep.capacity_for(M)
+        if cap > self._ep.fixed_max_tokens:
+            raise ValueError(f"prepare: {cap} tokens per rank exceed the equal-split exchange "
+                             f"(fixed_max_tokens={self._ep.fixed_max_tokens}); use ExpertParallelExperts.forward")
         tw = topk_weights.to(torch.float32)
         if apply_router_weight_on_input:
             if K != 1:
                 raise ValueError("apply_router_weight_on_input is only supported for topk=1")
             a1 = (a1.to(torch.float32) * tw).to(a1.dtype)
             tw = torch.ones_like(tw)
-        rows, lids, ws = self._ep.dispatch_fixed(a1.contiguous(), tw.contiguous(), topk_ids.to(torch.int32).contiguous())
-        first = self._ep.first_expert[self._ep.rank]
-        gids = torch.where(lids >= 0, lids + first, lids)             # back to global ids; -1 stays -1
+        rows, gids, ws = self._ep.dispatch_fixed(a1.contiguous(), tw.contiguous(), topk_ids.to(torch.int32).contiguous())
         self._shape = (M, K)
-        return rows, None, None, gids.view(-1, 1), ws.view(-1, 1)
+        return rows, None, None, gids, ws
 
     # ---- modular_kernel.py:354-376
     def finalize(self, output: torch.Tensor, fused_expert_output: torch.Tensor, topk_weights: torch.Tensor,
@@ -314,7 +326,9 @@ class LkmPrepareAndFinalize:
         if self._shape != (M, K):
             raise RuntimeError(f"finalize for [{M}, {K}] slots without the matching prepare ({self._shape})")
         y = fused_expert_output if fused_expert_output.dtype == torch.float32 else fused_expert_output.to(torch.float32)
-        output.copy_(self._ep.combine_fixed(y.contiguous(), M, K))
+        out = self._ep.combine_fixed(y.contiguous(), M, output.dtype if output.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32)
+        if out.data_ptr() != output.data_ptr():
+            output.copy_(out)
 
 
 def bind_vllm_base():

@@ -218,22 +218,41 @@ def eplb_map_to_physical_and_record(topk_ids: torch.Tensor, expert_load_view: to
     return out.to(topk_ids.dtype)
 
 
-def ep_pack(hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor, num_experts: int,
-            ep_size: int):
-    """Fixed-capacity EP dispatch pack -> (send_x [ep, M*K, H], send_ids int32 [ep, M*K] (-1 = not
-    routed to that rank), send_w fp32 [ep, M*K]); see lkm_ep_pack in include/lkm.h."""
-    _need_cuda(hidden, topk_weights, topk_ids)
+def ep_row_bytes(hidden_size: int, top_k: int) -> int:
+    """bytes of one exchanged token record [H x 16-bit | K x int32 ids | K x fp32 weights], padded to 16"""
+    return int(_clib.lib().lkm_ep_row_bytes(hidden_size, top_k))
+
+
+def ep_pack_tokens(hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor, num_experts: int,
+                   ep_size: int, capacity: int, send: torch.Tensor, slot_of: torch.Tensor, overflow: torch.Tensor,
+                   global_ids: bool = False) -> None:
+    """Token-granular fixed-capacity EP dispatch pack into caller-owned buffers (persistent: a captured graph
+    replays on the same addresses): send uint8 [ep, capacity, ep_row_bytes(H, K)], slot_of int32 [ep, M],
+    overflow int32 [1] (+= tokens dropped for lack of capacity); see lkm_ep_pack_tokens in include/lkm.h."""
+    _need_cuda(hidden, topk_weights, topk_ids, send, slot_of, overflow)
     M, K = topk_ids.shape
     H = hidden.size(1)
-    dev = hidden.device
     assert hidden.is_contiguous() and topk_ids.dtype == torch.int32 and topk_weights.dtype == torch.float32
-    send_x = torch.empty((ep_size, M * K, H), dtype=hidden.dtype, device=dev)
-    send_ids = torch.empty((ep_size, M * K), dtype=torch.int32, device=dev)
-    send_w = torch.empty((ep_size, M * K), dtype=torch.float32, device=dev)
-    _clib.check(_clib.lib().lkm_ep_pack(_stream(hidden), _ptr(hidden), _ptr(topk_ids.contiguous()),
-                                        _ptr(topk_weights.contiguous()), M, K, H, num_experts, ep_size,
-                                        _ptr(send_x), _ptr(send_ids), _ptr(send_w)))
-    return send_x, send_ids, send_w
+    assert topk_ids.is_contiguous() and topk_weights.is_contiguous()
+    assert send.dtype == torch.uint8 and send.is_contiguous() and send.numel() == ep_size * capacity * ep_row_bytes(H, K)
+    assert slot_of.dtype == torch.int32 and slot_of.is_contiguous() and slot_of.numel() == ep_size * M
+    assert overflow.dtype == torch.int32 and overflow.numel() == 1
+    _clib.check(_clib.lib().lkm_ep_pack_tokens(_stream(hidden), _ptr(hidden), _ptr(topk_ids), _ptr(topk_weights), M, K,
+                                               H, num_experts, ep_size, capacity, int(global_ids), _ptr(send),
+                                               _ptr(slot_of), _ptr(overflow)))
+
+
+def ep_combine(back: torch.Tensor, slot_of: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """back [ep, capacity, H] (fp32 or 16-bit), slot_of int32 [ep, M] -> out [M, H] (fp32 or 16-bit):
+    out[m] = sum_p back[p, slot_of[p, m]] in fp32, p ascending; see lkm_ep_combine."""
+    _need_cuda(back, slot_of, out)
+    ep, cap, H = back.shape
+    M = out.size(0)
+    assert back.is_contiguous() and out.is_contiguous() and slot_of.is_contiguous()
+    assert slot_of.dtype == torch.int32 and slot_of.numel() == ep * M and out.size(1) == H
+    _clib.check(_clib.lib().lkm_ep_combine(_stream(back), _ptr(back), _DT[back.dtype], _ptr(slot_of), M, H, ep, cap,
+                                           _ptr(out), _DT[out.dtype]))
+    return out
 
 
 def sort_slots(topk_ids: torch.Tensor, num_experts: int):
@@ -327,6 +346,31 @@ class RoutedExpertsEngine:
         self.engine.gpu_prefill(hidden.data_ptr(), out.data_ptr(), topk_ids.data_ptr(),
                                 topk_weights.data_ptr(), hidden.size(0), topk_ids.size(1),
                                 torch.cuda.current_stream(hidden.device).cuda_stream)
+        return out
+
+    def forward_rows(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor,
+                     out: torch.Tensor | None = None, out_dtype: torch.dtype = torch.float32,
+                     id_offset: int = 0) -> torch.Tensor:
+        """The operator on ROW-STRIDED views (last dimension contiguous), as the expert-parallel exchange hands
+        them over: hidden [R,H] act dtype, ids int32 [R,K], weights fp32 [R,K]; `id_offset` is subtracted from
+        ids >= 0 (global -> local under linear placement).  -> [R,H] contiguous, fp32 or the activation dtype."""
+        _need_cuda(hidden, topk_weights, topk_ids)
+        R, K = topk_ids.shape
+        assert hidden.dtype == self.act_dtype and topk_ids.dtype == torch.int32 and topk_weights.dtype == torch.float32
+        assert hidden.size(0) == R and topk_weights.shape == topk_ids.shape
+        for t_ in (hidden, topk_ids, topk_weights):
+            assert t_.dim() == 2 and (t_.size(1) == 1 or t_.stride(1) == 1), "rows must be contiguous in their last dimension"
+        if out is None:
+            out = torch.empty((R, self.H), dtype=out_dtype, device=hidden.device)
+        assert out.is_contiguous() and out.dtype in (torch.float32, self.act_dtype)
+        if R == 0:
+            return out
+        self.engine.forward_strided(torch.cuda.current_stream(hidden.device).cuda_stream, R, K, hidden.data_ptr(),
+                                    hidden.stride(0) if R > 1 else max(hidden.stride(0), self.H), topk_ids.data_ptr(),
+                                    topk_ids.stride(0) if R > 1 else max(topk_ids.stride(0), K), int(id_offset),
+                                    topk_weights.data_ptr(),
+                                    topk_weights.stride(0) if R > 1 else max(topk_weights.stride(0), K),
+                                    out.data_ptr(), _DT[out.dtype])
         return out
 
     def prefill_host(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:

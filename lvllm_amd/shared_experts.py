@@ -96,6 +96,7 @@ class SharedExpertSlots:
         if n_shared_experts <= 0:
             raise ValueError("n_shared_experts must be positive")
         self.n_routed, self.n_shared, self.top_k = n_routed_experts, n_shared_experts, top_k
+        self.shared_experts_score = float(shared_experts_score)
         self.extra = n_shared_experts + int(is_ep)
         self.fake_id = n_routed_experts + n_shared_experts
         width = top_k + self.extra

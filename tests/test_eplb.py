@@ -462,7 +462,7 @@ def _e2e_worker(rank, world, port, q):
     try:
         from lvllm_amd.ep import ExpertParallelExperts
         from tests.helpers import make_routing, torch_to_bits
-        from tests.test_ep_gloo import _torch_pack
+        from tests.helpers import TorchEpKernels
         E, red, K, H, I, M = 8, 4, 2, 64, 32, 24
         P, per = E + red, (E + red) // world
         g = torch.Generator().manual_seed(5)
@@ -474,12 +474,12 @@ def _e2e_worker(rank, world, port, q):
         st.expert_stores = [eplb.TensorExpertStore([local13, local2])]
         d_loc = orc.MoeDesc(E=per, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
 
-        def local_compute(x, lids, ws):
+        def local_compute(x, lids, ws, out_dtype):
             if x.shape[0] == 0:
-                return torch.zeros((0, H), dtype=torch.float32)
-            return torch.from_numpy(orc.moe(d_loc, torch_to_bits(local13), torch_to_bits(local2), torch_to_bits(x),
-                                            lids.numpy(), ws.numpy()))
-        ep = ExpertParallelExperts(local_compute, P, H, mode="a2a", pack=_torch_pack)
+                return torch.zeros((0, H), dtype=out_dtype)
+            return torch.from_numpy(orc.moe(d_loc, torch_to_bits(local13), torch_to_bits(local2), torch_to_bits(x.contiguous()),
+                                            lids.contiguous().numpy(), ws.contiguous().numpy())).to(out_dtype)
+        ep = ExpertParallelExperts(local_compute, P, H, mode="a2a", kernels=TorchEpKernels, return_dtype=torch.float32)
         gx = torch.Generator().manual_seed(100 + rank)
         x = (torch.randn((M, H), generator=gx) / 2).to(torch.bfloat16)
         tw, ids = make_routing(M, E, K, seed=200 + rank, skew=2.0)                 # skewed: expert 0 is hot

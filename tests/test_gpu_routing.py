@@ -136,21 +136,3 @@ def test_sort_slots_exact(n, E):
     np.testing.assert_array_equal(offsets.cpu().numpy(), oo)
     np.testing.assert_array_equal(sorted_slot.cpu().numpy(), os_)
     np.testing.assert_array_equal(pos.cpu().numpy(), op)
-
-
-@pytest.mark.parametrize("ep", [1, 2, 3, 8])
-def test_ep_pack_matches_torch_double(ep):
-    """lkm_ep_pack (HIP) == the torch restatement used by the gloo tests."""
-    ops = _ops()
-    from tests.test_ep_gloo import _torch_pack
-    M, K, H, E = 37, 4, 256, 16
-    g = torch.Generator().manual_seed(ep)
-    hidden = torch.randn((M, H), generator=g).to(torch.bfloat16)
-    ids = torch.randint(-1, E, (M, K), generator=g, dtype=torch.int32)
-    tw = torch.rand((M, K), generator=g)
-    sx, si, sw = ops.ep_pack(hidden.to(DEV), tw.to(DEV), ids.to(DEV), E, ep)
-    rx, ri, rw = _torch_pack(hidden, tw, ids, E, ep)
-    np.testing.assert_array_equal(si.cpu().numpy(), ri.numpy())
-    np.testing.assert_array_equal(sw.cpu().numpy(), rw.numpy())
-    routed = ri >= 0
-    assert torch.equal(sx.cpu()[routed], rx[routed])      # unrouted rows are unspecified

@@ -199,6 +199,39 @@ def test_eplb_shared_experts_and_ep_map_chain_in_the_reference_order():
     assert int(st.expert_load_pass.sum()) == 2 * 11 * K
 
 
+@pytest.mark.parametrize("gated", [False, True])
+def test_folded_shared_expert_is_not_scaled_by_the_routed_scaling_factor(gated):
+    """DeepSeek-V3 style: routed_scaling_factor 2.5 applied to the layer OUTPUT, one folded shared expert.  The
+    reference compensates with a shared slot weight of 1/rsf (fused_moe/layer.py:306-318): out = rsf * routed +
+    1 * shared (x sigmoid gate for the Qwen2-MoE form)."""
+    calls = []
+    rsf, n_sh, M = 2.5, 2, 9
+    w13, w2 = _weights(E)
+    g = torch.Generator().manual_seed(8)
+    s13 = (torch.randn((2 * n_sh * I, H), generator=g) / 4).to(torch.bfloat16)
+    s2 = (torch.randn((H, n_sh * I), generator=g) / 4).to(torch.bfloat16)
+    gate_w = (torch.randn((1, H), generator=g) / 4).to(torch.bfloat16) if gated else None
+    c13, c2, _, _ = se.split_shared_expert(s13, s2, n_sh)
+    e13, e2 = se.append_shared_experts(w13, c13), se.append_shared_experts(w2, c2)
+    slots = se.SharedExpertSlots(E, n_sh, K, max_num_tokens=32)
+    layer = RoutedExpertsLayer(_Engine(e13, e2, calls), RoutingConfig(K, E, routed_scaling_factor=rsf),
+                               shared_slots=slots, shared_gate_weight=gate_w, ops=_oracle_ops(calls))
+    x, logits = _x(M)
+    got = layer.forward(x, logits).float().numpy()
+    tw, ids = orc.topk_softmax(logits.numpy(), K)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    routed = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(x), ids, tw)
+    sw = np.ones((M, 1), np.float32)
+    if gated:
+        sw = torch.sigmoid(torch.nn.functional.linear(x, gate_w).float()).numpy()
+    shared = orc.moe(orc.MoeDesc(E=1, H=H, I=n_sh * I, act_dtype=orc.BF16, wfmt=orc.W_BF16), torch_to_bits(s13[None]),
+                     torch_to_bits(s2[None]), torch_to_bits(x), np.zeros((M, 1), np.int32), sw)
+    want = rsf * routed + shared
+    np.testing.assert_allclose(got, want, atol=0.03 * np.abs(want).max(), rtol=2e-2)
+    wrong = rsf * (routed + shared)                      # what an uncompensated slot weight of 1.0 gives
+    assert np.abs(got - wrong).max() > 10 * np.abs(got - want).max()
+
+
 # ------------------------------------------------------------------------------------------ the layer over EP + EPLB
 def _ep_layer_worker(rank, world, port, q):
     import os
@@ -207,7 +240,7 @@ def _ep_layer_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lvllm_amd.ep import ExpertParallelExperts
-        from tests.test_ep_gloo import _torch_pack
+        from tests.helpers import TorchEpKernels
         calls = []
         red = 4
         P, per = E + red, (E + red) // world
@@ -227,7 +260,8 @@ def _ep_layer_worker(rank, world, port, q):
                 return torch.from_numpy(orc.moe(d, torch_to_bits(l13), torch_to_bits(l2), torch_to_bits(x), ids.numpy(),
                                                 tw.numpy()))
         eng = _Live()
-        ep = ExpertParallelExperts(lambda rows, lids, ws: eng.decode(rows, ws, lids), P, H, mode="a2a", pack=_torch_pack)
+        ep = ExpertParallelExperts(lambda rows, lids, ws, dt: eng.decode(rows.contiguous(), ws.contiguous(), lids.contiguous()).to(dt),
+                                   P, H, mode="a2a", kernels=TorchEpKernels)
         layer = RoutedExpertsLayer(eng, RoutingConfig(K, E, routed_scaling_factor=2.0), eplb_state=st.layer_state(0),
                                    expert_parallel=ep, ops=_oracle_ops(calls))
         x, logits = _x(10, seed=30 + rank)

@@ -2,24 +2,33 @@
 """bench.py -- MoE-layer decode throughput of the MI355X-native routed-expert path.
 
 Metric (BASELINE.json): MoE-layer decode tokens/s + grouped-GEMM % of roofline, Mixtral-8x7B.
-Workload at N=1: BASELINE.json configs[1] -- Mixtral-8x7B bf16 experts (E=8, top-2, H=4096,
-I=14336), decode batch 32, synthetic hidden states / router logits / random-init weights, all
-resident in HBM before the timed region.  One "step" = one pass of the hot path over the batch:
+Headline workload: BASELINE.json configs[1] -- Mixtral-8x7B bf16 experts (E=8, top-2, H=4096, I=14336), decode
+batch 32 per GPU, synthetic hidden states / router logits / random-init weights, all resident in HBM before
+the timed region.  One "step" = one pass of the hot path over the batch:
 router top-k (a1) -> scatter (sort) -> grouped GEMM1 + SiLU-mul -> grouped GEMM2 -> top-k combine.
 
-N>1 (launched by torch.distributed.run, one rank per GPU, RCCL): experts are sharded E/N per
-rank (linear placement), every rank keeps its own 32-token batch, routed rows travel by
-all-to-all (lvllm_amd/ep.py) -- weak scaling; value = all ranks' tokens / max-over-ranks time.
+`python bench.py --gpus N` works by itself: without WORLD_SIZE in the environment it re-launches itself as N ranks
+under torch.distributed.run (one rank per GPU, RCCL); launched BY torch.distributed.run it simply is one of the
+ranks.  N>1: experts are sharded E/N per rank (linear placement), every rank keeps its own 32-token batch, each
+token visits the ranks that own its experts through ONE all-to-all out and ONE back (lvllm_amd/ep.py) -- weak
+scaling; value = all ranks' tokens / max-over-ranks time.  The whole expert-parallel step is captured in a
+hipGraph like the single-GPU step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
-GEMM1, algorithmic weight bytes / its mean duration from HIP events on the launch stream) and
-`cpu_baseline` (the CPU oracle = a port of the reference algorithm, timed on the host cores).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = GEMM1,
+algorithmic weight bytes / its mean duration from HIP events on the launch stream), `cpu_baseline` (N=1: the
+reference's own in-tree CPU kernel via oracle/_ref, and the CPU oracle port) and `extra`: the other BASELINE
+configurations timed the same way in the same run -- at N=1 Mixtral fp8-W8A8 M=32 (the north-star fp8 number),
+Mixtral int4-g128 M=128 (configs[2]); at every N that divides 256 the full configs[3] workload (DeepSeek-V3
+style: 256 fp8 experts, grouped sigmoid+bias top-8 of 4/8 groups, global decode batch 256, EP=N all-to-all).
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -32,15 +41,21 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 WORKLOADS = {
-    # name: (E, K, H, I, M, fmt)
+    # name: E experts, K top-k, H hidden, I intermediate, M tokens per GPU, weight format
     "mixtral8x7b_bf16_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="bf16"),
     "mixtral8x7b_int4g128_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="int4", g=128),
     "qwen3_30b_a3b_bf16_decode_m1": dict(E=128, K=8, H=2048, I=768, M=1, fmt="bf16"),
-    # per-rank slice of BASELINE.json configs[3] (DeepSeek-V3-style, EP=8): 32 local experts, the
-    # 256-token global batch x top-8 / 8 ranks = 256 routed rows per rank (rows arrive with top_k = 1)
+    # BASELINE.json configs[3]: DeepSeek-V3-style layer -- 256 fp8 (128x128 block) experts, group-limited sigmoid
+    # router with score-correction bias, GLOBAL decode batch 256 split over the ranks (M_global), experts sharded
+    # 256/N per rank.  N=1 holds all 256 experts (11.3 GB of fp8) on one GPU.
+    "dsv3_fp8w8a8_ep_decode_b256": dict(E=256, K=8, H=7168, I=2048, M_global=256, fmt="fp8", fp8_mode=1,
+                                        router=dict(kind="grouped", n_group=8, topk_group=4, scoring="sigmoid",
+                                                    routed_scaling=2.5, bias=True)),
+    "dsv3_fp8w8a16_ep_decode_b256": dict(E=256, K=8, H=7168, I=2048, M_global=256, fmt="fp8", fp8_mode=0,
+                                         router=dict(kind="grouped", n_group=8, topk_group=4, scoring="sigmoid",
+                                                     routed_scaling=2.5, bias=True)),
+    # per-rank slice of configs[3] with pre-dispatched rows (round-1 workload, kept for tools/report.py)
     "dsv3_ep8_rank_bf16_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="bf16"),
-    # BASELINE.json configs[4] shapes (GLM-4.5-Air prefill), bf16 weights stand in until fp8-W8A8 lands
-    "glm45air_bf16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="bf16"),
     "dsv3_ep8_rank_fp8w8a8_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="fp8", fp8_mode=1),
     "dsv3_ep8_rank_fp8w8a16_rows256": dict(E=32, K=1, H=7168, I=2048, M=256, fmt="fp8", fp8_mode=0),
     "mixtral8x7b_fp8w8a8_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="fp8", fp8_mode=1),
@@ -48,12 +63,19 @@ WORKLOADS = {
     "mixtral8x7b_mxfp4_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="mxfp4"),
     "mixtral8x7b_mxfp4_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="mxfp4"),
     "mixtral8x7b_nvfp4_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="nvfp4"),
-    "glm45air_fp8w8a16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=0),
-    "glm45air_fp8w8a8_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=1),
+    # BASELINE.json configs[4]: GLM-4.5-Air prefill, 8192 tokens (MFMA-bound: roofline in TFLOP/s)
+    "glm45air_bf16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="bf16", prefill=True),
+    "glm45air_fp8w8a16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=0, prefill=True),
+    "glm45air_fp8w8a8_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=1, prefill=True),
 }
+HEADLINE = "mixtral8x7b_bf16_decode_m32"
+EXTRA_N1 = ["mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128"]
+EXTRA_EP = "dsv3_fp8w8a8_ep_decode_b256"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TF = {"bf16": 2500.0, "fp8": 5000.0}   # dense, MI355X_MICROARCH.md
 
 
+# ------------------------------------------------------------------------------------------ synthetic weights
 def make_weights(E_local, first_expert, H, I, dev, fmt, g=128):
     """random-init experts, per-expert seeds so that any EP sharding sees the same model."""
     w13 = torch.empty((E_local, 2 * I, H), dtype=torch.bfloat16, device=dev)
@@ -79,15 +101,21 @@ def quantize_int4(w: torch.Tensor, g: int):
 
 
 def quantize_fp8_block(w: torch.Tensor, blk: int = 128):
-    """128x128 block fp8 (e4m3fn) quantisation on the GPU: scale = amax/448 per block."""
+    """128x128 block fp8 (e4m3fn) quantisation on the GPU: scale = amax/448 per block.  Expert by expert: the
+    fp32 staging copy of a 256-expert layer would not be worth its 45 GB."""
     E, N, K = w.shape
     nb, kb = -(-N // blk), -(-K // blk)
-    wp = torch.zeros((E, nb * blk, kb * blk), dtype=torch.float32, device=w.device)
-    wp[:, :N, :K] = w.float()
-    t = wp.view(E, nb, blk, kb, blk)
-    s = t.abs().amax(dim=(2, 4)).clamp(min=1e-4) / 448.0
-    q = (t / s[:, :, None, :, None]).view(E, nb * blk, kb * blk)[:, :N, :K].contiguous().to(torch.float8_e4m3fn)
-    return q.view(torch.uint8), s.contiguous()
+    q = torch.empty((E, N, K), dtype=torch.uint8, device=w.device)
+    s = torch.empty((E, nb, kb), dtype=torch.float32, device=w.device)
+    for e in range(E):
+        wp = torch.zeros((nb * blk, kb * blk), dtype=torch.float32, device=w.device)
+        wp[:N, :K] = w[e].float()
+        t = wp.view(nb, blk, kb, blk)
+        se = t.abs().amax(dim=(1, 3)).clamp(min=1e-4) / 448.0
+        qe = (t / se[:, None, :, None]).view(nb * blk, kb * blk)[:N, :K].contiguous().to(torch.float8_e4m3fn)
+        q[e] = qe.view(torch.uint8)
+        s[e] = se
+    return q, s
 
 
 _E2M1_MIDPOINTS = (0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0)
@@ -125,39 +153,85 @@ def quantize_nvfp4(w: torch.Tensor):
     return packed, sf.view(torch.uint8).contiguous(), (1.0 / gscale).float().contiguous()
 
 
-def build_engine(ops, wl, w13, w2, **kw):
-    """engine for a WORKLOADS entry from bf16 master weights; returns (engine, weight bytes per element,
-    oracle descriptor kwargs + arrays for the CPU baseline or None)."""
-    fmt, K = wl["fmt"], wl["K"]
+def build_engine(ops, wl, E_local, first, dev, **kw):
+    """engine over experts [first, first + E_local) of a WORKLOADS entry, built from bf16 master weights in chunks
+    of experts (a 256-expert fp8 layer never holds its 22 GB of masters); returns (engine, weight bytes per
+    element incl. scales, oracle descriptor kwargs + arrays for the CPU baseline (None above 16 experts), masters
+    (bf16 formats only))."""
+    fmt, K, H, I = wl["fmt"], wl["K"], wl["H"], wl["I"]
+    CH = 8
+    parts = []
+    for c0 in range(0, E_local, CH):
+        n = min(CH, E_local - c0)
+        w13, w2 = make_weights(n, first + c0, H, I, dev, fmt)
+        if fmt == "int4":
+            parts.append((*quantize_int4(w13, wl["g"]), *quantize_int4(w2, wl["g"])))
+        elif fmt == "mxfp4":
+            parts.append((*quantize_mxfp4(w13), *quantize_mxfp4(w2)))
+        elif fmt == "nvfp4":
+            a, b, c = quantize_nvfp4(w13)
+            d, e, f = quantize_nvfp4(w2)
+            parts.append((a, b, d, e, c, f))
+        elif fmt == "fp8":
+            parts.append((*quantize_fp8_block(w13), *quantize_fp8_block(w2)))
+        else:
+            parts.append((w13, w2))
+        del w13, w2
+    cat = [torch.cat([p[i] for p in parts]) if len(parts) > 1 else parts[0][i] for i in range(len(parts[0]))]
+    del parts
+    keep = E_local <= 16
     if fmt == "int4":
+        q13, s13, q2, s2 = cat
         g = wl["g"]
-        q13, s13 = quantize_int4(w13, g)
-        q2, s2 = quantize_int4(w2, g)
         eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="int4", w13_scale=s13,
                                       w2_scale=s2, group_n=1, group_k=g, **kw)
-        return eng, 0.5 + 2.0 / g, dict(wfmt="W_INT4", groupN=1, groupK=g, w13=q13, w2=q2, s13=s13, s2=s2)
+        return eng, 0.5 + 2.0 / g, dict(wfmt="W_INT4", groupN=1, groupK=g, w13=q13, w2=q2, s13=s13, s2=s2), None
     if fmt == "mxfp4":
-        q13, s13 = quantize_mxfp4(w13)
-        q2, s2 = quantize_mxfp4(w2)
+        q13, s13, q2, s2 = cat
         eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="mxfp4", w13_scale=s13,
                                       w2_scale=s2, group_n=1, group_k=32, **kw)
-        return eng, 0.5 + 1.0 / 32, dict(wfmt="W_MXFP4", groupN=1, groupK=32, w13=q13, w2=q2, s13=s13, s2=s2)
+        return eng, 0.5 + 1.0 / 32, dict(wfmt="W_MXFP4", groupN=1, groupK=32, w13=q13, w2=q2, s13=s13, s2=s2), None
     if fmt == "nvfp4":
-        q13, s13, g13 = quantize_nvfp4(w13)
-        q2, s2, g2 = quantize_nvfp4(w2)
+        q13, s13, q2, s2, g13, g2 = cat
         eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="nvfp4", w13_scale=s13,
                                       w2_scale=s2, group_n=1, group_k=16, w13_global_scale=g13,
                                       w2_global_scale=g2, **kw)
         return eng, 0.5 + 1.0 / 16, dict(wfmt="W_NVFP4", groupN=1, groupK=16, w13=q13, w2=q2, s13=s13, s2=s2,
-                                         gs13=g13, gs2=g2)
+                                         gs13=g13, gs2=g2), None
     if fmt == "fp8":
-        q13, s13 = quantize_fp8_block(w13)
-        q2, s2 = quantize_fp8_block(w2)
+        q13, s13, q2, s2 = cat
+        a8 = bool(wl.get("fp8_mode", 0))
         eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="fp8", w13_scale=s13,
                                       w2_scale=s2, group_n=128, group_k=128, fp8_mode=wl.get("fp8_mode", 0), **kw)
-        return eng, 1.0 + 4.0 / (128 * 128), None
+        oi = dict(wfmt="W_FP8", groupN=128, groupK=128, w8a8=a8, round_gemm1=a8, w13=q13, w2=q2, s13=s13,
+                  s2=s2) if keep else None
+        return eng, 1.0 + 4.0 / (128 * 128), oi, None
+    w13, w2 = cat
     eng = ops.RoutedExpertsEngine(w13, w2, top_k=K, act_dtype=torch.bfloat16, fmt="bf16", **kw)
-    return eng, 2.0, dict(wfmt="W_BF16", groupN=0, groupK=0, w13=w13, w2=w2)
+    return eng, 2.0, (dict(wfmt="W_BF16", groupN=0, groupK=0, w13=w13, w2=w2) if keep else None), (w13, w2)
+
+
+# ------------------------------------------------------------------------------------------ CPU baselines
+def host_info():
+    """what SURVEY 8d asks to state next to a CPU number: logical CPUs, sockets, NUMA nodes of this box"""
+    info = {"nproc": os.cpu_count() or 1}
+    try:
+        ids = {ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("physical id")}
+        info["sockets"] = max(1, len(ids))
+        model = [ln.split(":")[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")]
+        if model:
+            info["cpu"] = model[0]
+    except OSError:
+        pass
+    try:
+        info["numa_nodes"] = len([p for p in Path("/sys/devices/system/node").glob("node[0-9]*")])
+    except OSError:
+        pass
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    return info
 
 
 def time_reference_kernel(w13, w2, x, tw, ids, thread_cands, seconds, gpu_out):
@@ -193,16 +267,328 @@ def time_reference_kernel(w13, w2, x, tw, ids, thread_cands, seconds, gpu_out):
             "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err, "n": n, "t": t_cpu}
 
 
+def cpu_baseline(name, wl, oracle_in, masters, x, tw, ids, gpu_out, seconds):
+    """the CPU oracle (port of the reference algorithm) and, for 16-bit experts, the reference's own in-tree CPU
+    kernel (oracle/_ref) on the same inputs and this box's host cores"""
+    from oracle import oracle as orc
+    E, H, I, M = wl["E"], wl["H"], wl["I"], x.size(0)
+    twn, idn = tw.cpu().numpy(), ids.cpu().numpy()
+    xb = x.cpu().view(torch.int16).numpy().view(np.uint16)
+
+    def _np(t):
+        t = t.cpu()
+        return t.view(torch.int16).numpy().view(np.uint16) if t.dtype == torch.bfloat16 else t.numpy()
+    oi = dict(oracle_in)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=getattr(orc, oi.pop("wfmt")), groupN=oi.pop("groupN"),
+                    groupK=oi.pop("groupK"), w8a8=oi.pop("w8a8", False), round_gemm1=oi.pop("round_gemm1", False))
+    cargs = {k_: _np(v) for k_, v in oi.items()}
+    ref = orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)            # untimed first pass (page-in)
+    # The host may expose more logical CPUs than the container can actually run (measured on the
+    # bench box: 32 threads 49 ms, 64 threads 77 ms, 128 threads 137 ms, 256 threads 960 ms per
+    # step), so the team size is picked by a short probe; `cores` reports the size used.
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
+    best_t, best_c = None, cands[0]
+    for c in cands:
+        orc.set_threads(c)
+        c0 = time.perf_counter()
+        orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)
+        tc = time.perf_counter() - c0
+        if best_t is None or tc < best_t:
+            best_t, best_c = tc, c
+        if tc > 3 * best_t:
+            break
+    orc.set_threads(best_c)
+    n, t_cpu = 0, 0.0
+    while n < 2 or (t_cpu < seconds and n < 200):
+        c0 = time.perf_counter()
+        ref = orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)
+        t_cpu += time.perf_counter() - c0
+        n += 1
+    err = float(np.abs(gpu_out - ref).max() / max(1e-9, np.abs(ref).max()))
+    cpu = {"value": round(M / (t_cpu / n), 2), "unit": "tokens/s", "cores": orc.num_threads(), "kind": "port",
+           "sample": f"{n} full {name} layer passes (M={M}) through oracle/lkm_oracle.c, "
+                     f"{t_cpu:.1f} s of CPU work; lk_moe itself is a closed binary absent from the reference tree",
+           "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err, "host": host_info()}
+    # The reference's OWN in-tree CPU fused-MoE kernel (csrc/cpu/cpu_fused_moe.cpp, compiled into oracle/_ref
+    # where /root/reference exists; 16-bit experts only) on the same inputs and host cores: when it loads it
+    # IS the cpu_baseline ("reference") and the port's figure moves to cpu_baseline["port"].
+    if wl["fmt"] == "bf16" and masters is not None:
+        try:
+            cpu_ref = time_reference_kernel(masters[0], masters[1], x, tw, ids, cands, seconds, gpu_out)
+        except Exception as e:
+            print(f"[bench] oracle/_ref unavailable ({e}); cpu_baseline is the port", file=sys.stderr)
+            cpu_ref = None
+        if cpu_ref is not None:
+            cpu_ref["sample"] = (f"{cpu_ref.pop('n')} full {name} layer passes (M={M}) through the reference's "
+                                 f"csrc/cpu/cpu_fused_moe.cpp (AVX-512 'vec' micro-kernels, oracle/_ref), "
+                                 f"{cpu_ref.pop('t'):.1f} s of CPU work")
+            cpu_ref["host"] = cpu.pop("host")
+            cpu_ref["port"] = cpu
+            cpu = cpu_ref
+    return cpu
+
+
+# ------------------------------------------------------------------------------------------ one workload
+def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
+    """times `steps` steps of one WORKLOADS entry on this rank set; returns the result dict on rank 0 (None
+    elsewhere).  Every rank must call it with the same arguments (it contains collectives when world > 1)."""
+    from lvllm_amd import ops
+    from lvllm_amd.ep import ExpertParallelExperts
+    world, rank, dev = ctx["world"], ctx["rank"], ctx["dev"]
+    wl = WORKLOADS[name]
+    E, K, H, I, fmt = wl["E"], wl["K"], wl["H"], wl["I"], wl["fmt"]
+    if "M_global" in wl:
+        if wl["M_global"] % world:
+            return None
+        M, scaling = wl["M_global"] // world, "strong"
+    else:
+        M, scaling = wl["M"], "weak"
+    if E % world:
+        return None
+    use_ep = world > 1 or force_ep
+    E_local, first = E // world, rank * (E // world)
+    eng, bpe, oracle_in, masters = build_engine(ops, wl, E_local, first, dev, max_num_seqs=max(256, M * world),
+                                                max_batch_size=max(8192, M), num_processes=world, process_id=rank)
+    if args.tune:
+        eng.engine.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
+    if use_ep and args.ep_mode == "a2a":
+        # the engine sees ep x capacity token records of which ~1/ep carry local ids: plan for the rows that exist
+        eng.engine.set_tuning(valid_den=world)
+
+    # synthetic inputs (seed 7, SURVEY 8d): x = randn/10, router logits = randn
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    x = (torch.randn((M, H), generator=gen, device=dev) / 10).to(torch.bfloat16)
+    logits = torch.randn((M, E), generator=gen, device=dev, dtype=torch.float32)
+    if args.routing == "zipf":      # log-popularity bias: p(e) ~ 1/(e+1)
+        logits = logits + torch.log(1.0 / torch.arange(1, E + 1, device=dev, dtype=torch.float32))[None, :]
+    rt = wl.get("router", dict(kind="softmax"))
+    bias = None
+    if rt.get("bias"):
+        bias = torch.randn((E,), generator=torch.Generator(device=dev).manual_seed(99), device=dev) * 0.1
+
+    def route():
+        if rt["kind"] == "grouped":
+            return ops.grouped_topk(x, logits, K, True, rt["n_group"], rt["topk_group"], rt["scoring"],
+                                    rt["routed_scaling"], bias)
+        return ops.topk_softmax(logits, K, True)
+    prefill = bool(wl.get("prefill"))
+    out = torch.empty((M, H), dtype=torch.bfloat16 if prefill else torch.float32, device=dev)
+    ep = None
+    if not use_ep:
+        if prefill:
+            def step():
+                tw, ids = route()
+                eng.forward_rows(x, tw, ids, out=out)
+        else:
+            def step():
+                tw, ids = route()
+                eng.decode(x, tw, ids, out=out)
+    else:
+        def local_compute(rows, lids, ws, dt):
+            return eng.forward_rows(rows, ws, lids, out_dtype=dt)
+        ep = ExpertParallelExperts(local_compute, E, H, mode=args.ep_mode,
+                                   return_dtype=torch.float32 if args.ep_return == "f32" else None)
+
+        def step():
+            tw, ids = route()
+            ep.forward(x, tw, ids, force_collectives=True, out=out)
+
+    def barrier():
+        if ctx["dist"]:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (also creates the communicator and the persistent exchange buffers before any capture)
+    for _ in range(max(1, warmup)):
+        step()
+    barrier()
+    launch, graph = "eager", None
+    if not args.no_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            barrier()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                step()
+            graph.replay()
+            barrier()
+            launch = "hipgraph"
+        except Exception as e:  # capture is an optimisation of the launch path only
+            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            graph = None
+    if ctx["dist"]:
+        # all ranks must agree on the launch path (a rank replaying a graph against a rank launching eagerly is
+        # still the same sequence of collectives, but the timing would mix two things)
+        flag = torch.tensor([1 if graph is not None else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            graph, launch = None, "eager"
+    run = (lambda: graph.replay()) if graph is not None else step
+
+    # ---- timed region: exactly `steps` steps, barrier + synchronize on both sides
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if ctx["dist"]:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    ms_per_step = dt / steps * 1e3
+    tokens_per_s = M * world / (dt / steps)
+
+    # ---- optional: cold-cache variant (SURVEY 8d).  Not part of the timed steps above.
+    cold_ms = None
+    if args.flush_cache and rank == 0 and not use_ep:     # EP steps are collective: every rank would have to join
+        flush = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        n_cold = min(steps, 50)
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_cold)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_cold)]
+        for i in range(n_cold):
+            flush.fill_(i & 0xFF)
+            starts[i].record()
+            run()
+            ends[i].record()
+        torch.cuda.synchronize()
+        cold_ms = sum(a.elapsed_time(b) for a, b in zip(starts, ends)) / n_cold
+        del flush
+
+    # ---- dominant-kernel roofline: GEMM1 duration from HIP events on the launch stream (rank 0's engine)
+    res = None
+    tw, ids = route()
+    lids = ids
+    if world > 1:
+        lids = torch.where((ids >= first) & (ids < first + E_local), ids - first, torch.full_like(ids, -1))
+    if rank == 0:
+        # each GEMM is launched PROF_REP times back to back between its two events and the interval divided
+        # (lkm_set_tuning "prof_rep"): a single launch between two events also times the event packets,
+        # ~10 us on top of the kernel time rocprofv3 reports for the same launch
+        PROF_REP = 8
+        pout = torch.empty((M, H), dtype=torch.float32, device=dev)
+        if use_ep and args.ep_mode == "a2a":
+            eng.engine.set_tuning(valid_den=0)            # the profiled call below hands over this rank's own rows only
+        eng.engine.set_tuning(prof_rep=PROF_REP)
+        eng.engine.set_profiling(True)
+        acc = {"sort": 0.0, "gemm1": 0.0, "gemm2": 0.0, "combine": 0.0}
+        reps = 30 if not prefill else 5
+        for _ in range(3):
+            eng.decode(x, tw, lids, out=pout)
+        for _ in range(reps):
+            eng.decode(x, tw, lids, out=pout)
+            p = eng.engine.get_profile()
+            for k_ in acc:
+                acc[k_] += p[k_]
+        eng.engine.set_profiling(False)
+        eng.engine.set_tuning(prof_rep=0)
+        prof_ms = {k_: v / reps for k_, v in acc.items()}
+        e_act = int(torch.unique(lids[lids >= 0]).numel())
+        rows = int((lids >= 0).sum().item())
+        g1_bytes = e_act * 2 * I * H * bpe                           # algorithmic weight bytes of GEMM1 (bpe incl. scales)
+        layer_flops = 6.0 * rows * H * I
+        layer_bytes = e_act * 3 * I * H * bpe
+        g1_ms = max(prof_ms["gemm1"], 1e-6)
+        if prefill:     # MFMA-bound regime: the roofline of the dominant kernel is flops against the dense MFMA peak
+            g1_flops = 4.0 * rows * H * I
+            peak = MFMA_PEAK_TF["fp8" if (fmt == "fp8" and wl.get("fp8_mode")) else "bf16"]
+            ach = g1_flops / (g1_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "gemm1 (grouped, tiled)", "achieved": round(ach, 1), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "algorithmic_flops": g1_flops}
+        else:
+            achieved = g1_bytes / (g1_ms * 1e-3) / 1e9               # (a rank whose experts got no row: 0)
+            traffic = None
+            tf = ROOT / "profiles" / "hbm_traffic.json"
+            if tf.exists():
+                try:
+                    traffic = json.loads(tf.read_text()).get(name, {}).get("gemm1_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": "gemm1_act_kernel", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic,
+                        "traffic_source": None if traffic is None else
+                        "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE pass of this workload, gfx950-corrected "
+                        "(x2), committed with the kernel it measured -- static, NOT re-read in this run",
+                        "algorithmic_bytes": g1_bytes}
+        roofline.update({
+            "layer": {"routed_rows": rows, "experts_hit": e_act, "weight_bytes": layer_bytes, "flops": layer_flops,
+                      "GBps_over_step": round(layer_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                      "TFLOPs_over_step": round(layer_flops / (ms_per_step * 1e-3) / 1e12, 2)},
+            "kernel_ms": {k_: round(v, 4) for k_, v in prof_ms.items()},
+            "timing": f"HIP events on the launch stream around {PROF_REP} back-to-back launches, / {PROF_REP}"
+                      + (" (rank 0's engine on rank 0's own routed rows)" if world > 1 else "")})
+        res = {"workload": name, "value": round(tokens_per_s, 1), "unit": "tokens/s", "ms_per_step": round(ms_per_step, 4),
+               "steps": steps, "scaling": scaling,
+               "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act", "mxfp4": "mxfp4-w/bf16-act",
+                         "nvfp4": "nvfp4-w/bf16-act",
+                         "fp8": "fp8-w/" + ("fp8-act" if wl.get("fp8_mode") else "bf16-act")}[fmt],
+               "config": {"workload": name, "experts": E, "experts_per_gpu": E_local, "top_k": K, "hidden": H,
+                          "intermediate": I, "batch_per_gpu": M, "global_batch": M * world,
+                          "router": rt["kind"] if rt["kind"] == "softmax" else
+                          f"grouped {rt['scoring']}+bias top-{K} of {rt['topk_group']}/{rt['n_group']} groups x{rt['routed_scaling']}",
+                          "routing": args.routing,
+                          "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}",
+                          "launch": launch, "geometry": eng.engine.describe()},
+               "roofline": roofline}
+        if ep is not None and args.ep_mode == "a2a":
+            rb = 4 if args.ep_return == "f32" else 2
+            res["config"]["exchange"] = dict(ep.wire_bytes(M, K, ret_bytes=rb),
+                                             granularity="token records [x | ids | weights], capacity = tokens per rank",
+                                             return_dtype="fp32" if rb == 4 else "bf16")
+        if cold_ms is not None:
+            res["ms_per_step_cold"] = round(cold_ms, 4)     # events around each step, caches evicted before it
+        if with_cpu and world == 1 and oracle_in is not None:
+            gpu_out = eng.decode(x, tw, ids).cpu().numpy()
+            res["cpu_baseline"] = cpu_baseline(name, wl, oracle_in, masters, x, tw, ids, gpu_out, args.cpu_seconds)
+    barrier()
+    del graph, eng, ep, oracle_in, masters
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+# ------------------------------------------------------------------------------------------ launch
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
+    (the reference's tests spawn their ranks themselves too, tests/kernels/moe/parallel_utils.py:52-118)."""
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="mixtral8x7b_bf16_decode_m32", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default=HEADLINE, choices=list(WORKLOADS))
     ap.add_argument("--ep-mode", default="a2a", choices=["a2a", "ar"])
+    ap.add_argument("--ep-return", default="bf16", choices=["bf16", "f32"],
+                    help="dtype of the partial rows on the return all-to-all (bf16 = the activation dtype)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--force-ep", action="store_true", help="run the expert-parallel data path even with one rank (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="time the headline workload only")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget (s) for each CPU baseline sample (reference kernel, port)")
     ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf"],
                     help="router logits: randn (uniform-ish) or randn + Zipf(s=1) expert popularity bias (SURVEY 8d)")
@@ -212,248 +598,66 @@ def main():
                          "256 MB Infinity Cache (SURVEY 8d flush variant; the headline numbers are unaffected)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_ep = world > 1 or args.force_ep
-    if use_ep:
+    use_dist = world > 1 or args.force_ep
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    ctx = dict(world=world, rank=rank, dev=dev, dist=use_dist)
 
-    from lvllm_amd import ops
-    from lvllm_amd.ep import ExpertParallelExperts
-
-    wl = WORKLOADS[args.workload]
-    E, K, H, I, M, fmt = wl["E"], wl["K"], wl["H"], wl["I"], wl["M"], wl["fmt"]
-    assert E % world == 0 or world == 1, "experts must shard evenly for the bench"
-    E_local = E // world
-    first = rank * E_local
-    w13, w2 = make_weights(E_local, first, H, I, dev, fmt)
-    eng, bpe, oracle_in = build_engine(ops, wl, w13, w2, max_num_seqs=max(256, M * world),
-                                       num_processes=world, process_id=rank)
-    if args.tune:
-        eng.engine.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
-
-    # synthetic inputs (seed 7): x = randn/10, router logits = randn
-    gen = torch.Generator(device=dev).manual_seed(7 + rank)
-    x = (torch.randn((M, H), generator=gen, device=dev) / 10).to(torch.bfloat16)
-    logits = torch.randn((M, E), generator=gen, device=dev, dtype=torch.float32)
-    if args.routing == "zipf":      # log-popularity bias: p(e) ~ 1/(e+1)
-        logits = logits + torch.log(1.0 / torch.arange(1, E + 1, device=dev, dtype=torch.float32))[None, :]
-    out = torch.empty((M, H), dtype=torch.float32, device=dev)
-
-    if not use_ep:
-        def step():
-            tw, ids = ops.topk_softmax(logits, K, True)
-            eng.decode(x, tw, ids, out=out)
-    else:
-        def local_compute(rows, lids, ws):
-            return eng.decode(rows, ws.contiguous(), lids.contiguous())
-        ep = ExpertParallelExperts(local_compute, E, H, mode=args.ep_mode)
-
-        def step():
-            tw, ids = ops.topk_softmax(logits, K, True)
-            out.copy_(ep.forward(x, tw, ids, force_collectives=True))
-
-    def barrier():
-        if use_ep:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- warm-up (also the un-captured reference result)
-    for _ in range(max(1, args.warmup)):
-        step()
-    barrier()
-    launch = "eager"
-    graph = None
-    # EP steps (RCCL collectives) are timed with eager launches: capturing them into a hipGraph worked for the
-    # step itself on one rank but left the process hanging at teardown for ~10 minutes -- not worth the risk
-    if not use_ep and not args.no_graph:
-        try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                step()
-            torch.cuda.current_stream().wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=s):
-                step()
-            graph.replay()
-            torch.cuda.synchronize()
-            launch = "hipgraph"
-        except Exception as e:  # capture is an optimisation of the launch path only
-            print(f"[bench] graph capture unavailable ({e}); timing eager launches", file=sys.stderr)
-            graph = None
-    run = (lambda: graph.replay()) if graph is not None else step
-
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_ep:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    tokens_per_s = M * world / (dt / args.steps)
-
-    # ---- optional: cold-cache variant.  Not part of the timed K steps above.
-    cold_ms = None
-    if args.flush_cache and rank == 0:
-        flush = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-        n_cold = min(args.steps, 50)
-        starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_cold)]
-        ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_cold)]
-        if not use_ep:                                   # EP steps are collective: every rank would have to join
-            for i in range(n_cold):
-                flush.fill_(i & 0xFF)
-                starts[i].record()
-                run()
-                ends[i].record()
-            torch.cuda.synchronize()
-            cold_ms = sum(a.elapsed_time(b) for a, b in zip(starts, ends)) / n_cold
-        del flush
-
-    # ---- dominant-kernel roofline: GEMM1 duration from HIP events on the launch stream
-    roofline = None
-    prof_ms = None
-    if rank == 0:
-        tw, ids = ops.topk_softmax(logits, K, True)
-        if world > 1:
-            ids = torch.where((ids >= first) & (ids < first + E_local), ids - first, torch.full_like(ids, -1))
-        # each GEMM is launched PROF_REP times back to back between its two events and the interval divided
-        # (lkm_set_tuning "prof_rep"): a single launch between two events also times the event packets,
-        # ~10 us on top of the kernel time rocprofv3 reports for the same launch
-        PROF_REP = 8
-        eng.engine.set_tuning(prof_rep=PROF_REP)
-        eng.engine.set_profiling(True)
-        acc = {"sort": 0.0, "gemm1": 0.0, "gemm2": 0.0, "combine": 0.0}
-        reps = 30
-        for _ in range(5):
-            eng.decode(x, tw, ids, out=out)
-        for _ in range(reps):
-            eng.decode(x, tw, ids, out=out)
-            p = eng.engine.get_profile()
-            for k_ in acc:
-                acc[k_] += p[k_]
-        eng.engine.set_profiling(False)
-        eng.engine.set_tuning(prof_rep=0)
-        prof_ms = {k_: v / reps for k_, v in acc.items()}
-        e_act = int(torch.unique(ids[ids >= 0]).numel())
-        scale_bytes = 0.0                                           # bpe (build_engine) includes the scales
-        g1_bytes = e_act * 2 * I * H * (bpe + scale_bytes)          # algorithmic weight bytes of GEMM1
-        achieved = g1_bytes / (max(prof_ms["gemm1"], 1e-6) * 1e-3) / 1e9      # (a rank whose experts got no row: 0)
-        traffic = None
-        tf = ROOT / "profiles" / "hbm_traffic.json"
-        if tf.exists():
+    head = run_workload(args.workload, args, ctx, steps=args.steps, warmup=args.warmup,
+                        with_cpu=not args.no_cpu_baseline, force_ep=args.force_ep)
+    extras = []
+    if not args.no_extras and args.workload == HEADLINE:
+        es, ew = min(args.steps, 100), min(args.warmup, 10)
+        names = (EXTRA_N1 if world == 1 and not args.force_ep else []) + [EXTRA_EP]
+        for n in names:
             try:
-                traffic = json.loads(tf.read_text()).get(args.workload, {}).get("gemm1_bytes_per_launch")
-            except Exception:
-                traffic = None
-        rows = int((ids >= 0).sum().item())
-        layer_flops = 6.0 * rows * H * I
-        layer_bytes = e_act * 3 * I * H * (bpe + scale_bytes)
-        roofline = {"bound": "hbm", "kernel": "gemm1_act_kernel", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "algorithmic_bytes": g1_bytes,
-                    "layer": {"routed_rows": rows, "experts_hit": e_act, "weight_bytes": layer_bytes,
-                              "flops": layer_flops,
-                              "GBps_over_step": round(layer_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                              "TFLOPs_over_step": round(layer_flops / (ms_per_step * 1e-3) / 1e12, 2)},
-                    "kernel_ms": {k_: round(v, 4) for k_, v in prof_ms.items()},
-                    "timing": f"HIP events on the launch stream around {PROF_REP} back-to-back launches, / {PROF_REP}"}
-
-    # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and oracle_in is not None:
-        from oracle import oracle as orc
-        tw, ids = ops.topk_softmax(logits, K, True)
-        twn, idn = tw.cpu().numpy(), ids.cpu().numpy()
-        xb = x.cpu().view(torch.int16).numpy().view(np.uint16)
-        def _np(t):
-            t = t.cpu()
-            return t.view(torch.int16).numpy().view(np.uint16) if t.dtype == torch.bfloat16 else t.numpy()
-        oi = dict(oracle_in)
-        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=getattr(orc, oi.pop("wfmt")),
-                        groupN=oi.pop("groupN"), groupK=oi.pop("groupK"))
-        cargs = {k_: _np(v) for k_, v in oi.items()}
-        ref = orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)            # untimed first pass (page-in)
-        # The host may expose more logical CPUs than the container can actually run (measured on the
-        # bench box: 32 threads 49 ms, 64 threads 77 ms, 128 threads 137 ms, 256 threads 960 ms per
-        # step), so the team size is picked by a short probe; `cores` reports the size used.
-        ncpu = os.cpu_count() or 1
-        cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
-        best_t, best_c = None, cands[0]
-        for c in cands:
-            orc.set_threads(c)
-            c0 = time.perf_counter()
-            orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)
-            tc = time.perf_counter() - c0
-            if best_t is None or tc < best_t:
-                best_t, best_c = tc, c
-            if tc > 3 * best_t:
-                break
-        orc.set_threads(best_c)
-        n, t_cpu = 0, 0.0
-        while n < 2 or (t_cpu < args.cpu_seconds and n < 200):
-            c0 = time.perf_counter()
-            ref = orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)
-            t_cpu += time.perf_counter() - c0
-            n += 1
-        gpu_out = eng.decode(x, tw, ids).cpu().numpy()
-        err = float(np.abs(gpu_out - ref).max() / max(1e-9, np.abs(ref).max()))
-        cpu = {"value": round(M / (t_cpu / n), 2), "unit": "tokens/s", "cores": orc.num_threads(),
-               "kind": "port",
-               "sample": f"{n} full {args.workload} layer passes (M={M}) through oracle/lkm_oracle.c, "
-                         f"{t_cpu:.1f} s of CPU work; lk_moe itself is a closed binary absent from the reference tree",
-               "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err}
-        # The reference's OWN in-tree CPU fused-MoE kernel (csrc/cpu/cpu_fused_moe.cpp, compiled into oracle/_ref
-        # where /root/reference exists; 16-bit experts only) on the same inputs and host cores: when it loads it
-        # IS the cpu_baseline ("reference") and the port's figure moves to cpu_baseline["port"].
-        if fmt == "bf16":
-            try:
-                cpu_ref = time_reference_kernel(w13, w2, x, tw, ids, cands, args.cpu_seconds, gpu_out)
-            except Exception as e:
-                print(f"[bench] oracle/_ref unavailable ({e}); cpu_baseline is the port", file=sys.stderr)
-                cpu_ref = None
-            if cpu_ref is not None:
-                cpu_ref["sample"] = (f"{cpu_ref.pop('n')} full {args.workload} layer passes (M={M}) through the reference's "
-                                     f"csrc/cpu/cpu_fused_moe.cpp (AVX-512 'vec' micro-kernels, oracle/_ref), "
-                                     f"{cpu_ref.pop('t'):.1f} s of CPU work")
-                cpu_ref["port"] = cpu
-                cpu = cpu_ref
+                r = run_workload(n, args, ctx, steps=es, warmup=ew, with_cpu=False,
+                                 force_ep=args.force_ep and n == EXTRA_EP)
+            except Exception as e:   # an extra must never take the headline line with it
+                if use_dist:
+                    raise                # ... except where ranks would fall out of step
+                print(f"[bench] extra workload {n} failed: {type(e).__name__}: {e}", file=sys.stderr)
+                r = None
+            if r is not None:
+                extras.append(r)
 
     if rank == 0:
+        if head is None:
+            sys.exit(f"workload {args.workload} does not shard over {world} GPUs")
         line = {
-            "metric": "moe_layer_decode_tokens_per_s", "value": round(tokens_per_s, 1), "unit": "tokens/s",
+            "metric": "moe_layer_decode_tokens_per_s", "value": head["value"], "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act", "mxfp4": "mxfp4-w/bf16-act", "nvfp4": "nvfp4-w/bf16-act",
-                              "fp8": "fp8-w/" + ("fp8-act" if wl.get("fp8_mode") else "bf16-act")}[fmt], "data": "synthetic",
-            "config": {"workload": args.workload, "experts": E, "top_k": K, "hidden": H,
-                       "intermediate": I, "batch_per_gpu": M, "routing": args.routing,
-                       "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}",
-                       "launch": launch, "geometry": eng.engine.describe()},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
+            "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+            "config": head["config"], "roofline": head["roofline"], "cpu_baseline": head.get("cpu_baseline"),
         }
-        if cold_ms is not None:
-            line["ms_per_step_cold"] = round(cold_ms, 4)     # events around each step, caches evicted before it
+        if "ms_per_step_cold" in head:
+            line["ms_per_step_cold"] = head["ms_per_step_cold"]
+        if extras:
+            line["extra"] = extras
         print(json.dumps(line), flush=True)
-    if use_ep:
-        # rank 0 spent a few ms more (kernel profiling, the JSON line): tear the communicator down with every rank
-        # still alive and idle
+    if use_dist:
+        # Every rank is past its last collective; leave without tearing the communicator down: destroying a
+        # process group whose collectives live in captured graphs has hung at exit before, and the JSON line is out.
         dist.barrier()
         torch.cuda.synchronize()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

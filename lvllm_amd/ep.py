@@ -145,21 +145,23 @@ class ExpertParallelExperts:
         self._last = (b, M, K, cap)
         return rows, rids, rws
 
-    def combine_fixed(self, y: torch.Tensor, M: int, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    def combine_fixed(self, y: torch.Tensor, M: int, out_dtype: torch.dtype = torch.float32,
+                      out: torch.Tensor | None = None) -> torch.Tensor:
         """owners -> tokens, ONE collective: y [ep*cap, H] (the owners' weighted partial rows, return dtype) ->
         [M, H] out_dtype = fixed-order fp32 sum over the ranks a token visited"""
         b, M_, K, cap = self._last
         assert M_ == M and y.shape == (self.ep * cap, self.H) and y.dtype == b["back"].dtype, (y.shape, y.dtype)
         self.transport(b["back"], y.view(self.ep, cap, self.H))
-        out = torch.empty((M, self.H), dtype=out_dtype, device=y.device)
+        if out is None:
+            out = torch.empty((M, self.H), dtype=out_dtype, device=y.device)
         return self.kernels.ep_combine(b["back"], b["slot_of"], out)
 
-    def _forward_a2a_fixed(self, hidden, tw, ids, cap: int, out_dtype: torch.dtype) -> torch.Tensor:
+    def _forward_a2a_fixed(self, hidden, tw, ids, cap: int, out_dtype: torch.dtype, out=None) -> torch.Tensor:
         M, K = ids.shape
         rows, rids, rws = self.dispatch_fixed(hidden, tw, ids, cap)
         ret = self.return_dtype or hidden.dtype
         y = self.local_compute(rows, rids, rws, ret)
-        return self.combine_fixed(y, M, out_dtype)
+        return self.combine_fixed(y, M, out_dtype, out)
 
     def overflow_count(self) -> int:
         """tokens dropped so far for lack of record capacity (only possible with a capacity below the token
@@ -246,22 +248,28 @@ class ExpertParallelExperts:
 
     def forward(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor,
                 force_collectives: bool = False, capacity: int | None = None,
-                out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
-        """hidden [M,H] (this rank's tokens), GLOBAL expert ids int32 [M,K] -> [M,H] (fp32 by default).
+                out_dtype: torch.dtype = torch.float32, out: torch.Tensor | None = None) -> torch.Tensor:
+        """hidden [M,H] (this rank's tokens), GLOBAL expert ids int32 [M,K] -> [M,H] (fp32 by default; `out`, a
+        contiguous [M,H] tensor, receives it in place on the fixed path).
         force_collectives runs the collective data path even on a single rank (plumbing checks).
         capacity: see the module docstring (the token count every rank of the group agrees on)."""
+        if out is not None:
+            out_dtype = out.dtype
         if self.ep == 1 and not force_collectives:
-            return self.local_compute(hidden, topk_ids, topk_weights, out_dtype)
+            y = self.local_compute(hidden, topk_ids, topk_weights, out_dtype)
+            return y if out is None else out.copy_(y)
         M = topk_ids.size(0)
         if self.mode == "a2a":
             cap = self.capacity_for(M, capacity)
             if self.validate_uniform:
                 self._check_uniform(cap, "record capacity")
             if cap <= self.fixed_max_tokens:
-                return self._forward_a2a_fixed(hidden, topk_weights, topk_ids, cap, out_dtype)
-            out = self._forward_a2a(hidden, topk_weights, topk_ids)
+                return self._forward_a2a_fixed(hidden, topk_weights, topk_ids, cap, out_dtype, out)
+            y = self._forward_a2a(hidden, topk_weights, topk_ids)
         else:
             if self.validate_uniform:
                 self._check_uniform(M, "token count")
-            out = self._forward_ar(hidden, topk_weights, topk_ids)
-        return out if out.dtype == out_dtype else out.to(out_dtype)
+            y = self._forward_ar(hidden, topk_weights, topk_ids)
+        if out is not None:
+            return out.copy_(y)
+        return y if y.dtype == out_dtype else y.to(out_dtype)

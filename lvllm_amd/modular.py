@@ -229,9 +229,10 @@ class LkmExperts:
         if M == 0:
             return
 
-        def rowwise(t_):      # rows of the token-granular EP exchange arrive as row-strided views: used in place
-            return t_ if t_.dim() == 2 and (t_.size(1) == 1 or t_.stride(1) == 1) and t_.stride(0) % 8 == 0 else t_.contiguous()
-        x, ids, tw = rowwise(hidden_states), rowwise(ids), rowwise(tw)
+        def rowwise(t_, align):   # rows of the token-granular EP exchange arrive as row-strided views: used in place
+            ok = t_.dim() == 2 and (t_.size(1) == 1 or t_.stride(1) == 1) and t_.stride(0) % align == 0
+            return t_ if ok else t_.contiguous()
+        x, ids, tw = rowwise(hidden_states, 8), rowwise(ids, 1), rowwise(tw, 1)
         if output.is_contiguous() and output.dtype in (torch.float32, hidden_states.dtype):
             eng.forward_rows(x, tw, ids, out=output)
         else:

@@ -144,6 +144,87 @@ def test_ep_matches_single_rank_oracle(world, mode):
             np.testing.assert_allclose(results[r], ref, atol=1e-5, rtol=1e-5)
 
 
+def _uneven_worker(rank, world, port, q):
+    """ranks hold DIFFERENT token counts (one of them none at all) under a common record capacity"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lvllm_amd.ep import ExpertParallelExperts
+        w13, w2 = _weights()
+        ep = ExpertParallelExperts(lambda *a: None, E, H, mode="a2a", kernels=TorchEpKernels, capacity_tokens=16,
+                                   return_dtype=torch.float32, validate_uniform=True)
+        lo, n_loc = ep.first_expert[rank], ep.local_num
+        d = orc.MoeDesc(E=n_loc, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+
+        def local_compute(x, lids, ws, out_dtype):
+            y = orc.moe(d, torch_to_bits(w13[lo:lo + n_loc]), torch_to_bits(w2[lo:lo + n_loc]),
+                        torch_to_bits(x.contiguous()), lids.contiguous().numpy(), ws.contiguous().numpy())
+            return torch.from_numpy(y).to(out_dtype)
+        ep.local_compute = local_compute
+        a, tw, ids = _tokens(rank)
+        n = [M, 0, 5][rank]
+        out = ep.forward(a[:n], tw[:n], ids[:n])
+        q.put((rank, out.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_common_capacity_serves_unequal_token_counts():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w13, w2 = _weights()
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    for r, n in enumerate([M, 0, 5]):
+        a, tw, ids = _tokens(r)
+        assert results[r].shape == (n, H)
+        if n:
+            ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a[:n]), ids[:n].numpy(), tw[:n].numpy())
+            np.testing.assert_allclose(results[r], ref, atol=1e-5, rtol=1e-5)
+
+
+def test_pack_records_capacity_and_overflow_accounting():
+    """the record layout and the counted overflow of the token-granular pack (torch restatement; the HIP kernel must
+    equal it bit for bit: tests/test_gpu_ep.py)"""
+    from lvllm_amd.ep import owner_of
+    Mx, Kx, Hx, Ex, ep = 21, 4, 32, 16, 4
+    g = torch.Generator().manual_seed(3)
+    hidden = torch.randn((Mx, Hx), generator=g).to(torch.bfloat16)
+    ids = torch.randint(-1, Ex, (Mx, Kx), generator=g, dtype=torch.int32)
+    tw = torch.rand((Mx, Kx), generator=g)
+    rowb = TorchEpKernels.ep_row_bytes(Hx, Kx)
+    assert rowb % 16 == 0 and rowb >= Hx * 2 + Kx * 8
+    for cap in (Mx, 7):
+        send = torch.zeros((ep, cap, rowb), dtype=torch.uint8)
+        slot_of = torch.full((ep, Mx), -7, dtype=torch.int32)
+        overflow = torch.zeros(1, dtype=torch.int32)
+        TorchEpKernels.ep_pack_tokens(hidden, tw, ids, Ex, ep, cap, send, slot_of, overflow)
+        own = owner_of(ids, Ex, ep)
+        dropped = 0
+        for p in range(ep):
+            want_tokens = [m for m in range(Mx) if (own[m] == p).any()]
+            kept, lost = want_tokens[:cap], want_tokens[cap:]
+            dropped += len(lost)
+            assert [m for m in range(Mx) if slot_of[p, m] >= 0] == kept
+            assert [int(slot_of[p, m]) for m in kept] == list(range(len(kept)))      # ascending token order
+            rec_ids = send[p, :, Hx * 2:Hx * 2 + 4 * Kx].contiguous().view(torch.int32)
+            assert (rec_ids[len(kept):] == -1).all()
+            first = ep_first = p * (Ex // ep)
+            for c, m in enumerate(kept):
+                assert torch.equal(send[p, c, :Hx * 2].view(torch.bfloat16), hidden[m])
+                want = torch.where(own[m] == p, ids[m] - first, torch.full_like(ids[m], -1))
+                assert torch.equal(rec_ids[c], want.to(torch.int32))
+        assert int(overflow) == dropped and (cap < Mx) == (dropped > 0)
+
+
 def test_owner_of_matches_expert_map():
     from lvllm_amd.ep import owner_of
     for Eg in (8, 10, 7, 256):

@@ -665,8 +665,9 @@ def test_mixtral_full_size_properties(mixtral):
 
 
 def test_mixtral_full_size_vs_oracle(mixtral):
+    """BASELINE.json configs[1] at its full size: every one of the 32 x 4096 outputs against the oracle"""
     eng, w13, w2 = mixtral
-    M, E, K, H, I = 6, 8, 2, 4096, 14336
+    M, E, K, H, I = 32, 8, 2, 4096, 14336
     torch.manual_seed(3)
     a = (torch.randn((M, H)) / 10).to(torch.bfloat16)
     tw, ids = make_routing(M, E, K, seed=4)

@@ -227,7 +227,9 @@ class ExpertParallelExperts:
         dist.all_gather_into_tensor(xs, hidden.contiguous(), group=self.group)
         dist.all_gather_into_tensor(ii, ids.contiguous(), group=self.group)
         dist.all_gather_into_tensor(ww, tw.contiguous(), group=self.group)
-        emap = self.expert_map.to(dev)
+        if self.expert_map.device != dev:               # once, outside any graph capture (the warm-up step)
+            self.expert_map = self.expert_map.to(dev)
+        emap = self.expert_map
         local = torch.where(ii < 0, torch.full_like(ii, -1),
                             emap[ii.clamp(0, self.E - 1).to(torch.int64)])    # routed_experts.py:1332-1342
         part = self.local_compute(xs, local.contiguous(), ww, torch.float32)    # [ep*M, H] fp32

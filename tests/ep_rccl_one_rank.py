@@ -105,7 +105,7 @@ def main():
     from lvllm_amd.modular import LkmExperts, LkmPrepareAndFinalize
     pf, ex = LkmPrepareAndFinalize(E, H), LkmExperts()
     a1q, a1q_scale, meta, ids_d, w_d = pf.prepare(x2, tw2, ids2, E, None, False, None, True)
-    assert a1q_scale is None and meta is None and ids_d.shape == (M, K) and not a1q.is_contiguous()
+    assert a1q_scale is None and meta is None and ids_d.shape == (M, K) and not a1q.is_contiguous()  # rows are views into the receive buffer
     fused = torch.empty((a1q.size(0), H), dtype=torch.float32, device=dev)
     ex.apply(fused, a1q, w13, w2, w_d, ids_d, "silu", E, None, None, None, None, None, None, False)
     mout = torch.empty((M, H), dtype=torch.float32, device=dev)

@@ -102,7 +102,7 @@ def test_strided_rows_equal_contiguous_rows_bit_for_bit(M):
     rows = rec[:, :H * 2].view(torch.bfloat16)
     rids = rec[:, H * 2:H * 2 + 4 * K].view(torch.int32)
     rws = rec[:, H * 2 + 4 * K:H * 2 + 8 * K].view(torch.float32)
-    assert rows.stride(0) == rowb // 2 and not rows.is_contiguous()
+    assert rows.stride(0) == rowb // 2 and (M == 1 or not rows.is_contiguous())
     y32 = eng.forward_rows(rows, rws, rids, out_dtype=torch.float32, id_offset=first)
     y16 = eng.forward_rows(rows, rws, rids, out_dtype=torch.bfloat16, id_offset=first)
     assert torch.equal(y32, eng.decode(x.to(DEV), tw.to(DEV), ref_ids.to(DEV)))

@@ -25,7 +25,8 @@ def main():
         p2l = eplb.rebalance_experts(w, P, 1, 1, 8)
         l2p, cnt = eplb.compute_logical_maps(p2l, E, max_slots=red + 1)
         l2p, cnt = l2p[0].to(torch.int32).to(dev), cnt[0].to(torch.int32).to(dev)
-        prob = (w[0] / w[0].sum()).astype(np.float64)
+        prob = w[0].astype(np.float64)
+        prob /= prob.sum()
         ids = torch.from_numpy(rng.choice(E, size=(M, K), p=prob).astype(np.int32)).to(dev)
         load = torch.zeros(P, dtype=torch.int32, device=dev)
         sw = torch.ones((), dtype=torch.int32, device=dev)

@@ -55,10 +55,9 @@ def test_hbm_plan_for_the_survey_models():
 @pytest.mark.gpu
 @pytest.mark.parametrize("fmt", ["bf16", "mxfp4", "int4"])
 def test_planner_footprint_equals_engine_weight_bytes(fmt):
-    from bench import build_engine, make_weights
+    from bench import build_engine
     from lvllm_amd import ops
     E, H, I = 4, 1024, 1408            # I = 1408: rows padded to 64, K padded to the unit
     dev = torch.device("cuda", 0)
-    w13, w2 = make_weights(E, 0, H, I, dev, fmt)
-    eng, _, _ = build_engine(ops, dict(fmt=fmt, K=2, g=128), w13, w2)
+    eng = build_engine(ops, dict(fmt=fmt, K=2, g=128, H=H, I=I), E, 0, dev)[0]
     assert eng.engine.weight_bytes() == expert_layer_bytes(E, H, I, fmt, 128)

@@ -29,6 +29,40 @@ struct SlotIds {
 
 // meta[0] = number of active experts, meta[1] = total routed rows, meta[2] = max rows of one expert,
 // meta[3] = number of (expert, token-tile) work items when tile_rows > 0.
+// meta[8 + c], c = 0..8 (when xcd_cap > 0): XCD c works on tiles [meta[8+c], meta[9+c]) of the list -- contiguous
+// runs (the tiles of one expert are adjacent: the workgroups that share a weight panel or a token tile run on ONE
+// L2 at the same time), cut where the cumulative ROUTED ROWS cross c/8 of the total, so that ragged tiles (skewed
+// routing) give equal work, not equal counts; no run is longer than xcd_cap tiles (the launch bound).
+// Estimated cost of a tile = its routed rows + one tile height (a workgroup streams the same weight bytes however few
+// rows its tile holds): tkey[i] = cost of the tiles before tile i, in LDS; XCD c starts at the first tile whose key
+// reaches c/8 of the total (binary search by thread c), runs are then clamped to xcd_cap tiles.
+constexpr int kMaxXcdTiles = 4096;
+__device__ __forceinline__ void xcd_cut(const int32_t* tkey, int n_tiles, long long total_cost, int xcd_cap,
+                                        int32_t* xstart, int32_t* meta, int tid) {
+    if (tid >= 1 && tid <= 7) {
+        const long long want = total_cost * tid;
+        int lo = 0, hi = n_tiles;            // first idx with tkey[idx] * 8 >= want
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)tkey[mid] * 8 >= want) hi = mid;
+            else lo = mid + 1;
+        }
+        xstart[tid] = lo;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int s = 0;
+        meta[8] = 0;
+        for (int c = 0; c < 8; ++c) {
+            int nxt = c == 7 ? n_tiles : min(xstart[c + 1], n_tiles);
+            const int lo = n_tiles - (7 - c) * xcd_cap;       // what the remaining XCDs can still take
+            nxt = max(nxt, max(lo, s));
+            nxt = min(nxt, s + xcd_cap);
+            meta[9 + c] = nxt;
+            s = nxt;
+        }
+    }
+}
 // One workgroup of THREADS threads (64 / 256 / 1024 by problem size: the decode case M*K <= 64 runs as
 // a single wavefront, where barriers are free).
 template <int THREADS>
@@ -36,7 +70,7 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
     const SlotIds ids, int n_slots, int E, int32_t* __restrict__ counts,
     int32_t* __restrict__ offsets, int32_t* __restrict__ sorted_slot,
     int32_t* __restrict__ pos_of_slot, int32_t* __restrict__ active, int32_t* __restrict__ meta,
-    int tile_rows, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0) {
+    int tile_rows, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0, int xcd_cap) {
     constexpr int WAVES = THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     int32_t* cnt = smem;                 // [E]
@@ -44,6 +78,8 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
     int32_t* run = off + E;              // [E]
     int32_t* wsum = run + E;             // [4][WAVES] scan carries
     int32_t* wcnt = wsum + 4 * WAVES;    // [WAVES][E]
+    int32_t* xstart = wcnt + WAVES * E;  // [16]
+    int32_t* tkey = xstart + 16;         // [max tiles] (only when xcd_cap > 0)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     for (int e = tid; e < E; e += THREADS) {
@@ -103,6 +139,7 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
             for (int i = 0; i < t; ++i) {
                 tile_e[ex_t + i] = e;
                 tile_r0[ex_t + i] = i * tile_rows;
+                if (xcd_cap > 0) tkey[ex_t + i] = ex_c + i * tile_rows + (ex_t + i) * tile_rows;
             }
         }
         maxc = max(maxc, c);
@@ -115,6 +152,8 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
     for (int m = 32; m > 0; m >>= 1) maxc = max(maxc, __shfl_xor(maxc, m, 64));
     if (lane == 0) wsum[3 * WAVES + wv] = maxc;
     __syncthreads();
+    if (xcd_cap > 0 && tile_rows > 0)
+        xcd_cut(tkey, carry_til, (long long)carry_cnt + (long long)carry_til * tile_rows, xcd_cap, xstart, meta, tid);
     if (tid == 0) {
         int mm = 0;
         for (int w = 0; w < WAVES; ++w) mm = max(mm, wsum[3 * WAVES + w]);
@@ -195,9 +234,10 @@ __global__ __launch_bounds__(1024) void sort_scan_kernel(int n_chunks, int E, in
                                                         int32_t* __restrict__ active,
                                                         int32_t* __restrict__ meta, int tile_rows,
                                                         int tile_min, int32_t* __restrict__ tile_e,
-                                                        int32_t* __restrict__ tile_r0) {
+                                                        int32_t* __restrict__ tile_r0, int xcd_cap) {
     constexpr int THREADS = 1024, WAVES = 16;
     __shared__ int32_t wsum[4 * WAVES];
+    __shared__ int32_t tkey[kMaxXcdTiles], xstart[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int carry_cnt = 0, carry_act = 0, carry_til = 0, maxc = 0;
     for (int base = 0; base < E; base += THREADS) {
@@ -245,6 +285,7 @@ __global__ __launch_bounds__(1024) void sort_scan_kernel(int n_chunks, int E, in
             for (int i = 0; i < t; ++i) {
                 tile_e[ex_t + i] = e;
                 tile_r0[ex_t + i] = i * tile_rows;
+                if (xcd_cap > 0 && ex_t + i < kMaxXcdTiles) tkey[ex_t + i] = ex_c + i * tile_rows + (ex_t + i) * tile_rows;
             }
             // chunk bases: where chunk b's first slot of expert e lands
             int run = ex_c;
@@ -264,6 +305,8 @@ __global__ __launch_bounds__(1024) void sort_scan_kernel(int n_chunks, int E, in
     for (int m = 32; m > 0; m >>= 1) maxc = max(maxc, __shfl_xor(maxc, m, 64));
     if (lane == 0) wsum[3 * WAVES + wv] = maxc;
     __syncthreads();
+    if (xcd_cap > 0 && tile_rows > 0)      // (the host keeps xcd_cap = 0 when the tile list may exceed kMaxXcdTiles)
+        xcd_cut(tkey, carry_til, (long long)carry_cnt + (long long)carry_til * tile_rows, xcd_cap, xstart, meta, tid);
     if (tid == 0) {
         int mm = 0;
         for (int w = 0; w < WAVES; ++w) mm = max(mm, wsum[3 * WAVES + w]);
@@ -320,8 +363,8 @@ __global__ __launch_bounds__(kChunk) void sort_scatter_kernel(const SlotIds ids,
 }
 
 // out[m][h] = sum_k w[m,k] * sum_s y[s][pos(m,k)][h]   (fp32; s ascending, then k ascending)
-template <typename OutT>
-__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ y, int SK,
+template <typename OutT, typename YT>
+__global__ __launch_bounds__(256) void combine_kernel(const YT* __restrict__ y, int SK,
                                                       size_t sk_stride,
                                                       const int32_t* __restrict__ pos_of_slot,
                                                       const float* __restrict__ tw, int tw_ld, int M,
@@ -335,9 +378,9 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
         int p = pos_of_slot[m * K + k];
         if (p < 0) continue;
         float w = tw[(size_t)m * tw_ld + k];
-        const float* yp = y + (size_t)p * H + h;
-        f32x4 v = *(const f32x4*)yp;
-        for (int s = 1; s < SK; ++s) v += *(const f32x4*)(yp + s * sk_stride);
+        const YT* yp = y + (size_t)p * H + h;
+        f32x4 v = load4<YT>(yp);
+        for (int s = 1; s < SK; ++s) v += load4<YT>(yp + s * sk_stride);
         acc += w * v;
     }
     store4<OutT>(out + (size_t)m * H + h, acc);
@@ -347,18 +390,19 @@ template <int THREADS>
 static void launch_sort_t(hipStream_t st, const SlotIds ids, int n_slots, int E, int32_t* counts,
                           int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot,
                           int32_t* active, int32_t* meta, int tile_rows, int tile_min,
-                          int32_t* tile_e, int32_t* tile_r0) {
+                          int32_t* tile_e, int32_t* tile_r0, int xcd_cap) {
     constexpr int WAVES = THREADS / 64;
-    size_t lds = sizeof(int32_t) * ((size_t)3 * E + 4 * WAVES + (size_t)WAVES * E);
+    size_t lds = sizeof(int32_t) * ((size_t)3 * E + 4 * WAVES + (size_t)WAVES * E + 16 +
+                                    (xcd_cap > 0 ? (size_t)(tile_rows > 0 ? n_slots / tile_rows : 0) + E : 0));
     hipLaunchKernelGGL(sort_slots_kernel<THREADS>, dim3(1), dim3(THREADS), lds, st, ids, n_slots, E,
                        counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e,
-                       tile_r0);
+                       tile_r0, xcd_cap);
 }
 
 int launch_sort(hipStream_t st, const int32_t* ids_ptr, int top_k, int ids_ld, int id_offset, int n_slots, int E,
                 int32_t* counts, int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
                 int32_t* meta, int tile_rows, int tile_min, int32_t* tile_e, int32_t* tile_r0,
-                int32_t* hist, size_t hist_cap) {
+                int32_t* hist, size_t hist_cap, int xcd_cap) {
     const SlotIds ids{ids_ptr, top_k, ids_ld, id_offset};
     LKM_REQUIRE(E > 0 && E <= kMaxLocalExperts, "sort: local experts E=%d out of range (1..%d)", E, kMaxLocalExperts);
     LKM_REQUIRE(tile_rows == 0 || (tile_e && tile_r0), "sort: tile list requested without buffers");
@@ -367,7 +411,7 @@ int launch_sort(hipStream_t st, const int32_t* ids_ptr, int top_k, int ids_ld, i
         hipLaunchKernelGGL(sort_hist_kernel, dim3(n_chunks), dim3(kChunk), sizeof(int32_t) * E, st, ids,
                            n_slots, E, hist);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, st, n_chunks, E, hist, counts, offsets,
-                           active, meta, tile_rows, tile_min, tile_e, tile_r0);
+                           active, meta, tile_rows, tile_min, tile_e, tile_r0, xcd_cap);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(n_chunks), dim3(kChunk),
                            sizeof(int32_t) * (kChunk / 64) * E, st, ids, n_slots, E, hist, offsets,
                            sorted_slot, pos_of_slot);
@@ -375,11 +419,11 @@ int launch_sort(hipStream_t st, const int32_t* ids_ptr, int top_k, int ids_ld, i
         return LKM_OK;
     }
     if (n_slots <= 64 && E <= 64)
-        launch_sort_t<64>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e, tile_r0);
+        launch_sort_t<64>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e, tile_r0, xcd_cap);
     else if (n_slots <= 512 && E <= 256)
-        launch_sort_t<256>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e, tile_r0);
+        launch_sort_t<256>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e, tile_r0, xcd_cap);
     else
-        launch_sort_t<1024>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e, tile_r0);
+        launch_sort_t<1024>(st, ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e, tile_r0, xcd_cap);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }
@@ -489,20 +533,28 @@ int launch_read_probe(hipStream_t st, const void* src, size_t bytes, int n_block
     return LKM_OK;
 }
 
-int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
+template <typename YT>
+static void launch_combine_y(hipStream_t st, const void* y, int SK, size_t sk_stride, const int32_t* pos_of_slot,
+                             const float* tw, int tw_ld, int M, int K, int H, void* out, int out_dt) {
+    dim3 grid(ceil_div(H, 1024), M), block(256);
+    if (out_dt == LKM_DT_F32)
+        hipLaunchKernelGGL((combine_kernel<float, YT>), grid, block, 0, st, (const YT*)y, SK, sk_stride, pos_of_slot,
+                           tw, tw_ld, M, K, H, (float*)out);
+    else if (out_dt == LKM_DT_BF16)
+        hipLaunchKernelGGL((combine_kernel<bf16_out, YT>), grid, block, 0, st, (const YT*)y, SK, sk_stride,
+                           pos_of_slot, tw, tw_ld, M, K, H, (bf16_out*)out);
+    else
+        hipLaunchKernelGGL((combine_kernel<f16_out, YT>), grid, block, 0, st, (const YT*)y, SK, sk_stride,
+                           pos_of_slot, tw, tw_ld, M, K, H, (f16_out*)out);
+}
+
+int launch_combine(hipStream_t st, const void* y, int y_dt, int SK, size_t sk_stride,
                    const int32_t* pos_of_slot, const float* tw, int tw_ld, int M, int K, int H, void* out,
                    int out_dt) {
     if (M == 0) return LKM_OK;
-    dim3 grid(ceil_div(H, 1024), M), block(256);
-    if (out_dt == LKM_DT_F32)
-        hipLaunchKernelGGL(combine_kernel<float>, grid, block, 0, st, y, SK, sk_stride, pos_of_slot,
-                           tw, tw_ld, M, K, H, (float*)out);
-    else if (out_dt == LKM_DT_BF16)
-        hipLaunchKernelGGL(combine_kernel<bf16_out>, grid, block, 0, st, y, SK, sk_stride,
-                           pos_of_slot, tw, tw_ld, M, K, H, (bf16_out*)out);
-    else
-        hipLaunchKernelGGL(combine_kernel<f16_out>, grid, block, 0, st, y, SK, sk_stride,
-                           pos_of_slot, tw, tw_ld, M, K, H, (f16_out*)out);
+    if (y_dt == LKM_DT_BF16) launch_combine_y<bf16_out>(st, y, SK, sk_stride, pos_of_slot, tw, tw_ld, M, K, H, out, out_dt);
+    else if (y_dt == LKM_DT_F16) launch_combine_y<f16_out>(st, y, SK, sk_stride, pos_of_slot, tw, tw_ld, M, K, H, out, out_dt);
+    else launch_combine_y<float>(st, y, SK, sk_stride, pos_of_slot, tw, tw_ld, M, K, H, out, out_dt);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

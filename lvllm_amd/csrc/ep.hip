@@ -99,25 +99,6 @@ __global__ __launch_bounds__(kEpThreads) void ep_pack_tokens_kernel(
     }
 }
 
-template <typename T>
-__device__ __forceinline__ f32x4 ep_load4(const T* p);
-template <>
-__device__ __forceinline__ f32x4 ep_load4<float>(const float* p) {
-    return *(const f32x4*)p;
-}
-template <>
-__device__ __forceinline__ f32x4 ep_load4<bf16_out>(const bf16_out* p) {
-    const u32x2 v = *(const u32x2*)p;
-    return f32x4{bf16_bits_to_f32((unsigned short)(v.x & 0xffffu)), bf16_bits_to_f32((unsigned short)(v.x >> 16)),
-                 bf16_bits_to_f32((unsigned short)(v.y & 0xffffu)), bf16_bits_to_f32((unsigned short)(v.y >> 16))};
-}
-template <>
-__device__ __forceinline__ f32x4 ep_load4<f16_out>(const f16_out* p) {
-    const u32x2 v = *(const u32x2*)p;
-    return f32x4{f16_bits_to_f32((unsigned short)(v.x & 0xffffu)), f16_bits_to_f32((unsigned short)(v.x >> 16)),
-                 f16_bits_to_f32((unsigned short)(v.y & 0xffffu)), f16_bits_to_f32((unsigned short)(v.y >> 16))};
-}
-
 // out[m][h] = sum_p back[p][slot_of[p][m]][h], fp32, p ascending
 template <typename InT, typename OutT>
 __global__ __launch_bounds__(256) void ep_combine_kernel(const InT* __restrict__ back,
@@ -131,7 +112,7 @@ __global__ __launch_bounds__(256) void ep_combine_kernel(const InT* __restrict__
     for (int p = 0; p < ep; ++p) {
         const int c = slot_of[(size_t)p * M + m];
         if (c < 0) continue;
-        acc += ep_load4<InT>(back + ((size_t)p * cap + c) * H + h);
+        acc += load4<InT>(back + ((size_t)p * cap + c) * H + h);
     }
     store4<OutT>(out + (size_t)m * H + h, acc);
 }

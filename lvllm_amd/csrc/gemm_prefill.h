@@ -49,12 +49,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_prefill_kernel(GemmParams p) 
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int ti = blockIdx.y, bx = blockIdx.x;
     if (p.xcd_map) {     // XCD-aware 1-D mapping, see gemm_tiled_kernel
-        const int RG = p.xcd_map, n_items = p.meta[3];
-        const int ipx = (n_items + 7) >> 3;
+        const int RG = p.xcd_map;
         const int L = blockIdx.x, c = L & 7, sidx = L >> 3;
-        ti = c * ipx + sidx / RG;
+        const int first = p.meta[8 + c], n_c = p.meta[9 + c] - first;
+        if (sidx >= n_c * RG) return;
+        ti = first + sidx / RG;
         bx = sidx % RG;
-        if (sidx / RG >= ipx || ti >= n_items) return;
     }
     if (ti >= p.meta[3]) return;
     const int e = p.tile_e[ti], r0 = p.tile_r0[ti];
@@ -232,7 +232,7 @@ static int launch_prefill_t(hipStream_t st, const GemmParams& p, int max_tiles) 
     GemmParams pp = p;
     if (p.xcd_map) {
         pp.xcd_map = RG;
-        grid = dim3(8 * ceil_div(max_tiles, 8) * RG, 1);
+        grid = dim3(8 * p.xcd_map * RG, 1);
     }
     auto kern = gemm_prefill_kernel<ADT, GATED, IS_G1, WAVES>;
     LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -84,15 +84,16 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
     // loses 10 % -- the block count is a template parameter of the loop instead (run<NB>).
     int ti = blockIdx.y, bx = blockIdx.x;
     if (p.xcd_map) {
-        // 1-D grid; hardware places workgroup L on XCD L % 8.  XCD c takes a contiguous run of items
-        // (tiles of the same expert are adjacent in the list) and, inside it, row group fastest: the
-        // workgroups that share a token tile or a weight panel run on ONE L2 at the same time.
-        const int RG = p.xcd_map, n_items = p.meta[3];
-        const int ipx = (n_items + 7) >> 3;
+        // 1-D grid; hardware places workgroup L on XCD L % 8.  XCD c takes the contiguous run of tiles the sort
+        // kernel cut for it (dispatch.hip: meta[8 + c], balanced by routed rows; tiles of the same expert are
+        // adjacent in the list) and, inside it, row group fastest: the workgroups that share a token tile or a
+        // weight panel run on ONE L2 at the same time.
+        const int RG = p.xcd_map;
         const int L = blockIdx.x, c = L & 7, sidx = L >> 3;
-        ti = c * ipx + sidx / RG;
+        const int first = p.meta[8 + c], n_c = p.meta[9 + c] - first;
+        if (sidx >= n_c * RG) return;
+        ti = first + sidx / RG;
         bx = sidx % RG;
-        if (sidx / RG >= ipx || ti >= n_items) return;
     }
     if (ti >= p.meta[3]) return;
     const int e = p.tile_e[ti], r0 = p.tile_r0[ti];
@@ -461,9 +462,9 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     const int RG = ceil_div(p.T_half, WAVES * NT);
     dim3 grid(RG, max_tiles, IS_G1 ? 1 : p.SK), block(WAVES * 64);
     GemmParams pp = p;
-    if (p.xcd_map) {     // 1-D launch, see the kernel's work mapping
+    if (p.xcd_map) {     // 1-D launch, see the kernel's work mapping; p.xcd_map = longest run of one XCD
         pp.xcd_map = RG;
-        grid = dim3(8 * ceil_div(max_tiles, 8) * RG, 1, IS_G1 ? 1 : p.SK);
+        grid = dim3(8 * p.xcd_map * RG, 1, IS_G1 ? 1 : p.SK);
     }
     auto kern = p.stream_nt ? gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1, PD, true>
                             : gemm_tiled_kernel<WF, ADT, NT, TBW, WAVES, GATED, IS_G1, PD, false>;
@@ -480,6 +481,10 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
 template <typename ADTC>
 static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
                               int max_tiles, int* rc, ADTC);
+// fp8 x fp8, 256-row tiles: the MX-scaled-MFMA prefill kernel (gemm_prefill_a8.h)
+template <typename ADTC>
+static bool launch_prefill_a8_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
+                                 int max_tiles, int* rc, ADTC);
 
 // tiled variants built per format: (TM, WAVES, NT) = (64,4,1) (64,8,1) (128,8,1) (128,8,2 non-gated)
 // and, for 16-bit weights only, (256,8,1): the prefill tile (weights re-read once per 256 tokens)
@@ -508,6 +513,10 @@ struct W16Only {
             int rc = LKM_OK;                                                                          \
             if (launch_prefill_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc;    \
         }                                                                                             \
+        if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
+            int rc = LKM_OK;                                                                          \
+            if (launch_prefill_a8_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc; \
+        }                                                                                             \
         if (gated) {                                                                                  \
             LKM_TILED_CASE(2, 4, 1, true, true)                                                       \
             LKM_TILED_CASE(4, 4, 1, true, true)                                                       \
@@ -534,6 +543,10 @@ struct W16Only {
         if constexpr (W16Only<WF_>::value) {                                                          \
             int rc = LKM_OK;                                                                          \
             if (launch_prefill_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;   \
+        }                                                                                             \
+        if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
+            int rc = LKM_OK;                                                                          \
+            if (launch_prefill_a8_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;\
         }                                                                                             \
         LKM_TILED_CASE(2, 4, 1, false, false)                                                         \
         LKM_TILED_CASE(4, 4, 1, false, false)                                                         \

@@ -74,8 +74,8 @@ static int arena_reserve(int device, int E, size_t slots, size_t act_elems, size
     if (E > a.E_cap) {
         size_t h = 0;
         int32_t* p = nullptr;
-        // counts[E] offsets[E+1] active[E] meta[8] in one block
-        size_t n = (size_t)3 * E + 1 + 8;
+        // counts[E] offsets[E+1] active[E] meta[kMetaInts] in one block
+        size_t n = (size_t)3 * E + 1 + kMetaInts;
         if ((rc = grow(p, h, n, a.retired)) != LKM_OK) return rc;
         if (a.counts) a.retired.push_back(a.counts);
         a.counts = p;
@@ -157,7 +157,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -479,7 +479,7 @@ struct Plan {
     LaunchCfg s1, s2;   // skinny GEMM1 / GEMM2 (s1.tb == 0: not launched)
     LaunchCfg t1, t2;   // tiled  GEMM1 / GEMM2 (t1.tiled == 0: not launched)
     int split_rows;     // hybrid threshold (0: no split)
-    int xcd1;           // GEMM1: XCD-aware work mapping (gemm_tiled.h)
+    int xcd1, xcd2;     // GEMM1 / GEMM2: XCD-aware work mapping (gemm_tiled.h, dispatch.hip: per-XCD tile runs)
 };
 
 static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   // M, n_slots: as handed over (incl. -1 slots)
@@ -521,6 +521,11 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // are formed four token blocks at a time and the kernel fits its registers (GLM-4.5-Air prefill
             // 3677 -> 3179 us with two GEMM2 tiles per wave; Mixtral M=2048 1996 -> 1820; M=512 equal)
             if (h->a8 && avg_rows >= 192) tiled = 128;
+            // ... and from there on the MX-scaled-MFMA prefill kernel (gemm_prefill_a8.h: both operands by LDS-DMA,
+            // 256 x 256 tiles, one v_mfma_scale_f32_16x16x128_f8f6f4 per 128-k block) where the shape qualifies
+            if (h->a8 && avg_rows >= 192 && h->t_pf >= 0 && h->H % 128 == 0 && h->I % 128 == 0 &&
+                h->cfg.groupN % 16 == 0 && h->cfg.groupK == 128)
+                tiled = 256;
         } else if (h->wf == LKM_W_FP8_E4M3 && M >= 48) {
             // fp8 (both modes): tiles from 48 tokens on (profiles/r01_fp8_tile_threshold.log: Mixtral W8A8
             // M=48 275 -> 265 us, M=64 356 -> 273, M=96 379 -> 281; DSv3 rank slice, 256 rows over 32
@@ -550,7 +555,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
     // against 32 TB/s from the L2 (tools/probe_l2.hip), and the mapping lifts GLM-4.5-Air GEMM1's L2 hits
     // from 19 to 54 % -- but the step gains 2 % with uniform routing and LOSES 7 % with Zipf routing (equal
     // item counts per XCD are not equal work), GEMM2 +6 %, Mixtral M=4096 +27 %: profiles/r01_prefill_pmc.md.
-    pl->xcd1 = 0;
+    pl->xcd1 = pl->xcd2 = 0;
     pl->t1 = pl->t2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
     pl->s1 = pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
     if (tiled) {
@@ -560,13 +565,13 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         int waves = tiled >= 128 ? 8 : 4;
         if (tiled == 128 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && wg8 < 512) waves = 4;
         if (h->t_waves > 0) waves = h->t_waves;
-        const int nt1 = (h->t_nt1 > 0 && !split) ? h->t_nt1 : 1;
+        const int nt1 = (h->t_nt1 > 0 && !split && !(tiled == 256 && h->a8)) ? h->t_nt1 : 1;
         // two weight tiles per wave in GEMM2: 256-row tiles (GLM bf16: 3.61 vs 3.81 ms), fp8-W8A8 128-row tiles
         // (GEMM2 1343 -> 1141 us) and the 4-bit formats at 64-row tiles (half the token-fragment LDS reads per
         // weight byte; Mixtral M=128 GEMM2 int4 95 -> 92 us, NVFP4 85.6 -> 80.4, MXFP4 74.2 -> 67.5:
         // profiles/r01_int4_hoist_nt2.log)
         const bool w4_64 = wf_is_4bit(h->wf) && tiled == 64 && waves == 4 && !split;   // (the 8-wave variant exists with one tile only)
-        const int nt2 = (h->t_nt2 > 0 && !split) ? h->t_nt2 : ((tiled == 256 || (tiled == 128 && h->a8) || w4_64) ? 2 : 1);
+        const int nt2 = (tiled == 256 && h->a8) ? 1 : (h->t_nt2 > 0 && !split) ? h->t_nt2 : ((tiled == 256 || (tiled == 128 && h->a8) || w4_64) ? 2 : 1);
         // weight/token register ring depth (64-row tiles; the larger tiles have no registers to spare).
         // Measured at M=128 (profiles/r01_prefetch_depth.log): bf16 4/4 (473 vs 525 us at 2/2); the
         // formats that decode in registers keep GEMM1 at 2 (occupancy): int4 2/4 260 us vs 4/4 291 us,
@@ -584,7 +589,16 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             if (w4_64 && h->wf != LKM_W_MXFP4) pd2 = 2;
         }
         if (tiled == 128 && waves == 4) pd1 = pd2 = 4;   // EP=8 Mixtral rank: 154 vs 229 us at 2/2
-        const int pf = (tiled == 256 && h->t_pf > 0) ? h->t_pf : 0;
+        int pf = (tiled == 256 && h->t_pf > 0) ? h->t_pf : 0;
+        if (tiled == 256 && h->a8) {          // the fp8 x fp8 prefill kernel is the only 256-row variant of the format
+            pf = 8;
+            waves = 8;
+            // The XCD-aware runs (dispatch.hip) stay a knob ("xcd" = 1): on GLM-4.5-Air fp8 prefill they cut GEMM1's
+            // L2-miss traffic 5.8 -> 3.55 GB and lift the L2 hit rate 45 -> 66 %, yet the kernel runs 4-6 % SLOWER
+            // (1256 -> 1307, 1195 -> 1269 us on two boxes): it is bound by the round-trip latency of one 66 KiB DMA
+            // burst per CU, not by fabric bandwidth, and co-scheduled siblings wait on the same misses
+            // (profiles/r02_glm_a8_prefill.md)
+        }
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;
         // tiled GEMM2 split-K: few experts per rank (expert parallel) leave T2/waves workgroups per token
@@ -682,15 +696,19 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         while (sk_direct * 2 * K <= 16 && waves * sk_direct < 2048 && h->U2 / (sk_direct * 2) >= 2) sk_direct *= 2;
     }
     const bool direct = M == 1 && K <= 16 && pl.s1.tb == 1 && pl.s1.nt == 1 && !pl.t1.tiled && h->t_direct >= 0;
+    const int max_active = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
+    const int max_tiles = tile_rows ? (int)(n_slots / tile_rows) + max_active : 0;
+    // XCD-aware mapping: the sort kernel cuts the tile list into 8 runs of equal routed rows, none longer than
+    // xcd_cap tiles (twice the mean: the 1-D grid is sized by it)
+    const bool want_xcd = tile_rows && max_tiles <= 4096 && (h->t_xcd > 0 || pl.xcd1 || pl.xcd2);
+    const int xcd_cap = want_xcd ? 2 * ((max_tiles + 7) / 8) + 1 : 0;
     if (!direct) {
         rc = launch_sort(st, ids, K, (int)il.ids_ld, il.id_off, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
                          a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, a->hist,
-                         a->hist_cap);
+                         a->hist_cap, xcd_cap);
         if (rc != LKM_OK) return rc;
     }
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[1], st));
-    const int max_active = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
-    const int max_tiles = tile_rows ? (int)(n_slots / tile_rows) + max_active : 0;
     // weights are read once per step when an expert's rows fit one token tile
     const int stream_nt = tile_rows && !pl.split_rows
                               ? ((n_slots / (size_t)(max_active > 0 ? max_active : 1)) <= (size_t)tile_rows)
@@ -701,7 +719,9 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.s = h->s13;
     p1.spu = h->spu;
     p1.gs = h->gs13;
-    p1.xcd_map = (h->t_xcd > 0 || pl.xcd1) ? 1 : 0;
+    p1.xcd_map = (h->t_xcd > 0 || pl.xcd1) ? xcd_cap : 0;
+    p1.tile_uniform_scale = h->cfg.groupN > 0 && h->cfg.groupN % 16 == 0;
+    p1.dbg = h->t_dbg;
     p1.x_rows = M;
     p1.T_half = h->T1_half;
     p1.halves = h->gated ? 2 : 1;
@@ -754,7 +774,9 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.s = h->s2;
     p2.spu = h->spu;
     p2.gs = h->gs2;
-    p2.xcd_map = h->t_xcd > 0 ? 1 : 0;
+    p2.xcd_map = (h->t_xcd > 0 || pl.xcd2) ? xcd_cap : 0;
+    p2.tile_uniform_scale = p1.tile_uniform_scale;
+    p2.dbg = h->t_dbg;
     p2.x_rows = (long long)n_slots;
     p2.T_half = h->T2;
     p2.halves = 1;
@@ -784,6 +806,10 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.sk_stride = n_slots * (size_t)h->H;
     const int sk = pl.s2.tb ? pl.s2.sk : (pl.t2.tiled ? pl.t2.sk : 1);
     p2.SK = sk;
+    // block-fp8 W8A8 on the prefill kernel: GEMM2 rounds its output to the activation dtype like the reference's
+    // native_w8a8_block_matmul (output_dtype) -- half the bytes written here and read back by the combine
+    const int y_dt = (h->a8 && pl.t2.tiled == 256 && pl.t2.pf == 8 && !pl.s2.tb && sk == 1) ? h->adt : LKM_DT_F32;
+    p2.y_dt = y_dt;
     if (direct) {
         p2.direct_ids = ids;
         p2.direct_w = tw;
@@ -821,17 +847,17 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     }
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
 
-    rc = launch_combine(st, a->y, sk, p2.sk_stride, a->pos_of_slot, tw, (int)il.tw_ld, M, K, h->H, out, out_dt);
+    rc = launch_combine(st, a->y, y_dt, sk, p2.sk_stride, a->pos_of_slot, tw, (int)il.tw_ld, M, K, h->H, out, out_dt);
     if (rc != LKM_OK) return rc;
     if (prof) {
         LKM_HIP_CHECK(hipEventRecord(h->ev[4], st));
         h->prof_valid = true;
     }
     snprintf(h->last_desc, sizeof(h->last_desc),
-             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2 nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d pd=%d/%d split=%d | nt_loads=%d",
+             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2 nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d pd=%d/%d split=%d pf=%d xcd=%d/%d | nt_loads=%d",
              M, K, pl.s1.tb ? "skinny" : "", pl.t1.tiled ? (pl.s1.tb ? "+tiled" : "tiled") : "", pl.s1.nt,
              pl.s1.tb, pl.s1.kw, pl.s2.nt, pl.s2.tb, pl.s2.sk, pl.t1.nt, pl.t2.nt, tile_rows, pl.t1.waves,
-             pl.t1.pd, pl.t2.pd, pl.split_rows, stream_nt);
+             pl.t1.pd, pl.t2.pd, pl.split_rows, pl.t1.pf, p1.xcd_map ? 1 : 0, p2.xcd_map ? 1 : 0, stream_nt);
     return LKM_OK;
 }
 
@@ -932,8 +958,8 @@ extern "C" int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots,
     // active/meta scratch: borrow the tail of a temporary allocation
     int32_t* tmp = nullptr;
     const size_t hist_cap = n_slots > 4096 ? ((size_t)n_slots / 1024 + 1) * E : 0;
-    LKM_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(int32_t) * ((size_t)E + 8 + hist_cap)));
-    int32_t* hist = hist_cap ? tmp + E + 8 : nullptr;
+    LKM_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(int32_t) * ((size_t)E + kMetaInts + hist_cap)));
+    int32_t* hist = hist_cap ? tmp + E + kMetaInts : nullptr;
     int rc = launch_sort((hipStream_t)stream, ids, 1, 1, 0, n_slots, E, counts, offsets, sorted_slot,
                          pos_of_slot, tmp, tmp + E, 0, 0, nullptr, nullptr, hist, hist_cap);
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
@@ -1015,6 +1041,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "valid_den")) h->t_valid_den = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else if (!strcmp(key, "prof_rep")) h->t_prof_rep = value;
+    else if (!strcmp(key, "dbg")) h->t_dbg = value;
     else {
         set_error("lkm_set_tuning: unknown key '%s'", key);
         return LKM_E_INVALID;

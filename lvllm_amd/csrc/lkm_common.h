@@ -160,6 +160,26 @@ __device__ __forceinline__ void store4<f16_out>(f16_out* p, f32x4 v) {
     *(u32x2*)p = o;
 }
 
+// four consecutive values of a typed array as fp32
+template <typename T>
+__device__ __forceinline__ f32x4 load4(const T* p);
+template <>
+__device__ __forceinline__ f32x4 load4<float>(const float* p) {
+    return *(const f32x4*)p;
+}
+template <>
+__device__ __forceinline__ f32x4 load4<bf16_out>(const bf16_out* p) {
+    const u32x2 v = *(const u32x2*)p;
+    return f32x4{bf16_bits_to_f32((unsigned short)(v.x & 0xffffu)), bf16_bits_to_f32((unsigned short)(v.x >> 16)),
+                 bf16_bits_to_f32((unsigned short)(v.y & 0xffffu)), bf16_bits_to_f32((unsigned short)(v.y >> 16))};
+}
+template <>
+__device__ __forceinline__ f32x4 load4<f16_out>(const f16_out* p) {
+    const u32x2 v = *(const u32x2*)p;
+    return f32x4{f16_bits_to_f32((unsigned short)(v.x & 0xffffu)), f16_bits_to_f32((unsigned short)(v.x >> 16)),
+                 f16_bits_to_f32((unsigned short)(v.y & 0xffffu)), f16_bits_to_f32((unsigned short)(v.y >> 16))};
+}
+
 template <typename OutT>
 __device__ __forceinline__ void store1(OutT* p, float v);
 template <>

@@ -25,10 +25,11 @@ int launch_repack_s_fp4(hipStream_t st, const void* src, void* dst, const Repack
 int launch_sort(hipStream_t st, const int32_t* ids, int top_k, int ids_ld, int id_offset, int n_slots, int E,
                 int32_t* counts, int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
                 int32_t* meta, int tile_rows, int tile_min, int32_t* tile_e, int32_t* tile_r0,
-                int32_t* hist, size_t hist_cap);
+                int32_t* hist, size_t hist_cap, int xcd_cap = 0);
+constexpr int kMetaInts = 32;   // meta[0..3]: see dispatch.hip; meta[8..16]: per-XCD runs of the tile list
 int launch_quant_fp8_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, void* dst,
                           float* scales);
-int launch_combine(hipStream_t st, const float* y, int SK, size_t sk_stride,
+int launch_combine(hipStream_t st, const void* y, int y_dt, int SK, size_t sk_stride,
                    const int32_t* pos_of_slot, const float* tw, int tw_ld, int M, int K, int H, void* out,
                    int out_dt);
 
@@ -80,7 +81,12 @@ struct GemmParams {
     int direct_E, direct_id_off; // direct mode: local expert count and the offset subtracted from ids >= 0
                                  // (an id outside [0, E) after that is not local, like -1)
     long long x_rows;  // rows of the activation matrix behind `x` (bounds of the LDS-DMA buffer window)
-    int xcd_map;       // tiled kernels: != 0 -> XCD-aware 1-D work mapping (holds the row-group count in the kernel)
+    int xcd_map;       // tiled kernels: != 0 -> XCD-aware 1-D work mapping.  Host side: the longest run of tiles one
+                       // XCD may get (launch_sort's xcd_cap); the launcher replaces it by the row-group count
+    int y_dt;          // GEMM2: dtype of the per-row partials `out` (LKM_DT_F32, or the activation dtype where the
+                       // reference rounds the GEMM2 output itself: block-fp8 W8A8, native_w8a8_block_matmul output_dtype)
+    int dbg;           // development ablations of the prefill kernels (tuning key "dbg"; results are wrong when set)
+    int tile_uniform_scale;   // fp8: every 16-row weight tile has one block scale per K unit (groupN % 16 == 0)
     // activation
     int act_type;
     float alpha, limit;

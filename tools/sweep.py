@@ -12,7 +12,7 @@ import torch
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
-from bench import WORKLOADS, build_engine, make_weights  # noqa: E402
+from bench import WORKLOADS, build_engine  # noqa: E402
 from lvllm_amd import ops  # noqa: E402
 
 
@@ -28,11 +28,10 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.M:
         wl["M"] = args.M
+    wl.setdefault("M", wl.get("M_global", 0))
     E, K, H, I, M, fmt = wl["E"], wl["K"], wl["H"], wl["I"], wl["M"], wl["fmt"]
     dev = torch.device("cuda", 0)
-    w13, w2 = make_weights(E, 0, H, I, dev, fmt)
-    eng, bpe, _ = build_engine(ops, wl, w13, w2, max_num_seqs=max(256, M))
-    del w13, w2
+    eng, bpe = build_engine(ops, wl, E, 0, dev, max_num_seqs=max(256, M), max_batch_size=max(8192, M))[:2]
     gen = torch.Generator(device=dev).manual_seed(7)
     x = (torch.randn((M, H), generator=gen, device=dev) / 10).to(torch.bfloat16)
     logits = torch.randn((M, E), generator=gen, device=dev)
@@ -55,7 +54,7 @@ def main():
 
     print(f"# {args.workload} M={M} e_act={e_act} g1={g1_bytes/1e9:.3f} GB g2={g2_bytes/1e9:.3f} GB")
     if args.cfgs:
-        keys = ("nt1", "nt2", "kw1", "sk2", "tbmax", "tiled", "waves", "hybrid", "pd1", "pd2", "xcd", "pf", "direct", "valid_den")
+        keys = ("nt1", "nt2", "kw1", "sk2", "tbmax", "tiled", "waves", "hybrid", "pd1", "pd2", "xcd", "pf", "direct", "valid_den", "dbg")
         for spec in args.cfgs.split(";"):
             kv = {k: 0 for k in keys}
             if spec.strip():

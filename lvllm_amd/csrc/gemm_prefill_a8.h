@@ -111,10 +111,12 @@ __global__ __launch_bounds__(512) void gemm_prefill_a8_kernel(GemmParams p) {
             for (int ld = 0; ld < 2; ++ld)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + ((2 * wave + q) * 2 + ld) * 1024), 16,
                                                          alane, asoff[q] + (u * 2 + ld) * 1024, 0, aux);
+        if (!(p.dbg & 32))       // (ablation: weights only)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LdsPtr)(base + kA8WBytes + (q * 512 + wave * 64) * 16), 16,
                                                      bvoff[q], u * 128, 0, aux);
+        if (p.dbg & 64) return;  // (ablation: no scale vectors)
         if (wave == 0)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (LdsPtr)(base + kA8WsOff), 16, svoff, u * 64, 0, 0);
         else if (wave <= 4)

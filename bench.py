@@ -44,6 +44,8 @@ WORKLOADS = {
     # name: E experts, K top-k, H hidden, I intermediate, M tokens per GPU, weight format
     "mixtral8x7b_bf16_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="bf16"),
     "mixtral8x7b_int4g128_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="int4", g=128),
+    # the same checkpoint in the engine's opt-in fast int4 mode (LkmConfig.int4_mode: group scale on fp32 partial sums)
+    "mixtral8x7b_int4g128_fast_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="int4", g=128, int4_mode=1),
     "qwen3_30b_a3b_bf16_decode_m1": dict(E=128, K=8, H=2048, I=768, M=1, fmt="bf16"),
     # BASELINE.json configs[3]: DeepSeek-V3-style layer -- 256 fp8 (128x128 block) experts, group-limited sigmoid
     # router with score-correction bias, GLOBAL decode batch 256 split over the ranks (M_global), experts sharded
@@ -69,7 +71,7 @@ WORKLOADS = {
     "glm45air_fp8w8a8_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=1, prefill=True),
 }
 HEADLINE = "mixtral8x7b_bf16_decode_m32"
-EXTRA_N1 = ["mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128"]
+EXTRA_N1 = ["mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128", "mixtral8x7b_int4g128_fast_decode_m128"]
 EXTRA_EP = "dsv3_fp8w8a8_ep_decode_b256"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp8": 5000.0}   # dense, MI355X_MICROARCH.md
@@ -183,9 +185,12 @@ def build_engine(ops, wl, E_local, first, dev, **kw):
     if fmt == "int4":
         q13, s13, q2, s2 = cat
         g = wl["g"]
+        fast = int(wl.get("int4_mode", 0))
         eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="int4", w13_scale=s13,
-                                      w2_scale=s2, group_n=1, group_k=g, **kw)
-        return eng, 0.5 + 2.0 / g, dict(wfmt="W_INT4", groupN=1, groupK=g, w13=q13, w2=q2, s13=s13, s2=s2), None
+                                      w2_scale=s2, group_n=1, group_k=g, int4_mode=fast, **kw)
+        # the fast mode keeps its group scales as fp32 (4 bytes per row and 128-k block)
+        return eng, 0.5 + (4.0 if fast else 2.0) / g, dict(wfmt="W_INT4", groupN=1, groupK=g, int4_unrounded=bool(fast),
+                                                           w13=q13, w2=q2, s13=s13, s2=s2), None
     if fmt == "mxfp4":
         q13, s13, q2, s2 = cat
         eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="mxfp4", w13_scale=s13,
@@ -280,7 +285,8 @@ def cpu_baseline(name, wl, oracle_in, masters, x, tw, ids, gpu_out, seconds):
         return t.view(torch.int16).numpy().view(np.uint16) if t.dtype == torch.bfloat16 else t.numpy()
     oi = dict(oracle_in)
     d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=getattr(orc, oi.pop("wfmt")), groupN=oi.pop("groupN"),
-                    groupK=oi.pop("groupK"), w8a8=oi.pop("w8a8", False), round_gemm1=oi.pop("round_gemm1", False))
+                    groupK=oi.pop("groupK"), w8a8=oi.pop("w8a8", False), round_gemm1=oi.pop("round_gemm1", False),
+                    int4_unrounded=oi.pop("int4_unrounded", False))
     cargs = {k_: _np(v) for k_, v in oi.items()}
     ref = orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)            # untimed first pass (page-in)
     # The host may expose more logical CPUs than the container can actually run (measured on the
@@ -525,7 +531,8 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
                       + (" (rank 0's engine on rank 0's own routed rows)" if world > 1 else "")})
         res = {"workload": name, "value": round(tokens_per_s, 1), "unit": "tokens/s", "ms_per_step": round(ms_per_step, 4),
                "steps": steps, "scaling": scaling,
-               "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act", "mxfp4": "mxfp4-w/bf16-act",
+               "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act" + (" (fast mode: scale on fp32 partial sums)" if wl.get("int4_mode") else ""),
+                         "mxfp4": "mxfp4-w/bf16-act",
                          "nvfp4": "nvfp4-w/bf16-act",
                          "fp8": "fp8-w/" + ("fp8-act" if wl.get("fp8_mode") else "bf16-act")}[fmt],
                "config": {"workload": name, "experts": E, "experts_per_gpu": E_local, "top_k": K, "hidden": H,

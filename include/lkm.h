@@ -56,6 +56,13 @@ extern "C" {
 #define LKM_FP8_W8A16 0 /* lk_moe semantics: weight-only fp8, activations stay bf16/fp16      */
 #define LKM_FP8_W8A8 1  /* in-tree operator semantics: dynamic 1 x groupK activation quant     */
 
+/* uint4b8 compute mode */
+#define LKM_INT4_EXACT 0 /* weights dequantised to T((q-8)*s), the reference's rounding (fused_moe.py:237-276)      */
+#define LKM_INT4_FAST 1  /* opt-in: group scale applied to the fp32 partial sum of each 128-k block instead of to  *
+                          * the weights -- (q-8) exact, no per-weight rounding; 2.5x fewer VALU instructions per  *
+                          * weight, inside the reference's int4 tolerance (atol 2e-2) but not bit-identical to it; *
+                          * groupK must be a multiple of 128                                                        */
+
 /*
  * Mirrors lk_moe.MOEConfigV2 field for field (routed_experts.py:1490-1511), plus the three
  * things the reference encodes in the class name / pointer set (weight format, activation
@@ -85,7 +92,8 @@ typedef struct LkmConfig {
     int32_t weight_format;    /* LKM_W_*                                     */
     int32_t act_dtype;        /* LKM_DT_BF16 | LKM_DT_F16                    */
     int32_t fp8_mode;         /* LKM_FP8_*                                   */
-    int32_t reserved[8];
+    int32_t int4_mode;        /* LKM_INT4_*                                  */
+    int32_t reserved[7];
 } LkmConfig;
 
 typedef struct LkmEngine* LkmHandle;

@@ -494,6 +494,46 @@ int launch_quant_fp8_rows(hipStream_t st, const void* src, int ld_src, int adt, 
     return LKM_OK;
 }
 
+// ------------------------------------------------------------------ 128-element row sums (int4 fast mode)
+// sums[row][kb] = sum of x[row][kb*128 .. +127] in fp32: the activation-side term of
+//   sum_k s (v_k - 8) x_k = s (sum_k (BIAS + v_k) x_k - (BIAS + 8) sum_k x_k)      (lkm_common.h LKM_W_INT4_PS).
+// Same shape as the fp8 activation quantiser: sixteen lanes per (row, group), eight elements per lane, fixed order
+// (ascending within the lane, then the xor butterfly 8, 4, 2, 1).
+template <int ADT>
+__global__ __launch_bounds__(256) void rowsum128_rows_kernel(const unsigned short* __restrict__ src, int ld_src, int R,
+                                                             int K, float* __restrict__ sums) {
+#pragma clang fp contract(off)
+    const int KB = (K + 127) / 128;
+    const long long gid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    if (gid >= (long long)R * KB) return;
+    const int row = (int)(gid / KB), kb = (int)(gid % KB), sub = threadIdx.x & 15;
+    const int k = kb * 128 + sub * 8;
+    float s = 0.0f;
+    if (k < K) {
+        const u32x4 raw = *(const u32x4*)(src + (size_t)row * ld_src + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s += ActT<ADT>::to_f32((unsigned short)(raw[i] & 0xffffu));
+            s += ActT<ADT>::to_f32((unsigned short)(raw[i] >> 16));
+        }
+    }
+#pragma unroll
+    for (int m = 8; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (sub == 0) sums[(size_t)row * KB + kb] = s;
+}
+
+int launch_rowsum128_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, float* sums) {
+    if (R <= 0) return LKM_OK;
+    const long long groups = (long long)R * ((K + 127) / 128);
+    dim3 grid((unsigned)((groups + 15) / 16)), block(256);
+    if (adt == LKM_DT_BF16)
+        hipLaunchKernelGGL(rowsum128_rows_kernel<LKM_DT_BF16>, grid, block, 0, st, (const unsigned short*)src, ld_src, R, K, sums);
+    else
+        hipLaunchKernelGGL(rowsum128_rows_kernel<LKM_DT_F16>, grid, block, 0, st, (const unsigned short*)src, ld_src, R, K, sums);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
 // ------------------------------------------------------------------ HBM read ceiling probe
 // Pure streaming read of `bytes` with the same access shape as the GEMM weight stream (one 1-KiB
 // nontemporal global_load_dwordx4 per wave, `unroll` of them in flight, one contiguous 128-KiB

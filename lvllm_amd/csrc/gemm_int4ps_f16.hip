@@ -1,0 +1,5 @@
+// gemm_int4ps_f16.hip -- skinny grouped-GEMM kernels for uint4b8 weights in the fast mode (scale on partial sums).
+#include "gemm_skinny.h"
+namespace lkm {
+LKM_DEFINE_GEMM_LAUNCHERS(int4ps_f16, LKM_W_INT4_PS, LKM_DT_F16)
+}  // namespace lkm

@@ -37,7 +37,7 @@ struct Dec;
 template <int ADT>
 struct DecPlain {
     static constexpr int UNITK = 64, LOADS = 2, KSTEPS = 2;
-    static constexpr bool UNIT_SCALE = false, A8 = false;
+    static constexpr bool UNIT_SCALE = false, A8 = false, XS = false;
     struct Aux {};
     static __device__ __forceinline__ void load_aux(Aux&, const void*, size_t, int, int) {}
     // pointer form (tiled kernels): aux_ptr(unit 0 of a tile) + u * aux_step(spu)
@@ -56,7 +56,7 @@ struct Dec<LKM_W_F16, LKM_DT_F16> : DecPlain<LKM_DT_F16> {};
 template <int ADT>
 struct Dec<LKM_W_INT4_B8, ADT> {
     static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
-    static constexpr bool UNIT_SCALE = false, A8 = false;
+    static constexpr bool UNIT_SCALE = false, A8 = false, XS = false;
     struct Aux {
         u32x2 raw;   // up to four act-dtype scales of this lane's weight row for the 128-k unit
     };
@@ -133,7 +133,7 @@ struct Dec<LKM_W_INT4_B8, ADT> {
 template <int ADT>
 struct Dec<LKM_W_FP8_E4M3, ADT> {
     static constexpr int UNITK = 128, LOADS = 2, KSTEPS = 4;
-    static constexpr bool UNIT_SCALE = true, A8 = false;
+    static constexpr bool UNIT_SCALE = true, A8 = false, XS = false;
     struct Aux {
         f32x4 s;  // block scale of this lane's 4 output rows (g*4 + r)
     };
@@ -162,6 +162,40 @@ struct Dec<LKM_W_FP8_E4M3, ADT> {
     }
 };
 
+// uint4b8, fast mode (LKM_W_INT4_PS, lkm_common.h): 7 VALU per 16 x 32 fragment (three shifts, four v_and_or_b32)
+// where the bit-exact decoder above needs 16-19.  A nibble v in the low bits of the mantissa of BIAS = 2^7 (bf16)
+// / 2^10 (fp16) IS the value BIAS + v; the pair order of the re-packed dword (repack.hip) makes dword p of the
+// fragment (k = 2p, 2p + 1) one mask away from the raw dword shifted by 4p.  The per-(token, unit) term
+// (BIAS + 8) * sum_k x_k arrives as Streamer / tile `xs` (launch_rowsum128_rows), the group scale as fp32 per
+// (row, unit) in the fp8 layout; groups of 128 k and multiples only.
+template <int ADT>
+struct Dec<LKM_W_INT4_PS, ADT> {
+    static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
+    static constexpr bool UNIT_SCALE = true, A8 = false, XS = true;
+    static constexpr float BIAS8 = ADT == LKM_DT_BF16 ? 136.0f : 1032.0f;     // BIAS + 8
+    struct Aux {
+        f32x4 s;  // group scale of this lane's 4 output rows (g*4 + r) for the unit
+    };
+    static __device__ __forceinline__ void load_aux(Aux& a, const void* sbase, size_t tu, int lane, int) {
+        a.s = *(const f32x4*)((const float*)sbase + tu * 16 + (lane >> 4) * 4);
+    }
+    static __device__ __forceinline__ const char* aux_ptr(const void* sbase, size_t tu, int lane, int) {
+        return (const char*)((const float*)sbase + tu * 16 + (lane >> 4) * 4);
+    }
+    static __device__ __forceinline__ int aux_step(int) { return 64; }
+    static __device__ __forceinline__ void load_aux_at(Aux& a, const char* p) { a.s = *(const f32x4*)p; }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux&, int ks, int) {
+        constexpr unsigned ONE = ADT == LKM_DT_BF16 ? 0x43004300u : 0x64006400u;
+        const unsigned w = raw[0][ks];
+        u32x4 o;
+        o.x = (w & 0x000f000fu) | ONE;
+        o.y = ((w >> 4) & 0x000f000fu) | ONE;
+        o.z = ((w >> 8) & 0x000f000fu) | ONE;
+        o.w = ((w >> 12) & 0x000f000fu) | ONE;
+        return o;
+    }
+};
+
 // OCP MXFP4 (E2M1 values, one E8M0 scale per 32 k = per MFMA k-step): gfx950 converts a packed pair
 // of FP4 straight to the activation dtype AND applies the power-of-two scale in one instruction
 // (v_cvt_scalef32_pk_{bf16,f16}_fp4; only the exponent of the f32 scale operand is used -- measured,
@@ -170,7 +204,7 @@ struct Dec<LKM_W_FP8_E4M3, ADT> {
 template <int ADT>
 struct Dec<LKM_W_MXFP4, ADT> {
     static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
-    static constexpr bool UNIT_SCALE = false, A8 = false;
+    static constexpr bool UNIT_SCALE = false, A8 = false, XS = false;
     struct Aux {
         unsigned raw;   // the four E8M0 scales (k-steps 0..3 of the unit) of this lane's weight row
     };
@@ -210,7 +244,7 @@ struct Dec<LKM_W_MXFP4, ADT> {
 template <int ADT>
 struct Dec<LKM_W_NVFP4, ADT> {
     static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
-    static constexpr bool UNIT_SCALE = false, A8 = false;
+    static constexpr bool UNIT_SCALE = false, A8 = false, XS = false;
     struct Aux {
         u32x2 raw;   // the eight e4m3fn block scales of this lane's weight row for the 128-k unit
     };
@@ -248,7 +282,7 @@ struct Dec<LKM_W_NVFP4, ADT> {
 template <int ADT>
 struct Dec<LKM_W_FP8_A8, ADT> {
     static constexpr int UNITK = 128, LOADS = 2, KSTEPS = 4;
-    static constexpr bool UNIT_SCALE = true, A8 = true;
+    static constexpr bool UNIT_SCALE = true, A8 = true, XS = true;
     struct Aux {
         f32x4 s;
     };
@@ -274,7 +308,7 @@ struct Stage {
     static constexpr int XN = D::A8 ? D::KSTEPS / 2 : D::KSTEPS;
     u32x4 w[NTT][D::LOADS];
     u32x4 x[TB][XN];
-    float xs[TB];          // A8: activation scale of this lane's token for the unit
+    float xs[TB];          // XS: per-(token, unit) scalar of this lane's token (A8: activation scale; INT4_PS: k sum)
     typename D::Aux aux[NTT];
 };
 
@@ -308,7 +342,7 @@ struct Streamer {
         const bool tail = !STEADY && (u + 1) * D::UNITK > Kreal;   // wave-uniform
 #pragma unroll
         for (int b = 0; b < NTB; ++b) {
-            if constexpr (D::A8) st.xs[b] = xsp[b][u];
+            if constexpr (D::XS) st.xs[b] = xsp[b][u];
 #pragma unroll
             for (int i = 0; i < St::XN; ++i) {
                 // 16-byte token loads: 8 x 16-bit = k-step i, or 16 x fp8 = the k-step pair i;
@@ -358,6 +392,8 @@ struct Streamer {
                 for (int b = 0; b < NTB; ++b) {
                     if constexpr (D::A8)
                         acc[t][b] += scale4(st.aux[t].s, splat2_opaque(st.xs[b])) * part[t][b];
+                    else if constexpr (D::XS)      // INT4_PS: s * (sum (BIAS + v) x - (BIAS + 8) sum x)
+                        acc[t][b] += st.aux[t].s * sub4(part[t][b], splat2_opaque(D::BIAS8 * st.xs[b]));
                     else
                         acc[t][b] += st.aux[t].s * part[t][b];
                 }

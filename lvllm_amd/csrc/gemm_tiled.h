@@ -65,7 +65,7 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
     constexpr int XB = D::A8 ? 1 : 2;            // bytes per activation element (fp8 when W8A8)
     constexpr int ROWB = D::UNITK * XB;          // bytes of one token row per K unit
     constexpr int SLOTS = ROWB / 16;
-    constexpr int BUFB = TM * ROWB + (D::A8 ? TM * 4 : 0);   // + per-row activation scales (W8A8)
+    constexpr int BUFB = TM * ROWB + (D::XS ? TM * 4 : 0);   // + per-row scalars of the unit (W8A8 scales, INT4_PS sums)
     constexpr int PIECES = TM * SLOTS / THREADS;
     static_assert(PIECES >= 1 && TM * SLOTS % THREADS == 0, "staging split");
     extern __shared__ __attribute__((aligned(16))) char xlds[];   // [2]{[TM][ROWB], A8: float[TM]}
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
     }
     // W8A8: thread `tid` < TM also stages the activation scale of token row tid for the unit
     const float* xsrow = nullptr;
-    if (D::A8) {   // threads >= TM fetch row TM-1's scale too (unconditional load) and drop it
+    if (D::XS) {   // threads >= TM fetch row TM-1's scale too (unconditional load) and drop it
         const int r = r0 + (tid < TM ? tid : TM - 1);
         const int rr = r < m_e ? r : r0;
         const size_t rowidx = IS_G1 ? (size_t)(p.sorted_slot[off_e + rr] / p.top_k) : (size_t)(off_e + rr);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
                     xs[q] = v;
                 }
             }
-            if constexpr (D::A8) xsv = xsrow[u];
+            if constexpr (D::XS) xsv = xsrow[u];
         };
         auto load_w = [&](WStage& s, int u) __attribute__((always_inline)) {
     #pragma unroll
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
         auto store_x = [&](const u32x4 (&xs)[PIECES], float xsv, int buf) __attribute__((always_inline)) {
     #pragma unroll
             for (int q = 0; q < PCS; ++q) *(u32x4*)(xlds + buf * BUFB + xdst[q]) = xs[q];
-            if (D::A8 && tid < TM) *(float*)(xlds + buf * BUFB + TM * ROWB + tid * 4) = xsv;
+            if (D::XS && tid < TM) *(float*)(xlds + buf * BUFB + TM * ROWB + tid * 4) = xsv;
         };
         auto compute = [&](const WStage& s, int buf) __attribute__((always_inline)) {
             if (!wave_on) return;
@@ -284,9 +284,16 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
                     }
                 }
     #pragma unroll
-                for (int t = 0; t < NTT; ++t)
+                for (int b = 0; b < NB; ++b) {
+                    if constexpr (D::XS) {      // INT4_PS: s * (sum (BIAS + v) x - (BIAS + 8) sum x)
+                        const f32x2 c = splat2_opaque(D::BIAS8 * *(const float*)(xb + TM * ROWB + (b * 16 + j) * 4));
     #pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[t][b] += s.aux[t].s * part[t][b];
+                        for (int t = 0; t < NTT; ++t) acc[t][b] += s.aux[t].s * sub4(part[t][b], c);
+                    } else {
+    #pragma unroll
+                        for (int t = 0; t < NTT; ++t) acc[t][b] += s.aux[t].s * part[t][b];
+                    }
+                }
             } else if constexpr (WF == LKM_W_INT4_B8) {
                 // in-register decode costs ~19 VALU per fragment against 4 x TBW/4 MFMAs: decode k-step
                 // ks+1 while the MFMAs of k-step ks occupy the matrix pipe (one MFMA : DEC_PER VALU)
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
 template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1, int PD>
 static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr int ROWB = Dec<WF, ADT>::UNITK * (Dec<WF, ADT>::A8 ? 1 : 2);
-    constexpr size_t lds = (size_t)2 * (TBW * 16 * ROWB + (Dec<WF, ADT>::A8 ? TBW * 16 * 4 : 0));
+    constexpr size_t lds = (size_t)2 * (TBW * 16 * ROWB + (Dec<WF, ADT>::XS ? TBW * 16 * 4 : 0));
     const int RG = ceil_div(p.T_half, WAVES * NT);
     dim3 grid(RG, max_tiles, IS_G1 ? 1 : p.SK), block(WAVES * 64);
     GemmParams pp = p;
@@ -481,6 +488,10 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
 template <typename ADTC>
 static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
                               int max_tiles, int* rc, ADTC);
+// 4-bit formats, 32/64-row tiles: the LDS-DMA ring kernel (gemm_w4dma.h)
+template <int WF, int ADT>
+static bool launch_w4dma_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
+                            int max_tiles, int* rc);
 // fp8 x fp8, 256-row tiles: the MX-scaled-MFMA prefill kernel (gemm_prefill_a8.h)
 template <typename ADTC>
 static bool launch_prefill_a8_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
@@ -499,6 +510,10 @@ struct W16Only {
             return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1, 2>(st, p, max_tiles);      \
         }                                                                                       \
     }
+template <int WF>
+struct W4Only {
+    static constexpr bool value = WF == LKM_W_INT4_B8 || WF == LKM_W_INT4_PS || WF == LKM_W_MXFP4 || WF == LKM_W_NVFP4;
+};
 #define LKM_TILED_CASE(TBW, WAVES, NT, G, IS1)                                             \
     if (cfg.tiled == TBW * 16 && cfg.waves == WAVES && cfg.nt == NT) {                                  \
         if (cfg.pd >= 4) return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1, 4>(st, p, max_tiles); \
@@ -516,6 +531,10 @@ struct W16Only {
         if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
             int rc = LKM_OK;                                                                          \
             if (launch_prefill_a8_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc; \
+        }                                                                                             \
+        if constexpr (W4Only<WF_>::value) {                                                           \
+            int rc = LKM_OK;                                                                          \
+            if (launch_w4dma_if<WF_, ADT_>(st, cfg, p, gated, true, max_tiles, &rc)) return rc;       \
         }                                                                                             \
         if (gated) {                                                                                  \
             LKM_TILED_CASE(2, 4, 1, true, true)                                                       \
@@ -547,6 +566,10 @@ struct W16Only {
         if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
             int rc = LKM_OK;                                                                          \
             if (launch_prefill_a8_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;\
+        }                                                                                             \
+        if constexpr (W4Only<WF_>::value) {                                                           \
+            int rc = LKM_OK;                                                                          \
+            if (launch_w4dma_if<WF_, ADT_>(st, cfg, p, false, false, max_tiles, &rc)) return rc;      \
         }                                                                                             \
         LKM_TILED_CASE(2, 4, 1, false, false)                                                         \
         LKM_TILED_CASE(4, 4, 1, false, false)                                                         \

@@ -138,8 +138,9 @@ struct LkmEngine {
     int E, H, I, K;            // local experts, hidden, intermediate, top_k
     bool gated, interleaved;
     int wf, adt;
-    int wfk;                   // kernel format: wf, or LKM_W_FP8_A8 for fp8 W8A8
+    int wfk;                   // kernel format: wf, LKM_W_FP8_A8 for fp8 W8A8, LKM_W_INT4_PS for the fast int4 mode
     bool a8;
+    bool ps;                   // int4 fast mode: per-(row, 128-k) activation sums feed the GEMMs (arena xqs / aqs)
     // geometry
     int unitk;
     int T1_half, U1;           // w13: tiles per half, units along H
@@ -290,6 +291,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
         const int g = cfg->groupK;
         LKM_REQUIRE(g >= 32 && (g <= 128 ? 128 % g == 0 : g % 128 == 0), "lkm_create: int4 groupK=%d unsupported (32, 64, 128 or a multiple of 128)", g);
         LKM_REQUIRE(cfg->hidden_size % g == 0 && cfg->intermediate_size % g == 0, "lkm_create: groupK=%d must divide hidden and intermediate sizes", g);
+        LKM_REQUIRE(cfg->int4_mode == LKM_INT4_EXACT || cfg->int4_mode == LKM_INT4_FAST, "lkm_create: bad int4_mode %d", cfg->int4_mode);
+        LKM_REQUIRE(cfg->int4_mode != LKM_INT4_FAST || g % 128 == 0, "lkm_create: int4_mode FAST applies the group scale per 128-k block; groupK must be a multiple of 128 (got %d)", g);
     }
     int ndev = 0;
     LKM_HIP_CHECK(hipGetDeviceCount(&ndev));
@@ -313,7 +316,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     h->wf = wf;
     h->adt = adt;
     h->a8 = wf == LKM_W_FP8_E4M3 && cfg->fp8_mode == LKM_FP8_W8A8;
-    h->wfk = h->a8 ? LKM_W_FP8_A8 : wf;
+    h->ps = wf == LKM_W_INT4_B8 && cfg->int4_mode == LKM_INT4_FAST;
+    h->wfk = h->a8 ? LKM_W_FP8_A8 : (h->ps ? LKM_W_INT4_PS : wf);
     h->unitk = wf_unitk(wf);
     h->T1_half = round_up(ceil_div(h->I, 16), 4);
     h->U1 = ceil_div(h->H, h->unitk);
@@ -358,19 +362,40 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
         const void* dsrc;
         void* tmp;
         LKM_TRY(to_device(w13, b13, &dsrc, &tmp));
-        rc = launch_repack_w(nullptr, wf, dsrc, h->w13, d13);
+        rc = launch_repack_w(nullptr, h->ps ? LKM_W_INT4_PS : wf, dsrc, h->w13, d13);
         hipError_t se = hipDeviceSynchronize();
         if (tmp) (void)hipFree(tmp);
         if (rc != LKM_OK) return fail(rc);
         LKM_TRY_HIP(se);
         LKM_TRY(to_device(w2, b2, &dsrc, &tmp));
-        rc = launch_repack_w(nullptr, wf, dsrc, h->w2, d2);
+        rc = launch_repack_w(nullptr, h->ps ? LKM_W_INT4_PS : wf, dsrc, h->w2, d2);
         se = hipDeviceSynchronize();
         if (tmp) (void)hipFree(tmp);
         if (rc != LKM_OK) return fail(rc);
         LKM_TRY_HIP(se);
     }
-    if (wf == LKM_W_INT4_B8) {
+    if (h->ps) {     // fp32 scale per (row, 128-k unit), the layout of the fp8 block scales
+        const int g = cfg->groupK;
+        const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16;
+        const size_t n2 = (size_t)h->E * h->T2 * h->U2 * 16;
+        LKM_TRY_HIP(hipMalloc(&h->s13, n13 * 4));
+        LKM_TRY_HIP(hipMalloc(&h->s2, n2 * 4));
+        h->weight_bytes += (int64_t)(n13 + n2) * 4;
+        const void* dsrc;
+        void* tmp;
+        LKM_TRY(to_device(w13_scale, (size_t)h->E * halves * h->I * (h->H / g) * 2, &dsrc, &tmp));
+        rc = launch_repack_s_int4ps(nullptr, dsrc, h->s13, d13, g, adt);
+        hipError_t se = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (rc != LKM_OK) return fail(rc);
+        LKM_TRY_HIP(se);
+        LKM_TRY(to_device(w2_scale, (size_t)h->E * h->H * (h->I / g) * 2, &dsrc, &tmp));
+        rc = launch_repack_s_int4ps(nullptr, dsrc, h->s2, d2, g, adt);
+        se = hipDeviceSynchronize();
+        if (tmp) (void)hipFree(tmp);
+        if (rc != LKM_OK) return fail(rc);
+        LKM_TRY_HIP(se);
+    } else if (wf == LKM_W_INT4_B8) {
         const int g = cfg->groupK;
         const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16 * h->spu;
         const size_t n2 = (size_t)h->E * h->T2 * h->U2 * 16 * h->spu;
@@ -460,9 +485,10 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     const size_t y_rows = slots > 8 * (slots < 2048 ? slots : 2048) ? slots : 8 * (slots < 2048 ? slots : 2048);
     {
         const size_t kb1 = ceil_div(h->H, 128), kb2 = ceil_div(h->I, 128);
+        const bool xs = h->a8 || h->ps;       // per-(row, 128-k) scalars: activation scales / activation sums
         LKM_TRY(arena_reserve(h->device, h->E, slots, slots * h->ld_act, y_rows * h->H,
-                              h->a8 ? cap * h->H : 0, h->a8 ? cap * kb1 : 0, h->a8 ? slots * h->I : 0,
-                              h->a8 ? slots * kb2 : 0, &h->arena));
+                              h->a8 ? cap * h->H : 0, xs ? cap * kb1 : 0, h->a8 ? slots * h->I : 0,
+                              xs ? slots * kb2 : 0, &h->arena));
     }
     for (auto& e : h->ev) LKM_TRY_HIP(hipEventCreate(&e));
     *out = h;
@@ -565,7 +591,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         int waves = tiled >= 128 ? 8 : 4;
         if (tiled == 128 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && wg8 < 512) waves = 4;
         if (h->t_waves > 0) waves = h->t_waves;
-        const int nt1 = (h->t_nt1 > 0 && !split && !(tiled == 256 && h->a8)) ? h->t_nt1 : 1;
+        const int nt1 = (h->t_nt1 > 0 && !split && !(tiled == 256 && h->a8)) ? h->t_nt1 : 1;   // (4-bit DMA kernel: 1 or 2)
         // two weight tiles per wave in GEMM2: 256-row tiles (GLM bf16: 3.61 vs 3.81 ms), fp8-W8A8 128-row tiles
         // (GEMM2 1343 -> 1141 us) and the 4-bit formats at 64-row tiles (half the token-fragment LDS reads per
         // weight byte; Mixtral M=128 GEMM2 int4 95 -> 92 us, NVFP4 85.6 -> 80.4, MXFP4 74.2 -> 67.5:
@@ -589,7 +615,14 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             if (w4_64 && h->wf != LKM_W_MXFP4) pd2 = 2;
         }
         if (tiled == 128 && waves == 4) pd1 = pd2 = 4;   // EP=8 Mixtral rank: 154 vs 229 us at 2/2
-        int pf = (tiled == 256 && h->t_pf > 0) ? h->t_pf : 0;
+        int pf = (tiled == 256 && h->t_pf > 0 && !wf_is_4bit(h->wf)) ? h->t_pf : 0;
+        // 4-bit formats at 32/64-row tiles: the LDS-DMA ring kernel (gemm_w4dma.h) is an opt-in knob ("pf" = 4): three
+        // to four times the bytes in flight per CU, and no faster -- Mixtral M=128 GEMM1 int4 150 -> 183-193 us, MXFP4
+        // 112 -> 118 (108 at depth 3), NVFP4 145 -> 168, int4 fast mode 149 -> 150-157 (profiles/r02_w4dma_sweep.log):
+        // the 4-bit decode kernels are not bound by bytes in flight
+        if (wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && waves == 4 && !split && h->t_pf == 4 &&
+            h->H % 128 == 0 && h->I % 128 == 0)
+            pf = 4;
         if (tiled == 256 && h->a8) {          // the fp8 x fp8 prefill kernel is the only 256-row variant of the format
             pf = 8;
             waves = 8;
@@ -683,6 +716,11 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     if (h->a8) {   // dynamic 1x128 fp8 quantisation of the token rows (once per token, not per slot)
         LKM_REQUIRE((size_t)M * h->H <= a->xq_n && n_slots * h->I <= a->aq_n, "fp8 activation scratch too small");
         rc = launch_quant_fp8_rows(st, x, (int)il.x_ld, h->adt, M, h->H, a->xq, a->xqs);
+        if (rc != LKM_OK) return rc;
+    }
+    if (h->ps) {   // int4 fast mode: the activation-side term, one fp32 sum per (token, 128-k block)
+        LKM_REQUIRE((size_t)M * kb1 <= a->xqs_n && n_slots * kb2 <= a->aqs_n, "int4 activation-sum scratch too small");
+        rc = launch_rowsum128_rows(st, x, (int)il.x_ld, h->adt, M, h->H, a->xqs);
         if (rc != LKM_OK) return rc;
     }
     const int tile_rows = pl.t1.tiled ? pl.t1.tiled : pl.t2.tiled;
@@ -787,6 +825,10 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         rc = launch_quant_fp8_rows(st, a->act, h->ld_act, h->adt, (int)n_slots, h->I, a->aq, a->aqs);
         if (rc != LKM_OK) return rc;
     }
+    if (h->ps) {
+        rc = launch_rowsum128_rows(st, a->act, h->ld_act, h->adt, (int)n_slots, h->I, a->aqs);
+        if (rc != LKM_OK) return rc;
+    }
     p2.x = h->a8 ? (const void*)a->aq : a->act;
     p2.ldx = h->ld_act;
     p2.xscale = a->aqs;
@@ -880,6 +922,11 @@ static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, 
     if (h->a8) {
         if (h->arena->xq_n / (size_t)h->H < chunk) chunk = h->arena->xq_n / (size_t)h->H;
         if (h->arena->aq_n / ((size_t)K * h->I) < chunk) chunk = h->arena->aq_n / ((size_t)K * h->I);
+    }
+    if (h->a8 || h->ps) {
+        const size_t kb1 = ceil_div(h->H, 128), kb2 = ceil_div(h->I, 128);
+        if (h->arena->xqs_n / kb1 < chunk) chunk = h->arena->xqs_n / kb1;
+        if (h->arena->aqs_n / ((size_t)K * kb2) < chunk) chunk = h->arena->aqs_n / ((size_t)K * kb2);
     }
     LKM_REQUIRE(chunk > 0, "scratch arena too small for top_k=%d", K);
     const size_t xrow = (size_t)il.x_ld * 2, orow = (size_t)h->H * (out_dt == LKM_DT_F32 ? 4 : 2);
@@ -1067,7 +1114,10 @@ static void expert_slabs(const LkmEngine* h, int expert, ExpertSlabs* s) {
     const size_t t13 = halves * h->T1_half * h->U1;   // (16-row tile, k unit) pairs of one expert
     const size_t t2 = (size_t)h->T2 * h->U2;
     size_t sb13 = 0, sb2 = 0;                         // scale bytes of one expert
-    if (h->wf == LKM_W_INT4_B8) {
+    if (h->ps) {
+        sb13 = t13 * 16 * 4;
+        sb2 = t2 * 16 * 4;
+    } else if (h->wf == LKM_W_INT4_B8) {
         sb13 = t13 * 16 * h->spu * 2;
         sb2 = t2 * 16 * h->spu * 2;
     } else if (h->wf == LKM_W_MXFP4 || h->wf == LKM_W_NVFP4) {

@@ -101,6 +101,11 @@ static __device__ __forceinline__ f32x4 scale4(f32x4 a, f32x2 b) {
     return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 
+static __device__ __forceinline__ f32x4 sub4(f32x4 a, f32x2 b) {
+    const f32x2 lo = f32x2{a.x, a.y} - b, hi = f32x2{a.z, a.w} - b;
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+
 template <int DT>
 struct ActT;
 template <>
@@ -212,6 +217,13 @@ __device__ __forceinline__ void store1<f16_out>(f16_out* p, float v) {
 // quantised fp8 activations (W8A8, the in-tree operator's block-fp8 semantics); same HBM layout as
 // LKM_W_FP8_E4M3.
 #define LKM_W_FP8_A8 100
+// internal kernel-format code: uint4b8 weights in the FAST mode (LkmConfig.int4_mode = LKM_INT4_FAST): nibbles become
+// the activation-dtype values BIAS + v with one v_and_or_b32 per pair (exact), the group scale is applied to the
+// fp32 partial sum of each 128-k unit and the bias leaves through the per-(token, unit) activation sums:
+//   sum_k s (v_k - 8) x_k  =  s (sum_k (BIAS + v_k) x_k  -  (BIAS + 8) sum_k x_k).
+// Same bytes as LKM_W_INT4_B8 with the nibbles of a dword re-ordered (k -> position k/2 + 4 (k & 1)), fp32 scales in
+// the fp8 unit layout.  NOT the reference's rounding (it rounds (q-8) s to the activation dtype first): opt-in.
+#define LKM_W_INT4_PS 101
 
 template <int WF>
 struct WGeom;
@@ -229,6 +241,11 @@ struct WGeom<LKM_W_FP8_E4M3> {
 };
 template <>
 struct WGeom<LKM_W_INT4_B8> {
+    static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
+};
+
+template <>
+struct WGeom<LKM_W_INT4_PS> {
     static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
 };
 

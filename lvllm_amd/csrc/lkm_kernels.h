@@ -15,6 +15,7 @@ struct RepackDims {
 int launch_repack_w(hipStream_t st, int wf, const void* src, void* dst, const RepackDims& d);
 int launch_repack_s_int4(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group,
                          int spu);
+int launch_repack_s_int4ps(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group, int adt);
 int launch_repack_s_fp8(hipStream_t st, const void* src, void* dst, const RepackDims& d, int gN,
                         int gK);
 int launch_repack_s_fp4(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group,
@@ -29,6 +30,8 @@ int launch_sort(hipStream_t st, const int32_t* ids, int top_k, int ids_ld, int i
 constexpr int kMetaInts = 32;   // meta[0..3]: see dispatch.hip; meta[8..16]: per-XCD runs of the tile list
 int launch_quant_fp8_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, void* dst,
                           float* scales);
+// int4 fast mode: sums[r][kb] = fp32 sum of the 128 elements of group kb of row r (16-bit rows, row stride ld_src)
+int launch_rowsum128_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, float* sums);
 int launch_combine(hipStream_t st, const void* y, int y_dt, int SK, size_t sk_stride,
                    const int32_t* pos_of_slot, const float* tw, int tw_ld, int M, int K, int H, void* out,
                    int out_dt);

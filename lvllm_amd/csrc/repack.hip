@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void repack_w_kernel(const uint8_t* __restrict
                 out[2 * q + 1] = hi;
             }
         } else {  // 4-bit: bytes [E][N][K/2]; zero padding must decode to 0 => uint4b8 nibble 8, E2M1 nibble 0
-            constexpr unsigned PADB = WF == LKM_W_INT4_B8 ? 0x88u : 0x00u;
+            constexpr unsigned PADB = (WF == LKM_W_INT4_B8 || WF == LKM_W_INT4_PS) ? 0x88u : 0x00u;
             const uint8_t* p = src + ((size_t)e * N + n) * (d.K / 2);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -77,10 +77,16 @@ __global__ __launch_bounds__(256) void repack_w_kernel(const uint8_t* __restrict
                     unsigned b = (k0 + 2 * j < d.K) ? p[(k0 >> 1) + j] : PADB;
                     w |= b << (8 * j);
                 }
+                if (WF == LKM_W_INT4_PS) {   // k -> nibble position k/2 + 4 (k & 1): pair p = (w >> 4p) & 0x000f000f
+                    unsigned r = 0;
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) r |= ((w >> (4 * kk)) & 0xfu) << (4 * ((kk >> 1) + 4 * (kk & 1)));
+                    w = r;
+                }
                 out[s] = w;
             }
         }
-    } else if (WF == LKM_W_INT4_B8) {   // padded rows decode to 0 (E2M1: the zero fill already does)
+    } else if (WF == LKM_W_INT4_B8 || WF == LKM_W_INT4_PS) {   // padded rows decode to 0 (E2M1: the zero fill already does)
         out[0] = out[1] = out[2] = out[3] = 0x88888888u;
     }
     u32x4 o;
@@ -114,6 +120,41 @@ __global__ __launch_bounds__(256) void repack_s_int4_kernel(const unsigned short
     unsigned short s = 0;
     if (idx < d.n_half && k < d.K) s = src[((size_t)e * N + n) * (d.K / group) + k / group];
     dst[v] = s;
+}
+
+// int4 fast mode: src act-dtype group scales [E][N][K/g] (g a multiple of 128) -> dst fp32 [E][tile][unit][16 rows]
+template <int ADT>
+__global__ __launch_bounds__(256) void repack_s_int4ps_kernel(const unsigned short* __restrict__ src,
+                                                              float* __restrict__ dst, RepackDims d, int group) {
+    const size_t n_out = (size_t)d.E * d.halves * d.T_half * d.U * 16;
+    size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_out) return;
+    size_t t = v;
+    const int i = (int)(t & 15);
+    t >>= 4;
+    const int u = (int)(t % d.U);
+    t /= d.U;
+    const int tile = (int)(t % (d.halves * d.T_half));
+    const int e = (int)(t / (d.halves * d.T_half));
+    const int half = tile / d.T_half;
+    const int idx = (tile % d.T_half) * 16 + i;
+    const int N = d.n_half * d.halves;
+    const int n = d.interleaved ? idx * d.halves + half : half * d.n_half + idx;
+    const int k = u * 128;
+    float s = 0.0f;
+    if (idx < d.n_half && k < d.K) s = ActT<ADT>::to_f32(src[((size_t)e * N + n) * (d.K / group) + k / group]);
+    dst[v] = s;
+}
+
+int launch_repack_s_int4ps(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group, int adt) {
+    const size_t n_out = (size_t)d.E * d.halves * d.T_half * d.U * 16;
+    dim3 grid((unsigned)ceil_div64((int64_t)n_out, 256)), block(256);
+    if (adt == LKM_DT_BF16)
+        hipLaunchKernelGGL(repack_s_int4ps_kernel<LKM_DT_BF16>, grid, block, 0, st, (const unsigned short*)src, (float*)dst, d, group);
+    else
+        hipLaunchKernelGGL(repack_s_int4ps_kernel<LKM_DT_F16>, grid, block, 0, st, (const unsigned short*)src, (float*)dst, d, group);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
 }
 
 // 4-bit float block scales (one byte each): src [E][N][K/g] (MXFP4: E8M0, g=32; NVFP4: e4m3fn, g=16)
@@ -170,7 +211,7 @@ __global__ __launch_bounds__(256) void repack_s_fp8_kernel(const float* __restri
 }
 
 int launch_repack_w(hipStream_t st, int wf, const void* src, void* dst, const RepackDims& d) {
-    const int loads = wf_loads(wf);
+    const int loads = wf_loads(wf == LKM_W_INT4_PS ? LKM_W_INT4_B8 : wf);
     const size_t nvec = (size_t)d.E * d.halves * d.T_half * d.U * loads * 64;
     dim3 grid((unsigned)ceil_div64((int64_t)nvec, 256)), block(256);
     switch (wf) {
@@ -185,6 +226,9 @@ int launch_repack_w(hipStream_t st, int wf, const void* src, void* dst, const Re
         break;
     case LKM_W_INT4_B8:
         hipLaunchKernelGGL(repack_w_kernel<LKM_W_INT4_B8>, grid, block, 0, st, (const uint8_t*)src, (u32x4*)dst, d);
+        break;
+    case LKM_W_INT4_PS:
+        hipLaunchKernelGGL(repack_w_kernel<LKM_W_INT4_PS>, grid, block, 0, st, (const uint8_t*)src, (u32x4*)dst, d);
         break;
     case LKM_W_MXFP4:
     case LKM_W_NVFP4:

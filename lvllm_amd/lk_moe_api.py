@@ -47,6 +47,8 @@ class MOEConfigV2:
         self.use_gpu_prefill = False
         # extension (not in the reference): fp8 compute mode, 0 = W8A16 (lk_moe semantics)
         self.fp8_mode = _clib.FP8_W8A16
+        # extension: uint4b8 compute mode, 0 = the reference's rounding T((q-8) s), 1 = scale on fp32 partial sums
+        self.int4_mode = _clib.INT4_EXACT
 
     def _to_c(self, weight_format: int, act_dtype: int) -> _clib.LkmConfig:
         c = _clib.LkmConfig()
@@ -54,7 +56,7 @@ class MOEConfigV2:
         for name in ("num_processes", "process_id", "gpu_id", "expert_num", "top_k", "hidden_size",
                      "intermediate_size", "max_batch_size", "max_num_seqs", "stride",
                      "group_min_len", "group_max_len", "groupN", "groupK", "activation_type",
-                     "fp8_mode"):
+                     "fp8_mode", "int4_mode"):
             setattr(c, name, int(getattr(self, name)))
         c.has_gate_proj = int(bool(self.has_gate_proj))
         c.use_gpu_prefill = int(bool(self.use_gpu_prefill))

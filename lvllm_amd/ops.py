@@ -290,7 +290,7 @@ class RoutedExpertsEngine:
                  has_gate_proj: bool = True, activation_type: int = 0, swiglu_alpha: float = 1.702,
                  swiglu_limit: float = 7.0, max_num_seqs: int = 256, max_batch_size: int = 8192,
                  group_max_len: int = 0, num_processes: int = 1, process_id: int = 0,
-                 gpu_id: int | None = None, fp8_mode: int = _clib.FP8_W8A16,
+                 gpu_id: int | None = None, fp8_mode: int = _clib.FP8_W8A16, int4_mode: int = _clib.INT4_EXACT,
                  w13_global_scale: torch.Tensor | None = None,
                  w2_global_scale: torch.Tensor | None = None):
         E = w13.shape[0]
@@ -308,6 +308,7 @@ class RoutedExpertsEngine:
         cfg.activation_type = activation_type
         cfg.swiglu_alpha, cfg.swiglu_limit = swiglu_alpha, swiglu_limit
         cfg.fp8_mode = fp8_mode
+        cfg.int4_mode = int4_mode
         self.cfg = cfg
         self.H, self.K, self.act_dtype = H, top_k, act_dtype
         cls = _CLS[(fmt, act_dtype)]

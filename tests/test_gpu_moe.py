@@ -71,6 +71,54 @@ def test_int4_golden_cases():
                                    err_msg=f"case {i} vs reference (dequantised-weight oracle)")
 
 
+def test_int4_fast_mode_golden_cases_and_random_shapes():
+    """LkmConfig.int4_mode = FAST (opt-in): (q - 8) exact, the group scale applied to the fp32 partial sum of each
+    128-k block, the +BIAS of the in-register decode removed through the activation sums.  Checked against the oracle's
+    restatement of exactly that arithmetic (MoeDesc.int4_unrounded: weights (q-8)*s kept in fp32), against the
+    reference's goldens at the reference's tolerance (test_moe.py:565-693, atol 2e-2) and against the bit-exact
+    decoder (they differ by the bf16 / fp16 rounding of the weights the fast mode does not perform)."""
+    from lvllm_amd import _clib
+    n_fast = 0
+    for i, c in load_golden("moe_int4.npz"):
+        m, n, k, e, topk, g, dt = [int(v) for v in c["meta"]]
+        if g % 128:
+            continue
+        n_fast += 1
+        tdt = torch.bfloat16 if dt == orc.BF16 else torch.float16
+        eng = _eng(torch.from_numpy(c["q1"]), torch.from_numpy(c["q2"]), top_k=topk, act_dtype=tdt,
+                   fmt="int4", w13_scale=bits_to_torch(c["s1"], dt), w2_scale=bits_to_torch(c["s2"], dt),
+                   group_n=1, group_k=g, int4_mode=_clib.INT4_FAST)
+        out = _run_decode(eng, bits_to_torch(c["a"], dt), c["tw"], c["ids"])
+        d = orc.MoeDesc(E=e, H=k, I=n, act_dtype=dt, wfmt=orc.W_INT4, groupN=1, groupK=g, int4_unrounded=True)
+        ref = orc.moe(d, c["q1"], c["q2"], c["a"], c["ids"], c["tw"], s13=c["s1"], s2=c["s2"])
+        np.testing.assert_allclose(out, ref, atol=ATOL * max(1.0, float(np.abs(ref).max())), rtol=RTOL, err_msg=f"case {i} vs oracle")
+        np.testing.assert_allclose(out, orc.bits_to_f32(c["out"], dt), atol=2e-2, rtol=0,
+                                   err_msg=f"case {i} vs reference (dequantised-weight oracle)")
+    assert n_fast >= 1, "no golden case with a group of 128"
+    # every launch geometry: single token (direct path), streamer, 32- and 64-row tiles, multi-tile, ragged K tail
+    for M, E, K, H, I, g, dt in [(1, 8, 2, 512, 256, 128, torch.bfloat16), (5, 4, 2, 256, 384, 128, torch.float16),
+                                 (40, 8, 2, 1024, 512, 128, torch.bfloat16), (150, 4, 2, 512, 640, 128, torch.bfloat16),
+                                 (300, 2, 2, 768, 256, 256, torch.bfloat16)]:
+        a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, dt, seed=M, drop=0.1)
+        odt = orc.BF16 if dt == torch.bfloat16 else orc.F16
+        q13, s13 = orc.quant_int4(torch_to_bits(w13), odt, g)
+        q2, s2 = orc.quant_int4(torch_to_bits(w2), odt, g)
+        kw = dict(top_k=K, act_dtype=dt, fmt="int4", w13_scale=bits_to_torch(s13, odt), w2_scale=bits_to_torch(s2, odt),
+                  group_n=1, group_k=g)
+        fast = _eng(torch.from_numpy(q13), torch.from_numpy(q2), int4_mode=_clib.INT4_FAST, **kw)
+        out = _run_decode(fast, a, tw, ids)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=odt, wfmt=orc.W_INT4, groupN=1, groupK=g, int4_unrounded=True)
+        ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+        scale = float(np.abs(ref).max())
+        np.testing.assert_allclose(out, ref, atol=ATOL * scale, rtol=RTOL, err_msg=fast.engine.describe())
+        exact = _run_decode(_eng(torch.from_numpy(q13), torch.from_numpy(q2), **kw), a, tw, ids)
+        np.testing.assert_allclose(out, exact, atol=2e-2 * scale, rtol=2e-2)
+    with pytest.raises(Exception):      # the mode needs whole 128-k blocks per scale group
+        _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=2, act_dtype=torch.bfloat16, fmt="int4",
+             w13_scale=bits_to_torch(s13, orc.BF16), w2_scale=bits_to_torch(s2, orc.BF16), group_n=1, group_k=64,
+             int4_mode=_clib.INT4_FAST)
+
+
 def test_fp8_w8a16_golden_inputs():
     for i, c in load_golden("moe_fp8_block.npz"):
         m, n, k, e, topk = [int(v) for v in c["meta"]]

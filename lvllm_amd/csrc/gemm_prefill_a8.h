@@ -62,6 +62,9 @@ __global__ __launch_bounds__(512) void gemm_prefill_a8_kernel(GemmParams p) {
     constexpr int TPH = GATED ? 8 : 16;                       // tiles per half taken by one workgroup
     const int tbase = bx * TPH;
     const int U = p.U;
+    // ragged last tile of an expert (GLM-4.5-Air: 512 +- 22 rows over 256-row tiles): only the 64-token quarters that
+    // hold rows are fetched, and a wave whose quarter is empty keeps the DMA / barrier cadence but multiplies nothing
+    const int nq = ((m_e - r0 < 256 ? m_e - r0 : 256) + 63) >> 6;
 
     // global tile of local tile tl (0..15): gated = 8 gate tiles then the 8 up tiles of the same rows
     auto gtile = [&](int tl) __attribute__((always_inline)) {
@@ -113,13 +116,14 @@ __global__ __launch_bounds__(512) void gemm_prefill_a8_kernel(GemmParams p) {
                                                          alane, asoff[q] + (u * 2 + ld) * 1024, 0, aux);
         if (!(p.dbg & 32))       // (ablation: weights only)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LdsPtr)(base + kA8WBytes + (q * 512 + wave * 64) * 16), 16,
-                                                     bvoff[q], u * 128, 0, aux);
+        for (int q = 0; q < 4; ++q)     // instruction q moves token rows [64 q, 64 q + 64)
+            if (q < nq)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LdsPtr)(base + kA8WBytes + (q * 512 + wave * 64) * 16), 16,
+                                                         bvoff[q], u * 128, 0, aux);
         if (p.dbg & 64) return;  // (ablation: no scale vectors)
         if (wave == 0)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (LdsPtr)(base + kA8WsOff), 16, svoff, u * 64, 0, 0);
-        else if (wave <= 4)
+        else if (wave <= nq)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xs, (LdsPtr)(base + kA8XsOff + (wave - 1) * 256), 4, svoff,
                                                      u * 4, 0, 0);
     };
@@ -174,11 +178,12 @@ __global__ __launch_bounds__(512) void gemm_prefill_a8_kernel(GemmParams p) {
     // by the barrier and in phase ever after -- queue on the VALU while the matrix pipe idles, and vice versa:
     // measured 32 % MFMA-busy, 42 % VALU-busy, in sequence.)
     f32x4 part[2][4];
-    float fprev[4];
+    f32x2 fprev[4];     // {f, f} pairs behind an empty asm: packed fp32 with default operand selects only (the op_sel
+                        // hazard of lkm_common.h splat2_opaque; tools/scan_pk_swizzle.py checks the generated code)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         part[0][b] = part[1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        fprev[b] = 0.f;
+        fprev[b] = splat2_opaque(0.f);
     }
     // unit u lives in buffer BUF; on entry ring[0..2] = its tiles 0..2, fb / xsv = its token operands
     auto unit = [&](int u, auto BUF) __attribute__((always_inline)) {
@@ -195,18 +200,19 @@ __global__ __launch_bounds__(512) void gemm_prefill_a8_kernel(GemmParams p) {
             if constexpr (t + 3 < 8) load_a(ring[(t + 3) & 3], IC<buf>{}, IC<t + 3>{});
             else load_a(ring[(t + 3) & 3], IC<buf ^ 1>{}, IC<t + 3 - 8>{});
             const ATile& r = ring[t & 3];
-            float fnow[4];
+            f32x2 fnow[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) fnow[b] = r.ws * xsv[b];
+            for (int b = 0; b < 4; ++b) fnow[b] = splat2_opaque(r.ws * xsv[b]);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 part[t & 1][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
                     r.a, fb[b], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
                 const f32x4 pp = part[(t & 1) ^ 1][b];
-                const float f = fprev[b];
+                const f32x2 f = fprev[b];
                 f32x4& c = acc[tp][b];
-                c = f32x4{__builtin_fmaf(pp.x, f, c.x), __builtin_fmaf(pp.y, f, c.y), __builtin_fmaf(pp.z, f, c.z),
-                          __builtin_fmaf(pp.w, f, c.w)};
+                const f32x2 lo = __builtin_elementwise_fma(f32x2{pp.x, pp.y}, f, f32x2{c.x, c.y});
+                const f32x2 hi = __builtin_elementwise_fma(f32x2{pp.z, pp.w}, f, f32x2{c.z, c.w});
+                c = f32x4{lo.x, lo.y, hi.x, hi.y};
                 // the update is complete HERE: without this the optimiser sinks the (memory-free) MFMAs of tiles
                 // 0..4 below the barrier of tile 5, every operand stays live across it and 200 VGPRs spill
                 asm volatile("" : "+v"(c));
@@ -220,11 +226,11 @@ __global__ __launch_bounds__(512) void gemm_prefill_a8_kernel(GemmParams p) {
             // issue order inside the step: the three operand reads of tile t+3 and the four scale products first, then
             // MFMA b / the four multiply-adds of the previous tile's block b, alternating
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             }
             // keep the operand reads of tile t+3 and the MFMAs of tile t in THIS step: hoisting every read of the
             // unit to its top would need all eight A operands live at once (64 VGPRs more than the file holds)
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_a8_kernel(GemmParams p) {
     load_a(ring[0], IC<0>{}, IC<0>{});
     load_a(ring[1], IC<0>{}, IC<1>{});
     load_a(ring[2], IC<0>{}, IC<2>{});
-    if (p.dbg & 2) {          // ablation: DMA / barrier cadence only, no operand reads, no MFMAs
+    if ((p.dbg & 2) || wc >= nq) {   // a wave without token rows (or the ablation): DMA / barrier cadence only
         for (int u = 0; u < U; ++u) {
             sync_all();
             if (u + 2 < U) {
@@ -259,10 +265,11 @@ __global__ __launch_bounds__(512) void gemm_prefill_a8_kernel(GemmParams p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const f32x4 pp = part[lastp][b];
-            const float f = fprev[b];
+            const f32x2 f = fprev[b];
             f32x4& c = acc[7][b];
-            c = f32x4{__builtin_fmaf(pp.x, f, c.x), __builtin_fmaf(pp.y, f, c.y), __builtin_fmaf(pp.z, f, c.z),
-                      __builtin_fmaf(pp.w, f, c.w)};
+            const f32x2 lo = __builtin_elementwise_fma(f32x2{pp.x, pp.y}, f, f32x2{c.x, c.y});
+            const f32x2 hi = __builtin_elementwise_fma(f32x2{pp.z, pp.w}, f, f32x2{c.z, c.w});
+            c = f32x4{lo.x, lo.y, hi.x, hi.y};
         }
     }
 

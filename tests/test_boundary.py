@@ -56,7 +56,7 @@ def test_config_struct_layout_matches_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = re.findall(r"(?:int32_t|float)\s+([a-z_A-Z0-9]+)(?:\[\d+\])?;", body)
     assert fields == [f[0] for f in _clib.LkmConfig._fields_]
-    assert ctypes.sizeof(_clib.LkmConfig) == 4 * (len(fields) - 1) + 4 * 7 == 128
+    assert ctypes.sizeof(_clib.LkmConfig) == 4 * (len(fields) - 1) + 4 * 7 == 124
 
 
 def test_lk_moe_surface_matches_reference_call_sites():

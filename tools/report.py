@@ -18,11 +18,13 @@ RUNS = [
     ("2 Mixtral-8x7B bf16 M=32", "mixtral8x7b_bf16_decode_m32", 200, 2.5e3, 2.0),
     ("2b Mixtral-8x7B fp8-W8A8 M=32", "mixtral8x7b_fp8w8a8_decode_m32", 200, 2.5e3, 1.0),
     ("3 Mixtral-8x7B int4-g128 M=128", "mixtral8x7b_int4g128_decode_m128", 200, 2.5e3, 0.5),
+    ("3' same, int4 fast mode (opt-in)", "mixtral8x7b_int4g128_fast_decode_m128", 200, 2.5e3, 0.5),
     ("3b Mixtral-8x7B MXFP4 M=128", "mixtral8x7b_mxfp4_decode_m128", 200, 2.5e3, 0.5),
     ("3c Mixtral-8x7B NVFP4 M=128", "mixtral8x7b_nvfp4_decode_m128", 200, 2.5e3, 0.5),
     ("3d Mixtral-8x7B MXFP4 M=32", "mixtral8x7b_mxfp4_decode_m32", 200, 2.5e3, 0.5),
     ("4 DSv3-style fp8-W8A8, EP=8 rank slice (32 experts, 256 rows)", "dsv3_ep8_rank_fp8w8a8_rows256", 200, 2.5e3, 1.0),
     ("4b same, fp8-W8A16 (lk_moe semantics)", "dsv3_ep8_rank_fp8w8a16_rows256", 200, 2.5e3, 1.0),
+    ("4c DSv3-style fp8-W8A8, all 256 experts on one GPU, M=256, grouped sigmoid router", "dsv3_fp8w8a8_ep_decode_b256", 100, 2.5e3, 1.0),
     ("5 GLM-4.5-Air prefill M=8192 (bf16 weights)", "glm45air_bf16_prefill_m8192", 20, 2.5e3, 2.0),
     ("5b GLM-4.5-Air prefill M=8192 (fp8-W8A8)", "glm45air_fp8w8a8_prefill_m8192", 20, 2.5e3, 1.0),
 ]
@@ -52,7 +54,8 @@ def main():
                 continue
             raw.append(j)
             rf, lay, km = j["roofline"], j["roofline"]["layer"], j["roofline"]["kernel_ms"]
-            g1 = rf["achieved"] if rf["unit"] == "GB/s" else rf.get("algorithmic_flops", 0) * 0  # prefill: MFMA-bound, see the TFLOP/s column
+            # prefill workloads report their dominant kernel in TFLOP/s: show the weight bytes / time here all the same
+            g1 = rf["achieved"] if rf["unit"] == "GB/s" else lay["weight_bytes"] * 2 / 3 / (km["gemm1"] * 1e-3) / 1e9
             rows.append(
                 f"| {name} | {routing} | {j['ms_per_step']*1e3:.1f} | {j['value']:.0f} | {lay['routed_rows']} / {lay['experts_hit']} | "
                 f"{km['sort']*1e3:.1f} / {km['gemm1']*1e3:.1f} / {km['gemm2']*1e3:.1f} / {km['combine']*1e3:.1f} | "

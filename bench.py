@@ -387,9 +387,15 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
                 tw, ids = route()
                 eng.forward_rows(x, tw, ids, out=out)
         else:
+            # decode: routing + scatter metadata in one launch (lkm_forward_routed; --tune fuse=-1 gives the five-launch
+            # step back, fuse=1 also folds the combine into GEMM2; same bits in all three)
+            fl = dict(scoring_func=rt.get("scoring", "softmax"), e_score_correction_bias=bias, out=out)
+            if rt["kind"] == "grouped":
+                fl.update(num_expert_group=rt["n_group"], topk_group=rt["topk_group"],
+                          routed_scaling_factor=rt["routed_scaling"])
+
             def step():
-                tw, ids = route()
-                eng.decode(x, tw, ids, out=out)
+                eng.forward_logits(x, logits, K, True, **fl)
     else:
         def local_compute(rows, lids, ws, dt):
             return eng.forward_rows(rows, ws, lids, out_dtype=dt)
@@ -484,10 +490,16 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
         eng.engine.set_profiling(True)
         acc = {"sort": 0.0, "gemm1": 0.0, "gemm2": 0.0, "combine": 0.0}
         reps = 30 if not prefill else 5
+        if not use_ep and not prefill:      # the timed step's own launches: "sort" = router + sort
+            def prof_call():
+                eng.forward_logits(x, logits, K, True, **{**fl, "out": pout})
+        else:
+            def prof_call():
+                eng.decode(x, tw, lids, out=pout)
         for _ in range(3):
-            eng.decode(x, tw, lids, out=pout)
+            prof_call()
         for _ in range(reps):
-            eng.decode(x, tw, lids, out=pout)
+            prof_call()
             p = eng.engine.get_profile()
             for k_ in acc:
                 acc[k_] += p[k_]

@@ -176,6 +176,21 @@ int lkm_grouped_topk(void* stream, const void* logits, int32_t logits_dtype, con
                      float* out_weights, int32_t* out_ids);
 
 /*
+ * Routing + experts in one call (the decode step of FusedMoE.forward_impl: router.select_experts followed by
+ * quant_method.apply, moe_runner.py:577-614): the routing of lkm_topk_softmax (n_group == 0) or lkm_grouped_topk
+ * (n_group > 0) on `router_logits` [M, router_experts], then lkm_forward_strided on its result.  Same outputs, bit
+ * for bit, as the two calls made one after the other; for decode batches (M * top_k <= 1024, router_experts <= 256,
+ * M > 1) the router and the token->expert scatter metadata come out of ONE launch.  topk_weights_out [M,K] fp32 and
+ * topk_ids_out [M,K] int32 (the router's global ids) are always written: callers need them for EPLB load recording
+ * and shared-expert handling.  id_offset as in lkm_forward_strided.  DEVICE pointers, asynchronous, capturable.
+ */
+int lkm_forward_routed(LkmHandle h, void* stream, int32_t num_tokens, int32_t top_k, const void* hidden,
+                       int64_t hidden_ld, const void* router_logits, int32_t logits_dtype, int32_t router_experts,
+                       const float* score_bias, int32_t n_group, int32_t topk_group, int32_t scoring,
+                       int32_t renormalize, float routed_scaling, int32_t id_offset, float* topk_weights_out,
+                       int32_t* topk_ids_out, void* out, int32_t out_dtype);
+
+/*
  * Router GEMM + routing in one call: logits = hidden . gate_w^T (+ gate_bias), then the
  * routing of lkm_topk_softmax (n_group == 0) or lkm_grouped_topk (n_group > 0) on those logits.
  * Replaces the gate projection + router of moe_runner.py:903-908 / router/gate_linear.py:17-34

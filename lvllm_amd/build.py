@@ -30,15 +30,33 @@ def _hipcc() -> str:
     return exe
 
 
+_INC = None
+
+
+def _closure(src: Path) -> list[Path]:
+    """The files `src` includes, transitively (quoted includes, resolved next to the including file): an object
+    depends on these and on nothing else, so touching one header recompiles only the units that see it."""
+    import re
+    global _INC
+    if _INC is None:
+        _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+    seen: dict[Path, None] = {}
+    todo = [src]
+    while todo:
+        f = todo.pop()
+        for name in _INC.findall(f.read_text(errors="ignore")):
+            q = (f.parent / name).resolve()
+            if q.exists() and q not in seen:
+                seen[q] = None
+                todo.append(q)
+    return sorted(seen)
+
+
 def _digest(src: Path, headers: list[Path]) -> str:
     h = hashlib.sha256()
     h.update(" ".join(FLAGS).encode())
-    text = src.read_bytes()
-    # extension headers of the ABI (include/lkm_*.h) and .inc fragments count only for the sources that include them, so
-    # adding one does not recompile the 24 GEMM instantiation units
-    extra = [p for p in sorted((PKG.parent / "include").glob("lkm_*.h")) + sorted(CSRC.glob("*.inc"))
-             if p.name.encode() in text]
-    for p in [src, *headers, *extra]:
+    for p in [src, *_closure(src)]:
+        h.update(p.name.encode())
         h.update(p.read_bytes())
     return h.hexdigest()[:16]
 

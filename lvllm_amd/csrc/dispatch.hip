@@ -9,6 +9,7 @@
 //   combine  finalizeMoeRoutingKernel (permute_unpermute_kernels/moe_permute_unpermute_kernel.inl:
 //            91-143) / moe_sum: out[m] = sum_k w[m,k] * y[pos(m,k)], fp32, ascending k.
 #include "lkm_kernels.h"
+#include "routing_dev.h"
 
 namespace lkm {
 
@@ -65,14 +66,14 @@ __device__ __forceinline__ void xcd_cut(const int32_t* tkey, int n_tiles, long l
 }
 // One workgroup of THREADS threads (64 / 256 / 1024 by problem size: the decode case M*K <= 64 runs as
 // a single wavefront, where barriers are free).
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void sort_slots_kernel(
-    const SlotIds ids, int n_slots, int E, int32_t* __restrict__ counts,
+template <int THREADS, typename Ids>
+__device__ __forceinline__ void sort_slots_body(
+    const Ids& ids, int n_slots, int E, int32_t* __restrict__ counts,
     int32_t* __restrict__ offsets, int32_t* __restrict__ sorted_slot,
     int32_t* __restrict__ pos_of_slot, int32_t* __restrict__ active, int32_t* __restrict__ meta,
-    int tile_rows, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0, int xcd_cap) {
+    int tile_rows, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0, int xcd_cap,
+    int32_t* smem) {
     constexpr int WAVES = THREADS / 64;
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
     int32_t* cnt = smem;                 // [E]
     int32_t* off = cnt + E;              // [E]
     int32_t* run = off + E;              // [E]
@@ -205,6 +206,65 @@ __global__ __launch_bounds__(THREADS) void sort_slots_kernel(
         __syncthreads();
     }
     for (int p = total + tid; p < n_slots; p += THREADS) sorted_slot[p] = -1;
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void sort_slots_kernel(
+    const SlotIds ids, int n_slots, int E, int32_t* __restrict__ counts,
+    int32_t* __restrict__ offsets, int32_t* __restrict__ sorted_slot,
+    int32_t* __restrict__ pos_of_slot, int32_t* __restrict__ active, int32_t* __restrict__ meta,
+    int tile_rows, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0, int xcd_cap) {
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    sort_slots_body<THREADS>(ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows,
+                             tile_min, tile_e, tile_r0, xcd_cap, smem);
+}
+
+// ------------------------------------------------------------------ router + scatter metadata in one launch
+// Decode batches (M*K <= kRouteSortSlots): the THREADS/64 wavefronts of the one workgroup first route the rows
+// (routing_dev.h: the same code as the stand-alone router kernels, one wavefront per row), leave ids / weights in
+// global memory for the caller and the ids in LDS, then run the counting sort on the LDS copy -- one launch and no
+// global round trip between the router and the scatter.
+constexpr int kRouteSortSlots = 1024;
+struct LdsIds {
+    const int32_t* s;
+    int off;
+    __device__ __forceinline__ int at(int i, int E) const {
+        int id = s[i];
+        if (id >= 0) id -= off;
+        return (id < 0 || id >= E) ? -1 : id;
+    }
+};
+
+template <int THREADS, int SLOTS>
+__global__ __launch_bounds__(THREADS) void route_sort_kernel(
+    const RouteArgs ra, int id_off, int E, int32_t* __restrict__ counts,
+    int32_t* __restrict__ offsets, int32_t* __restrict__ sorted_slot,
+    int32_t* __restrict__ pos_of_slot, int32_t* __restrict__ active, int32_t* __restrict__ meta,
+    int tile_rows, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0, int xcd_cap) {
+    constexpr int WAVES = THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    __shared__ int32_t s_ids[kRouteSortSlots];
+    __shared__ float s_ch[WAVES][SLOTS * 64];    // group-limited routing only
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rpw = route_rows_per_wave(ra.E, ra.K, ra.n_group);
+    route_rows<SLOTS>(ra, wv * rpw, WAVES * rpw, lane, s_ch[wv], s_ids);
+    __syncthreads();
+    // the sort runs on as few wavefronts as the problem needs (one for <= 64 slots: its barriers are then free); the
+    // others are done -- a barrier counts the wavefronts that have not ended
+    const LdsIds ids{s_ids, id_off};
+    const int n_slots = ra.M * ra.K;
+    if (n_slots <= 64 && E <= 64) {
+        if (wv >= 1) return;
+        sort_slots_body<64>(ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows,
+                            tile_min, tile_e, tile_r0, xcd_cap, smem);
+    } else if (THREADS == 256 || (n_slots <= 512 && E <= 256)) {
+        if (wv >= 4) return;
+        sort_slots_body<256>(ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows,
+                             tile_min, tile_e, tile_r0, xcd_cap, smem);
+    } else {
+        sort_slots_body<THREADS>(ids, n_slots, E, counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows,
+                                 tile_min, tile_e, tile_r0, xcd_cap, smem);
+    }
 }
 
 // ------------------------------------------------------------------ multi-workgroup sort (prefill sizes)
@@ -397,6 +457,42 @@ static void launch_sort_t(hipStream_t st, const SlotIds ids, int n_slots, int E,
     hipLaunchKernelGGL(sort_slots_kernel<THREADS>, dim3(1), dim3(THREADS), lds, st, ids, n_slots, E,
                        counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e,
                        tile_r0, xcd_cap);
+}
+
+// router + sort in one launch: worth it while the ONE workgroup routes the batch in at most two passes of its 16
+// wavefronts (a row's routing is a ~2 us dependency chain; the stand-alone router spreads rows over the chip)
+bool launch_route_sort_ok(int M, int K, int E_router, int n_group, int E_local) {
+    const int rpw = route_rows_per_wave(E_router, K, n_group);
+    return (long long)M * K <= kRouteSortSlots && K <= 64 && E_router <= 256 && E_local <= 256 && M <= 2 * 16 * rpw;
+}
+template <int THREADS, int SLOTS>
+static void launch_route_sort_t(hipStream_t st, const RouteArgs& ra, int id_offset, int E, int32_t* counts,
+                                int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
+                                int32_t* meta, int tile_rows, int tile_min, int32_t* tile_e, int32_t* tile_r0,
+                                int xcd_cap, size_t tiles) {
+    constexpr int W = THREADS / 64;
+    const size_t lds = sizeof(int32_t) * ((size_t)3 * E + 4 * W + (size_t)W * E + 16 + tiles);
+    hipLaunchKernelGGL((route_sort_kernel<THREADS, SLOTS>), dim3(1), dim3(THREADS), lds, st, ra, id_offset, E, counts,
+                       offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e, tile_r0, xcd_cap);
+}
+int launch_route_sort(hipStream_t st, const RouteArgs& ra, int id_offset, int E, int32_t* counts, int32_t* offsets,
+                      int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active, int32_t* meta, int tile_rows,
+                      int tile_min, int32_t* tile_e, int32_t* tile_r0, int xcd_cap) {
+    const int n_slots = ra.M * ra.K;
+    LKM_REQUIRE(launch_route_sort_ok(ra.M, ra.K, ra.E, ra.n_group, E), "route+sort: M=%d K=%d E=%d out of range", ra.M, ra.K, ra.E);
+    const size_t tiles = xcd_cap > 0 ? (size_t)(tile_rows > 0 ? n_slots / tile_rows : 0) + E : 0;
+    const int rpw = route_rows_per_wave(ra.E, ra.K, ra.n_group);
+    const bool small = ceil_div(ra.M, rpw) <= 4;        // 4 wavefronts route it in one pass: cheaper barriers in the sort
+#define LKM_RS(T, S) launch_route_sort_t<T, S>(st, ra, id_offset, E, counts, offsets, sorted_slot, pos_of_slot, active, \
+                                               meta, tile_rows, tile_min, tile_e, tile_r0, xcd_cap, tiles)
+    switch (route_slots(ra.E)) {
+    case 1: if (small) LKM_RS(256, 1); else LKM_RS(1024, 1); break;
+    case 2: if (small) LKM_RS(256, 2); else LKM_RS(1024, 2); break;
+    default: if (small) LKM_RS(256, 4); else LKM_RS(1024, 4); break;
+    }
+#undef LKM_RS
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
 }
 
 int launch_sort(hipStream_t st, const int32_t* ids_ptr, int top_k, int ids_ld, int id_offset, int n_slots, int E,

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "lkm_kernels.h"
+#include "routing_dev.h"
 #include "../../include/lkm_eplb.h"
 
 namespace lkm {
@@ -158,7 +159,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0, t_fuse = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -691,6 +692,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
 struct InLayout {
     int64_t x_ld, ids_ld, tw_ld;
     int id_off;
+    const RouteArgs* route = nullptr;   // lkm_forward_routed: the router runs inside the sort launch
 };
 
 // one chunk: rows [0,M) of the given pointers
@@ -740,7 +742,11 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     // xcd_cap tiles (twice the mean: the 1-D grid is sized by it)
     const bool want_xcd = tile_rows && max_tiles <= 4096 && (h->t_xcd > 0 || pl.xcd1 || pl.xcd2);
     const int xcd_cap = want_xcd ? 2 * ((max_tiles + 7) / 8) + 1 : 0;
-    if (!direct) {
+    if (!direct && il.route) {
+        rc = launch_route_sort(st, *il.route, il.id_off, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
+                               a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, xcd_cap);
+        if (rc != LKM_OK) return rc;
+    } else if (!direct) {
         rc = launch_sort(st, ids, K, (int)il.ids_ld, il.id_off, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
                          a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, a->hist,
                          a->hist_cap, xcd_cap);
@@ -876,6 +882,22 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
                  K, pl.s1.kw, sk_direct);
         return LKM_OK;
     }
+    // few active experts (Mixtral-class decode): GEMM2 and the top-k combine in one launch -- the waves of a workgroup
+    // take the (expert, K slice) items of one tile group and sum through LDS in combine_kernel's order.  Bit-identical,
+    // one launch fewer, and not faster: Mixtral bf16 M=32 GEMM2 137.6 -> 142.9 us against a 2.8 us combine kernel
+    // (eight experts' streams per CU instead of four adjacent tiles of one; profiles/r02_decode_fusion.md)
+    const bool fuse2 = pl.s2.tb && !pl.t2.tiled && !pl.split_rows && pl.s2.nt <= 2 && pl.s2.tb <= 2 &&
+                       max_active * sk <= ((pl.s2.nt == 1 && pl.s2.tb == 1) ? 16 : 8) &&
+                       (size_t)sk * n_slots * pl.s2.nt * 64 <= 65536 &&
+                       y_dt == LKM_DT_F32 && h->t_fuse >= 1;   // opt-in (tuning key fuse = 1): measured 2.7 us SLOWER than the two launches
+    if (fuse2) {
+        p2.comb_pos = a->pos_of_slot;
+        p2.comb_M = M;
+        p2.comb_tw_ld = (int)il.tw_ld;
+        p2.direct_w = tw;
+        p2.direct_out_dt = out_dt;
+        p2.out = out;
+    }
     for (int r = 0; r < rep; ++r) {
         if (pl.s2.tb) {
             p2.groups = h->T2 / pl.s2.nt;
@@ -889,18 +911,37 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     }
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
 
-    rc = launch_combine(st, a->y, y_dt, sk, p2.sk_stride, a->pos_of_slot, tw, (int)il.tw_ld, M, K, h->H, out, out_dt);
-    if (rc != LKM_OK) return rc;
+    if (!fuse2) {
+        rc = launch_combine(st, a->y, y_dt, sk, p2.sk_stride, a->pos_of_slot, tw, (int)il.tw_ld, M, K, h->H, out, out_dt);
+        if (rc != LKM_OK) return rc;
+    }
     if (prof) {
         LKM_HIP_CHECK(hipEventRecord(h->ev[4], st));
         h->prof_valid = true;
     }
     snprintf(h->last_desc, sizeof(h->last_desc),
-             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2 nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d pd=%d/%d split=%d pf=%d xcd=%d/%d | nt_loads=%d",
+             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2%s nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d pd=%d/%d split=%d pf=%d xcd=%d/%d | nt_loads=%d",
              M, K, pl.s1.tb ? "skinny" : "", pl.t1.tiled ? (pl.s1.tb ? "+tiled" : "tiled") : "", pl.s1.nt,
-             pl.s1.tb, pl.s1.kw, pl.s2.nt, pl.s2.tb, pl.s2.sk, pl.t1.nt, pl.t2.nt, tile_rows, pl.t1.waves,
+             pl.s1.tb, pl.s1.kw, fuse2 ? "+combine" : "", pl.s2.nt, pl.s2.tb, pl.s2.sk, pl.t1.nt, pl.t2.nt, tile_rows, pl.t1.waves,
              pl.t1.pd, pl.t2.pd, pl.split_rows, pl.t1.pf, p1.xcd_map ? 1 : 0, p2.xcd_map ? 1 : 0, stream_nt);
     return LKM_OK;
+}
+
+// tokens per chunk: the arena was sized with cfg.top_k; a different K only changes how many tokens fit a chunk
+static size_t chunk_tokens(const LkmEngine* h, int K) {
+    size_t chunk = h->arena->cap_slots / (size_t)K;
+    if (h->arena->act_elems / ((size_t)K * h->ld_act) < chunk) chunk = h->arena->act_elems / ((size_t)K * h->ld_act);
+    if (h->arena->y_elems / ((size_t)K * h->H) < chunk) chunk = h->arena->y_elems / ((size_t)K * h->H);
+    if (h->a8) {
+        if (h->arena->xq_n / (size_t)h->H < chunk) chunk = h->arena->xq_n / (size_t)h->H;
+        if (h->arena->aq_n / ((size_t)K * h->I) < chunk) chunk = h->arena->aq_n / ((size_t)K * h->I);
+    }
+    if (h->a8 || h->ps) {
+        const size_t kb1 = ceil_div(h->H, 128), kb2 = ceil_div(h->I, 128);
+        if (h->arena->xqs_n / kb1 < chunk) chunk = h->arena->xqs_n / kb1;
+        if (h->arena->aqs_n / ((size_t)K * kb2) < chunk) chunk = h->arena->aqs_n / ((size_t)K * kb2);
+    }
+    return chunk;
 }
 
 static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, const int32_t* ids,
@@ -915,19 +956,7 @@ static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, 
     const InLayout il = layout ? *layout : InLayout{h->H, K, K, 0};
     LKM_REQUIRE(il.x_ld >= h->H && il.x_ld % 8 == 0 && il.x_ld < ((int64_t)1 << 31), "hidden row stride %lld must be >= H, a multiple of 8 and < 2^31", (long long)il.x_ld);
     LKM_REQUIRE(il.ids_ld >= K && il.tw_ld >= K && il.ids_ld < ((int64_t)1 << 31) && il.tw_ld < ((int64_t)1 << 31), "ids / weights row strides must be >= top_k");
-    // the arena was sized with cfg.top_k; a different K only changes how many tokens fit a chunk
-    size_t chunk = h->arena->cap_slots / (size_t)K;
-    if (h->arena->act_elems / ((size_t)K * h->ld_act) < chunk) chunk = h->arena->act_elems / ((size_t)K * h->ld_act);
-    if (h->arena->y_elems / ((size_t)K * h->H) < chunk) chunk = h->arena->y_elems / ((size_t)K * h->H);
-    if (h->a8) {
-        if (h->arena->xq_n / (size_t)h->H < chunk) chunk = h->arena->xq_n / (size_t)h->H;
-        if (h->arena->aq_n / ((size_t)K * h->I) < chunk) chunk = h->arena->aq_n / ((size_t)K * h->I);
-    }
-    if (h->a8 || h->ps) {
-        const size_t kb1 = ceil_div(h->H, 128), kb2 = ceil_div(h->I, 128);
-        if (h->arena->xqs_n / kb1 < chunk) chunk = h->arena->xqs_n / kb1;
-        if (h->arena->aqs_n / ((size_t)K * kb2) < chunk) chunk = h->arena->aqs_n / ((size_t)K * kb2);
-    }
+    const size_t chunk = chunk_tokens(h, K);
     LKM_REQUIRE(chunk > 0, "scratch arena too small for top_k=%d", K);
     const size_t xrow = (size_t)il.x_ld * 2, orow = (size_t)h->H * (out_dt == LKM_DT_F32 ? 4 : 2);
     for (size_t m0 = 0; m0 < (size_t)M; m0 += chunk) {
@@ -963,6 +992,57 @@ extern "C" int lkm_forward_strided(LkmHandle h, void* stream, int32_t num_tokens
     LKM_REQUIRE(id_offset >= 0, "forward_strided: id_offset must be >= 0");
     const InLayout il{hidden_ld, ids_ld, weights_ld, id_offset};
     return run_device(h, (hipStream_t)stream, num_tokens, top_k, hidden, topk_ids, topk_weights, out, out_dtype, &il);
+}
+
+extern "C" int lkm_forward_routed(LkmHandle h, void* stream, int32_t num_tokens, int32_t top_k, const void* hidden,
+                                  int64_t hidden_ld, const void* router_logits, int32_t logits_dtype,
+                                  int32_t router_experts, const float* score_bias, int32_t n_group,
+                                  int32_t topk_group, int32_t scoring, int32_t renormalize, float routed_scaling,
+                                  int32_t id_offset, float* topk_weights_out, int32_t* topk_ids_out, void* out,
+                                  int32_t out_dtype) {
+    LKM_REQUIRE(h, "null engine handle");
+    LKM_REQUIRE(out_dtype == LKM_DT_F32 || out_dtype == h->adt, "forward_routed: out_dtype must be fp32 or the activation dtype");
+    LKM_REQUIRE(id_offset >= 0, "forward_routed: id_offset must be >= 0");
+    const int M = num_tokens, K = top_k, E = router_experts;
+    LKM_REQUIRE(M >= 0 && E > 0 && K > 0 && K <= E && K <= 64, "forward_routed: bad shape M=%d E=%d K=%d", M, E, K);
+    if (M == 0) return LKM_OK;
+    LKM_REQUIRE(router_logits && topk_weights_out && topk_ids_out, "forward_routed: null device pointer");
+    // one chunk, batched path: the router rides in the sort launch; otherwise the two calls it stands for
+    const bool fused = M > 1 && launch_route_sort_ok(M, K, E, n_group, h->E) && h->t_fuse >= 0 &&
+                       chunk_tokens(h, K) >= (size_t)M;
+    InLayout il{hidden_ld, K, K, id_offset};
+    if (!fused) {
+        int rc = n_group > 0 ? lkm_grouped_topk(stream, router_logits, logits_dtype, score_bias, M, E, K, n_group,
+                                                topk_group, scoring, renormalize, routed_scaling, topk_weights_out,
+                                                topk_ids_out)
+                             : lkm_topk_softmax(stream, router_logits, logits_dtype, score_bias, M, E, K, scoring,
+                                                renormalize, routed_scaling, topk_weights_out, topk_ids_out);
+        if (rc != LKM_OK) return rc;
+        return run_device(h, (hipStream_t)stream, M, K, hidden, topk_ids_out, topk_weights_out, out, out_dtype, &il);
+    }
+    LKM_REQUIRE(E <= kMaxSlots * 64, "forward_routed: router_experts=%d > %d unsupported", E, kMaxSlots * 64);
+    LKM_REQUIRE(logits_dtype >= LKM_DT_F32 && logits_dtype <= LKM_DT_F16, "forward_routed: bad logits dtype");
+    LKM_REQUIRE(scoring == 0 || scoring == 1, "forward_routed: scoring must be 0 (softmax) or 1 (sigmoid)");
+    if (n_group > 0) {
+        LKM_REQUIRE(n_group <= 64 && E % n_group == 0, "forward_routed: n_group=%d must divide E=%d and be <= 64", n_group, E);
+        LKM_REQUIRE(topk_group > 0 && topk_group <= n_group, "forward_routed: bad topk_group=%d", topk_group);
+        LKM_REQUIRE(K <= topk_group * (E / n_group), "forward_routed: K=%d exceeds kept experts", K);
+    }
+    RouteArgs ra{};
+    ra.src = LogitSrc{router_logits, logits_dtype, 1, 0, nullptr, LKM_DT_F32, nullptr};
+    ra.bias = score_bias;
+    ra.M = M;
+    ra.E = E;
+    ra.K = K;
+    ra.n_group = n_group > 0 ? n_group : 0;
+    ra.topk_group = topk_group;
+    ra.scoring = scoring;
+    ra.renorm = renormalize;
+    ra.rsf = routed_scaling;
+    ra.out_w = topk_weights_out;
+    ra.out_ids = topk_ids_out;
+    il.route = &ra;
+    return run_device(h, (hipStream_t)stream, M, K, hidden, topk_ids_out, topk_weights_out, out, out_dtype, &il);
 }
 
 extern "C" int lkm_prefill_host(LkmHandle h, int32_t num_tokens, int32_t top_k,
@@ -1085,6 +1165,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "xcd")) h->t_xcd = value;
     else if (!strcmp(key, "pf")) h->t_pf = value;
     else if (!strcmp(key, "direct")) h->t_direct = value;
+    else if (!strcmp(key, "fuse")) h->t_fuse = value;
     else if (!strcmp(key, "valid_den")) h->t_valid_den = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else if (!strcmp(key, "prof_rep")) h->t_prof_rep = value;

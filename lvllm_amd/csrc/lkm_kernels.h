@@ -27,6 +27,13 @@ int launch_sort(hipStream_t st, const int32_t* ids, int top_k, int ids_ld, int i
                 int32_t* counts, int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
                 int32_t* meta, int tile_rows, int tile_min, int32_t* tile_e, int32_t* tile_r0,
                 int32_t* hist, size_t hist_cap, int xcd_cap = 0);
+// router + sort in one launch for decode batches (RouteArgs: routing_dev.h); same outputs as the router kernel
+// followed by launch_sort
+struct RouteArgs;
+bool launch_route_sort_ok(int M, int K, int E_router, int n_group, int E_local);
+int launch_route_sort(hipStream_t st, const RouteArgs& ra, int id_offset, int E, int32_t* counts, int32_t* offsets,
+                      int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active, int32_t* meta, int tile_rows,
+                      int tile_min, int32_t* tile_e, int32_t* tile_r0, int xcd_cap);
 constexpr int kMetaInts = 32;   // meta[0..3]: see dispatch.hip; meta[8..16]: per-XCD runs of the tile list
 int launch_quant_fp8_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, void* dst,
                           float* scales);
@@ -83,6 +90,11 @@ struct GemmParams {
     int direct_out_dt;           // LKM_DT_* of `out` in the direct GEMM2
     int direct_E, direct_id_off; // direct mode: local expert count and the offset subtracted from ids >= 0
                                  // (an id outside [0, E) after that is not local, like -1)
+    // GEMM2 + combine in one launch (skinny streamer, few active experts: gemm2_combine_kernel): non-null comb_pos
+    // switches it on; `out` is then the layer output [comb_M][ldo] of dtype direct_out_dt, direct_w the routing
+    // weights [comb_M][comb_tw_ld]
+    const int32_t* comb_pos;     // pos_of_slot [comb_M * top_k]
+    int comb_M, comb_tw_ld;
     long long x_rows;  // rows of the activation matrix behind `x` (bounds of the LDS-DMA buffer window)
     int xcd_map;       // tiled kernels: != 0 -> XCD-aware 1-D work mapping.  Host side: the longest run of tiles one
                        // XCD may get (launch_sort's xcd_cap); the launcher replaces it by the row-group count

@@ -11,243 +11,31 @@
 // oracle/lkm_oracle.c so ids AND weights are bit-reproducible; contraction is off for that reason.
 #include "lkm_common.h"
 #include "lkm_kernels.h"
+#include "routing_dev.h"
 
 namespace lkm {
 
-constexpr int kMaxSlots = 8;  // E <= 512
-
-__device__ __forceinline__ float load_logit(const void* p, int dt, size_t i) {
-    if (dt == LKM_DT_F32) return ((const float*)p)[i];
-    unsigned short h = ((const unsigned short*)p)[i];
-    return dt == LKM_DT_BF16 ? bf16_bits_to_f32(h) : f16_bits_to_f32(h);
+// One launch routes M rows: 4 wavefronts per workgroup, one row per wavefront (four when E <= 16: a row then takes
+// 16 lanes), register slots by expert count (routing_dev.h).
+template <int SLOTS>
+__global__ __launch_bounds__(256) void route_kernel(const RouteArgs ra) {
+    __shared__ float lds_ch[4][SLOTS * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rpw = route_rows_per_wave(ra.E, ra.K, ra.n_group);
+    route_rows<SLOTS>(ra, (blockIdx.x * 4 + wv) * rpw, gridDim.x * 4 * rpw, lane, lds_ch[wv], nullptr);
 }
 
-// Where a row's logits come from: a tensor in any of the three dtypes, or -- behind the router GEMM
-// (router_gemm.hip) -- n_slabs f32 split-K partials that are summed in ascending slab order, plus the
-// gate bias, optionally rounded to the gate's output dtype (F.linear in bf16/f16), optionally copied out.
-struct LogitSrc {
-    const void* p;
-    int dt;
-    int n_slabs;
-    long long slab_stride;   // floats between slabs
-    const float* gate_bias;  // [E] or null
-    int round_dt;            // LKM_DT_F32 = keep fp32
-    float* logits_out;       // [M,E] fp32 or null
-    __device__ __forceinline__ float load(int row, int E, int e) const {
-#pragma clang fp contract(off)
-        const size_t i = (size_t)row * E + e;
-        if (n_slabs <= 1 && !gate_bias && round_dt == LKM_DT_F32 && !logits_out) return load_logit(p, dt, i);
-        float v = load_logit(p, dt, i);
-        for (int s0 = 1; s0 < n_slabs; s0 += 8) {   // up to 8 independent loads in flight, summed in slab order
-            float part[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                part[q] = s0 + q < n_slabs ? ((const float*)p)[(size_t)(s0 + q) * slab_stride + i] : 0.0f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v = v + part[q];
-        }
-        if (gate_bias) v = v + gate_bias[e];
-        if (round_dt == LKM_DT_BF16) v = bf16_bits_to_f32(f32_to_bf16_bits(v));
-        if (round_dt == LKM_DT_F16) v = f16_bits_to_f32(f32_to_f16_bits(v));
-        if (logits_out) logits_out[i] = v;
-        return v;
+static int launch_route(hipStream_t st, const RouteArgs& ra) {
+    const int rpw = route_rows_per_wave(ra.E, ra.K, ra.n_group);
+    const dim3 grid(ceil_div(ra.M, 4 * rpw)), block(256);
+    switch (route_slots(ra.E)) {
+    case 1: hipLaunchKernelGGL(route_kernel<1>, grid, block, 0, st, ra); break;
+    case 2: hipLaunchKernelGGL(route_kernel<2>, grid, block, 0, st, ra); break;
+    case 4: hipLaunchKernelGGL(route_kernel<4>, grid, block, 0, st, ra); break;
+    default: hipLaunchKernelGGL(route_kernel<8>, grid, block, 0, st, ra); break;
     }
-};
-
-// scores for one row, in registers: sc[s] = score of expert s*64+lane (0 for e >= E)
-__device__ __forceinline__ void row_scores(const LogitSrc& src, int row, int E, int lane,
-                                           int scoring, float (&sc)[kMaxSlots]) {
-#pragma clang fp contract(off)
-    float v[kMaxSlots];
-#pragma unroll
-    for (int s = 0; s < kMaxSlots; ++s) {
-        int e = s * 64 + lane;
-        v[s] = (e < E) ? src.load(row, E, e) : -__builtin_inff();
-    }
-    if (scoring == 0) {
-        float mx = v[0];
-#pragma unroll
-        for (int s = 1; s < kMaxSlots; ++s) mx = fmaxf(mx, v[s]);
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-        float sum = 0.0f;
-#pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s) {
-            int e = s * 64 + lane;
-            if (e < E) {
-                v[s] = lkm_expf(v[s] - mx);
-                sum += v[s];
-            } else {
-                v[s] = 0.0f;
-            }
-        }
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) sum = sum + __shfl_xor(sum, m, 64);
-        float rinv = 1.0f / sum;
-#pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s) sc[s] = v[s] * rinv;
-    } else {
-#pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s) {
-            int e = s * 64 + lane;
-            sc[s] = (e < E) ? 1.0f / (1.0f + lkm_expf(-v[s])) : 0.0f;
-        }
-    }
-}
-
-// wave-wide arg-max of (value, index) with "lowest index wins ties"; also carries a payload.
-__device__ __forceinline__ void wave_argmax(float& bv, int& be, float& bp) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        float ov = __shfl_xor(bv, m, 64);
-        int oe = __shfl_xor(be, m, 64);
-        float op = __shfl_xor(bp, m, 64);
-        if (ov > bv || (ov == bv && oe < be)) {
-            bv = ov;
-            be = oe;
-            bp = op;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void topk_softmax_kernel(
-    LogitSrc src, const float* __restrict__ bias, int M, int E, int K,
-    int scoring, int renorm, float rsf, float* __restrict__ out_w, int32_t* __restrict__ out_ids) {
-#pragma clang fp contract(off)
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float sc[kMaxSlots], ch[kMaxSlots];
-    row_scores(src, row, E, lane, scoring, sc);
-#pragma unroll
-    for (int s = 0; s < kMaxSlots; ++s) {
-        int e = s * 64 + lane;
-        if (__builtin_isnan(sc[s]) || __builtin_isinf(sc[s])) sc[s] = 0.0f;  // :466-471
-        if (e < E)
-            ch[s] = bias ? sc[s] + bias[e] : sc[s];
-        else
-            ch[s] = -__builtin_inff();
-    }
-    float sel_sum = 0.0f;
-    for (int k = 0; k < K; ++k) {
-        float bv = ch[0], bp = sc[0];
-        int be = lane;
-#pragma unroll
-        for (int s = 1; s < kMaxSlots; ++s) {
-            if (ch[s] > bv) {
-                bv = ch[s];
-                bp = sc[s];
-                be = s * 64 + lane;
-            }
-        }
-        wave_argmax(bv, be, bp);
-        if (lane == 0) {
-            out_w[(size_t)row * K + k] = bp;
-            out_ids[(size_t)row * K + k] = be;
-            if (renorm) sel_sum += bp;
-        }
-#pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s)
-            if (be == s * 64 + lane) ch[s] = -__builtin_inff();
-    }
-    if (lane == 0) {
-        float scale = rsf;
-        if (renorm) scale /= (sel_sum > 0.0f ? sel_sum : 1.0f);  // :581-592
-        for (int k = 0; k < K; ++k) out_w[(size_t)row * K + k] *= scale;
-    }
-}
-
-__global__ __launch_bounds__(256) void grouped_topk_kernel(
-    LogitSrc src, const float* __restrict__ bias, int M, int E, int K,
-    int n_group, int topk_group, int scoring, int renorm, float rsf, float* __restrict__ out_w,
-    int32_t* __restrict__ out_ids) {
-#pragma clang fp contract(off)
-    __shared__ float lds_ch[4][kMaxSlots * 64];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wv;
-    const bool active = row < M;  // keep the wave alive for __syncthreads
-    const int gsz = E / n_group;
-    float sc[kMaxSlots], ch[kMaxSlots];
-    if (active) {
-        row_scores(src, row, E, lane, scoring, sc);
-#pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s) {
-            int e = s * 64 + lane;
-            ch[s] = (e < E) ? (bias ? sc[s] + bias[e] : sc[s]) : -__builtin_inff();
-            lds_ch[wv][s * 64 + lane] = ch[s];
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-    // lane g scores group g in ascending expert order (same order as the oracle)
-    float gs = -__builtin_inff();
-    if (lane < n_group) {
-        const float* c = &lds_ch[wv][lane * gsz];
-        if (bias) {
-            float a = -__builtin_inff(), b = -__builtin_inff();
-            for (int i = 0; i < gsz; ++i) {
-                float x = c[i];
-                if (x > a) {
-                    b = a;
-                    a = x;
-                } else if (x > b) {
-                    b = x;
-                }
-            }
-            gs = (gsz > 1) ? a + b : a;
-        } else {
-            float a = c[0];
-            for (int i = 1; i < gsz; ++i) a = (c[i] > a) ? c[i] : a;
-            gs = a;
-        }
-    }
-    unsigned long long keep = 0ull;
-    bool taken = !(lane < n_group);
-    for (int t = 0; t < topk_group; ++t) {
-        // lanes already taken / out of range must never win, not even on ties with -inf values
-        float bv = gs, bp = 0.0f;
-        int be = taken ? (1 << 20) + lane : lane;
-        if (taken) bv = -__builtin_inff();
-        wave_argmax(bv, be, bp);
-        keep |= 1ull << (be & 63);
-        if (lane == be) taken = true;
-    }
-#pragma unroll
-    for (int s = 0; s < kMaxSlots; ++s) {
-        int e = s * 64 + lane;
-        if (e < E && !((keep >> (e / gsz)) & 1ull)) ch[s] = -__builtin_inff();
-    }
-    float sum = 0.0f;
-    for (int k = 0; k < K; ++k) {
-        float bv = ch[0], bp = sc[0];
-        int be = lane;
-#pragma unroll
-        for (int s = 1; s < kMaxSlots; ++s) {
-            if (ch[s] > bv) {
-                bv = ch[s];
-                bp = sc[s];
-                be = s * 64 + lane;
-            }
-        }
-        wave_argmax(bv, be, bp);
-        if (lane == 0) {
-            out_w[(size_t)row * K + k] = bp;
-            out_ids[(size_t)row * K + k] = be;
-            sum += bp;
-        }
-#pragma unroll
-        for (int s = 0; s < kMaxSlots; ++s)
-            if (be == s * 64 + lane) ch[s] = -__builtin_inff();
-    }
-    if (lane == 0) {
-        for (int k = 0; k < K; ++k) {
-            float w = out_w[(size_t)row * K + k];
-            if (renorm) w = w / sum;
-            if (rsf != 1.0f) w = w * rsf;
-            out_w[(size_t)row * K + k] = w;
-        }
-    }
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
 }
 
 __global__ void map_ids_kernel(const int32_t* __restrict__ ids, int64_t n,
@@ -267,16 +55,14 @@ extern "C" int lkm_topk_softmax(void* stream, const void* logits, int32_t logits
                                 const float* bias, int32_t M, int32_t E, int32_t K,
                                 int32_t scoring, int32_t renormalize, float routed_scaling,
                                 float* out_weights, int32_t* out_ids) {
-    LKM_REQUIRE(M >= 0 && E > 0 && K > 0 && K <= E, "topk_softmax: bad shape M=%d E=%d K=%d", M, E, K);
+    LKM_REQUIRE(M >= 0 && E > 0 && K > 0 && K <= E && K <= 64, "topk_softmax: bad shape M=%d E=%d K=%d", M, E, K);
     LKM_REQUIRE(E <= kMaxSlots * 64, "topk_softmax: E=%d > %d unsupported", E, kMaxSlots * 64);
     LKM_REQUIRE(logits_dtype >= LKM_DT_F32 && logits_dtype <= LKM_DT_F16, "topk_softmax: bad dtype");
     LKM_REQUIRE(scoring == 0 || scoring == 1, "topk_softmax: scoring must be 0 (softmax) or 1 (sigmoid)");
     if (M == 0) return LKM_OK;
     const LogitSrc src{logits, logits_dtype, 1, 0, nullptr, LKM_DT_F32, nullptr};
-    hipLaunchKernelGGL(topk_softmax_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, (hipStream_t)stream,
-                       src, bias, M, E, K, scoring, renormalize, routed_scaling, out_weights, out_ids);
-    LKM_HIP_CHECK(hipGetLastError());
-    return LKM_OK;
+    const RouteArgs ra{src, bias, M, E, K, 0, 0, scoring, renormalize, routed_scaling, out_weights, out_ids};
+    return launch_route((hipStream_t)stream, ra);
 }
 
 extern "C" int lkm_grouped_topk(void* stream, const void* logits, int32_t logits_dtype,
@@ -284,7 +70,7 @@ extern "C" int lkm_grouped_topk(void* stream, const void* logits, int32_t logits
                                 int32_t n_group, int32_t topk_group, int32_t scoring,
                                 int32_t renormalize, float routed_scaling, float* out_weights,
                                 int32_t* out_ids) {
-    LKM_REQUIRE(M >= 0 && E > 0 && K > 0, "grouped_topk: bad shape");
+    LKM_REQUIRE(M >= 0 && E > 0 && K > 0 && K <= 64, "grouped_topk: bad shape");
     LKM_REQUIRE(E <= kMaxSlots * 64, "grouped_topk: E=%d > %d unsupported", E, kMaxSlots * 64);
     LKM_REQUIRE(n_group > 0 && n_group <= 64 && E % n_group == 0, "grouped_topk: n_group=%d must divide E=%d and be <= 64", n_group, E);
     LKM_REQUIRE(topk_group > 0 && topk_group <= n_group, "grouped_topk: bad topk_group=%d", topk_group);
@@ -293,11 +79,8 @@ extern "C" int lkm_grouped_topk(void* stream, const void* logits, int32_t logits
     LKM_REQUIRE(scoring == 0 || scoring == 1, "grouped_topk: scoring must be 0 or 1");
     if (M == 0) return LKM_OK;
     const LogitSrc src{logits, logits_dtype, 1, 0, nullptr, LKM_DT_F32, nullptr};
-    hipLaunchKernelGGL(grouped_topk_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, (hipStream_t)stream,
-                       src, bias, M, E, K, n_group, topk_group, scoring, renormalize, routed_scaling,
-                       out_weights, out_ids);
-    LKM_HIP_CHECK(hipGetLastError());
-    return LKM_OK;
+    const RouteArgs ra{src, bias, M, E, K, n_group, topk_group, scoring, renormalize, routed_scaling, out_weights, out_ids};
+    return launch_route((hipStream_t)stream, ra);
 }
 
 
@@ -492,7 +275,7 @@ extern "C" int lkm_router_gemm_topk(void* stream, const void* x, int32_t x_dtype
                                     int32_t topk_group, int32_t logits_dtype, void* workspace,
                                     int64_t workspace_bytes, float* logits_out, float* out_weights,
                                     int32_t* out_ids) {
-    LKM_REQUIRE(M >= 0 && E > 0 && K > 0 && K <= E && H > 0, "router: bad shape M=%d H=%d E=%d K=%d", M, H, E, K);
+    LKM_REQUIRE(M >= 0 && E > 0 && K > 0 && K <= E && K <= 64 && H > 0, "router: bad shape M=%d H=%d E=%d K=%d", M, H, E, K);
     LKM_REQUIRE(E <= kMaxSlots * 64, "router: E=%d > %d unsupported", E, kMaxSlots * 64);
     LKM_REQUIRE(x_dtype == LKM_DT_BF16 || x_dtype == LKM_DT_F16, "router: hidden states must be bf16 or fp16");
     LKM_REQUIRE(w_dtype == x_dtype || w_dtype == LKM_DT_F32, "router: gate weights must have the activation dtype or be fp32 (got %d)", w_dtype);
@@ -563,14 +346,9 @@ extern "C" int lkm_router_gemm_topk(void* stream, const void* x, int32_t x_dtype
     LKM_HIP_CHECK(hipGetLastError());
     }
     const LogitSrc src{part, LKM_DT_F32, KS, (long long)M * E, gate_bias, logits_dtype, logits_out};
-    if (n_group > 0)
-        hipLaunchKernelGGL(grouped_topk_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, src, score_bias, M, E,
-                           K, n_group, topk_group, scoring, renormalize, routed_scaling, out_weights, out_ids);
-    else
-        hipLaunchKernelGGL(topk_softmax_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, src, score_bias, M, E,
-                           K, scoring, renormalize, routed_scaling, out_weights, out_ids);
-    LKM_HIP_CHECK(hipGetLastError());
-    return LKM_OK;
+    const RouteArgs ra{src, score_bias, M, E, K, n_group > 0 ? n_group : 0, topk_group, scoring, renormalize, routed_scaling,
+                       out_weights, out_ids};
+    return launch_route(st, ra);
 }
 
 extern "C" int lkm_map_expert_ids(void* stream, const int32_t* ids, int64_t n,

@@ -103,6 +103,14 @@ class RoutedExpertsLayer:
         return self.ops.topk_softmax(router_logits, r.top_k, r.renormalize, r.e_score_correction_bias, r.scoring_func,
                                      scale)
 
+    def _decode_buffer(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        buf = self._decode_out
+        if buf is None or buf.device != hidden_states.device or buf.size(1) != hidden_states.size(1):
+            buf = torch.empty((self.max_num_seqs, hidden_states.size(1)), dtype=torch.float32,
+                              device=hidden_states.device)
+            self._decode_out = buf
+        return buf
+
     # ---- the whole step
     def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor | None = None) -> torch.Tensor:
         """[M, H] activations (+ [M, E] logits unless the layer owns the gate) -> [M, H] in the activation dtype:
@@ -111,6 +119,25 @@ class RoutedExpertsLayer:
         M = hidden_states.size(0)
         if M == 0:
             return torch.empty_like(hidden_states)
+        r = self.routing
+        if (self.gate_weight is None and router_logits is not None and self.eplb_state is None
+                and self.shared_slots is None and self.expert_map is None and self.expert_parallel is None
+                and 1 < M <= self.max_num_seqs and router_logits.size(0) == M and hasattr(self.engine, "forward_logits")):
+            # plain decode step: routing + scatter metadata + experts through lkm_forward_routed (one launch fewer
+            # than select_experts + decode, same bits)
+            buf = self._decode_buffer(hidden_states)
+            out, _, _ = self.engine.forward_logits(
+                hidden_states, router_logits, r.top_k, r.renormalize, scoring_func=r.scoring_func,
+                num_expert_group=r.num_expert_group if r.use_grouped_topk else 0,
+                topk_group=r.topk_group if r.use_grouped_topk else 0,
+                routed_scaling_factor=r.routed_scaling_factor if r.apply_routed_scaling_in_router else 1.0,
+                e_score_correction_bias=r.e_score_correction_bias, out=buf[:M])
+            if self.check_nan_in_output:
+                torch.nan_to_num(out, nan=0.0, out=out)
+            out = out.to(hidden_states.dtype)
+            if r.routed_scaling_factor != 1.0 and not r.apply_routed_scaling_in_router:
+                out *= r.routed_scaling_factor
+            return out
         topk_weights, topk_ids = self.select_experts(hidden_states, router_logits)
         if self.eplb_state is not None:                       # BaseRouter._apply_eplb_mapping, base_router.py:204-223
             s = self.eplb_state
@@ -140,11 +167,7 @@ class RoutedExpertsLayer:
                 torch.nan_to_num(out, nan=0.0, out=out)
             out = out.to(hidden_states.dtype)
         elif M <= self.max_num_seqs:                          # the cpu_decode contract: fp32 into the shared buffer
-            buf = self._decode_out
-            if buf is None or buf.device != hidden_states.device or buf.size(1) != hidden_states.size(1):
-                buf = torch.empty((self.max_num_seqs, hidden_states.size(1)), dtype=torch.float32,
-                                  device=hidden_states.device)
-                self._decode_out = buf
+            buf = self._decode_buffer(hidden_states)
             out = self.engine.decode(hidden_states, topk_weights, topk_ids, out=buf[:M])
             if self.check_nan_in_output:                      # routed_experts.py:1852-1854
                 torch.nan_to_num(out, nan=0.0, out=out)
@@ -153,7 +176,6 @@ class RoutedExpertsLayer:
             out = self.engine.prefill(hidden_states, topk_weights, topk_ids)
             if self.check_nan_in_output:                      # routed_experts.py:1895-1898
                 out = torch.where(torch.isfinite(out), out, torch.zeros_like(out))
-        r = self.routing
         if r.routed_scaling_factor != 1.0 and not r.apply_routed_scaling_in_router:   # moe_runner.py:391-408
             out *= r.routed_scaling_factor
         return out

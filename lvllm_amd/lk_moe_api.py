@@ -111,6 +111,19 @@ class _MOE:
                                                   _vp(topk_weights_ptr), int(weights_ld), _vp(out_ptr),
                                                   int(out_dtype)))
 
+    # ---- extension: router + experts in one call (decode: router and scatter metadata in one launch) ----
+    def forward_routed(self, stream: int, num_tokens: int, top_k: int, hidden_ptr: int, hidden_ld: int,
+                       logits_ptr: int, logits_dtype: int, router_experts: int, score_bias_ptr: int,
+                       n_group: int, topk_group: int, scoring: int, renormalize: bool, routed_scaling: float,
+                       id_offset: int, topk_weights_ptr: int, topk_ids_ptr: int, out_ptr: int,
+                       out_dtype: int) -> None:
+        _clib.check(self._lib.lkm_forward_routed(self._h, _vp(stream), num_tokens, top_k, _vp(hidden_ptr),
+                                                 int(hidden_ld), _vp(logits_ptr), int(logits_dtype),
+                                                 int(router_experts), _vp(score_bias_ptr), int(n_group),
+                                                 int(topk_group), int(scoring), int(bool(renormalize)),
+                                                 float(routed_scaling), int(id_offset), _vp(topk_weights_ptr),
+                                                 _vp(topk_ids_ptr), _vp(out_ptr), int(out_dtype)))
+
     # ---- measurement / introspection (extensions) --------------------------------------
     def set_profiling(self, enable: bool) -> None:
         _clib.check(self._lib.lkm_set_profiling(self._h, int(enable)))

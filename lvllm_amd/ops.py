@@ -374,6 +374,41 @@ class RoutedExpertsEngine:
                                     out.data_ptr(), _DT[out.dtype])
         return out
 
+    def forward_logits(self, hidden: torch.Tensor, router_logits: torch.Tensor, topk: int, renormalize: bool, *,
+                       scoring_func: str = "softmax", num_expert_group: int = 0, topk_group: int = 0,
+                       routed_scaling_factor: float = 1.0, e_score_correction_bias: torch.Tensor | None = None,
+                       out: torch.Tensor | None = None, out_dtype: torch.dtype = torch.float32,
+                       id_offset: int = 0):
+        """Routing + experts in one call (include/lkm.h lkm_forward_routed): topk_softmax / grouped_topk on
+        `router_logits` [M, E_router], then the operator on the result; for decode batches the router and the
+        scatter metadata are one launch.  Bit-identical to topk_softmax()/grouped_topk() followed by
+        forward_rows().  -> (out [M,H], topk_weights fp32 [M,K], topk_ids int32 [M,K])"""
+        _need_cuda(hidden, router_logits, e_score_correction_bias)
+        if scoring_func not in _SCORING:
+            raise ValueError(f"Unsupported scoring function: {scoring_func}")
+        if router_logits.dtype not in _DT:
+            raise ValueError(f"unsupported gating dtype {router_logits.dtype}")
+        assert hidden.dtype == self.act_dtype and hidden.dim() == 2 and (hidden.size(1) == 1 or hidden.stride(1) == 1)
+        g = router_logits.contiguous()
+        M, E = g.shape
+        assert hidden.size(0) == M, "Number of tokens mismatch"
+        bias = None
+        if e_score_correction_bias is not None:
+            bias = e_score_correction_bias.to(torch.float32).contiguous()
+        w = torch.empty((M, topk), dtype=torch.float32, device=g.device)
+        ids = torch.empty((M, topk), dtype=torch.int32, device=g.device)
+        if out is None:
+            out = torch.empty((M, self.H), dtype=out_dtype, device=hidden.device)
+        assert out.is_contiguous() and out.dtype in (torch.float32, self.act_dtype)
+        if M == 0:
+            return out, w, ids
+        self.engine.forward_routed(torch.cuda.current_stream(hidden.device).cuda_stream, M, topk, hidden.data_ptr(),
+                                   hidden.stride(0) if M > 1 else max(hidden.stride(0), self.H), g.data_ptr(),
+                                   _DT[g.dtype], E, 0 if bias is None else bias.data_ptr(), int(num_expert_group), int(topk_group),
+                                   _SCORING[scoring_func], renormalize, float(routed_scaling_factor), int(id_offset),
+                                   w.data_ptr(), ids.data_ptr(), out.data_ptr(), _DT[out.dtype])
+        return out, w, ids
+
     def prefill_host(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
         """CPU tensors in, fp32 CPU tensor out   (cf. RoutedExperts._cpu_prefill)"""
         assert not hidden.is_cuda

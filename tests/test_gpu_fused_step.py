@@ -1,0 +1,145 @@
+"""GPU: the fused decode step -- router + scatter metadata in one launch (lkm_forward_routed) and GEMM2 + combine in
+one launch (gemm2_combine_kernel) -- must reproduce the five-launch step BIT FOR BIT (same arithmetic, same
+order), and the five-launch step is what every other parity test pins to the oracle and the reference goldens.
+Router outputs are additionally checked against the oracle router (ids bit-exact, weights bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from tests.helpers import make_routing, torch_to_bits
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _eng(*a, **k):
+    from lvllm_amd.ops import RoutedExpertsEngine
+    return RoutedExpertsEngine(*a, **k)
+
+
+def _weights(E, H, I, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    w13 = (torch.randn((E, 2 * I, H), generator=g) / 10).to(dtype)
+    w2 = (torch.randn((E, H, I), generator=g) / 10).to(dtype)
+    return w13, w2
+
+
+def _engine(fmt, E, K, H, I, dtype, seed):
+    from lvllm_amd import _clib
+    w13, w2 = _weights(E, H, I, dtype, seed)
+    odt = orc.BF16 if dtype == torch.bfloat16 else orc.F16
+    if fmt == "bf16":
+        return _eng(w13.to(DEV), w2.to(DEV), top_k=K, act_dtype=dtype)
+    if fmt == "int4":
+        q13, s13 = orc.quant_int4(torch_to_bits(w13), odt, 128)
+        q2, s2 = orc.quant_int4(torch_to_bits(w2), odt, 128)
+        from tests.helpers import bits_to_torch
+        return _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dtype, fmt="int4",
+                    w13_scale=bits_to_torch(s13, odt), w2_scale=bits_to_torch(s2, odt), group_n=1, group_k=128)
+    if fmt in ("fp8", "fp8a8"):
+        q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+        q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+        return _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dtype, fmt="fp8",
+                    w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128,
+                    fp8_mode=_clib.FP8_W8A8 if fmt == "fp8a8" else _clib.FP8_W8A16)
+    raise AssertionError(fmt)
+
+
+@pytest.mark.parametrize("fmt,M,E,K,H,I", [
+    ("bf16", 32, 8, 2, 4096, 512), ("bf16", 32, 8, 2, 512, 1024), ("bf16", 2, 8, 2, 256, 128), ("bf16", 7, 4, 4, 384, 200), ("bf16", 64, 8, 2, 136, 72),
+    ("bf16", 40, 16, 2, 256, 256), ("bf16", 300, 8, 2, 256, 128), ("bf16", 20, 6, 3, 128, 64),
+    ("int4", 24, 8, 2, 512, 256), ("fp8", 32, 8, 2, 512, 512), ("fp8a8", 32, 8, 2, 512, 512), ("fp8a8", 9, 4, 2, 256, 384),
+])
+def test_gemm2_combine_fused_equals_two_launches(fmt, M, E, K, H, I):
+    """fuse=-1 (GEMM2 -> y -> combine) against fuse=1 (one launch); both output dtypes; ragged routing with empty experts
+    and -1 (non-local) ids; a global-id offset as the expert-parallel receiver uses it."""
+    eng = _engine(fmt, E, K, H, I, torch.bfloat16, seed=M + E)
+    g = torch.Generator().manual_seed(M)
+    a = (torch.randn((M, H), generator=g) / 10).to(torch.bfloat16).to(DEV)
+    n_fused = 0
+    for skew, drop, off in [(0.0, 0.0, 0), (1.5, 0.2, 0), (0.0, 0.1, 3)]:
+        tw, ids = make_routing(M, E, K, seed=M * 3 + E, skew=skew, drop=drop)
+        ids_g = np.where(ids >= 0, ids + off, ids).astype(np.int32)
+        twd, idd = torch.from_numpy(tw).to(DEV), torch.from_numpy(ids_g).to(DEV)
+        for odt in (torch.float32, torch.bfloat16):
+            eng.engine.set_tuning(fuse=1)          # opt-in: GEMM2 + combine in one launch
+            got = eng.forward_rows(a, twd, idd, out_dtype=odt, id_offset=off).cpu()
+            desc = eng.engine.describe()
+            n_fused += "g2+combine" in desc
+            eng.engine.set_tuning(fuse=-1)
+            base = eng.forward_rows(a, twd, idd, out_dtype=odt, id_offset=off).cpu()
+            assert "g2+combine" not in eng.engine.describe()
+            assert torch.equal(got.view(torch.int16 if odt == torch.bfloat16 else torch.int32),
+                               base.view(torch.int16 if odt == torch.bfloat16 else torch.int32)), (desc, skew, drop, off)
+    if H == 4096:      # Mixtral-like: 256 output tiles per expert, no split-K -> the fused launch must be the plan
+        assert n_fused > 0, "the planner never chose the fused GEMM2 + combine: " + desc
+
+
+@pytest.mark.parametrize("M,E,K,scoring,bias,grouped", [
+    (32, 8, 2, "softmax", False, None), (2, 8, 2, "softmax", False, None), (17, 64, 6, "sigmoid", True, None),
+    (128, 8, 2, "softmax", False, None), (5, 128, 8, "softmax", False, None), (64, 16, 4, "sigmoid", False, None),
+    (33, 64, 6, "sigmoid", True, (8, 4)), (128, 256, 8, "sigmoid", True, (8, 4)), (16, 32, 4, "softmax", False, (4, 2)),
+    (600, 8, 2, "softmax", False, None), (1, 8, 2, "softmax", False, None),
+])
+def test_forward_routed_equals_router_then_forward(M, E, K, scoring, bias, grouped):
+    """lkm_forward_routed == lkm_topk_softmax / lkm_grouped_topk followed by lkm_forward_strided, bit for bit
+    (out, weights, ids), for sizes inside and outside the one-launch range; router outputs == the oracle router."""
+    from lvllm_amd import ops
+    H, I = 256, 128
+    eng = _engine("bf16", E, K, H, I, torch.bfloat16, seed=E)
+    g = torch.Generator().manual_seed(M * 5 + E)
+    x = (torch.randn((M, H), generator=g) / 10).to(torch.bfloat16).to(DEV)
+    logits = torch.randn((M, E), generator=g, dtype=torch.float32)
+    b = (torch.randn((E,), generator=g) * 0.1) if bias else None
+    kw = dict(scoring_func=scoring, e_score_correction_bias=None if b is None else b.to(DEV))
+    rsf = 2.5 if grouped else 1.0
+    if grouped:
+        kw.update(num_expert_group=grouped[0], topk_group=grouped[1], routed_scaling_factor=rsf)
+    out_d, w_d, ids_d = eng.forward_logits(x, logits.to(DEV), K, True, **kw)      # default plan: router + sort fused
+    eng.engine.set_tuning(fuse=1)                                               # + GEMM2 + combine fused
+    out, w, ids = eng.forward_logits(x, logits.to(DEV), K, True, **kw)
+    assert torch.equal(out_d.view(torch.int32), out.view(torch.int32)) and torch.equal(ids_d, ids) and torch.equal(w_d, w)
+    if grouped:
+        w0, i0 = ops.grouped_topk(x, logits.to(DEV), K, True, grouped[0], grouped[1], scoring, rsf, kw["e_score_correction_bias"])
+    else:
+        w0, i0 = ops.topk_softmax(logits.to(DEV), K, True, kw["e_score_correction_bias"], scoring, rsf)
+    eng.engine.set_tuning(fuse=-1)
+    base = eng.forward_rows(x, w0, i0)
+    assert torch.equal(ids, i0) and torch.equal(w.view(torch.int32), w0.view(torch.int32))
+    assert torch.equal(out.view(torch.int32), base.view(torch.int32)), eng.engine.describe()
+    # the router against the oracle
+    sc = 0 if scoring == "softmax" else 1
+    if grouped:
+        wr, ir = orc.grouped_topk(logits.numpy(), K, grouped[0], grouped[1], bias=None if b is None else b.numpy(),
+                                  scoring=sc, renormalize=True, routed_scaling=rsf)
+    else:
+        wr, ir = orc.topk_softmax(logits.numpy(), K, bias=None if b is None else b.numpy(), scoring=sc,
+                                  renormalize=True, routed_scaling=rsf)
+    np.testing.assert_array_equal(ids.cpu().numpy(), ir)
+    np.testing.assert_array_equal(w.cpu().numpy().view(np.int32), wr.view(np.int32))
+
+
+def test_forward_routed_in_graph_and_bf16_out():
+    """captured in a hipGraph and replayed (decode in the reference only exists under capture, moe_runner.py:609-614)"""
+    M, E, K, H, I = 32, 8, 2, 512, 256
+    eng = _engine("bf16", E, K, H, I, torch.bfloat16, seed=1)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn((M, H), generator=g) / 10).to(torch.bfloat16).to(DEV)
+    logits = torch.randn((M, E), generator=g, dtype=torch.float32).to(DEV)
+    out = torch.empty((M, H), dtype=torch.bfloat16, device=DEV)
+    eng.engine.set_tuning(fuse=1)
+    eager, w_e, i_e = eng.forward_logits(x, logits, K, True, out_dtype=torch.bfloat16)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.forward_logits(x, logits, K, True, out=out)
+    torch.cuda.current_stream().wait_stream(s)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=s):
+        _, w_g, i_g = eng.forward_logits(x, logits, K, True, out=out)
+    out.zero_()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), eager.view(torch.int16))
+    assert torch.equal(i_g, i_e) and torch.equal(w_g, w_e)

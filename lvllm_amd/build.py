@@ -52,23 +52,23 @@ def _closure(src: Path) -> list[Path]:
     return sorted(seen)
 
 
-def _digest(src: Path, headers: list[Path]) -> str:
+def _digest(src: Path, flags: list[str]) -> str:
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(flags).encode())
     for p in [src, *_closure(src)]:
         h.update(p.name.encode())
         h.update(p.read_bytes())
     return h.hexdigest()[:16]
 
 
-def _compile(src: Path, headers: list[Path], verbose: bool) -> Path:
-    tag = _digest(src, headers)
-    obj = OBJ / f"{src.stem}.{tag}.o"
+def _compile(src: Path, flags: list[str], objdir: Path, verbose: bool) -> Path:
+    tag = _digest(src, flags)
+    obj = objdir / f"{src.stem}.{tag}.o"
     if obj.exists():
         return obj
-    for old in OBJ.glob(f"{src.stem}.*.o"):
+    for old in objdir.glob(f"{src.stem}.*.o"):
         old.unlink()
-    cmd = [_hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    cmd = [_hipcc(), *flags, "-c", str(src), "-o", str(obj)]
     if verbose:
         print("[lkm build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -78,23 +78,32 @@ def _compile(src: Path, headers: list[Path], verbose: bool) -> Path:
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags: tuple[str, ...] = (),
-          out: Path | None = None) -> Path:
-    """Compile (if stale) and link liblkm.so; returns its path.  extra_flags/out build an
-    experimental variant next to the default library (development only)."""
-    global FLAGS, OBJ, LIB
+          out: Path | None = None, only: str = "") -> Path:
+    """Compile (if stale) and link liblkm.so; returns its path.  extra_flags/out build an experimental variant next
+    to the default library (development only); `only` (comma list) restricts the extra flags to the sources whose file name
+    contains one of its entries -- the others are taken from the default build's object cache."""
+    global OBJ, LIB
+    base_flags, base_obj = list(FLAGS), CSRC / "_obj"
+    var_flags, var_obj = base_flags, base_obj
     if extra_flags or out:
-        FLAGS = [*FLAGS, *extra_flags]
-        tag = hashlib.sha256(" ".join(extra_flags).encode()).hexdigest()[:8]
-        OBJ = CSRC / f"_obj_{tag}"
+        var_flags = [*base_flags, *extra_flags]
+        tag = hashlib.sha256((" ".join(extra_flags) + "|" + only).encode()).hexdigest()[:8]
+        var_obj = CSRC / f"_obj_{tag}"
+        OBJ = var_obj
         LIB = out or PKG / f"liblkm_{tag}.so"
-    OBJ.mkdir(parents=True, exist_ok=True)
+    base_obj.mkdir(parents=True, exist_ok=True)
+    var_obj.mkdir(parents=True, exist_ok=True)
     srcs = sorted(CSRC.glob("*.hip"))
-    headers = sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "lkm.h"]
     if force:
-        for o in OBJ.glob("*.o"):
+        for o in var_obj.glob("*.o"):
             o.unlink()
+
+    def one(s: Path) -> Path:
+        if only and not any(o in s.name for o in only.split(",")):
+            return _compile(s, base_flags, base_obj, verbose)
+        return _compile(s, var_flags, var_obj, verbose)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, headers, verbose), srcs))
+        objs = list(ex.map(one, srcs))
     stamp = OBJ / "link.stamp"
     want = "no-hip-rt " + " ".join(o.name for o in objs)
     if LIB.exists() and stamp.exists() and stamp.read_text() == want and not force:
@@ -114,6 +123,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags: tuple[str, ..
 if __name__ == "__main__":
     extra = tuple(a[len("--flag="):] for a in sys.argv if a.startswith("--flag="))
     outs = [a[len("--out="):] for a in sys.argv if a.startswith("--out=")]
+    onlys = [a[len("--only="):] for a in sys.argv if a.startswith("--only=")]
     p = build(force="--force" in sys.argv, verbose="-q" not in sys.argv, extra_flags=extra,
-              out=Path(outs[0]).resolve() if outs else None)
+              out=Path(outs[0]).resolve() if outs else None, only=onlys[0] if onlys else "")
     print(p)

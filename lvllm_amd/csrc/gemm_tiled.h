@@ -48,6 +48,10 @@ constexpr int tiled_min_blocks(int wf, int tbw, int waves, bool gated_g1, int pd
     return 1;
 }
 
+#ifndef LKM_ABL
+#define LKM_ABL 0
+#endif
+
 template <int WF, int ADT, int NT, int TBW, int WAVES, bool GATED, bool IS_G1, int PD, bool NTL>
 __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED && IS_G1, PD)) void gemm_tiled_kernel(GemmParams p) {
     typedef Dec<WF, ADT> D;
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
                 u32x4 a[2][NTT];
                 typename D::Mult mu[NTT];
                 auto dec = [&](int t, int ks) __attribute__((always_inline)) {
-                    if constexpr (HOIST) return D::frag_m(s.w[t], ks, mu[t]);
+                    if constexpr ((LKM_ABL & 32) != 0) return s.w[t][0] + u32x4{(unsigned)ks, 0u, 0u, 0u};
+                    else if constexpr (HOIST) return D::frag_m(s.w[t], ks, mu[t]);
                     else return D::frag(s.w[t], s.aux[t], ks, dparam);
                 };
                 if constexpr (HOIST) {
@@ -343,7 +348,10 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
                 for (int ks = 0; ks < D::KSTEPS; ++ks) {
                     u32x4 a[NTT];
     #pragma unroll
-                    for (int t = 0; t < NTT; ++t) a[t] = D::frag(s.w[t], s.aux[t], ks, dparam);
+                    for (int t = 0; t < NTT; ++t) {
+                        if constexpr ((LKM_ABL & 32) != 0) a[t] = s.w[t][0] + u32x4{(unsigned)ks, 0u, 0u, 0u};
+                        else a[t] = D::frag(s.w[t], s.aux[t], ks, dparam);
+                    }
     #pragma unroll
                     for (int b0 = 0; b0 < NB; b0 += BCH) {
                         u32x4 bf[BCH];
@@ -385,12 +393,15 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
             static_for<PD>([&](auto H) __attribute__((always_inline)) {
                 constexpr int h = decltype(H)::v;
                 const int uu = u + h;
-                load_x(xs[h % XD], xsv[h % XD], uu + XD, Steady{});   // token rows first: their wait
-                load_w(ws[(h + PD - 1) % PD], uu + PD - 1);           // leaves the weights in flight
+                // LKM_ABL: compile-time ablations of the steady loop for experiments (python -m lvllm_amd.build
+                // --flag=-DLKM_ABL=n --only=gemm_tiled; results are wrong): 4 no barrier, 8 no token staging, 16 no
+                // weight loads, 32 no weight decode (compute() below)
+                if constexpr (!(LKM_ABL & 8)) load_x(xs[h % XD], xsv[h % XD], uu + XD, Steady{});   // token rows first: their wait
+                if constexpr (!(LKM_ABL & 16)) load_w(ws[(h + PD - 1) % PD], uu + PD - 1);           // leaves the weights in flight
                 __builtin_amdgcn_sched_barrier(0);                    // loads are issued before the MFMAs
                 compute(ws[h], h & 1);
-                store_x(xs[(h + 1) % XD], xsv[(h + 1) % XD], (h + 1) & 1);
-                __syncthreads();
+                if constexpr (!(LKM_ABL & 8)) store_x(xs[(h + 1) % XD], xsv[(h + 1) % XD], (h + 1) & 1);
+                if constexpr (!(LKM_ABL & 4)) __syncthreads();
             });
         }
         for (; u < U; u += PD) {

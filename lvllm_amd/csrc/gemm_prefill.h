@@ -80,7 +80,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_prefill_kernel(GemmParams p) 
         const int half = GATED ? tl / 8 : 0, idx = GATED ? tl % 8 : tl;
         const int t = tbase + idx;
         const int gt = half * p.T_half + (t < p.T_half ? t : 0);          // clamped: padded tile counts
-        asoff[q] = __builtin_amdgcn_readfirstlane(gt * U * 2048);
+        asoff[q] = __builtin_amdgcn_readfirstlane((int)(gt * p.w_tstride * 16));
     }
     const int alane = lane * 16;
     int bvoff[BPT];
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_prefill_kernel(GemmParams p) 
             for (int ks = 0; ks < 2; ++ks)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     rs_w, (LdsPtr)(lds + buf * kPfBufBytes + ((ATW * wave + q) * 2 + ks) * 1024), 16, alane,
-                    asoff[q] + (u * 2 + ks) * 1024, 0, 0);
+                    asoff[q] + u * (int)(p.w_ustride * 16) + ks * 1024, 0, 0);
 #pragma unroll
         for (int q = 0; q < BPT; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(512) void gemm_prefill_a8_kernel(GemmParams p) {
     const __amdgpu_buffer_rsrc_t rs_xs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xscale, 0, 0x7fffffff, 0x00020000);
     int asoff[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) asoff[q] = __builtin_amdgcn_readfirstlane(gtile(2 * wave + q) * U * 2048);
+    for (int q = 0; q < 2; ++q) asoff[q] = __builtin_amdgcn_readfirstlane((int)(gtile(2 * wave + q) * p.w_tstride * 16));
+    const int wub = (int)(p.w_ustride * 16);       // bytes between consecutive K units of a tile (GemmParams::w_ustride)
     const int alane = lane * 16;
     int bvoff[4];
 #pragma unroll
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_a8_kernel(GemmParams p) {
 #pragma unroll
             for (int ld = 0; ld < 2; ++ld)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + ((2 * wave + q) * 2 + ld) * 1024), 16,
-                                                         alane, asoff[q] + (u * 2 + ld) * 1024, 0, aux);
+                                                         alane, asoff[q] + u * wub + ld * 1024, 0, aux);
         if (!(p.dbg & 32))       // (ablation: weights only)
 #pragma unroll
         for (int q = 0; q < 4; ++q)     // instruction q moves token rows [64 q, 64 q + 64)

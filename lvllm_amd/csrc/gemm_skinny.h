@@ -327,14 +327,14 @@ struct Streamer {
     // vmcnt(0).  STEADY: the unit is not the last one of the K range, i.e. never a ragged K tail.
     template <int NTB, bool STEADY>
     static __device__ __forceinline__ void load(St& st, const u32x4* const (&wp)[NTT],
-                                                const char* const (&auxp)[NTT], int aux_step,
+                                                const char* const (&auxp)[NTT], int aux_step, int wstep,
                                                 const unsigned char* const (&xp)[TB],
                                                 const float* const (&xsp)[TB], int u, int Kreal, int gk) {
 #pragma unroll
         for (int t = 0; t < NTT; ++t) {
 #pragma unroll
             for (int l = 0; l < D::LOADS; ++l)
-                st.w[t][l] = __builtin_nontemporal_load(wp[t] + ((size_t)u * D::LOADS + l) * 64);
+                st.w[t][l] = __builtin_nontemporal_load(wp[t] + (size_t)u * wstep + l * 64);
             D::load_aux_at(st.aux[t], auxp[t] + (size_t)u * aux_step);
         }
         // Token rows beyond the expert's count point at a valid row (their D columns are never
@@ -411,14 +411,14 @@ struct Streamer {
 
     template <int NTB>
     static __device__ __forceinline__ void run_n(f32x4 (&acc)[NTT][TB], const u32x4* const (&wp)[NTT],
-                                                 const char* const (&auxp)[NTT], int aux_step, int spu,
+                                                 const char* const (&auxp)[NTT], int aux_step, int wstep, int spu,
                                                  const unsigned char* const (&xp)[TB],
                                                  const float* const (&xsp)[TB], int u0, int u1, int Kreal,
                                                  int lane) {
         const int gk = (lane >> 4) * (16 / XB);
         St st[2];
         if (u0 >= u1) return;
-        load<NTB, false>(st[0], wp, auxp, aux_step, xp, xsp, u0, Kreal, gk);
+        load<NTB, false>(st[0], wp, auxp, aux_step, wstep, xp, xsp, u0, Kreal, gk);
         // steady pairs: both look-ahead units stay below u1 - 1
         const int um = u1 - 2 - u0 > 0 ? u0 + (u1 - 2 - u0) / 2 * 2 : u0;
         int u = u0;
@@ -426,11 +426,11 @@ struct Streamer {
             // sched_barrier: the next stage's loads are ISSUED before this stage's MFMAs (the
             // scheduler otherwise sinks them below the MFMAs that last read those registers and the
             // prefetch distance shrinks from a stage to a few instructions)
-            load<NTB, true>(st[1], wp, auxp, aux_step, xp, xsp, u + 1, Kreal, gk);
+            load<NTB, true>(st[1], wp, auxp, aux_step, wstep, xp, xsp, u + 1, Kreal, gk);
             __builtin_amdgcn_sched_barrier(0);
             compute<NTB>(st[0], acc, spu);
             __builtin_amdgcn_sched_barrier(0);
-            load<NTB, true>(st[0], wp, auxp, aux_step, xp, xsp, u + 2, Kreal, gk);
+            load<NTB, true>(st[0], wp, auxp, aux_step, wstep, xp, xsp, u + 2, Kreal, gk);
             __builtin_amdgcn_sched_barrier(0);
             compute<NTB>(st[1], acc, spu);
             __builtin_amdgcn_sched_barrier(0);
@@ -440,7 +440,7 @@ struct Streamer {
             for (int h = 0; h < 2; ++h) {
                 const int uu = u + h;
                 if (uu < u1) {
-                    if (uu + 1 < u1) load<NTB, false>(st[h ^ 1], wp, auxp, aux_step, xp, xsp, uu + 1, Kreal, gk);
+                    if (uu + 1 < u1) load<NTB, false>(st[h ^ 1], wp, auxp, aux_step, wstep, xp, xsp, uu + 1, Kreal, gk);
                     compute<NTB>(st[h], acc, spu);
                 }
             }
@@ -450,25 +450,25 @@ struct Streamer {
     // ntb (wave-uniform) selects the statically sized loop; 3 blocks run as 4 (the 4th block's rows
     // alias valid rows and are never stored)
     static __device__ __forceinline__ void run(f32x4 (&acc)[NTT][TB], const u32x4* const (&wp)[NTT],
-                                               const char* const (&auxp)[NTT], int aux_step, int spu,
+                                               const char* const (&auxp)[NTT], int aux_step, int wstep, int spu,
                                                const unsigned char* const (&xp)[TB],
                                                const float* const (&xsp)[TB], int u0, int u1, int Kreal,
                                                int lane, int ntb) {
         if constexpr (TB == 1) {
-            run_n<1>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+            run_n<1>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
         } else if constexpr (TB == 2) {
             if (ntb <= 1)
-                run_n<1>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+                run_n<1>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
             else
-                run_n<2>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+                run_n<2>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
         } else {
             static_assert(TB == 4, "token blocks per wave: 1, 2 or 4");
             if (ntb <= 1)
-                run_n<1>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+                run_n<1>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
             else if (ntb == 2)
-                run_n<2>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+                run_n<2>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
             else
-                run_n<4>(acc, wp, auxp, aux_step, spu, xp, xsp, u0, u1, Kreal, lane);
+                run_n<4>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
         }
     }
 };
@@ -567,12 +567,12 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
 
     const u32x4* wp[NTT];
     const char* auxp[NTT];
-    const int aux_step = D::aux_step(p.spu);
+    const int aux_step = D::aux_step(p.spu), wstep = (int)p.w_ustride;
 #pragma unroll
     for (int t = 0; t < NTT; ++t) {
         const int tile = (GATED && t >= NT) ? p.T_half + tile0 + (t - NT) : tile0 + t;
         const size_t tl = (size_t)e * T_all + tile;
-        wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
+        wp[t] = (const u32x4*)p.w + (size_t)e * p.w_estride + (size_t)tile * p.w_tstride + lane;
         auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
     const int u0 = (int)((long long)wave * p.U / KW), u1 = (int)((long long)(wave + 1) * p.U / KW);
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        Streamer<WF, ADT, NTT, TB>::run(acc, wp, auxp, aux_step, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
+        Streamer<WF, ADT, NTT, TB>::run(acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 
         if (KW > 1) {
             // fixed-order cross-wave sum: wave KW-1 stores, KW-2 .. 1 add, wave 0 takes the total
@@ -663,11 +663,11 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 
     const u32x4* wp[NT];
     const char* auxp[NT];
-    const int aux_step = D::aux_step(p.spu);
+    const int aux_step = D::aux_step(p.spu), wstep = (int)p.w_ustride;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const size_t tl = (size_t)e * p.T_half + tile0 + t;
-        wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
+        wp[t] = (const u32x4*)p.w + (size_t)e * p.w_estride + (size_t)(tile0 + t) * p.w_tstride + lane;
         auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
     const int u0 = (int)((long long)sk * p.U / p.SK), u1 = (int)((long long)(sk + 1) * p.U / p.SK);
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        Streamer<WF, ADT, NT, TB>::run(acc, wp, auxp, aux_step, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
+        Streamer<WF, ADT, NT, TB>::run(acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
@@ -733,11 +733,11 @@ __global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K)
     if (e >= 0) {
         const u32x4* wp[NT];
         const char* auxp[NT];
-        const int aux_step = D::aux_step(p.spu);
+        const int aux_step = D::aux_step(p.spu), wstep = (int)p.w_ustride;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const size_t tl = (size_t)e * p.T_half + tile0 + t;
-            wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
+            wp[t] = (const u32x4*)p.w + (size_t)e * p.w_estride + (size_t)(tile0 + t) * p.w_tstride + lane;
             auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
         }
         const int u0 = (int)((long long)sk * p.U / SK), u1 = (int)((long long)(sk + 1) * p.U / SK);
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K)
         constexpr int XB = D::A8 ? 1 : 2;
         const unsigned char* xp[1] = {(const unsigned char*)p.x + (size_t)k * p.ldx * XB};
         const float* xsp[1] = {p.xscale + (size_t)k * p.ld_xscale};
-        Streamer<WF, ADT, NT, 1>::run(acc, wp, auxp, aux_step, dparam, xp, xsp, u0, u1, p.Kreal, lane, 1);
+        Streamer<WF, ADT, NT, 1>::run(acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, 1);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) ((f32x4*)red)[(wave * NT + t) * 64 + lane] = acc[t][0];
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(64 * MAXW) void gemm2_combine_kernel(GemmParams p) 
     const int n_slots = p.comb_M * K;
     const int tile0 = blockIdx.x * NT;
     const int n_items = p.meta[0] * SK;
-    const int aux_step = D::aux_step(p.spu);
+    const int aux_step = D::aux_step(p.spu), wstep = (int)p.w_ustride;
     // this thread's output of the epilogue: its sorted positions and routing weights are fetched NOW, under the weight
     // stream, so that nothing but LDS reads stands between the last MFMA and the store
     constexpr int Q = NT * 4;   // f32x4 columns of a row of this tile group
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(64 * MAXW) void gemm2_combine_kernel(GemmParams p) 
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const size_t tl = (size_t)e * p.T_half + tile0 + t;
-            wp[t] = (const u32x4*)p.w + tl * p.U * D::LOADS * 64 + lane;
+            wp[t] = (const u32x4*)p.w + (size_t)e * p.w_estride + (size_t)(tile0 + t) * p.w_tstride + lane;
             auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
         }
         const int u0 = (int)((long long)sk * p.U / SK), u1 = (int)((long long)(sk + 1) * p.U / SK);
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(64 * MAXW) void gemm2_combine_kernel(GemmParams p) 
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            Streamer<WF, ADT, NT, TB>::run(acc, wp, auxp, aux_step, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
+            Streamer<WF, ADT, NT, TB>::run(acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
                 const int r_tok = sb + b * 16 + j;

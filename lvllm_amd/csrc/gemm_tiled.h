@@ -121,12 +121,12 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
     // result: every load of the K loop is unconditional (see the loop comment)
     const u32x4* wp[NTT];
     const char* auxp[NTT];
-    const int aux_step = D::aux_step(p.spu);
+    const int aux_step = D::aux_step(p.spu), wstep = (int)p.w_ustride;
 #pragma unroll
     for (int t = 0; t < NTT; ++t) {
         const int tile = (IS_G1 && GATED && t >= NT) ? p.T_half + tile0 + (t - NT) : tile0 + t;
         const size_t tl = (size_t)e * T_all + (wave_on ? tile : 0);
-        wp[t] = (const u32x4*)p.w + (tl * p.U + u0) * D::LOADS * 64 + lane;
+        wp[t] = (const u32x4*)p.w + (size_t)e * p.w_estride + (size_t)(wave_on ? tile : 0) * p.w_tstride + (size_t)u0 * p.w_ustride + lane;
         auxp[t] = D::aux_ptr(p.s, tl * p.U + u0, lane, p.spu);
     }
 
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
             for (int t = 0; t < NTT; ++t) {
     #pragma unroll
                 for (int l = 0; l < D::LOADS; ++l) {
-                    const u32x4* a = wp[t] + ((size_t)u * D::LOADS + l) * 64;
+                    const u32x4* a = wp[t] + (size_t)u * wstep + l * 64;
                     s.w[t][l] = NTL ? __builtin_nontemporal_load(a) : *a;
                 }
                 D::load_aux_at(s.aux[t], auxp[t] + (size_t)u * aux_step);

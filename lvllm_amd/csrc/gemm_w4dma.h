@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_w4dma_kernel(GemmParams p) {
     for (int t = 0; t < NTT; ++t) {
         const int tile = (IS_G1 && GATED && t >= NT) ? p.T_half + tile0 + (t - NT) : tile0 + t;
         const int tl = wave_on ? tile : 0;
-        woff[t] = __builtin_amdgcn_readfirstlane((tl * p.U + u0) * 1024);
+        woff[t] = __builtin_amdgcn_readfirstlane((int)((tl * p.w_tstride + u0 * p.w_ustride) * 16));
         aoff[t] = __builtin_amdgcn_readfirstlane((tl * p.U + u0) * auxB);
     }
     constexpr int PIECES = TM * SLOTS / THREADS;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_w4dma_kernel(GemmParams p) {
 #pragma unroll
             for (int t = 0; t < NTT; ++t)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + WOFF + (wave * NTT + t) * 1024), 16,
-                                                         lane * 16, woff[t] + u * 1024, 0, 2);
+                                                         lane * 16, woff[t] + u * (int)(p.w_ustride * 16), 0, 2);
 #pragma unroll
             for (int t = 0; t < NTT; ++t)
                 if (lane * 4 < auxB)

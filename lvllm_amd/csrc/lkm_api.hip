@@ -5,6 +5,7 @@
 // HBM; scratch (sort metadata, intermediate, split-K partials) is a per-device arena shared by all
 // engines because the layers of a model execute one after another on the worker's stream.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -160,6 +161,8 @@ struct LkmEngine {
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
     int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0, t_fuse = 0;
+    bool unit_major = false;  // weight image layout (RepackDims::unit_major)
+    int loads = 2;            // 16-byte loads per lane per (tile, unit)
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -354,8 +357,17 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     LKM_TRY_HIP(hipMalloc(&h->w2, w2_vec * 16));
     h->weight_bytes = (int64_t)(w13_vec + w2_vec) * 16;
 
-    RepackDims d13{h->E, h->I, halves, h->interleaved ? 1 : 0, h->H, h->T1_half, h->U1, h->a8 ? 1 : 0};
-    RepackDims d2{h->E, h->H, 1, 0, h->I, h->T2, h->U2, h->a8 ? 1 : 0};
+    // weight image layout (GemmParams::w_*stride): tile-major; LKM_W_UNIT_MAJOR=1 in the environment stores all tiles'
+    // unit-u chunks contiguously instead (development A/B: a synthetic stream reads that order 3-10 % faster,
+    // tools/probe_stream.hip, but the kernels gain nothing consistent: streamers -2 %, tile kernels +2-3 %,
+    // profiles/r02_weight_layout_ab.log)
+    {
+        const char* env = getenv("LKM_W_UNIT_MAJOR");
+        h->unit_major = env && env[0] == '1';
+    }
+    h->loads = loads;
+    RepackDims d13{h->E, h->I, halves, h->interleaved ? 1 : 0, h->H, h->T1_half, h->U1, h->a8 ? 1 : 0, h->unit_major ? 1 : 0};
+    RepackDims d2{h->E, h->H, 1, 0, h->I, h->T2, h->U2, h->a8 ? 1 : 0, h->unit_major ? 1 : 0};
     {
         const size_t n13 = (size_t)h->E * halves * h->I, n2 = (size_t)h->E * h->H;
         const size_t b13 = n13 * h->H / 2 * wbytes_per_elem_x2(wf);
@@ -762,6 +774,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.w = h->w13;
     p1.s = h->s13;
     p1.spu = h->spu;
+    set_w_layout(p1, h->T1_half * (h->gated ? 2 : 1), h->U1, h->loads, h->unit_major);
     p1.gs = h->gs13;
     p1.xcd_map = (h->t_xcd > 0 || pl.xcd1) ? xcd_cap : 0;
     p1.tile_uniform_scale = h->cfg.groupN > 0 && h->cfg.groupN % 16 == 0;
@@ -817,6 +830,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.w = h->w2;
     p2.s = h->s2;
     p2.spu = h->spu;
+    set_w_layout(p2, h->T2, h->U2, h->loads, h->unit_major);
     p2.gs = h->gs2;
     p2.xcd_map = (h->t_xcd > 0 || pl.xcd2) ? xcd_cap : 0;
     p2.tile_uniform_scale = p1.tile_uniform_scale;

@@ -11,6 +11,7 @@ struct RepackDims {
     int K;                               // source K (elements)
     int T_half, U;                       // dest tiles per half, units
     int a8;                              // fp8 only: k mapping for fp8 activations (W8A8)
+    int unit_major;                      // weight image: [e][unit][tile] instead of [e][tile][unit] (GemmParams::w_*stride)
 };
 int launch_repack_w(hipStream_t st, int wf, const void* src, void* dst, const RepackDims& d);
 int launch_repack_s_int4(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group,
@@ -51,6 +52,11 @@ struct GemmParams {
     // weights (pre-shuffled), scales (pre-shuffled or null)
     const void* w;
     const void* s;
+    // weight addressing, in 16-byte vectors per lane group of 64: vector of (expert e, tile t, unit u, load l) =
+    // e * w_estride + t * w_tstride + u * w_ustride + l * 64 + lane.  Two layouts (RepackDims::unit_major):
+    // tile-major (a tile's units contiguous) and unit-major (all tiles' unit-u chunks contiguous: what the chip reads
+    // at one moment is one contiguous region)
+    long long w_estride, w_tstride, w_ustride;
     int spu;     // int4: scales per 128-k unit (1,2,4)
     const float* gs;   // NVFP4: per-expert f32 multiplier [E] (NULL = 1)
     int T_half;  // tiles per half (gate / up); w2: tiles total
@@ -106,6 +112,11 @@ struct GemmParams {
     int act_type;
     float alpha, limit;
 };
+inline void set_w_layout(GemmParams& p, int T_all, int U, int loads, bool unit_major) {
+    p.w_estride = (long long)T_all * U * loads * 64;
+    p.w_tstride = unit_major ? (long long)loads * 64 : (long long)U * loads * 64;
+    p.w_ustride = unit_major ? (long long)T_all * loads * 64 : (long long)loads * 64;
+}
 struct LaunchCfg {
     int nt, tb, kw, sk;
     int tiled;   // 0: skinny streamer (token operand straight from L2);

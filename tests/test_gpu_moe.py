@@ -925,3 +925,22 @@ def test_modular_experts_top1_preweighted_and_fp8_quant_config():
     want = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=ATOL, rtol=RTOL)
     assert LkmQuant.from_vllm(QC(), torch.bfloat16).fp8_mode == _clib.FP8_W8A16
+
+
+@pytest.mark.parametrize("fmt,M", [("bf16", 20), ("bf16", 200), ("int4", 24), ("int4", 150), ("fp8a8", 40), ("fp8a8", 600)])
+def test_unit_major_weight_image_is_bit_identical(fmt, M, monkeypatch):
+    """LKM_W_UNIT_MAJOR=1 (read by lkm_create) stores the weight image [expert][unit][tile] instead of
+    [expert][tile][unit]; every kernel addresses it through GemmParams::w_*stride, so streamer, tile and prefill paths
+    must give the same bits in both layouts."""
+    from tests.test_gpu_fused_step import _engine
+    E, K, H, I = 4, 2, 512, 384
+    g = torch.Generator().manual_seed(M)
+    a = (torch.randn((M, H), generator=g) / 10).to(torch.bfloat16).to(DEV)
+    tw, ids = make_routing(M, E, K, seed=M, skew=0.5, drop=0.1)
+    twd, idd = torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)
+    monkeypatch.delenv("LKM_W_UNIT_MAJOR", raising=False)
+    base = _engine(fmt, E, K, H, I, torch.bfloat16, seed=3).forward_rows(a, twd, idd).cpu()
+    monkeypatch.setenv("LKM_W_UNIT_MAJOR", "1")
+    eng = _engine(fmt, E, K, H, I, torch.bfloat16, seed=3)
+    got = eng.forward_rows(a, twd, idd).cpu()
+    assert torch.equal(got.view(torch.int32), base.view(torch.int32)), eng.engine.describe()

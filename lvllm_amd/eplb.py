@@ -364,6 +364,8 @@ class EngineExpertStore:
             if cfg is None:
                 raise ValueError("num_local is required for a bare lk_moe engine object")
             num_local = cfg.expert_num
+        # An engine with folded shared experts holds routed + n_shared slots (shared_experts.py): pass
+        # num_local = the ROUTED physical slots; the trailing shared slots are replicated on every rank and never move.
         self.moe = moe
         self.num_local = int(num_local)
         self.expert_nbytes = moe.expert_bytes()
@@ -704,6 +706,10 @@ class EplbState:
         idx = self.physical_to_logical_map.to(phys.device)
         logical.scatter_add_(1, idx.clamp(min=0), torch.where(idx >= 0, phys, torch.zeros_like(phys)))
         if self.world > 1:
+            # the collective runs where the group's backend can reach the tensor (gloo: host memory)
+            backend = dist.get_backend(self.group)
+            if "nccl" not in str(backend) and logical.is_cuda:
+                logical = logical.cpu()
             dist.all_reduce(logical, group=self.group)
         return logical.float().cpu()
 

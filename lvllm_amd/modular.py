@@ -199,6 +199,16 @@ class LkmExperts:
             self._engine_key = key
         return self._engine
 
+    def invalidate(self) -> None:
+        """Drop the cached engine: the next apply() copies and pre-shuffles w1 / w2 again.  lkm_create COPIES the
+        weights, so an in-place update of the tensors (weight reload, an EPLB rearrangement of torch parameters
+        through TensorExpertStore) is invisible to the engine until this is called; rearrangements through
+        EngineExpertStore move the engine's own images and need no invalidation.  After the first apply() the
+        caller may free w1 / w2 (as the reference does, routed_experts.py:1420-1432) -- keep passing tensors with
+        the same data_ptr / shape as the cache key, or hold on to the engine."""
+        self._engine = None
+        self._engine_key = None
+
     def apply(self, output: torch.Tensor, hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor,
               topk_weights: torch.Tensor, topk_ids: torch.Tensor, activation: Any, global_num_experts: int,
               expert_map: torch.Tensor | None, a1q_scale: torch.Tensor | None, a2_scale: torch.Tensor | None,

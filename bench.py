@@ -416,6 +416,27 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
         step()
     barrier()
     launch, graph = "eager", None
+    wd = ctx.get("wd")
+    if wd is not None and not args.no_graph:
+        # the same K steps launched eagerly first: a complete measurement to fall back on should the captured step
+        # (collectives inside a hipGraph) not come back on this machine
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        te = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        e_dt = float(te.item())
+        wd.arm(180.0, {
+            "metric": "moe_layer_decode_tokens_per_s", "value": round(M * world / (e_dt / steps), 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(e_dt / steps * 1e3, 4),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": fmt, "data": "synthetic",
+            "config": {"workload": name, "experts": E, "experts_per_gpu": E_local, "top_k": K, "hidden": H,
+                       "intermediate": I, "batch_per_gpu": M, "global_batch": M * world,
+                       "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}", "launch": "eager"},
+            "roofline": None, "cpu_baseline": None} if name == args.workload else wd.fallback,
+            f"graph capture / replay of workload {name}")
     if not args.no_graph:
         try:
             s = torch.cuda.Stream()
@@ -455,6 +476,8 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
     dt = float(t.item())
     ms_per_step = dt / steps * 1e3
     tokens_per_s = M * world / (dt / steps)
+    if wd is not None:
+        wd.disarm()
 
     # ---- optional: cold-cache variant.  Not part of the timed steps above.
     cold_ms = None
@@ -581,6 +604,44 @@ def _free_port() -> int:
     return p
 
 
+class Watchdog:
+    """Multi-rank runs only.  The captured expert-parallel step (RCCL collectives inside a hipGraph) and the extra
+    workloads have run on ONE rank before the driver's N > 1 runs; if a step of them never completes there, rank 0 still
+    prints the best line it already holds (the eager-launch timing of the same K steps, or the finished headline
+    line) and every rank leaves, instead of the whole run timing out with nothing."""
+
+    def __init__(self, rank: int):
+        import threading
+        self.rank, self.deadline, self.fallback, self.what = rank, None, None, ""
+        self._lock = threading.Lock()
+        threading.Thread(target=self._loop, daemon=True).start()
+
+    def arm(self, seconds: float, fallback: dict | None, what: str) -> None:
+        with self._lock:
+            self.deadline, self.fallback, self.what = time.monotonic() + seconds, fallback, what
+
+    def disarm(self) -> None:
+        with self._lock:
+            self.deadline = None
+
+    def _loop(self) -> None:
+        while True:
+            time.sleep(1.0)
+            with self._lock:
+                fired = self.deadline is not None and time.monotonic() > self.deadline
+                fb, what = self.fallback, self.what
+            if fired:
+                print(f"[bench] rank {self.rank}: {what} did not complete in time", file=sys.stderr, flush=True)
+                if self.rank == 0 and fb is not None:
+                    fb = dict(fb)
+                    fb["note"] = f"{what} did not complete; this line is what was measured before it"
+                    print(json.dumps(fb), flush=True)
+                else:
+                    time.sleep(3.0)         # let rank 0 write its line first
+                sys.stdout.flush()
+                os._exit(0 if fb is not None else 3)
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
     (the reference's tests spawn their ranks themselves too, tests/kernels/moe/parallel_utils.py:52-118)."""
@@ -634,11 +695,28 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    ctx = dict(world=world, rank=rank, dev=dev, dist=use_dist)
+    ctx = dict(world=world, rank=rank, dev=dev, dist=use_dist, wd=Watchdog(rank) if world > 1 else None)
 
     head = run_workload(args.workload, args, ctx, steps=args.steps, warmup=args.warmup,
                         with_cpu=not args.no_cpu_baseline, force_ep=args.force_ep)
+    def make_line(head, extras):
+        line = {
+            "metric": "moe_layer_decode_tokens_per_s", "value": head["value"], "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
+            "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+            "config": head["config"], "roofline": head["roofline"], "cpu_baseline": head.get("cpu_baseline"),
+        }
+        if "ms_per_step_cold" in head:
+            line["ms_per_step_cold"] = head["ms_per_step_cold"]
+        if extras:
+            line["extra"] = extras
+        return line
+
     extras = []
+    if ctx["wd"] is not None and not args.no_extras and args.workload == HEADLINE:
+        # (rank 0 holds the finished headline line from here on; the other ranks only need a non-None marker)
+        ctx["wd"].arm(600.0, make_line(head, []) if head is not None else ({} if rank else None), "the extra workloads")
     if not args.no_extras and args.workload == HEADLINE:
         es, ew = min(args.steps, 100), min(args.warmup, 10)
         names = (EXTRA_N1 if world == 1 and not args.force_ep else []) + [EXTRA_EP]
@@ -654,21 +732,12 @@ def main():
             if r is not None:
                 extras.append(r)
 
+    if ctx["wd"] is not None:
+        ctx["wd"].disarm()
     if rank == 0:
         if head is None:
             sys.exit(f"workload {args.workload} does not shard over {world} GPUs")
-        line = {
-            "metric": "moe_layer_decode_tokens_per_s", "value": head["value"], "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
-            "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
-            "config": head["config"], "roofline": head["roofline"], "cpu_baseline": head.get("cpu_baseline"),
-        }
-        if "ms_per_step_cold" in head:
-            line["ms_per_step_cold"] = head["ms_per_step_cold"]
-        if extras:
-            line["extra"] = extras
-        print(json.dumps(line), flush=True)
+        print(json.dumps(make_line(head, extras)), flush=True)
     if use_dist:
         # Every rank is past its last collective; leave without tearing the communicator down: destroying a
         # process group whose collectives live in captured graphs has hung at exit before, and the JSON line is out.

@@ -446,7 +446,10 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
             torch.cuda.current_stream().wait_stream(s)
             barrier()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=s):
+            # thread_local: with a process group alive, c10d's watchdog thread queries events while this thread
+            # captures; in the default (global) mode such a call from ANY thread invalidates the capture -- seen as
+            # hipErrorStreamCaptureInvalidated in about one of three test-suite runs of the one-rank RCCL step
+            with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local" if ctx["dist"] else "global"):
                 step()
             graph.replay()
             barrier()

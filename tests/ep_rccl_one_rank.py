@@ -70,7 +70,9 @@ def main():
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=s):
+    # thread_local: c10d's watchdog thread queries events while this thread captures; in the default global mode a call
+    # from any thread invalidates the capture (hipErrorStreamCaptureInvalidated, about one run in three inside the suite)
+    with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
         step()
     x2 = (torch.randn((M, H), generator=g) / 2).to(torch.bfloat16).to(dev)
     l2 = torch.randn((M, E), generator=g).to(dev)

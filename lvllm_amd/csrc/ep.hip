@@ -16,7 +16,7 @@
 namespace lkm {
 
 constexpr int kEpThreads = 256;
-constexpr int kEpTokPerWg = 16;      // tokens copied by one workgroup
+constexpr int kEpTokPerWg = 16;      // tokens copied by one workgroup (4 for decode-sized steps)
 constexpr int kEpMaxTokens = 8192;   // LDS: one int per token
 
 __host__ __device__ inline int64_t ep_row_bytes(int H, int K) { return ((int64_t)H * 2 + (int64_t)K * 8 + 15) / 16 * 16; }
@@ -33,7 +33,7 @@ __device__ __forceinline__ int ep_owner(int id, int base, int rem, int cut, int*
 // p (ascending token index -> deterministic record order; M*K ids, a few KB), then copies its own chunk.
 __global__ __launch_bounds__(kEpThreads) void ep_pack_tokens_kernel(
     const unsigned short* __restrict__ hidden, const int32_t* __restrict__ ids, const float* __restrict__ tw,
-    int M, int K, int H, int E, int ep, int cap, int global_ids, unsigned char* __restrict__ send,
+    int M, int K, int H, int E, int ep, int cap, int global_ids, int tok_per_wg, unsigned char* __restrict__ send,
     int32_t* __restrict__ slot_of, int32_t* __restrict__ overflow) {
     __shared__ int32_t s_slot[kEpMaxTokens];
     __shared__ int32_t s_wsum[kEpThreads / 64];
@@ -74,9 +74,11 @@ __global__ __launch_bounds__(kEpThreads) void ep_pack_tokens_kernel(
         }
         if (tid == 0 && carry > cap) atomicAdd(overflow, carry - cap);
     }
-    // my chunk of tokens: one wavefront per token, 16-byte copies
-    const int t0 = blockIdx.x * kEpTokPerWg;
-    for (int t = wv; t < kEpTokPerWg; t += kEpThreads / 64) {
+    // my chunk of tokens: one wavefront per token, 16-byte copies, four of them in flight per lane (a copy loop that
+    // waits for every load before its store took 15 us for 32 tokens of 8 KB: decode-sized steps now get one token per
+    // wavefront, tok_per_wg = 4, and spread over M/4 workgroups)
+    const int t0 = blockIdx.x * tok_per_wg;
+    for (int t = wv; t < tok_per_wg; t += kEpThreads / 64) {
         const int m = t0 + t;
         if (m >= M) break;
         int c = s_slot[m];
@@ -86,7 +88,16 @@ __global__ __launch_bounds__(kEpThreads) void ep_pack_tokens_kernel(
         unsigned char* rec = blockp + (size_t)c * rowb;
         const u32x4* src = (const u32x4*)(hidden + (size_t)m * H);
         u32x4* dst = (u32x4*)rec;
-        for (int i = lane; i < H / 8; i += 64) dst[i] = src[i];
+        const int nv = H / 8;
+        for (int i = lane; i < nv; i += 256) {
+            u32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i + q * 64 < nv) v[q] = src[i + q * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i + q * 64 < nv) dst[i + q * 64] = v[q];
+        }
         int32_t* rid = (int32_t*)(rec + (size_t)H * 2);
         float* rw = (float*)(rec + (size_t)H * 2 + (size_t)K * 4);
         for (int k = lane; k < K; k += 64) {
@@ -147,9 +158,11 @@ extern "C" int lkm_ep_pack_tokens(void* stream, const void* hidden, const int32_
     LKM_REQUIRE(capacity > 0, "ep_pack_tokens: capacity must be > 0");
     LKM_REQUIRE(send && slot_of && overflow && (M == 0 || (hidden && topk_ids && topk_weights)), "ep_pack_tokens: null pointer");
     // M == 0 (a rank without tokens this step) still has to mark its record slots empty
-    hipLaunchKernelGGL(ep_pack_tokens_kernel, dim3(M > 0 ? ceil_div(M, kEpTokPerWg) : 1, ep_size), dim3(kEpThreads), 0,
+    // every workgroup ranks all tokens first (M*K ids): few tokens per workgroup while that is cheap
+    const int tpw = M <= 256 ? 4 : kEpTokPerWg;
+    hipLaunchKernelGGL(ep_pack_tokens_kernel, dim3(M > 0 ? ceil_div(M, tpw) : 1, ep_size), dim3(kEpThreads), 0,
                        (hipStream_t)stream, (const unsigned short*)hidden, topk_ids, topk_weights, M, K, H,
-                       num_experts, ep_size, capacity, global_ids, (unsigned char*)send, slot_of, overflow);
+                       num_experts, ep_size, capacity, global_ids, tpw, (unsigned char*)send, slot_of, overflow);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

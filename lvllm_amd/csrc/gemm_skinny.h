@@ -315,11 +315,16 @@ struct Stage {
 // Streams units [u0,u1) of NTT tiles against TB token blocks into acc[NTT][TB].
 // xp[b]  : byte pointer to this lane's token row of block b (fp8 rows when D::A8, else 16-bit rows)
 // xsp[b] : A8 only, pointer to that row's per-unit activation scales
-template <int WF, int ADT, int NTT, int TB>
+// WSU (fp8 x fp8 only): every 16-row weight tile has ONE block scale per K unit (block-quantised checkpoints: 128 x 128),
+// so the scales of a tile's whole K range are fetched once -- lane l holds unit l (wsu[t][0]) and unit 64 + l
+// (wsu[t][1]) -- and a unit's scale is a v_readlane instead of one 16-byte vector load per tile per unit (2 of the 12
+// load instructions of a unit, 16 staging registers).
+template <int WF, int ADT, int NTT, int TB, bool WSU = false>
 struct Streamer {
     typedef Dec<WF, ADT> D;
     typedef Stage<D, NTT, TB> St;
     static constexpr int XB = D::A8 ? 1 : 2;
+    static_assert(!WSU || D::A8, "unit-scale registers: fp8 x fp8 only");
 
     // NTB = token blocks actually in use (compile time): the loop below contains no conditional load,
     // which is what lets s_waitcnt leave the next stage in flight -- vector-memory loads retire in
@@ -335,7 +340,7 @@ struct Streamer {
 #pragma unroll
             for (int l = 0; l < D::LOADS; ++l)
                 st.w[t][l] = __builtin_nontemporal_load(wp[t] + (size_t)u * wstep + l * 64);
-            D::load_aux_at(st.aux[t], auxp[t] + (size_t)u * aux_step);
+            if constexpr (!WSU) D::load_aux_at(st.aux[t], auxp[t] + (size_t)u * aux_step);
         }
         // Token rows beyond the expert's count point at a valid row (their D columns are never
         // stored, and a B column cannot contaminate another), so the loads are unconditional.
@@ -360,7 +365,8 @@ struct Streamer {
     }
 
     template <int NTB>
-    static __device__ __forceinline__ void compute(const St& st, f32x4 (&acc)[NTT][TB], int spu) {
+    static __device__ __forceinline__ void compute(const St& st, f32x4 (&acc)[NTT][TB], int spu, int u,
+                                                   const float (&wsu)[NTT][2]) {
         if constexpr (D::UNIT_SCALE) {
             f32x4 part[NTT][NTB];
 #pragma unroll
@@ -372,14 +378,22 @@ struct Streamer {
 #pragma unroll
                 for (int t = 0; t < NTT; ++t) {
                     if constexpr (D::A8) {
-                        const long a = D::frag8(st.w[t], ks);
+                        // the whole 128-k unit in ONE MX-scaled MFMA (unit E8M0 scales, C = 0; twice the rate of the
+                        // legacy fp8 MFMA, a quarter of the instructions): the two 16-byte loads of a lane ARE its
+                        // 32-byte operand -- the weight image (repack.hip, a8) and the token loads above pair
+                        // k = ld*64 + g*16 + [0,16) on both sides.  Same instruction as the prefill kernel.
+                        if (ks == 0) {
+                            typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+                            const i32x8_t a = {(int)st.w[t][0].x, (int)st.w[t][0].y, (int)st.w[t][0].z, (int)st.w[t][0].w,
+                                               (int)st.w[t][1].x, (int)st.w[t][1].y, (int)st.w[t][1].z, (int)st.w[t][1].w};
 #pragma unroll
-                        for (int b = 0; b < NTB; ++b)
-                            part[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                                a,
-                                __builtin_bit_cast(long, u32x2{st.x[b][ks >> 1][(ks & 1) * 2],
-                                                               st.x[b][ks >> 1][(ks & 1) * 2 + 1]}),
-                                part[t][b], 0, 0, 0);
+                            for (int b = 0; b < NTB; ++b) {
+                                const i32x8_t bb = {(int)st.x[b][0].x, (int)st.x[b][0].y, (int)st.x[b][0].z, (int)st.x[b][0].w,
+                                                    (int)st.x[b][1].x, (int)st.x[b][1].y, (int)st.x[b][1].z, (int)st.x[b][1].w};
+                                part[t][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                                    a, bb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                            }
+                        }
                     } else {
                         const u32x4 a = D::frag(st.w[t], st.aux[t], ks, spu);
 #pragma unroll
@@ -390,7 +404,11 @@ struct Streamer {
             for (int t = 0; t < NTT; ++t)
 #pragma unroll
                 for (int b = 0; b < NTB; ++b) {
-                    if constexpr (D::A8)
+                    if constexpr (WSU) {
+                        const float ws = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                            __builtin_bit_cast(int, u < 64 ? wsu[t][0] : wsu[t][1]), u & 63));
+                        acc[t][b] += scale4(f32x4{ws, ws, ws, ws}, splat2_opaque(st.xs[b])) * part[t][b];
+                    } else if constexpr (D::A8)
                         acc[t][b] += scale4(st.aux[t].s, splat2_opaque(st.xs[b])) * part[t][b];
                     else if constexpr (D::XS)      // INT4_PS: s * (sum (BIAS + v) x - (BIAS + 8) sum x)
                         acc[t][b] += st.aux[t].s * sub4(part[t][b], splat2_opaque(D::BIAS8 * st.xs[b]));
@@ -414,7 +432,7 @@ struct Streamer {
                                                  const char* const (&auxp)[NTT], int aux_step, int wstep, int spu,
                                                  const unsigned char* const (&xp)[TB],
                                                  const float* const (&xsp)[TB], int u0, int u1, int Kreal,
-                                                 int lane) {
+                                                 int lane, const float (&wsu)[NTT][2]) {
         const int gk = (lane >> 4) * (16 / XB);
         St st[2];
         if (u0 >= u1) return;
@@ -428,11 +446,11 @@ struct Streamer {
             // prefetch distance shrinks from a stage to a few instructions)
             load<NTB, true>(st[1], wp, auxp, aux_step, wstep, xp, xsp, u + 1, Kreal, gk);
             __builtin_amdgcn_sched_barrier(0);
-            compute<NTB>(st[0], acc, spu);
+            compute<NTB>(st[0], acc, spu, u, wsu);
             __builtin_amdgcn_sched_barrier(0);
             load<NTB, true>(st[0], wp, auxp, aux_step, wstep, xp, xsp, u + 2, Kreal, gk);
             __builtin_amdgcn_sched_barrier(0);
-            compute<NTB>(st[1], acc, spu);
+            compute<NTB>(st[1], acc, spu, u + 1, wsu);
             __builtin_amdgcn_sched_barrier(0);
         }
         for (; u < u1; u += 2) {
@@ -441,7 +459,7 @@ struct Streamer {
                 const int uu = u + h;
                 if (uu < u1) {
                     if (uu + 1 < u1) load<NTB, false>(st[h ^ 1], wp, auxp, aux_step, wstep, xp, xsp, uu + 1, Kreal, gk);
-                    compute<NTB>(st[h], acc, spu);
+                    compute<NTB>(st[h], acc, spu, uu, wsu);
                 }
             }
         }
@@ -453,22 +471,22 @@ struct Streamer {
                                                const char* const (&auxp)[NTT], int aux_step, int wstep, int spu,
                                                const unsigned char* const (&xp)[TB],
                                                const float* const (&xsp)[TB], int u0, int u1, int Kreal,
-                                               int lane, int ntb) {
+                                               int lane, int ntb, const float (&wsu)[NTT][2]) {
         if constexpr (TB == 1) {
-            run_n<1>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
+            run_n<1>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane, wsu);
         } else if constexpr (TB == 2) {
             if (ntb <= 1)
-                run_n<1>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
+                run_n<1>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane, wsu);
             else
-                run_n<2>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
+                run_n<2>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane, wsu);
         } else {
             static_assert(TB == 4, "token blocks per wave: 1, 2 or 4");
             if (ntb <= 1)
-                run_n<1>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
+                run_n<1>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane, wsu);
             else if (ntb == 2)
-                run_n<2>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
+                run_n<2>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane, wsu);
             else
-                run_n<4>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane);
+                run_n<4>(acc, wp, auxp, aux_step, wstep, spu, xp, xsp, u0, u1, Kreal, lane, wsu);
         }
     }
 };
@@ -537,6 +555,37 @@ __device__ __forceinline__ int direct_expert(const GemmParams& p, int k) {
     return (e < 0 || e >= p.direct_E) ? -1 : e;
 }
 
+// fp8 x fp8 with one block scale per (16-row tile, K unit): lane l <- the scales of units l and 64 + l of each tile
+// (Streamer<..., WSU>); false = the per-row scale loads stay (scale granularity below 16 rows, or more than 128 units)
+template <typename D, int N>
+__device__ __forceinline__ bool load_unit_scales(const GemmParams& p, const size_t (&tl)[N], int lane, float (&wsu)[N][2]) {
+#pragma unroll
+    for (int t = 0; t < N; ++t) wsu[t][0] = wsu[t][1] = 0.0f;
+    if constexpr (D::A8) {
+        if (!p.tile_uniform_scale || p.U > 128 || (p.dbg & 256)) return false;     // (dbg 256: A/B switch)
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            const float* sb = (const float*)p.s + tl[t] * p.U * 16;      // row 0 of (tile, unit 0): 16 floats per unit
+            const int u0 = lane < p.U ? lane : p.U - 1, u1 = lane + 64 < p.U ? lane + 64 : p.U - 1;
+            wsu[t][0] = sb[(size_t)u0 * 16];
+            wsu[t][1] = sb[(size_t)u1 * 16];
+        }
+        return true;
+    } else {
+        return false;
+    }
+}
+// one call site for both streamer variants
+#define LKM_STREAM_RUN(NTT_, TB_, ...)                                                   \
+    do {                                                                                 \
+        if constexpr (D::A8) {                                                           \
+            if (use_wsu) Streamer<WF, ADT, NTT_, TB_, true>::run(__VA_ARGS__, wsu);      \
+            else Streamer<WF, ADT, NTT_, TB_, false>::run(__VA_ARGS__, wsu);             \
+        } else {                                                                         \
+            Streamer<WF, ADT, NTT_, TB_, false>::run(__VA_ARGS__, wsu);                  \
+        }                                                                                \
+    } while (0)
+
 // ------------------------------------------------------------------ GEMM1 + activation
 // grid = (groups, max_active_experts); block = 64*KW threads: the KW waves of a workgroup split K
 // and reduce through LDS (needed when an expert has too few tiles to fill the chip, e.g. M=1).
@@ -567,14 +616,18 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
 
     const u32x4* wp[NTT];
     const char* auxp[NTT];
+    size_t tlv[NTT];
     const int aux_step = D::aux_step(p.spu), wstep = (int)p.w_ustride;
 #pragma unroll
     for (int t = 0; t < NTT; ++t) {
         const int tile = (GATED && t >= NT) ? p.T_half + tile0 + (t - NT) : tile0 + t;
         const size_t tl = (size_t)e * T_all + tile;
+        tlv[t] = tl;
         wp[t] = (const u32x4*)p.w + (size_t)e * p.w_estride + (size_t)tile * p.w_tstride + lane;
         auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
+    float wsu[NTT][2];
+    const bool use_wsu = load_unit_scales<D>(p, tlv, lane, wsu);
     const int u0 = (int)((long long)wave * p.U / KW), u1 = (int)((long long)(wave + 1) * p.U / KW);
     const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
 
@@ -598,7 +651,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        Streamer<WF, ADT, NTT, TB>::run(acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
+        LKM_STREAM_RUN(NTT, TB, acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 
         if (KW > 1) {
             // fixed-order cross-wave sum: wave KW-1 stores, KW-2 .. 1 add, wave 0 takes the total
@@ -663,13 +716,17 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 
     const u32x4* wp[NT];
     const char* auxp[NT];
+    size_t tlv[NT];
     const int aux_step = D::aux_step(p.spu), wstep = (int)p.w_ustride;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const size_t tl = (size_t)e * p.T_half + tile0 + t;
+        tlv[t] = tl;
         wp[t] = (const u32x4*)p.w + (size_t)e * p.w_estride + (size_t)(tile0 + t) * p.w_tstride + lane;
         auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
+    float wsu[NT][2];
+    const bool use_wsu = load_unit_scales<D>(p, tlv, lane, wsu);
     const int u0 = (int)((long long)sk * p.U / p.SK), u1 = (int)((long long)(sk + 1) * p.U / p.SK);
     const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
 
@@ -692,7 +749,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        Streamer<WF, ADT, NT, TB>::run(acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
+        LKM_STREAM_RUN(NT, TB, acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
@@ -733,19 +790,24 @@ __global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K)
     if (e >= 0) {
         const u32x4* wp[NT];
         const char* auxp[NT];
+        size_t tlv[NT];
         const int aux_step = D::aux_step(p.spu), wstep = (int)p.w_ustride;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const size_t tl = (size_t)e * p.T_half + tile0 + t;
+            tlv[t] = tl;
             wp[t] = (const u32x4*)p.w + (size_t)e * p.w_estride + (size_t)(tile0 + t) * p.w_tstride + lane;
             auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
         }
+        float wsu[NT][2] = {};
+        constexpr bool use_wsu = false;      // (128-register kernel: the per-row scale loads stay)
+        (void)tlv;
         const int u0 = (int)((long long)sk * p.U / SK), u1 = (int)((long long)(sk + 1) * p.U / SK);
         const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
         constexpr int XB = D::A8 ? 1 : 2;
         const unsigned char* xp[1] = {(const unsigned char*)p.x + (size_t)k * p.ldx * XB};
         const float* xsp[1] = {p.xscale + (size_t)k * p.ld_xscale};
-        Streamer<WF, ADT, NT, 1>::run(acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, 1);
+        LKM_STREAM_RUN(NT, 1, acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, 1);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) ((f32x4*)red)[(wave * NT + t) * 64 + lane] = acc[t][0];
@@ -818,12 +880,17 @@ __global__ __launch_bounds__(64 * MAXW) void gemm2_combine_kernel(GemmParams p) 
         const int m_e = p.counts[e], off_e = p.offsets[e];
         const u32x4* wp[NT];
         const char* auxp[NT];
+        size_t tlv[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const size_t tl = (size_t)e * p.T_half + tile0 + t;
+            tlv[t] = tl;
             wp[t] = (const u32x4*)p.w + (size_t)e * p.w_estride + (size_t)(tile0 + t) * p.w_tstride + lane;
             auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
         }
+        float wsu[NT][2] = {};
+        constexpr bool use_wsu = false;      // (128-register kernel: the per-row scale loads stay)
+        (void)tlv;
         const int u0 = (int)((long long)sk * p.U / SK), u1 = (int)((long long)(sk + 1) * p.U / SK);
         const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
         for (int sb = 0; sb < m_e; sb += 16 * TB) {
@@ -844,7 +911,7 @@ __global__ __launch_bounds__(64 * MAXW) void gemm2_combine_kernel(GemmParams p) 
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            Streamer<WF, ADT, NT, TB>::run(acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
+            LKM_STREAM_RUN(NT, TB, acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
 #pragma unroll
             for (int b = 0; b < TB; ++b) {
                 const int r_tok = sb + b * 16 + j;

@@ -143,3 +143,24 @@ def test_forward_routed_in_graph_and_bf16_out():
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int16), eager.view(torch.int16))
     assert torch.equal(i_g, i_e) and torch.equal(w_g, w_e)
+
+
+@pytest.mark.parametrize("ldt", [torch.float32, torch.bfloat16, torch.float16])
+def test_forward_routed_local_expert_window_and_logit_dtypes(ldt):
+    """the router sees ALL experts (global ids), the engine holds a window of them (expert-parallel rank): ids outside
+    [id_offset, id_offset + E_local) are skipped like -1; logits in the three dtypes the router accepts"""
+    from lvllm_amd import ops
+    E_router, E_local, first, K, H, I, M = 16, 8, 4, 2, 256, 128, 40
+    eng = _engine("bf16", E_local, K, H, I, torch.bfloat16, seed=5)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn((M, H), generator=g) / 10).to(torch.bfloat16).to(DEV)
+    logits = torch.randn((M, E_router), generator=g).to(ldt).to(DEV)
+    out, w, ids = eng.forward_logits(x, logits, K, True, id_offset=first)
+    w0, i0 = ops.topk_softmax(logits, K, True)
+    assert torch.equal(ids, i0) and torch.equal(w.view(torch.int32), w0.view(torch.int32))
+    assert int(((i0 < first) | (i0 >= first + E_local)).sum()) > 0, "the case must contain non-local ids"
+    eng.engine.set_tuning(fuse=-1)
+    base = eng.forward_rows(x, w0, i0, id_offset=first)
+    assert torch.equal(out.view(torch.int32), base.view(torch.int32))
+    local = torch.where((i0 >= first) & (i0 < first + E_local), i0 - first, torch.full_like(i0, -1))
+    assert torch.equal(base, eng.decode(x, w0, local))

@@ -434,31 +434,36 @@ struct Streamer {
                                                  const float* const (&xsp)[TB], int u0, int u1, int Kreal,
                                                  int lane, const float (&wsu)[NTT][2]) {
         const int gk = (lane >> 4) * (16 / XB);
-        St st[2];
+        // PD register stages, loads PD - 1 units ahead of their MFMAs.  (Three stages for the fp8 x fp8 kernels --
+        // +34 registers, twice the weight bytes in flight per wave -- changed nothing: GEMM1 150.8 vs 151.0 us.)
+        constexpr int PD = 2;
+        St st[PD];
         if (u0 >= u1) return;
-        load<NTB, false>(st[0], wp, auxp, aux_step, wstep, xp, xsp, u0, Kreal, gk);
-        // steady pairs: both look-ahead units stay below u1 - 1
-        const int um = u1 - 2 - u0 > 0 ? u0 + (u1 - 2 - u0) / 2 * 2 : u0;
-        int u = u0;
-        for (; u < um; u += 2) {
-            // sched_barrier: the next stage's loads are ISSUED before this stage's MFMAs (the
-            // scheduler otherwise sinks them below the MFMAs that last read those registers and the
-            // prefetch distance shrinks from a stage to a few instructions)
-            load<NTB, true>(st[1], wp, auxp, aux_step, wstep, xp, xsp, u + 1, Kreal, gk);
-            __builtin_amdgcn_sched_barrier(0);
-            compute<NTB>(st[0], acc, spu, u, wsu);
-            __builtin_amdgcn_sched_barrier(0);
-            load<NTB, true>(st[0], wp, auxp, aux_step, wstep, xp, xsp, u + 2, Kreal, gk);
-            __builtin_amdgcn_sched_barrier(0);
-            compute<NTB>(st[1], acc, spu, u + 1, wsu);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        for (; u < u1; u += 2) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+        for (int s0 = 0; s0 < PD - 1; ++s0)
+            if (u0 + s0 < u1) load<NTB, false>(st[s0], wp, auxp, aux_step, wstep, xp, xsp, u0 + s0, Kreal, gk);
+        // steady groups of PD units: every look-ahead unit stays below u1 - 1 (never the possibly ragged last unit)
+        const int n_steady = u1 - PD - u0 > 0 ? (u1 - PD - u0) / PD * PD : 0;
+        int u = u0;
+        for (; u < u0 + n_steady; u += PD) {
+#pragma unroll
+            for (int h = 0; h < PD; ++h) {
+                // sched_barrier: the look-ahead stage's loads are ISSUED before this stage's MFMAs (the scheduler
+                // otherwise sinks them below the MFMAs that last read those registers and the prefetch distance
+                // shrinks from a stage to a few instructions)
+                load<NTB, true>(st[(h + PD - 1) % PD], wp, auxp, aux_step, wstep, xp, xsp, u + h + PD - 1, Kreal, gk);
+                __builtin_amdgcn_sched_barrier(0);
+                compute<NTB>(st[h], acc, spu, u + h, wsu);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        for (; u < u1; u += PD) {
+#pragma unroll
+            for (int h = 0; h < PD; ++h) {
                 const int uu = u + h;
                 if (uu < u1) {
-                    if (uu + 1 < u1) load<NTB, false>(st[h ^ 1], wp, auxp, aux_step, wstep, xp, xsp, uu + 1, Kreal, gk);
+                    if (uu + PD - 1 < u1)
+                        load<NTB, false>(st[(h + PD - 1) % PD], wp, auxp, aux_step, wstep, xp, xsp, uu + PD - 1, Kreal, gk);
                     compute<NTB>(st[h], acc, spu, uu, wsu);
                 }
             }
@@ -556,13 +561,13 @@ __device__ __forceinline__ int direct_expert(const GemmParams& p, int k) {
 }
 
 // fp8 x fp8 with one block scale per (16-row tile, K unit): lane l <- the scales of units l and 64 + l of each tile
-// (Streamer<..., WSU>); false = the per-row scale loads stay (scale granularity below 16 rows, or more than 128 units)
-template <typename D, int N>
-__device__ __forceinline__ bool load_unit_scales(const GemmParams& p, const size_t (&tl)[N], int lane, float (&wsu)[N][2]) {
+// (Streamer<..., WSU>).  WSU is a template parameter of the two decode kernels: a kernel that carries both scale paths
+// needs 198 registers (two waves per SIMD), the specialised one 164 (three).
+template <typename D, int N, bool WSU>
+__device__ __forceinline__ void load_unit_scales(const GemmParams& p, const size_t (&tl)[N], int lane, float (&wsu)[N][2]) {
 #pragma unroll
     for (int t = 0; t < N; ++t) wsu[t][0] = wsu[t][1] = 0.0f;
-    if constexpr (D::A8) {
-        if (!p.tile_uniform_scale || p.U > 128 || (p.dbg & 256)) return false;     // (dbg 256: A/B switch)
+    if constexpr (WSU) {
 #pragma unroll
         for (int t = 0; t < N; ++t) {
             const float* sb = (const float*)p.s + tl[t] * p.U * 16;      // row 0 of (tile, unit 0): 16 floats per unit
@@ -570,27 +575,20 @@ __device__ __forceinline__ bool load_unit_scales(const GemmParams& p, const size
             wsu[t][0] = sb[(size_t)u0 * 16];
             wsu[t][1] = sb[(size_t)u1 * 16];
         }
-        return true;
-    } else {
-        return false;
     }
 }
-// one call site for both streamer variants
-#define LKM_STREAM_RUN(NTT_, TB_, ...)                                                   \
-    do {                                                                                 \
-        if constexpr (D::A8) {                                                           \
-            if (use_wsu) Streamer<WF, ADT, NTT_, TB_, true>::run(__VA_ARGS__, wsu);      \
-            else Streamer<WF, ADT, NTT_, TB_, false>::run(__VA_ARGS__, wsu);             \
-        } else {                                                                         \
-            Streamer<WF, ADT, NTT_, TB_, false>::run(__VA_ARGS__, wsu);                  \
-        }                                                                                \
-    } while (0)
+// the host side of the choice (launchers): fp8 x fp8, one block scale per 16-row tile, at most 128 K units
+template <int WF>
+static bool use_unit_scales(const GemmParams& p) {
+    return WF == LKM_W_FP8_A8 && p.tile_uniform_scale && p.U <= 128 && !(p.dbg & 256);      // (dbg 256: A/B switch)
+}
+#define LKM_STREAM_RUN(NTT_, TB_, ...) Streamer<WF, ADT, NTT_, TB_, WSU>::run(__VA_ARGS__, wsu)
 
 // ------------------------------------------------------------------ GEMM1 + activation
 // grid = (groups, max_active_experts); block = 64*KW threads: the KW waves of a workgroup split K
 // and reduce through LDS (needed when an expert has too few tiles to fill the chip, e.g. M=1).
 // DIRECT (single-token decode): blockIdx.y is the slot; expert = direct_ids[slot], one row, no sort output.
-template <int WF, int ADT, int NT, int TB, bool GATED, bool DIRECT = false>
+template <int WF, int ADT, int NT, int TB, bool GATED, bool DIRECT = false, bool WSU = false>
 __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
     typedef Dec<WF, ADT> D;
     constexpr int NTT = GATED ? 2 * NT : NT;
@@ -627,7 +625,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
         auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
     float wsu[NTT][2];
-    const bool use_wsu = load_unit_scales<D>(p, tlv, lane, wsu);
+    load_unit_scales<D, NTT, WSU>(p, tlv, lane, wsu);
     const int u0 = (int)((long long)wave * p.U / KW), u1 = (int)((long long)(wave + 1) * p.U / KW);
     const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
 
@@ -699,7 +697,7 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
 
 // ------------------------------------------------------------------ GEMM2 (split-K partials)
 // grid = (ceil(groups*SK / 4), max_active_experts); block = 256 = 4 independent waves.
-template <int WF, int ADT, int NT, int TB>
+template <int WF, int ADT, int NT, int TB, bool WSU = false>
 __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
     typedef Dec<WF, ADT> D;
     const int ai = blockIdx.y;
@@ -726,7 +724,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
         auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
     }
     float wsu[NT][2];
-    const bool use_wsu = load_unit_scales<D>(p, tlv, lane, wsu);
+    load_unit_scales<D, NT, WSU>(p, tlv, lane, wsu);
     const int u0 = (int)((long long)sk * p.U / p.SK), u1 = (int)((long long)(sk + 1) * p.U / p.SK);
     const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
 
@@ -800,7 +798,7 @@ __global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K)
             auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
         }
         float wsu[NT][2] = {};
-        constexpr bool use_wsu = false;      // (128-register kernel: the per-row scale loads stay)
+        constexpr bool WSU = false;      // (128-register kernels: the per-row scale loads stay)
         (void)tlv;
         const int u0 = (int)((long long)sk * p.U / SK), u1 = (int)((long long)(sk + 1) * p.U / SK);
         const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
@@ -889,7 +887,7 @@ __global__ __launch_bounds__(64 * MAXW) void gemm2_combine_kernel(GemmParams p) 
             auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
         }
         float wsu[NT][2] = {};
-        constexpr bool use_wsu = false;      // (128-register kernel: the per-row scale loads stay)
+        constexpr bool WSU = false;      // (128-register kernels: the per-row scale loads stay)
         (void)tlv;
         const int u0 = (int)((long long)sk * p.U / SK), u1 = (int)((long long)(sk + 1) * p.U / SK);
         const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
@@ -1000,14 +998,16 @@ static int launch_g1_t(hipStream_t st, const GemmParams& p, bool gated, int kw, 
     }
     if (gated) {
         if constexpr (NT <= 2 && NT * TB <= 4) {
-            hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, true>), grid, block, lds, st, p);
+            if (use_unit_scales<WF>(p)) hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, true, false, WF == LKM_W_FP8_A8>), grid, block, lds, st, p);
+            else hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, true>), grid, block, lds, st, p);
         } else {
             set_error("gemm1: gated variant nt=%d tb=%d is not built (register budget)", NT, TB);
             return LKM_E_INVALID;
         }
     } else {
         if constexpr (NT * TB <= 8) {
-            hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, false>), grid, block, lds, st, p);
+            if (use_unit_scales<WF>(p)) hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, false, false, WF == LKM_W_FP8_A8>), grid, block, lds, st, p);
+            else hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, false>), grid, block, lds, st, p);
         } else {
             set_error("gemm1: variant nt=%d tb=%d is not built (register budget)", NT, TB);
             return LKM_E_INVALID;
@@ -1043,7 +1043,8 @@ static int launch_g2_t(hipStream_t st, const GemmParams& p, int max_active) {
     }
     dim3 grid(ceil_div(p.groups * p.SK, 4), max_active), block(256);
     if constexpr (NT * TB <= 8) {
-        hipLaunchKernelGGL((gemm2_kernel<WF, ADT, NT, TB>), grid, block, 0, st, p);
+        if (use_unit_scales<WF>(p)) hipLaunchKernelGGL((gemm2_kernel<WF, ADT, NT, TB, WF == LKM_W_FP8_A8>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm2_kernel<WF, ADT, NT, TB>), grid, block, 0, st, p);
     } else {
         set_error("gemm2: variant nt=%d tb=%d is not built (register budget)", NT, TB);
         return LKM_E_INVALID;

@@ -690,7 +690,10 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
     int sk = 1;
     {
         long long waves = (long long)n_act * (h->T2 / nt2);
-        while (sk < 8 && waves * sk < kMinWaves && h->U2 / (sk * 2) >= 2) sk *= 2;
+        // fp8 x fp8 with two tiles per wave: 1024 waves of the 164-register kernel (three per SIMD) already cover the
+        // chip; splitting K only adds slab traffic (Mixtral fp8-W8A8 M=32: GEMM2 78.6 -> 75.0 us at sk 1)
+        const long long min_waves = h->a8 ? kMinWaves / 2 : kMinWaves;
+        while (sk < 8 && waves * sk < min_waves && h->U2 / (sk * 2) >= 2) sk *= 2;
     }
     if (h->t_sk2 > 0) sk = h->t_sk2;
     if (split) sk = 1;   // the tiled GEMM2 writes slab 0 only

@@ -698,7 +698,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    ctx = dict(world=world, rank=rank, dev=dev, dist=use_dist, wd=Watchdog(rank) if world > 1 else None)
+    ctx = dict(world=world, rank=rank, dev=dev, dist=use_dist, wd=Watchdog(rank) if (world > 1 or (use_dist and os.environ.get("LKM_BENCH_WATCHDOG") == "1")) else None)
 
     head = run_workload(args.workload, args, ctx, steps=args.steps, warmup=args.warmup,
                         with_cpu=not args.no_cpu_baseline, force_ep=args.force_ep)

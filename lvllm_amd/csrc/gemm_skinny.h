@@ -584,6 +584,11 @@ static bool use_unit_scales(const GemmParams& p) {
 }
 #define LKM_STREAM_RUN(NTT_, TB_, ...) Streamer<WF, ADT, NTT_, TB_, WSU>::run(__VA_ARGS__, wsu)
 
+template <int I>
+struct SlotsC {
+    static constexpr int v = I;
+};
+
 // ------------------------------------------------------------------ GEMM1 + activation
 // grid = (groups, max_active_experts); block = 64*KW threads: the KW waves of a workgroup split K
 // and reduce through LDS (needed when an expert has too few tiles to fill the chip, e.g. M=1).
@@ -596,7 +601,45 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
     const int ai = blockIdx.y;
     int e, m_e, off_e;
     if constexpr (DIRECT) {
-        e = direct_expert(p, ai);
+        if (p.route_on) {
+            // the router of the one row, by the first wavefront of EVERY workgroup (the same device code as the router
+            // kernels, so the same bits); selection k sits in lane k
+            __shared__ int32_t sh_id[64];
+            __shared__ float sh_ch[kMaxSlots * 64];
+            if ((threadIdx.x >> 6) == 0) {
+                const int ln = threadIdx.x & 63;
+                float w = 0.0f;
+                int id = -1;
+                const RouteArgs& ra = p.route;
+                auto go = [&](auto SC) __attribute__((always_inline)) {
+                    constexpr int S = decltype(SC)::v;
+                    if (ra.n_group > 0)
+                        grouped_topk_row<S>(ra.src, ra.bias, 0, ra.E, ra.K, ra.n_group, ra.topk_group, ra.scoring, ra.renorm,
+                                            ra.rsf, ln, sh_ch, w, id);
+                    else
+                        topk_row<S, 64>(ra.src, ra.bias, 0, ra.E, ra.K, ra.scoring, ra.renorm, ra.rsf, ln, w, id);
+                };
+                switch (route_slots(ra.E)) {
+                case 1: go(SlotsC<1>{}); break;
+                case 2: go(SlotsC<2>{}); break;
+                case 4: go(SlotsC<4>{}); break;
+                default: go(SlotsC<8>{}); break;
+                }
+                if (ln < ra.K) {
+                    sh_id[ln] = id;
+                    if (blockIdx.x == 0 && blockIdx.y == 0) {
+                        ra.out_ids[ln] = id;
+                        ra.out_w[ln] = w;
+                    }
+                }
+            }
+            __syncthreads();
+            e = sh_id[ai];
+            if (e >= 0) e -= p.direct_id_off;
+            if (e < 0 || e >= p.direct_E) e = -1;
+        } else {
+            e = direct_expert(p, ai);
+        }
         if (e < 0) return;
         m_e = 1;
         off_e = ai;

@@ -758,6 +758,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     const bool want_xcd = tile_rows && max_tiles <= 4096 && (h->t_xcd > 0 || pl.xcd1 || pl.xcd2);
     const int xcd_cap = want_xcd ? 2 * ((max_tiles + 7) / 8) + 1 : 0;
     if (!direct && il.route) {
+        LKM_REQUIRE(M > 1, "forward_routed: single-token step planned off the direct path");
         rc = launch_route_sort(st, *il.route, il.id_off, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
                                a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, xcd_cap);
         if (rc != LKM_OK) return rc;
@@ -815,6 +816,10 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         p1.direct_w = tw;
         p1.direct_E = h->E;
         p1.direct_id_off = il.id_off;
+        if (il.route) {          // lkm_forward_routed at M = 1: GEMM1 routes the row itself (ids / tw = its outputs)
+            p1.route_on = 1;
+            p1.route = *il.route;
+        }
     }
     for (int r = 0; r < rep; ++r) {
         if (pl.s1.tb) {
@@ -1025,8 +1030,14 @@ extern "C" int lkm_forward_routed(LkmHandle h, void* stream, int32_t num_tokens,
     if (M == 0) return LKM_OK;
     LKM_REQUIRE(router_logits && topk_weights_out && topk_ids_out, "forward_routed: null device pointer");
     // one chunk, batched path: the router rides in the sort launch; otherwise the two calls it stands for
-    const bool fused = M > 1 && launch_route_sort_ok(M, K, E, n_group, h->E) && h->t_fuse >= 0 &&
-                       chunk_tokens(h, K) >= (size_t)M;
+    bool fused = M > 1 && launch_route_sort_ok(M, K, E, n_group, h->E) && h->t_fuse >= 0 &&
+                 chunk_tokens(h, K) >= (size_t)M;
+    if (M == 1 && h->t_fuse >= 0 && chunk_tokens(h, K) >= 1) {
+        // single token: the direct path (two launches) routes inside GEMM1 -- when the plan takes that path
+        Plan pl;
+        pick_cfg(h, 1, (size_t)K, &pl);
+        fused = K <= 16 && pl.s1.tb == 1 && pl.s1.nt == 1 && !pl.t1.tiled && h->t_direct >= 0;
+    }
     InLayout il{hidden_ld, K, K, id_offset};
     if (!fused) {
         int rc = n_group > 0 ? lkm_grouped_topk(stream, router_logits, logits_dtype, score_bias, M, E, K, n_group,

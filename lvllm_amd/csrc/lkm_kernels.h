@@ -2,6 +2,7 @@
 // liblkm.so (kernels live in routing.hip / dispatch.hip / repack.hip / gemm_skinny.hip).
 #pragma once
 #include "lkm_common.h"
+#include "routing_dev.h"
 
 namespace lkm {
 
@@ -30,7 +31,6 @@ int launch_sort(hipStream_t st, const int32_t* ids, int top_k, int ids_ld, int i
                 int32_t* hist, size_t hist_cap, int xcd_cap = 0);
 // router + sort in one launch for decode batches (RouteArgs: routing_dev.h); same outputs as the router kernel
 // followed by launch_sort
-struct RouteArgs;
 bool launch_route_sort_ok(int M, int K, int E_router, int n_group, int E_local);
 int launch_route_sort(hipStream_t st, const RouteArgs& ra, int id_offset, int E, int32_t* counts, int32_t* offsets,
                       int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active, int32_t* meta, int tile_rows,
@@ -101,6 +101,11 @@ struct GemmParams {
     // weights [comb_M][comb_tw_ld]
     const int32_t* comb_pos;     // pos_of_slot [comb_M * top_k]
     int comb_M, comb_tw_ld;
+    // single-token decode through lkm_forward_routed: the direct GEMM1 routes the one row itself (every workgroup, on
+    // its first wavefront: ~2 us under the start of the weight stream instead of a router launch and its gap);
+    // workgroup (0, 0) also stores the ids / weights for GEMM2 and the caller (direct_ids / direct_w point at them)
+    int route_on;
+    RouteArgs route;
     long long x_rows;  // rows of the activation matrix behind `x` (bounds of the LDS-DMA buffer window)
     int xcd_map;       // tiled kernels: != 0 -> XCD-aware 1-D work mapping.  Host side: the longest run of tiles one
                        // XCD may get (launch_sort's xcd_cap); the launcher replaces it by the row-group count

@@ -81,6 +81,8 @@ def test_gemm2_combine_fused_equals_two_launches(fmt, M, E, K, H, I):
     (128, 8, 2, "softmax", False, None), (5, 128, 8, "softmax", False, None), (64, 16, 4, "sigmoid", False, None),
     (33, 64, 6, "sigmoid", True, (8, 4)), (128, 256, 8, "sigmoid", True, (8, 4)), (16, 32, 4, "softmax", False, (4, 2)),
     (600, 8, 2, "softmax", False, None), (1, 8, 2, "softmax", False, None),
+    (1, 128, 8, "softmax", False, None), (1, 256, 8, "sigmoid", True, (8, 4)), (1, 64, 6, "sigmoid", True, None),
+    (1, 512, 8, "softmax", False, None),
 ])
 def test_forward_routed_equals_router_then_forward(M, E, K, scoring, bias, grouped):
     """lkm_forward_routed == lkm_topk_softmax / lkm_grouped_topk followed by lkm_forward_strided, bit for bit

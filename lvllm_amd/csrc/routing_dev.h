@@ -111,6 +111,51 @@ __device__ __forceinline__ void wave_argmax(float& bv, int& be, float& bp) {
     }
 }
 
+// Maximum over the 64 lanes by DPP (no LDS crossbar: ~10 cycles a step instead of ~100 for a ds_bpermute butterfly):
+// inclusive prefix maximum inside each row of 16 (row_shr 1, 2, 4, 8; lanes without a source keep -inf), then the
+// rows' last lanes fan out (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3): lane 63 holds the maximum.
+// The maximum is exact in any order, so the bits of the selection do not depend on how it is reduced.
+__device__ __forceinline__ float wave_max64(float v) {
+    const int ninf = __builtin_bit_cast(int, -__builtin_inff());
+#define LKM_DPP_MAX(CTRL, RMASK)                                                                              \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v), CTRL, \
+                                                                       RMASK, 0xf, false)))
+    LKM_DPP_MAX(0x111, 0xf);
+    LKM_DPP_MAX(0x112, 0xf);
+    LKM_DPP_MAX(0x114, 0xf);
+    LKM_DPP_MAX(0x118, 0xf);
+    LKM_DPP_MAX(0x142, 0xa);
+    LKM_DPP_MAX(0x143, 0xc);
+#undef LKM_DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// One selection round of a row held by a whole wavefront: the largest ch (lowest expert index among equals, like the
+// butterfly's tie rule) -> (be, bp = its score), and that entry is struck out.  Wave maximum by DPP, the index by a
+// ballot per register slot (slot-major = expert order) and a scalar find-first, the payload by v_readlane: a round is
+// ~200 cycles instead of six dependent 3-value shuffles.
+template <int SLOTS>
+__device__ __forceinline__ void select_max64(float (&ch)[SLOTS], const float (&sc)[SLOTS], int lane, int& be, float& bp) {
+    float m = ch[0];
+#pragma unroll
+    for (int s = 1; s < SLOTS; ++s) m = fmaxf(m, ch[s]);
+    const float vmax = wave_max64(m);
+    bool found = false;
+    be = 0;
+    bp = 0.0f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const unsigned long long mk = __ballot(ch[s] == vmax);
+        if (!found && mk != 0ull) {                       // wave-uniform
+            const int L = __ffsll((long long)mk) - 1;
+            be = s * 64 + L;
+            bp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc[s]), L));
+            if (lane == L) ch[s] = -__builtin_inff();
+            found = true;
+        }
+    }
+}
+
 // Plain top-k of one row (softmax / sigmoid scores, optional selection bias).  Lane sub == k of the row's group
 // (k < K <= LPR) returns selection k in (w, id): the weight is final (renormalised, scaled).
 template <int SLOTS, int LPR>
@@ -132,25 +177,32 @@ __device__ __forceinline__ void topk_row(const LogitSrc& src, const float* __res
     w = 0.0f;
     id = -1;
     for (int k = 0; k < K; ++k) {
-        float bv = ch[0], bp = sc[0];
-        int be = sub;
+        float bp;
+        int be;
+        if constexpr (LPR == 64) {
+            select_max64<SLOTS>(ch, sc, sub, be, bp);
+        } else {
+            float bv = ch[0];
+            bp = sc[0];
+            be = sub;
 #pragma unroll
-        for (int s = 1; s < SLOTS; ++s) {
-            if (ch[s] > bv) {
-                bv = ch[s];
-                bp = sc[s];
-                be = s * LPR + sub;
+            for (int s = 1; s < SLOTS; ++s) {
+                if (ch[s] > bv) {
+                    bv = ch[s];
+                    bp = sc[s];
+                    be = s * LPR + sub;
+                }
             }
+            wave_argmax<LPR>(bv, be, bp);
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (be == s * LPR + sub) ch[s] = -__builtin_inff();
         }
-        wave_argmax<LPR>(bv, be, bp);
         if (sub == k) {
             w = bp;
             id = be;
         }
         if (renorm) sel_sum += bp;       // ascending k, the same value in every lane of the group
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
-            if (be == s * LPR + sub) ch[s] = -__builtin_inff();
     }
     float scale = rsf;
     if (renorm) scale /= (sel_sum > 0.0f ? sel_sum : 1.0f);  // :581-592
@@ -201,13 +253,13 @@ __device__ __forceinline__ void grouped_topk_row(const LogitSrc& src, const floa
     unsigned long long keep = 0ull;
     bool taken = !(lane < n_group);
     for (int t = 0; t < topk_group; ++t) {
-        // lanes already taken / out of range must never win, not even on ties with -inf values
-        float bv = gs, bp = 0.0f;
-        int be = taken ? (1 << 20) + lane : lane;
-        if (taken) bv = -__builtin_inff();
-        wave_argmax<64>(bv, be, bp);
-        keep |= 1ull << (be & 63);
-        if (lane == be) taken = true;
+        // lanes already taken / out of range must never win, not even on ties with -inf values: they are left out of
+        // the ballot (lowest lane among the equal maxima of the lanes still in play)
+        const float vmax = wave_max64(taken ? -__builtin_inff() : gs);
+        const unsigned long long mk = __ballot(!taken && gs == vmax);
+        const int L = mk != 0ull ? __ffsll((long long)mk) - 1 : 0;
+        keep |= 1ull << L;
+        if (lane == L) taken = true;
     }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -218,25 +270,14 @@ __device__ __forceinline__ void grouped_topk_row(const LogitSrc& src, const floa
     w = 0.0f;
     id = -1;
     for (int k = 0; k < K; ++k) {
-        float bv = ch[0], bp = sc[0];
-        int be = lane;
-#pragma unroll
-        for (int s = 1; s < SLOTS; ++s) {
-            if (ch[s] > bv) {
-                bv = ch[s];
-                bp = sc[s];
-                be = s * 64 + lane;
-            }
-        }
-        wave_argmax<64>(bv, be, bp);
+        float bp;
+        int be;
+        select_max64<SLOTS>(ch, sc, lane, be, bp);
         if (lane == k) {
             w = bp;
             id = be;
         }
         sum += bp;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
-            if (be == s * 64 + lane) ch[s] = -__builtin_inff();
     }
     if (renorm) w = w / sum;
     if (rsf != 1.0f) w = w * rsf;

@@ -53,6 +53,25 @@ struct LogitSrc {
 template <int LPR, typename T>
 __device__ __forceinline__ T group_xor(T v, int m) { return __shfl_xor(v, m, 64); }
 
+// Maximum over the 64 lanes by DPP (no LDS crossbar: ~10 cycles a step instead of ~100 for a ds_bpermute butterfly):
+// inclusive prefix maximum inside each row of 16 (row_shr 1, 2, 4, 8; lanes without a source keep -inf), then the
+// rows' last lanes fan out (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3): lane 63 holds the maximum.
+// The maximum is exact in any order, so the bits of the selection do not depend on how it is reduced.
+__device__ __forceinline__ float wave_max64(float v) {
+    const int ninf = __builtin_bit_cast(int, -__builtin_inff());
+#define LKM_DPP_MAX(CTRL, RMASK)                                                                              \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v), CTRL, \
+                                                                       RMASK, 0xf, false)))
+    LKM_DPP_MAX(0x111, 0xf);
+    LKM_DPP_MAX(0x112, 0xf);
+    LKM_DPP_MAX(0x114, 0xf);
+    LKM_DPP_MAX(0x118, 0xf);
+    LKM_DPP_MAX(0x142, 0xa);
+    LKM_DPP_MAX(0x143, 0xc);
+#undef LKM_DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // scores for one row, in registers: sc[s] = score of expert s*LPR+sub (0 for e >= E)
 template <int SLOTS, int LPR>
 __device__ __forceinline__ void row_scores(const LogitSrc& src, int row, int E, int sub,
@@ -68,8 +87,12 @@ __device__ __forceinline__ void row_scores(const LogitSrc& src, int row, int E, 
         float mx = v[0];
 #pragma unroll
         for (int s = 1; s < SLOTS; ++s) mx = fmaxf(mx, v[s]);
+        if constexpr (LPR == 64) {
+            mx = wave_max64(mx);             // exact in any order (the SUM below keeps the butterfly: its order is part of the bits)
+        } else {
 #pragma unroll
-        for (int m = LPR / 2; m > 0; m >>= 1) mx = fmaxf(mx, group_xor<LPR>(mx, m));
+            for (int m = LPR / 2; m > 0; m >>= 1) mx = fmaxf(mx, group_xor<LPR>(mx, m));
+        }
         float sum = 0.0f;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
@@ -109,25 +132,6 @@ __device__ __forceinline__ void wave_argmax(float& bv, int& be, float& bp) {
             bp = op;
         }
     }
-}
-
-// Maximum over the 64 lanes by DPP (no LDS crossbar: ~10 cycles a step instead of ~100 for a ds_bpermute butterfly):
-// inclusive prefix maximum inside each row of 16 (row_shr 1, 2, 4, 8; lanes without a source keep -inf), then the
-// rows' last lanes fan out (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3): lane 63 holds the maximum.
-// The maximum is exact in any order, so the bits of the selection do not depend on how it is reduced.
-__device__ __forceinline__ float wave_max64(float v) {
-    const int ninf = __builtin_bit_cast(int, -__builtin_inff());
-#define LKM_DPP_MAX(CTRL, RMASK)                                                                              \
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ninf, __builtin_bit_cast(int, v), CTRL, \
-                                                                       RMASK, 0xf, false)))
-    LKM_DPP_MAX(0x111, 0xf);
-    LKM_DPP_MAX(0x112, 0xf);
-    LKM_DPP_MAX(0x114, 0xf);
-    LKM_DPP_MAX(0x118, 0xf);
-    LKM_DPP_MAX(0x142, 0xa);
-    LKM_DPP_MAX(0x143, 0xc);
-#undef LKM_DPP_MAX
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // One selection round of a row held by a whole wavefront: the largest ch (lowest expert index among equals, like the

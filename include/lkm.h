@@ -181,8 +181,9 @@ int lkm_grouped_topk(void* stream, const void* logits, int32_t logits_dtype, con
  * (n_group > 0) on `router_logits` [M, router_experts], then lkm_forward_strided on its result.  Same outputs, bit
  * for bit, as the two calls made one after the other; for decode batches (M * top_k <= 1024, router_experts <= 256,
  * at most two passes of one workgroup over the rows) the router and the token->expert scatter metadata come out of ONE
- * launch, and for a single token (M = 1, top_k <= 16) the first wavefront of every GEMM1 workgroup routes the row
- * itself: the whole step is two launches.  topk_weights_out [M,K] fp32 and
+ * launch, and for one to four tokens (top_k <= 16, experts small enough that a repeated expert costs less than two
+ * launches: always at M = 1) the first wavefront of every GEMM1 workgroup routes its token's row itself and GEMM2 forms
+ * the weighted sum per token: the whole step is two launches.  topk_weights_out [M,K] fp32 and
  * topk_ids_out [M,K] int32 (the router's global ids) are always written: callers need them for EPLB load recording
  * and shared-expert handling.  id_offset as in lkm_forward_strided.  DEVICE pointers, asynchronous, capturable.
  */

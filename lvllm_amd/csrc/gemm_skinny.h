@@ -611,13 +611,14 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
                 float w = 0.0f;
                 int id = -1;
                 const RouteArgs& ra = p.route;
+                const int rrow = ai / ra.K;          // this workgroup's token (slot ai = token * K + k)
                 auto go = [&](auto SC) __attribute__((always_inline)) {
                     constexpr int S = decltype(SC)::v;
                     if (ra.n_group > 0)
-                        grouped_topk_row<S>(ra.src, ra.bias, 0, ra.E, ra.K, ra.n_group, ra.topk_group, ra.scoring, ra.renorm,
-                                            ra.rsf, ln, sh_ch, w, id);
+                        grouped_topk_row<S>(ra.src, ra.bias, rrow, ra.E, ra.K, ra.n_group, ra.topk_group, ra.scoring,
+                                            ra.renorm, ra.rsf, ln, sh_ch, w, id);
                     else
-                        topk_row<S, 64>(ra.src, ra.bias, 0, ra.E, ra.K, ra.scoring, ra.renorm, ra.rsf, ln, w, id);
+                        topk_row<S, 64>(ra.src, ra.bias, rrow, ra.E, ra.K, ra.scoring, ra.renorm, ra.rsf, ln, w, id);
                 };
                 switch (route_slots(ra.E)) {
                 case 1: go(SlotsC<1>{}); break;
@@ -627,14 +628,14 @@ __global__ __launch_bounds__(512) void gemm1_act_kernel(GemmParams p) {
                 }
                 if (ln < ra.K) {
                     sh_id[ln] = id;
-                    if (blockIdx.x == 0 && blockIdx.y == 0) {
-                        ra.out_ids[ln] = id;
-                        ra.out_w[ln] = w;
+                    if (blockIdx.x == 0 && ai % ra.K == 0) {      // one workgroup per token publishes its routing
+                        ra.out_ids[(size_t)rrow * ra.K + ln] = id;
+                        ra.out_w[(size_t)rrow * ra.K + ln] = w;
                     }
                 }
             }
             __syncthreads();
-            e = sh_id[ai];
+            e = sh_id[ai % p.route.K];
             if (e >= 0) e -= p.direct_id_off;
             if (e < 0 || e >= p.direct_E) e = -1;
         } else {
@@ -819,12 +820,13 @@ __global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K)
     const int g = lane >> 4, j = lane & 15;
     const int SK = p.SK;
     const int k = wave / SK, sk = wave % SK;
-    const int e = direct_expert(p, k);
+    const int tok = blockIdx.y, slot0 = tok * K;          // a few tokens: one grid row each, slots tok*K .. tok*K+K-1
+    const int e = direct_expert(p, slot0 + k);
     const int tile0 = blockIdx.x * NT;
     // slot k's routing weight, fetched under the weight stream (a first-touch global load after the barrier would add
     // its whole latency to this latency-bound launch); handed to the summing lanes through LDS
     float* redw = red + (size_t)blockDim.x * NT * 4;      // [K] behind the partials
-    const float wk = (sk == 0 && e >= 0) ? p.direct_w[k] : 0.0f;
+    const float wk = (sk == 0 && e >= 0) ? p.direct_w[slot0 + k] : 0.0f;
     f32x4 acc[NT][1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -846,8 +848,8 @@ __global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K)
         const int u0 = (int)((long long)sk * p.U / SK), u1 = (int)((long long)(sk + 1) * p.U / SK);
         const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
         constexpr int XB = D::A8 ? 1 : 2;
-        const unsigned char* xp[1] = {(const unsigned char*)p.x + (size_t)k * p.ldx * XB};
-        const float* xsp[1] = {p.xscale + (size_t)k * p.ld_xscale};
+        const unsigned char* xp[1] = {(const unsigned char*)p.x + (size_t)(slot0 + k) * p.ldx * XB};
+        const float* xsp[1] = {p.xscale + (size_t)(slot0 + k) * p.ld_xscale};
         LKM_STREAM_RUN(NT, 1, acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, 1);
     }
 #pragma unroll
@@ -862,12 +864,12 @@ __global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K)
         if (n >= p.n_real) continue;
         f32x4 out = {0.f, 0.f, 0.f, 0.f};
         for (int kk = 0; kk < K; ++kk) {
-            if (direct_expert(p, kk) < 0) continue;
+            if (direct_expert(p, slot0 + kk) < 0) continue;
             f32x4 v = ((const f32x4*)red)[((kk * SK) * NT + t) * 64 + lane];
             for (int s = 1; s < SK; ++s) v += ((const f32x4*)red)[((kk * SK + s) * NT + t) * 64 + lane];
             out += redw[kk] * v;
         }
-        OutT* o = (OutT*)p.out + n;
+        OutT* o = (OutT*)p.out + (size_t)tok * p.ldo + n;
         if (n + 4 <= p.n_real) {
             store4<OutT>(o, out);
         } else {
@@ -1006,7 +1008,7 @@ template <int WF, int ADT>
 static int launch_g2_direct_t(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, int K) {
     const int waves = K * p.SK;
     LKM_REQUIRE(waves >= 1 && waves <= 16, "gemm2 direct: K*sk=%d waves do not fit one workgroup", waves);
-    dim3 grid(p.T_half / cfg.nt), block(64 * waves);
+    dim3 grid(p.T_half / cfg.nt, (unsigned)(p.x_rows / K)), block(64 * waves);      // x_rows = M * K slots
     const size_t lds = (size_t)waves * cfg.nt * 64 * sizeof(f32x4) + 16 * sizeof(float);
     typedef typename std::conditional<ADT == LKM_DT_BF16, bf16_out, f16_out>::type ActOut;
 #define LKM_G2D(NT)                                                                                       \

@@ -703,6 +703,24 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
     pl->s2 = LaunchCfg{nt2, tb, 1, sk, 0, 0, 0, 0};
 }
 
+// the no-scatter decode path (run_chunk): at most four tokens, streamer geometry of one tile / one token block per wave
+constexpr int kDirectMaxTokens = 4;      // (tuning key "direct": -1 off, n > 0 = at most n tokens, up to 16)
+static int direct_max_tokens(const LkmEngine* h) {
+    return h->t_direct < 0 ? 0 : (h->t_direct > 0 ? (h->t_direct < 16 ? h->t_direct : 16) : kDirectMaxTokens);
+}
+static bool direct_plan(const LkmEngine* h, int M, int K, const Plan& pl) {
+    if (!(M >= 1 && M <= direct_max_tokens(h) && K <= 16 && pl.s1.tb == 1 && pl.s1.nt == 1 && !pl.t1.tiled && !pl.t2.tiled))
+        return false;
+    if (M == 1 || h->t_direct > 0) return true;      // (an explicit token limit is taken at its word: experiments)
+    // Without the scatter every SLOT streams its expert: two tokens that pick the same expert read it twice.  Expected
+    // repeats across tokens ~ C(M,2) K^2 / E, each costing one expert's bytes at ~6.5 TB/s, against the ~6 us the two
+    // saved launches are worth.  Many small experts (Qwen3-30B-A3B: 9.4 MB each, M <= 4; measured 35.6 vs 45.4 us at
+    // M = 2, 55 vs 66 at M = 4) take the path, few large ones (Mixtral: 352 MB each; M = 3: 319 vs 226 us) do not.
+    const double repeats = 0.5 * M * (M - 1) * (double)K * K / (double)h->E;
+    const double expert_us = (double)h->weight_bytes / (double)h->E / 6.5e6;
+    return repeats * expert_us <= 6.0;
+}
+
 // strides (elements) of the three input arrays and the id offset of lkm_forward_strided
 struct InLayout {
     int64_t x_ld, ids_ld, tw_ld;
@@ -741,16 +759,17 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         if (rc != LKM_OK) return rc;
     }
     const int tile_rows = pl.t1.tiled ? pl.t1.tiled : pl.t2.tiled;
-    // Single-token decode: the K slots of the one token are K distinct experts, so the scatter is the
-    // identity: GEMM1 reads the router's ids itself (one workgroup row per slot) and GEMM2 multiplies all K
-    // slots and forms the weighted sum in one workgroup -- two launches instead of four (Qwen3-30B-A3B
-    // M=1: 38 -> 2x us is launch latency, not bandwidth).
+    // Decode of one to four tokens: no scatter -- GEMM1 reads the router's ids itself (one workgroup row per SLOT, the
+    // token's row as B operand) and GEMM2 multiplies the K slots of a token and forms the weighted sum in one workgroup
+    // (grid row = token): two launches instead of four.  (Qwen3-30B-A3B M=1: 38 -> 32 us: launch latency, not bandwidth.
+    // Two tokens that pick the same expert stream its weights twice -- concurrently, out of L2 -- which is why this stops
+    // at four tokens.)
     int sk_direct = 1;
-    if (M == 1 && K <= 16) {
-        const long long waves = (long long)K * (h->T2 / 1);
+    if (M <= direct_max_tokens(h) && K <= 16) {
+        const long long waves = (long long)n_slots * (h->T2 / 1);
         while (sk_direct * 2 * K <= 16 && waves * sk_direct < 2048 && h->U2 / (sk_direct * 2) >= 2) sk_direct *= 2;
     }
-    const bool direct = M == 1 && K <= 16 && pl.s1.tb == 1 && pl.s1.nt == 1 && !pl.t1.tiled && h->t_direct >= 0;
+    const bool direct = direct_plan(h, M, K, pl) && il.ids_ld == K && il.tw_ld == K;
     const int max_active = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
     const int max_tiles = tile_rows ? (int)(n_slots / tile_rows) + max_active : 0;
     // XCD-aware mapping: the sort kernel cuts the tile list into 8 runs of equal routed rows, none longer than
@@ -758,7 +777,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     const bool want_xcd = tile_rows && max_tiles <= 4096 && (h->t_xcd > 0 || pl.xcd1 || pl.xcd2);
     const int xcd_cap = want_xcd ? 2 * ((max_tiles + 7) / 8) + 1 : 0;
     if (!direct && il.route) {
-        LKM_REQUIRE(M > 1, "forward_routed: single-token step planned off the direct path");
+        LKM_REQUIRE(launch_route_sort_ok(M, K, il.route->E, il.route->n_group, h->E), "forward_routed: step planned off both fused paths");
         rc = launch_route_sort(st, *il.route, il.id_off, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
                                a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, xcd_cap);
         if (rc != LKM_OK) return rc;
@@ -824,7 +843,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     for (int r = 0; r < rep; ++r) {
         if (pl.s1.tb) {
             p1.groups = h->T1_half / pl.s1.nt;
-            rc = launch_gemm1(st, h->wfk, h->adt, pl.s1, p1, h->gated, direct ? K : max_active);
+            rc = launch_gemm1(st, h->wfk, h->adt, pl.s1, p1, h->gated, direct ? (int)n_slots : max_active);
             if (rc != LKM_OK) return rc;
         }
         if (pl.t1.tiled) {
@@ -900,8 +919,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
             h->prof_valid = true;
         }
         snprintf(h->last_desc, sizeof(h->last_desc),
-                 "M=1 K=%d | direct (no sort / combine launch) | skinny g1 nt=1 tb=1 kw=%d, g2+combine nt=1 sk=%d | nt_loads=1",
-                 K, pl.s1.kw, sk_direct);
+                 "M=%d K=%d | direct (no sort / combine launch) | skinny g1 nt=1 tb=1 kw=%d, g2+combine nt=1 sk=%d | nt_loads=1",
+                 M, K, pl.s1.kw, sk_direct);
         return LKM_OK;
     }
     // few active experts (Mixtral-class decode): GEMM2 and the top-k combine in one launch -- the waves of a workgroup
@@ -1032,11 +1051,11 @@ extern "C" int lkm_forward_routed(LkmHandle h, void* stream, int32_t num_tokens,
     // one chunk, batched path: the router rides in the sort launch; otherwise the two calls it stands for
     bool fused = M > 1 && launch_route_sort_ok(M, K, E, n_group, h->E) && h->t_fuse >= 0 &&
                  chunk_tokens(h, K) >= (size_t)M;
-    if (M == 1 && h->t_fuse >= 0 && chunk_tokens(h, K) >= 1) {
-        // single token: the direct path (two launches) routes inside GEMM1 -- when the plan takes that path
+    if (M <= direct_max_tokens(h) && h->t_fuse >= 0 && chunk_tokens(h, K) >= (size_t)M) {
+        // one to four tokens: the direct path (two launches) routes inside GEMM1 -- when the plan takes that path
         Plan pl;
-        pick_cfg(h, 1, (size_t)K, &pl);
-        fused = K <= 16 && pl.s1.tb == 1 && pl.s1.nt == 1 && !pl.t1.tiled && h->t_direct >= 0;
+        pick_cfg(h, M, (size_t)M * K, &pl);
+        if (direct_plan(h, M, K, pl)) fused = true;
     }
     InLayout il{hidden_ld, K, K, id_offset};
     if (!fused) {

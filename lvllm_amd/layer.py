@@ -122,9 +122,10 @@ class RoutedExpertsLayer:
         r = self.routing
         if (self.gate_weight is None and router_logits is not None and self.eplb_state is None
                 and self.shared_slots is None and self.expert_map is None and self.expert_parallel is None
-                and 1 < M <= self.max_num_seqs and router_logits.size(0) == M and hasattr(self.engine, "forward_logits")):
-            # plain decode step: routing + scatter metadata + experts through lkm_forward_routed (one launch fewer
-            # than select_experts + decode, same bits)
+                and M <= self.max_num_seqs and router_logits.size(0) == M and hasattr(self.engine, "forward_logits")):
+            # plain decode step: routing + experts through lkm_forward_routed (router + scatter metadata in one launch;
+            # one to four tokens of a many-expert layer: router inside GEMM1, two launches in all; same bits as
+            # select_experts + decode)
             buf = self._decode_buffer(hidden_states)
             out, _, _ = self.engine.forward_logits(
                 hidden_states, router_logits, r.top_k, r.renormalize, scoring_func=r.scoring_func,

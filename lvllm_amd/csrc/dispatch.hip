@@ -38,6 +38,17 @@ struct SlotIds {
 // rows its tile holds): tkey[i] = cost of the tiles before tile i, in LDS; XCD c starts at the first tile whose key
 // reaches c/8 of the total (binary search by thread c), runs are then clamped to xcd_cap tiles.
 constexpr int kMaxXcdTiles = 4096;
+// Token tiles of one expert.  tile_rows arrives packed (lkm_kernels.h pack_tile_rows): low 16 bits = tile height,
+// high bits = granule g.  g == 0: tile i starts at row i * height (the last tile is ragged).  g > 0 (the round-3
+// fp8 prefill kernel): the expert's ceil(c / g) granules are dealt to its ceil(c / height) tiles as evenly as
+// possible -- GLM-4.5-Air's 512 +- 22 rows become three tiles of 176 instead of 256 + 256 + a stub that still streams
+// every weight byte.  A kernel reads a tile's height as the distance to the next tile of the same expert.
+__device__ __forceinline__ int tile_first_row(int c, int t, int i, int tile_rows, int gran) {
+    if (gran <= 0) return i * tile_rows;
+    const int nb = (c + gran - 1) / gran;
+    const int base = nb / t, rem = nb % t;
+    return gran * (i * base + min(i, rem));
+}
 __device__ __forceinline__ void xcd_cut(const int32_t* tkey, int n_tiles, long long total_cost, int xcd_cap,
                                         int32_t* xstart, int32_t* meta, int tid) {
     if (tid >= 1 && tid <= 7) {
@@ -71,8 +82,9 @@ __device__ __forceinline__ void sort_slots_body(
     const Ids& ids, int n_slots, int E, int32_t* __restrict__ counts,
     int32_t* __restrict__ offsets, int32_t* __restrict__ sorted_slot,
     int32_t* __restrict__ pos_of_slot, int32_t* __restrict__ active, int32_t* __restrict__ meta,
-    int tile_rows, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0, int xcd_cap,
+    int tile_rows_packed, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0, int xcd_cap,
     int32_t* smem) {
+    const int tile_rows = tile_rows_packed & 0xffff, tile_gran = tile_rows_packed >> 16;
     constexpr int WAVES = THREADS / 64;
     int32_t* cnt = smem;                 // [E]
     int32_t* off = cnt + E;              // [E]
@@ -139,7 +151,7 @@ __device__ __forceinline__ void sort_slots_body(
             if (a) active[ex_a] = e;
             for (int i = 0; i < t; ++i) {
                 tile_e[ex_t + i] = e;
-                tile_r0[ex_t + i] = i * tile_rows;
+                tile_r0[ex_t + i] = tile_first_row(c, t, i, tile_rows, tile_gran);
                 if (xcd_cap > 0) tkey[ex_t + i] = ex_c + i * tile_rows + (ex_t + i) * tile_rows;
             }
         }
@@ -292,9 +304,10 @@ __global__ __launch_bounds__(1024) void sort_scan_kernel(int n_chunks, int E, in
                                                         int32_t* __restrict__ counts,
                                                         int32_t* __restrict__ offsets,
                                                         int32_t* __restrict__ active,
-                                                        int32_t* __restrict__ meta, int tile_rows,
+                                                        int32_t* __restrict__ meta, int tile_rows_packed,
                                                         int tile_min, int32_t* __restrict__ tile_e,
                                                         int32_t* __restrict__ tile_r0, int xcd_cap) {
+    const int tile_rows = tile_rows_packed & 0xffff, tile_gran = tile_rows_packed >> 16;
     constexpr int THREADS = 1024, WAVES = 16;
     __shared__ int32_t wsum[4 * WAVES];
     __shared__ int32_t tkey[kMaxXcdTiles], xstart[16];
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(1024) void sort_scan_kernel(int n_chunks, int E, in
             if (a) active[ex_a] = e;
             for (int i = 0; i < t; ++i) {
                 tile_e[ex_t + i] = e;
-                tile_r0[ex_t + i] = i * tile_rows;
+                tile_r0[ex_t + i] = tile_first_row(c, t, i, tile_rows, tile_gran);
                 if (xcd_cap > 0 && ex_t + i < kMaxXcdTiles) tkey[ex_t + i] = ex_c + i * tile_rows + (ex_t + i) * tile_rows;
             }
             // chunk bases: where chunk b's first slot of expert e lands
@@ -453,7 +466,7 @@ static void launch_sort_t(hipStream_t st, const SlotIds ids, int n_slots, int E,
                           int32_t* tile_e, int32_t* tile_r0, int xcd_cap) {
     constexpr int WAVES = THREADS / 64;
     size_t lds = sizeof(int32_t) * ((size_t)3 * E + 4 * WAVES + (size_t)WAVES * E + 16 +
-                                    (xcd_cap > 0 ? (size_t)(tile_rows > 0 ? n_slots / tile_rows : 0) + E : 0));
+                                    (xcd_cap > 0 ? (size_t)((tile_rows & 0xffff) > 0 ? n_slots / (tile_rows & 0xffff) : 0) + E : 0));
     hipLaunchKernelGGL(sort_slots_kernel<THREADS>, dim3(1), dim3(THREADS), lds, st, ids, n_slots, E,
                        counts, offsets, sorted_slot, pos_of_slot, active, meta, tile_rows, tile_min, tile_e,
                        tile_r0, xcd_cap);
@@ -480,7 +493,7 @@ int launch_route_sort(hipStream_t st, const RouteArgs& ra, int id_offset, int E,
                       int tile_min, int32_t* tile_e, int32_t* tile_r0, int xcd_cap) {
     const int n_slots = ra.M * ra.K;
     LKM_REQUIRE(launch_route_sort_ok(ra.M, ra.K, ra.E, ra.n_group, E), "route+sort: M=%d K=%d E=%d out of range", ra.M, ra.K, ra.E);
-    const size_t tiles = xcd_cap > 0 ? (size_t)(tile_rows > 0 ? n_slots / tile_rows : 0) + E : 0;
+    const size_t tiles = xcd_cap > 0 ? (size_t)((tile_rows & 0xffff) > 0 ? n_slots / (tile_rows & 0xffff) : 0) + E : 0;
     const int rpw = route_rows_per_wave(ra.E, ra.K, ra.n_group);
     const bool small = ceil_div(ra.M, rpw) <= 4;        // 4 wavefronts route it in one pass: cheaper barriers in the sort
 #define LKM_RS(T, S) launch_route_sort_t<T, S>(st, ra, id_offset, E, counts, offsets, sorted_slot, pos_of_slot, active, \

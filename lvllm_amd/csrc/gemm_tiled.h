@@ -507,6 +507,10 @@ static bool launch_w4dma_if(hipStream_t st, const LaunchCfg& cfg, const GemmPara
 template <typename ADTC>
 static bool launch_prefill_a8_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
                                  int max_tiles, int* rc, ADTC);
+// ... round 3: weights straight to registers, tokens through a 4-stage LDS ring (gemm_prefill_a8w.h)
+template <typename ADTC>
+static bool launch_prefill_a8w_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
+                                  int max_tiles, int* rc, ADTC);
 
 // tiled variants built per format: (TM, WAVES, NT) = (64,4,1) (64,8,1) (128,8,1) (128,8,2 non-gated)
 // and, for 16-bit weights only, (256,8,1): the prefill tile (weights re-read once per 256 tokens)
@@ -541,6 +545,7 @@ struct W4Only {
         }                                                                                             \
         if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
             int rc = LKM_OK;                                                                          \
+            if (launch_prefill_a8w_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc; \
             if (launch_prefill_a8_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc; \
         }                                                                                             \
         if constexpr (W4Only<WF_>::value) {                                                           \
@@ -576,6 +581,7 @@ struct W4Only {
         }                                                                                             \
         if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
             int rc = LKM_OK;                                                                          \
+            if (launch_prefill_a8w_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;\
             if (launch_prefill_a8_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;\
         }                                                                                             \
         if constexpr (W4Only<WF_>::value) {                                                           \

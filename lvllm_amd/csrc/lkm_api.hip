@@ -562,8 +562,14 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             if (h->a8 && avg_rows >= 192) tiled = 128;
             // ... and from there on the MX-scaled-MFMA prefill kernel (gemm_prefill_a8.h: both operands by LDS-DMA,
             // 256 x 256 tiles, one v_mfma_scale_f32_16x16x128_f8f6f4 per 128-k block) where the shape qualifies
+            // (the kernels address tokens, token scales and an expert's weights through 2 GiB buffer windows; a chunk
+            // that does not fit them keeps the 128-row tiles instead of failing the step: prefill_a8w_ok)
+            const bool win_ok = (size_t)M * (size_t)h->H < (size_t)0x7fffffff &&
+                                n_slots * (size_t)h->ld_act < (size_t)0x7fffffff &&
+                                (size_t)h->T1_half * (h->gated ? 2 : 1) * h->U1 * 2048 < (size_t)0x7fffffff &&
+                                (size_t)h->T2 * h->U2 * 2048 < (size_t)0x7fffffff;
             if (h->a8 && avg_rows >= 192 && h->t_pf >= 0 && h->H % 128 == 0 && h->I % 128 == 0 &&
-                h->cfg.groupN % 16 == 0 && h->cfg.groupK == 128)
+                h->cfg.groupN % 16 == 0 && h->cfg.groupK == 128 && win_ok)
                 tiled = 256;
         } else if (h->wf == LKM_W_FP8_E4M3 && M >= 48) {
             // fp8 (both modes): tiles from 48 tokens on (profiles/r01_fp8_tile_threshold.log: Mixtral W8A8
@@ -636,8 +642,10 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         if (wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && waves == 4 && !split && h->t_pf == 4 &&
             h->H % 128 == 0 && h->I % 128 == 0)
             pf = 4;
-        if (tiled == 256 && h->a8) {          // the fp8 x fp8 prefill kernel is the only 256-row variant of the format
-            pf = 8;
+        if (tiled == 256 && h->a8) {          // the fp8 x fp8 prefill kernels are the only 256-row variants of the format
+            // 9 = round 3 (gemm_prefill_a8w.h: weights straight to registers, tokens through a 4-stage LDS ring, equal
+            // token tiles); 8 = round 2 (gemm_prefill_a8.h: both operands through two LDS buffers), kept behind "pf" = 8
+            pf = h->t_pf == 8 ? 8 : 9;
             waves = 8;
             // The XCD-aware runs (dispatch.hip) stay a knob ("xcd" = 1): on GLM-4.5-Air fp8 prefill they cut GEMM1's
             // L2-miss traffic 5.8 -> 3.55 GB and lift the L2 hit rate 45 -> 66 %, yet the kernel runs 4-6 % SLOWER
@@ -759,6 +767,9 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         if (rc != LKM_OK) return rc;
     }
     const int tile_rows = pl.t1.tiled ? pl.t1.tiled : pl.t2.tiled;
+    // the round-3 fp8 prefill kernel takes token tiles of any height up to 256 in 32-row steps: the sort deals an
+    // expert's rows to its tiles evenly (dispatch.hip tile_first_row)
+    const int tile_rows_sort = (pl.t1.pf == 9 && pl.t2.pf == 9) ? pack_tile_rows(tile_rows, 32) : tile_rows;
     // Decode of one to four tokens: no scatter -- GEMM1 reads the router's ids itself (one workgroup row per SLOT, the
     // token's row as B operand) and GEMM2 multiplies the K slots of a token and forms the weighted sum in one workgroup
     // (grid row = token): two launches instead of four.  (Qwen3-30B-A3B M=1: 38 -> 32 us: launch latency, not bandwidth.
@@ -779,11 +790,11 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     if (!direct && il.route) {
         LKM_REQUIRE(launch_route_sort_ok(M, K, il.route->E, il.route->n_group, h->E), "forward_routed: step planned off both fused paths");
         rc = launch_route_sort(st, *il.route, il.id_off, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
-                               a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, xcd_cap);
+                               a->active, a->meta, tile_rows_sort, pl.split_rows, a->tile_e, a->tile_r0, xcd_cap);
         if (rc != LKM_OK) return rc;
     } else if (!direct) {
         rc = launch_sort(st, ids, K, (int)il.ids_ld, il.id_off, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
-                         a->active, a->meta, tile_rows, pl.split_rows, a->tile_e, a->tile_r0, a->hist,
+                         a->active, a->meta, tile_rows_sort, pl.split_rows, a->tile_e, a->tile_r0, a->hist,
                          a->hist_cap, xcd_cap);
         if (rc != LKM_OK) return rc;
     }
@@ -897,7 +908,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.SK = sk;
     // block-fp8 W8A8 on the prefill kernel: GEMM2 rounds its output to the activation dtype like the reference's
     // native_w8a8_block_matmul (output_dtype) -- half the bytes written here and read back by the combine
-    const int y_dt = (h->a8 && pl.t2.tiled == 256 && pl.t2.pf == 8 && !pl.s2.tb && sk == 1) ? h->adt : LKM_DT_F32;
+    const int y_dt = (h->a8 && pl.t2.tiled == 256 && pl.t2.pf >= 8 && !pl.s2.tb && sk == 1) ? h->adt : LKM_DT_F32;
     p2.y_dt = y_dt;
     if (direct) {
         p2.direct_ids = ids;

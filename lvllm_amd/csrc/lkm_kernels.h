@@ -35,6 +35,9 @@ bool launch_route_sort_ok(int M, int K, int E_router, int n_group, int E_local);
 int launch_route_sort(hipStream_t st, const RouteArgs& ra, int id_offset, int E, int32_t* counts, int32_t* offsets,
                       int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active, int32_t* meta, int tile_rows,
                       int tile_min, int32_t* tile_e, int32_t* tile_r0, int xcd_cap);
+// tile_rows of the two sort launchers may carry a granule in its high half: pack_tile_rows(256, 32) = 256-row tiles,
+// an expert's rows dealt to its tiles as evenly as 32-row granules allow (dispatch.hip tile_first_row)
+inline int pack_tile_rows(int rows, int gran) { return rows | (gran << 16); }
 constexpr int kMetaInts = 32;   // meta[0..3]: see dispatch.hip; meta[8..16]: per-XCD runs of the tile list
 int launch_quant_fp8_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, void* dst,
                           float* scales);

@@ -182,12 +182,16 @@ def test_fp8_w8a8_larger_random():
     np.testing.assert_allclose(out, out16, atol=0.035 * float(np.abs(out16).max()), rtol=0.035)
 
 
+@pytest.mark.parametrize("pf", [9, 8])
 @pytest.mark.parametrize("gated", [True, False])
-@pytest.mark.parametrize("M,E,H,I,xcd", [(600, 4, 512, 384, 0), (1500, 3, 256, 640, 1), (2300, 20, 384, 128, 1)])
-def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated):
-    """gemm_prefill_a8.h (256 x 256 tiles, v_mfma_scale_f32_16x16x128_f8f6f4 with unit E8M0 scales, block scales
-    applied to each instruction's fp32 result) against the oracle and against the legacy-fp8-MFMA tiled kernel:
-    ragged last tiles, an odd number of K units, padded weight-tile counts, with and without the XCD-aware runs"""
+@pytest.mark.parametrize("M,E,H,I,xcd", [(600, 4, 512, 384, 0), (1500, 3, 256, 640, 1), (2300, 20, 384, 128, 1),
+                                         (900, 2, 1536, 256, 0)])
+def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated, pf):
+    """gemm_prefill_a8w.h (pf 9: weights straight to registers, tokens through a 4-stage LDS ring, equal token tiles)
+    and gemm_prefill_a8.h (pf 8: both operands through two LDS buffers) -- 256 x 256 tiles on
+    v_mfma_scale_f32_16x16x128_f8f6f4 with unit E8M0 scales, block scales applied to each instruction's fp32 result --
+    against the oracle and against the legacy-fp8-MFMA tiled kernel: ragged tiles, 1 to 12 K units (fewer than the
+    pipeline depth, not a multiple of the register ring), padded weight-tile counts, with and without the XCD runs"""
     from lvllm_amd import _clib
     K = 2
     a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=M, gated=gated, drop=0.05, skew=0.5)
@@ -196,9 +200,9 @@ def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated):
     eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
                w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128,
                fp8_mode=_clib.FP8_W8A8, has_gate_proj=gated, activation_type=0 if gated else 2, max_batch_size=4096)
-    eng.engine.set_tuning(tiled=256, xcd=1 if xcd else -1)
+    eng.engine.set_tuning(tiled=256, xcd=1 if xcd else -1, pf=8 if pf == 8 else 0)
     out = _run_decode(eng, a, tw, ids)
-    assert "tm=256" in eng.engine.describe() and "pf=8" in eng.engine.describe(), eng.engine.describe()
+    assert "tm=256" in eng.engine.describe() and f"pf={pf}" in eng.engine.describe(), eng.engine.describe()
     d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128, round_gemm1=True,
                     w8a8=True, has_gate=gated, activation=orc.ACT_SILU if gated else orc.ACT_RELU2)
     ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
@@ -215,7 +219,7 @@ def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated):
     close(out, ref, 1e-2, 2e-2)
     eng.engine.set_tuning(tiled=128, xcd=-1)
     close(out, _run_decode(eng, a, tw, ids), 4e-3, 1e-2)
-    eng.engine.set_tuning(tiled=0, xcd=0)
+    eng.engine.set_tuning(tiled=0, xcd=0, pf=0)
 
 
 def _rand_case(M, E, K, H, I, dtype, seed, gated=True, drop=0.0, skew=0.0):

@@ -71,7 +71,10 @@ WORKLOADS = {
     "glm45air_fp8w8a8_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=1, prefill=True),
 }
 HEADLINE = "mixtral8x7b_bf16_decode_m32"
-EXTRA_N1 = ["mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128", "mixtral8x7b_int4g128_fast_decode_m128"]
+EXTRA_N1 = ["mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128", "mixtral8x7b_int4g128_fast_decode_m128",
+            # BASELINE.json configs[4] (the MFMA-bound grouped GEMM) and the headline workload under Zipf routing
+            # ("uniform and Zipf"; methodology benchmarks/kernels/benchmark_moe.py:96-333)
+            "glm45air_fp8w8a8_prefill_m8192", ("mixtral8x7b_bf16_decode_m32", "zipf")]
 EXTRA_EP = "dsv3_fp8w8a8_ep_decode_b256"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp8": 5000.0}   # dense, MI355X_MICROARCH.md
@@ -249,12 +252,13 @@ def time_reference_kernel(w13, w2, x, tw, ids, thread_cands, seconds, gpu_out):
     xc, twc, idc = x.cpu(), tw.cpu(), ids.cpu()
     ref.set_threads(thread_cands[0])
     ref.fused_moe(xc, p13, p2, twc, idc)                            # untimed first pass
-    best_t, best_c = None, thread_cands[0]
+    best_t, best_c, probe = None, thread_cands[0], {}
     for c in thread_cands:                                          # same team-size probe as for the port
         ref.set_threads(c)
         c0 = time.perf_counter()
         ref.fused_moe(xc, p13, p2, twc, idc)
         tc = time.perf_counter() - c0
+        probe[str(c)] = round(tc * 1e3, 2)
         if best_t is None or tc < best_t:
             best_t, best_c = tc, c
         if tc > 3 * best_t:
@@ -269,7 +273,8 @@ def time_reference_kernel(w13, w2, x, tw, ids, thread_cands, seconds, gpu_out):
     o = out.float().numpy()
     err = float(np.abs(gpu_out - o).max() / max(1e-9, np.abs(o).max()))
     return {"value": round(x.size(0) / (t_cpu / n), 2), "unit": "tokens/s", "cores": best_c, "kind": "reference",
-            "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err, "n": n, "t": t_cpu}
+            "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err, "n": n, "t": t_cpu,
+            "team_probe_ms": probe}
 
 
 def cpu_baseline(name, wl, oracle_in, masters, x, tw, ids, gpu_out, seconds):
@@ -294,12 +299,13 @@ def cpu_baseline(name, wl, oracle_in, masters, x, tw, ids, gpu_out, seconds):
     # step), so the team size is picked by a short probe; `cores` reports the size used.
     ncpu = os.cpu_count() or 1
     cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
-    best_t, best_c = None, cands[0]
+    best_t, best_c, probe = None, cands[0], {}
     for c in cands:
         orc.set_threads(c)
         c0 = time.perf_counter()
         orc.moe(d, x=xb, ids=idn, tw=twn, **cargs)
         tc = time.perf_counter() - c0
+        probe[str(c)] = round(tc * 1e3, 2)
         if best_t is None or tc < best_t:
             best_t, best_c = tc, c
         if tc > 3 * best_t:
@@ -315,7 +321,11 @@ def cpu_baseline(name, wl, oracle_in, masters, x, tw, ids, gpu_out, seconds):
     cpu = {"value": round(M / (t_cpu / n), 2), "unit": "tokens/s", "cores": orc.num_threads(), "kind": "port",
            "sample": f"{n} full {name} layer passes (M={M}) through oracle/lkm_oracle.c, "
                      f"{t_cpu:.1f} s of CPU work; lk_moe itself is a closed binary absent from the reference tree",
-           "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err, "host": host_info()}
+           "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err, "host": host_info(),
+           # one pass per candidate team size (threads -> ms); the probe stops once a size is 3x slower than the best:
+           # the host exposes more logical CPUs than the container runs well (SURVEY 8d asks for "all host cores":
+           # these timings are why `cores` is smaller)
+           "team_probe_ms": probe}
     # The reference's OWN in-tree CPU fused-MoE kernel (csrc/cpu/cpu_fused_moe.cpp, compiled into oracle/_ref
     # where /root/reference exists; 16-bit experts only) on the same inputs and host cores: when it loads it
     # IS the cpu_baseline ("reference") and the port's figure moves to cpu_baseline["port"].
@@ -336,7 +346,27 @@ def cpu_baseline(name, wl, oracle_in, masters, x, tw, ids, gpu_out, seconds):
 
 
 # ------------------------------------------------------------------------------------------ one workload
-def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
+def mfma_peak_tf(wl):
+    """dense MFMA peak (TFLOP/s) of the instruction the format's kernels multiply with: fp8 x fp8 runs on the MX-scaled
+    fp8 MFMA (5 PF); every other format is decoded to the 16-bit activation dtype in registers (2.5 PF)"""
+    return MFMA_PEAK_TF["fp8" if (wl["fmt"] == "fp8" and wl.get("fp8_mode")) else "bf16"]
+
+
+def roof_fields(flops, bytes_, ms, peak_tf):
+    """the two rooflines of one kernel side by side (BASELINE.json's metric names the MFMA roofline, the decode
+    kernels are HBM-bound): achieved TFLOP/s and GB/s, their fractions of the dense MFMA peak and of the 8 TB/s HBM
+    peak, and the fraction of the binding roof min(MFMA peak, arithmetic intensity x HBM peak)"""
+    tf = flops / (ms * 1e-3) / 1e12
+    gbs = bytes_ / (ms * 1e-3) / 1e9
+    ai = flops / max(1.0, bytes_)
+    roof_tf = min(peak_tf, ai * HBM_PEAK_GBS / 1e3)
+    return {"tflops": round(tf, 2), "mfma_peak_tflops": peak_tf, "mfma_frac": round(tf / peak_tf, 4),
+            "GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+            "arithmetic_intensity_flop_per_byte": round(ai, 2), "roof_tflops": round(roof_tf, 2),
+            "roof_bound": "mfma" if roof_tf >= peak_tf else "hbm", "frac_of_roof": round(tf / roof_tf, 4)}
+
+
+def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, routing=None):
     """times `steps` steps of one WORKLOADS entry on this rank set; returns the result dict on rank 0 (None
     elsewhere).  Every rank must call it with the same arguments (it contains collectives when world > 1)."""
     from lvllm_amd import ops
@@ -366,7 +396,8 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
     x = (torch.randn((M, H), generator=gen, device=dev) / 10).to(torch.bfloat16)
     logits = torch.randn((M, E), generator=gen, device=dev, dtype=torch.float32)
-    if args.routing == "zipf":      # log-popularity bias: p(e) ~ 1/(e+1)
+    routing = routing or args.routing
+    if routing == "zipf":      # log-popularity bias: p(e) ~ 1/(e+1)
         logits = logits + torch.log(1.0 / torch.arange(1, E + 1, device=dev, dtype=torch.float32))[None, :]
     rt = wl.get("router", dict(kind="softmax"))
     bias = None
@@ -538,9 +569,10 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
         layer_flops = 6.0 * rows * H * I
         layer_bytes = e_act * 3 * I * H * bpe
         g1_ms = max(prof_ms["gemm1"], 1e-6)
+        g1_flops = 4.0 * rows * H * I                                # gate + up projections of every routed row
+        both = roof_fields(g1_flops, g1_bytes, g1_ms, mfma_peak_tf(wl))
         if prefill:     # MFMA-bound regime: the roofline of the dominant kernel is flops against the dense MFMA peak
-            g1_flops = 4.0 * rows * H * I
-            peak = MFMA_PEAK_TF["fp8" if (fmt == "fp8" and wl.get("fp8_mode")) else "bf16"]
+            peak = mfma_peak_tf(wl)
             ach = g1_flops / (g1_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "gemm1 (grouped, tiled)", "achieved": round(ach, 1), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "algorithmic_flops": g1_flops}
@@ -560,7 +592,12 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
                         "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE pass of this workload, gfx950-corrected "
                         "(x2), committed with the kernel it measured -- static, NOT re-read in this run",
                         "algorithmic_bytes": g1_bytes}
+        roofline.update(both)       # mfma_frac, hbm_frac, roof = min(MFMA, AI x HBM), frac_of_roof: both rooflines, always
+        step_fl = roof_fields(layer_flops, layer_bytes, ms_per_step, mfma_peak_tf(wl))
         roofline.update({
+            "step": {"mfma_frac": step_fl["mfma_frac"], "hbm_frac": step_fl["hbm_frac"], "frac_of_roof": step_fl["frac_of_roof"],
+                     "roof_bound": step_fl["roof_bound"],
+                     "what": "the whole layer step (router, scatter, GEMM1, GEMM2, combine) against the same two peaks"},
             "layer": {"routed_rows": rows, "experts_hit": e_act, "weight_bytes": layer_bytes, "flops": layer_flops,
                       "GBps_over_step": round(layer_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                       "TFLOPs_over_step": round(layer_flops / (ms_per_step * 1e-3) / 1e12, 2)},
@@ -577,7 +614,7 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False):
                           "intermediate": I, "batch_per_gpu": M, "global_batch": M * world,
                           "router": rt["kind"] if rt["kind"] == "softmax" else
                           f"grouped {rt['scoring']}+bias top-{K} of {rt['topk_group']}/{rt['n_group']} groups x{rt['routed_scaling']}",
-                          "routing": args.routing,
+                          "routing": routing,
                           "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}",
                           "launch": launch, "geometry": eng.engine.describe()},
                "roofline": roofline}
@@ -724,9 +761,14 @@ def main():
         es, ew = min(args.steps, 100), min(args.warmup, 10)
         names = (EXTRA_N1 if world == 1 and not args.force_ep else []) + [EXTRA_EP]
         for n in names:
+            n, rt_over = n if isinstance(n, tuple) else (n, None)
+            if WORKLOADS[n].get("prefill"):
+                es_n, ew_n = min(es, 20), min(ew, 3)      # a 1-2 ms step: 20 steps are 30-40 ms of GPU time
+            else:
+                es_n, ew_n = es, ew
             try:
-                r = run_workload(n, args, ctx, steps=es, warmup=ew, with_cpu=False,
-                                 force_ep=args.force_ep and n == EXTRA_EP)
+                r = run_workload(n, args, ctx, steps=es_n, warmup=ew_n, with_cpu=False,
+                                 force_ep=args.force_ep and n == EXTRA_EP, routing=rt_over)
             except Exception as e:   # an extra must never take the headline line with it
                 if use_dist:
                     raise                # ... except where ranks would fall out of step

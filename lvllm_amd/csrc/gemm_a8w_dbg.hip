@@ -1,0 +1,25 @@
+// gemm_a8w_dbg.hip -- ablation builds of the round-3 fp8 x fp8 prefill kernel (gemm_prefill_a8w.h), gated GEMM1 with
+// bf16 activations only: tuning key "dbg" selects one; results are wrong by construction, only the time is read.
+#include "gemm_prefill_a8w.h"
+namespace lkm {
+int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, int dbg) {
+    switch (dbg) {
+#define LKM_A8W_DBG_CASE(D) case D: return launch_prefill_a8w_t<LKM_DT_BF16, true, true, D>(st, p, max_tiles);
+        LKM_A8W_DBG_CASE(1)            // compute skeleton: no loads / DMA in the K loop
+        LKM_A8W_DBG_CASE(2)            // data movement + barriers only
+        LKM_A8W_DBG_CASE(1 | 8)        // skeleton without LDS reads
+        LKM_A8W_DBG_CASE(1 | 16)       // skeleton without VALU
+        LKM_A8W_DBG_CASE(1 | 8 | 16)   // MFMAs only
+        LKM_A8W_DBG_CASE(1 | 32)       // skeleton without MFMA
+        LKM_A8W_DBG_CASE(1 | 64)       // skeleton without the per-unit barrier
+        LKM_A8W_DBG_CASE(1 | 8 | 16 | 64)
+        LKM_A8W_DBG_CASE(2 | 64)       // data movement without the barrier
+        LKM_A8W_DBG_CASE(1 | 2)        // neither: prologue + epilogue + the loop's own bookkeeping and barriers
+        LKM_A8W_DBG_CASE(1 | 2 | 64)
+#undef LKM_A8W_DBG_CASE
+    default:
+        set_error("fp8 W8A8 prefill kernel: ablation dbg=%d not built", dbg);
+        return LKM_E_INVALID;
+    }
+}
+}  // namespace lkm

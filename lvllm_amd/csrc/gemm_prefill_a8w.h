@@ -50,15 +50,24 @@ constexpr int kNumVgpr = 40;
 constexpr int kB = 40, kP = 56, kX = 72, kF = 74, kOne = 78, kA = 80, kAcc = 128;
 constexpr int kStage = 256 * 128, kStages = 4;
 constexpr int kScBase = kStage * kStages, kScBuf = 256 * 16;
-constexpr int kLdsBytes = kScBase + 2 * kScBuf;          // 139 264
+constexpr int kTbl = kScBase + 3 * kScBuf;               // two row tables (current / next item) of 2 KiB
+constexpr int kStA = kTbl + 2 * 2048;                    // per-wave landing zones of the item metadata (2 x 8 x 256 B)
+constexpr int kStB = kStA + 2048;
+constexpr int kRaw = kStB + 2048;                        // 256 gathered sorted_slot entries of the next item
+constexpr int kWs = kRaw + 1024;                         // weight-block scales: [2 items][8 waves][2 tiles][64 units] fp32
+constexpr int kLdsBytes = kWs + 2 * 8 * 512;             // 160 768: four token stages, three token-scale groups, two row
+                                                         // tables, the landing zones, the weight-block scales
 }  // namespace a8w
 
 typedef __attribute__((ext_vector_type(4))) int a8w_i32x4;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // clobber lists: tell the compiler (for the kernel descriptor's register count) which fixed registers the asm owns
+// clobber lists: every fixed register is named in the asm statements of the K loop, so that the compiler neither counts
+// them free (its SGPR-spill lanes went to v69 -- an MFMA result register -- when only the B registers were listed) nor
+// undercounts the kernel descriptor's register file
 #define A8W_CLOB_B "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55"
-#define A8W_CLOB_TOP "v255"
+#define A8W_CLOB_TOP "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
 #define A8W_MFMA(P, A, B) \
     "v_mfma_scale_f32_16x16x128_f8f6f4 v[" P ":" P "+3], v[" A ":" A "+7], v[" B ":" B "+7], 0, v[%c[one]], v[%c[one]] op_sel_hi:[0,0,0]\n\t"
@@ -72,7 +81,11 @@ typedef __attribute__((ext_vector_type(4))) int a8w_i32x4;
 // products, multiply both weight tiles, and -- between the MFMAs -- add the PREVIOUS block's partial sums into its
 // accumulators.  SLOT: A ring slot of the unit.  HASPREV: block b-1 of the same unit exists.  The prefetch address is
 // the caller's: (same stage, block b+1) or (next stage, block 0).
-template <int SLOT, int B, bool HASPREV, int BOFF, int XOFF>
+// DBG (ablations, assembler conditionals): 8 = no LDS reads, 16 = no VALU (scale products, accumulator updates),
+// 32 = no MFMA
+#define A8W_IF(bit) ".if (%c[dbg] & " #bit ") == 0\n\t"
+#define A8W_FI ".endif\n\t"
+template <int SLOT, int B, bool HASPREV, int BOFF, int XOFF, int DBG>
 __device__ __forceinline__ void a8w_block_t(int vblo, int vbhi, int vxs, int ws0, int ws1) {
     constexpr int par = B & 1, npar = par ^ 1;
     constexpr int BC = a8w::kB + par * 8, BN = a8w::kB + npar * 8;
@@ -81,45 +94,80 @@ __device__ __forceinline__ void a8w_block_t(int vblo, int vbhi, int vxs, int ws0
     constexpr int FC = a8w::kF + par * 2, FP = a8w::kF + npar * 2;
     constexpr int A = a8w::kA + SLOT * 16;
     constexpr int ACC = a8w::kAcc + (HASPREV ? B - 1 : 0) * 8;
-    if constexpr (HASPREV) {
-        asm volatile(
-            "ds_read_b128 v[%c[bn]:%c[bn]+3], %[vblo] offset:%c[boff]\n\t"
-            "ds_read_b128 v[%c[bn]+4:%c[bn]+7], %[vbhi] offset:%c[boff]\n\t"
-            "ds_read_b32 v[%c[xn]], %[vxs] offset:%c[xoff]\n\t"
-            "v_mul_f32 v[%c[fc]], %[ws0], v[%c[xc]]\n\t"
-            "v_mul_f32 v[%c[fc]+1], %[ws1], v[%c[xc]]\n\t"
-            A8W_MFMA("%c[pc]", "%c[a]", "%c[bc]")
-            A8W_FMAC4("%c[acc]", "%c[fp]", "%c[pp]")
-            A8W_MFMA("%c[pc]+4", "%c[a]+8", "%c[bc]")
-            A8W_FMAC4("%c[acc]+4", "%c[fp]+1", "%c[pp]+4")
-            "s_waitcnt lgkmcnt(0)\n\t"
-            :
-            : [bn] "i"(BN), [bc] "i"(BC), [pc] "i"(PC), [pp] "i"(PP), [xc] "i"(XC), [xn] "i"(XN), [fc] "i"(FC),
-              [fp] "i"(FP), [a] "i"(A), [acc] "i"(ACC), [one] "i"(a8w::kOne), [boff] "i"(BOFF), [xoff] "i"(XOFF),
-              [vblo] "v"(vblo), [vbhi] "v"(vbhi), [vxs] "v"(vxs), [ws0] "s"(ws0), [ws1] "s"(ws1)
-            : "memory", A8W_CLOB_B, A8W_CLOB_TOP);
-    } else {
-        asm volatile(
-            "ds_read_b128 v[%c[bn]:%c[bn]+3], %[vblo] offset:%c[boff]\n\t"
-            "ds_read_b128 v[%c[bn]+4:%c[bn]+7], %[vbhi] offset:%c[boff]\n\t"
-            "ds_read_b32 v[%c[xn]], %[vxs] offset:%c[xoff]\n\t"
-            "v_mul_f32 v[%c[fc]], %[ws0], v[%c[xc]]\n\t"
-            "v_mul_f32 v[%c[fc]+1], %[ws1], v[%c[xc]]\n\t"
-            A8W_MFMA("%c[pc]", "%c[a]", "%c[bc]")
-            A8W_MFMA("%c[pc]+4", "%c[a]+8", "%c[bc]")
-            "s_waitcnt lgkmcnt(0)\n\t"
-            :
-            : [bn] "i"(BN), [bc] "i"(BC), [pc] "i"(PC), [xc] "i"(XC), [xn] "i"(XN), [fc] "i"(FC), [a] "i"(A),
-              [one] "i"(a8w::kOne), [boff] "i"(BOFF), [xoff] "i"(XOFF), [vblo] "v"(vblo), [vbhi] "v"(vbhi),
-              [vxs] "v"(vxs), [ws0] "s"(ws0), [ws1] "s"(ws1)
-            : "memory", A8W_CLOB_B, A8W_CLOB_TOP);
-    }
+    asm volatile(
+        A8W_IF(8)
+        "ds_read_b128 v[%c[bn]:%c[bn]+3], %[vblo] offset:%c[boff]\n\t"
+        "ds_read_b128 v[%c[bn]+4:%c[bn]+7], %[vbhi] offset:%c[boff]\n\t"
+        "ds_read_b32 v[%c[xn]], %[vxs] offset:%c[xoff]\n\t"
+        A8W_FI
+        A8W_IF(16)
+        "v_mul_f32 v[%c[fc]], %[ws0], v[%c[xc]]\n\t"
+        "v_mul_f32 v[%c[fc]+1], %[ws1], v[%c[xc]]\n\t"
+        A8W_FI
+        A8W_IF(32)
+        A8W_MFMA("%c[pc]", "%c[a]", "%c[bc]")
+        A8W_FI
+        ".if %c[hasprev] && ((%c[dbg] & 16) == 0)\n\t"
+        A8W_FMAC4("%c[acc]", "%c[fp]", "%c[pp]")
+        A8W_FI
+        A8W_IF(32)
+        A8W_MFMA("%c[pc]+4", "%c[a]+8", "%c[bc]")
+        A8W_FI
+        ".if %c[hasprev] && ((%c[dbg] & 16) == 0)\n\t"
+        A8W_FMAC4("%c[acc]+4", "%c[fp]+1", "%c[pp]+4")
+        A8W_FI
+        "s_waitcnt lgkmcnt(0)\n\t"
+        :
+        : [bn] "i"(BN), [bc] "i"(BC), [pc] "i"(PC), [pp] "i"(PP), [xc] "i"(XC), [xn] "i"(XN), [fc] "i"(FC),
+          [fp] "i"(FP), [a] "i"(A), [acc] "i"(ACC), [one] "i"(a8w::kOne), [boff] "i"(BOFF), [xoff] "i"(XOFF),
+          [hasprev] "i"(HASPREV ? 1 : 0), [dbg] "i"(DBG),
+          [vblo] "v"(vblo), [vbhi] "v"(vbhi), [vxs] "v"(vxs), [ws0] "s"(ws0), [ws1] "s"(ws1)
+        : "memory", A8W_CLOB_B, A8W_CLOB_TOP);
+}
+
+// Block 0 of a unit (no previous block): as above, plus what the unit's OTHER work needs, fetched under the block's MFMAs
+// and complete at the asm's end (lgkmcnt(0)), all from LDS (a scalar load here would park every later lgkmcnt(0) behind
+// the scalar cache): the weight-block scales of the NEXT unit and the source offsets of the unit's four token pieces
+// and one scale piece (row table).
+template <int SLOT, int DBG>
+__device__ __forceinline__ void a8w_block0(int vblo, int vbhi, int vxs, int ws0, int ws1, int wsaddr, int taddr, int tsaddr,
+                                           int& ws0n, int& ws1n, int (&t)[4], int& ts) {
+    constexpr int A = a8w::kA + SLOT * 16;
+    asm volatile(
+        A8W_IF(8)
+        "ds_read_b128 v[%c[bn]:%c[bn]+3], %[vblo] offset:2048\n\t"
+        "ds_read_b128 v[%c[bn]+4:%c[bn]+7], %[vbhi] offset:2048\n\t"
+        "ds_read_b32 v[%c[xn]], %[vxs] offset:256\n\t"
+        A8W_FI
+        "ds_read_b32 %[ws0n], %[wsaddr]\n\t"
+        "ds_read_b32 %[ws1n], %[wsaddr] offset:256\n\t"
+        "ds_read_b32 %[t0], %[taddr]\n\t"
+        "ds_read_b32 %[t1], %[taddr] offset:256\n\t"
+        "ds_read_b32 %[t2], %[taddr] offset:512\n\t"
+        "ds_read_b32 %[t3], %[taddr] offset:768\n\t"
+        "ds_read_b32 %[ts], %[tsaddr]\n\t"
+        A8W_IF(16)
+        "v_mul_f32 v[%c[fc]], %[ws0], v[%c[xc]]\n\t"
+        "v_mul_f32 v[%c[fc]+1], %[ws1], v[%c[xc]]\n\t"
+        A8W_FI
+        A8W_IF(32)
+        A8W_MFMA("%c[pc]", "%c[a]", "%c[bc]")
+        A8W_MFMA("%c[pc]+4", "%c[a]+8", "%c[bc]")
+        A8W_FI
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : [ws0n] "=&v"(ws0n), [ws1n] "=&v"(ws1n), [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]),
+          [ts] "=&v"(ts)
+        : [bn] "i"(a8w::kB + 8), [bc] "i"(a8w::kB), [pc] "i"(a8w::kP), [xc] "i"(a8w::kX), [xn] "i"(a8w::kX + 1),
+          [fc] "i"(a8w::kF), [a] "i"(A), [one] "i"(a8w::kOne), [dbg] "i"(DBG), [vblo] "v"(vblo), [vbhi] "v"(vbhi),
+          [vxs] "v"(vxs), [ws0] "s"(ws0), [ws1] "s"(ws1), [wsaddr] "v"(wsaddr), [taddr] "v"(taddr), [tsaddr] "v"(tsaddr)
+        : "memory", A8W_CLOB_B, A8W_CLOB_TOP);
 }
 
 // the accumulator update of a unit's LAST block (its MFMAs were the last two instructions of the matrix pipe: 16 wait
 // states cover the 11 an 8-pass result needs before a VALU may read it)
-template <int B>
+template <int B, int DBG>
 __device__ __forceinline__ void a8w_flush() {
+    if constexpr (DBG & 16) return;
     constexpr int par = B & 1;
     constexpr int PP = a8w::kP + par * 8, FP = a8w::kF + par * 2, ACC = a8w::kAcc + B * 8;
     asm volatile("s_nop 15\n\t"
@@ -156,10 +204,61 @@ __device__ __forceinline__ void a8w_dma16(int lds_addr, int voff, a8w_i32x4 rs, 
                  : [la] "s"(lds_addr), [voff] "v"(voff), [rs] "s"(rs), [soff] "s"(soff)
                  : "memory");
 }
+// 64 lanes x 4 bytes from per-lane 64-bit addresses to lds_addr + lane * 4 (item metadata: whatever is in flight between
+// two points of the K loop lives in LDS, never in a register the compiler could copy before the data has landed)
+__device__ __forceinline__ void a8w_dma4_flat(int lds_addr, const void* addr) {
+    int keep;
+    asm volatile("s_mov_b32 %[keep], m0\n\t"
+                 "s_mov_b32 m0, %[la]\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dword %[ad], off\n\t"
+                 "s_mov_b32 m0, %[keep]\n\t"
+                 : [keep] "=&s"(keep)
+                 : [la] "s"(lds_addr), [ad] "v"(addr)
+                 : "memory");
+}
 #endif   // __HIP_DEVICE_COMPILE__
 
+// silu(g) * u with the hardware exp / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of the shared
+// deterministic expf + IEEE division of store_gemm1_frag: the epilogue of a 256 x 256 tile is 32 fragments per lane, and
+// at ~50 VALU per element it cost 8 us of every 60-us tile.  Same rounding points as the block-fp8 reference
+// (activation_kernels.cu:57-75: gate and up rounded to the activation dtype by the GEMM, T(silu_f32(g)) * u); only
+// the last bit of the fp32 sigmoid differs, far inside the operator's tolerance (tests/kernels/moe/test_block_fp8.py).
+template <int ADT>
+__device__ __forceinline__ void a8w_store_silu_mul(const GemmParams& p, const f32x4& gate, const f32x4& upv, size_t out_row, int n) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = gate[r], up = upv[r];
+        if (p.round_gemm1) {
+            a = ActT<ADT>::to_f32(ActT<ADT>::from_f32(a));
+            up = ActT<ADT>::to_f32(ActT<ADT>::from_f32(up));
+        }
+        const float sg = a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * -1.44269504088896341f));
+        v[r] = p.round_gemm1 ? ActT<ADT>::to_f32(ActT<ADT>::from_f32(sg)) * up : sg * up;
+    }
+    unsigned short* o = (unsigned short*)p.out + out_row * p.ldo + n;
+    if (n + 4 <= p.n_real) {
+        *(u32x2*)o = u32x2{ActT<ADT>::pack2(v[0], v[1]), ActT<ADT>::pack2(v[2], v[3])};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < p.n_real) o[r] = ActT<ADT>::from_f32(v[r]);
+    }
+}
+
 // DBG (development ablations, results wrong by construction): 1 = no loads / DMA inside the K loop (compute skeleton),
-// 2 = no MFMA blocks (data movement + barriers only).  Tuning key "dbg"; bit 4 (serialised units) is a run-time flag.
+// 2 = no token blocks (data movement + barriers only), 8 / 16 / 32 = blocks without LDS reads / VALU / MFMA, 64 = no
+// per-unit barrier.  Tuning key "dbg"; bit 4 (serialised units) is a run-time flag.  The ablation kernels live in
+// their own translation unit (gemm_a8w_dbg.hip).
+//
+// PERSISTENT: the grid is one workgroup per CU; a workgroup walks its share of the (token tile, weight row group) items
+// and the load pipeline runs THROUGH the item boundary (the last three units of an item fetch the first three of the
+// next one), so an item pays its epilogue and nothing else -- no workgroup launch, no metadata round trips, no pipeline
+// refill (measured on GLM-4.5-Air: 325 of 1030 us were prologue + epilogue + launch of the 3 590 one-item workgroups,
+// profiles/r03_a8w_ablations_v1.log "dbg=3").  Per-item state is five scalars; what the lanes need of an item -- the
+// source row of each of its 256 token rows, pre-multiplied by the two row strides -- sits in a 2-KiB LDS table per item
+// (current / next), written once (256 gathered sorted_slot entries) and read back five words per lane and unit.
 template <int ADT, bool GATED, bool IS_G1, int DBG = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))) void gemm_prefill_a8w_kernel(GemmParams p) {
     static_assert(!GATED || IS_G1, "only GEMM1 is gated");
@@ -167,39 +266,105 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     using namespace a8w;
     typedef __attribute__((address_space(3))) char* LdsPtr;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    int ti = blockIdx.y, bx = blockIdx.x;
-    if (p.xcd_map) {     // XCD-aware 1-D mapping: see gemm_tiled_kernel and dispatch.hip (xcd_cut)
-        const int RG = p.xcd_map;
-        const int L = blockIdx.x, c = L & 7, sidx = L >> 3;
-        const int first = p.meta[8 + c], n_c = p.meta[9 + c] - first;
-        if (sidx >= n_c * RG) return;
-        ti = first + sidx / RG;
-        bx = sidx % RG;
-    }
-    const int n_tiles = p.meta[3];
-    if (ti >= n_tiles) return;
-    const int e = p.tile_e[ti], r0 = p.tile_r0[ti];
-    const int m_e = p.counts[e], off_e = p.offsets[e];
-    // rows of this token tile: up to the next tile of the same expert (the sort cuts an expert into equal tiles)
-    int rows = m_e - r0;
-    if (ti + 1 < n_tiles && p.tile_e[ti + 1] == e) rows = p.tile_r0[ti + 1] - r0;
-    if (rows > 256) rows = 256;
-    const int NQ = __builtin_amdgcn_readfirstlane((rows + 31) >> 5);       // 32-row pairs of blocks that hold rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
-    const int T_all = p.T_half * p.halves;
+    const int T_half = __builtin_amdgcn_readfirstlane(p.T_half);
+    const int T_all = T_half * p.halves;
     const int U = __builtin_amdgcn_readfirstlane(p.U);
+    const int n_grp = (U + 3) >> 2;
     const bool dbg_serial = __builtin_amdgcn_readfirstlane(p.dbg & 4) != 0;
-    constexpr int TPH = GATED ? 8 : 16;                       // tiles per half taken by one workgroup
-    const int tbase = bx * TPH;
-    // the wave's two weight tiles: gated = gate tile w and up tile w of the same rows; else two adjacent tiles
-    auto clampt = [&](int t) { return t < p.T_half ? t : p.T_half - 1; };
-    const int gt0 = GATED ? clampt(tbase + wave) : clampt(tbase + 2 * wave);
-    const int gt1 = GATED ? p.T_half + clampt(tbase + wave) : clampt(tbase + 2 * wave + 1);
+    constexpr int TPH = GATED ? 8 : 16;                       // tiles per half taken by one item
+    const int RG = __builtin_amdgcn_readfirstlane((T_half + TPH - 1) / TPH);
+    const int n_tiles = __builtin_amdgcn_readfirstlane(p.meta[3]);
+    // ---- this workgroup's items: position s of its part's list = (tile first + s / RG, row group s % RG), s = w, w +
+    // stride, ...  With the XCD-aware runs (dispatch.hip xcd_cut) a part is one XCD's run of tiles and its workgroups
+    // the ones the dispatcher places there (block b -> XCD b % 8: a speed assumption, never a correctness one)
+    int first = 0, n_c = n_tiles, w = blockIdx.x, stride = gridDim.x;
+    if (p.xcd_map) {
+        const int c = blockIdx.x & 7;
+        first = p.meta[8 + c];
+        n_c = p.meta[9 + c] - first;
+        w = blockIdx.x >> 3;
+        stride = gridDim.x >> 3;
+    }
+    first = __builtin_amdgcn_readfirstlane(first);
+    const int n_items = __builtin_amdgcn_readfirstlane(n_c * RG);
+    w = __builtin_amdgcn_readfirstlane(w);
+    stride = __builtin_amdgcn_readfirstlane(stride);
+    if (w >= n_items) return;
 
-    // ---- buffer resources (wave-uniform by construction: kernel arguments and e)
-    auto make_rs = [&](const void* base, unsigned bytes) {
+    // ---- item descriptors: wave-uniform scalars only
+    struct Meta {
+        int valid, bx, e, r0, e2, r02, m_e, off_e;
+    };
+    const int lds0 = (int)(unsigned)(uintptr_t)(LdsPtr)lds;
+    // Metadata of the item two ahead, in two dependent stages of 4-byte LDS-DMA (behind the asm blocks' "memory" clobbers
+    // and the epilogue's stores the compiler cannot keep such loads scalar, and a load it issues itself is waited for with
+    // vmcnt(0): the whole pipeline; a register destination written by an asm load is copied around by the register
+    // allocator before the data lands).  Stage A at an item switch: the tile-list entry and its successor -> this wave's
+    // landing zone; stage B two barriers later: the expert's row count and offset; both read back with a plain LDS read
+    // after the ledger says they have landed.
+    auto meta_a = [&](int s) __attribute__((always_inline)) {
+        Meta m;
+        m.valid = s < n_items;
+        const int ss = m.valid ? s : 0;
+        const int ti = first + ss / RG;
+        m.bx = ss % RG;
+        const int tn = ti + 1 < n_tiles ? ti + 1 : ti;
+        m.e2 = ti + 1 < n_tiles ? 0 : -1;      // (-1: no successor)
+        const int* a = (lane & 1) ? p.tile_r0 : p.tile_e;
+        a += (lane & 2) ? tn : ti;              // lanes 0..3: tile_e[ti], tile_r0[ti], tile_e[tn], tile_r0[tn]
+        a8w_dma4_flat(lds0 + kStA + wave * 256, a);
+        m.e = m.r0 = m.r02 = m.m_e = m.off_e = 0;
+        return m;
+    };
+    auto meta_a_done = [&](Meta& m) __attribute__((always_inline)) {      // (landed: caller's ledger)
+        a8w_i32x4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds0 + kStA + wave * 256) : "memory");
+        m.e = __builtin_amdgcn_readfirstlane(v.x);
+        m.r0 = __builtin_amdgcn_readfirstlane(v.y);
+        if (m.e2 != -1) m.e2 = __builtin_amdgcn_readfirstlane(v.z);
+        m.r02 = __builtin_amdgcn_readfirstlane(v.w);
+    };
+    auto meta_b = [&](Meta& m) __attribute__((always_inline)) {
+        const int* a = ((lane & 1) ? p.offsets : p.counts) + m.e;
+        a8w_dma4_flat(lds0 + kStB + wave * 256, a);
+    };
+    auto meta_b_done = [&](Meta& m) __attribute__((always_inline)) {
+        int c, o;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(c), "=&v"(o) : "v"(lds0 + kStB + wave * 256) : "memory");
+        m.m_e = __builtin_amdgcn_readfirstlane(c);
+        m.off_e = __builtin_amdgcn_readfirstlane(o);
+    };
+    struct Item {
+        int nq;        // 32-row pairs of token blocks that hold rows; 0 = no such item
+        int rows, orow0, tbase, e;
+    };
+    auto make_item = [&](const Meta& m) __attribute__((always_inline)) {
+        Item it;
+        int rows = m.m_e - m.r0;
+        if (m.e2 == m.e) rows = m.r02 - m.r0;
+        if (rows > 256) rows = 256;
+        if (rows < 1) rows = 1;
+        it.rows = rows;
+        it.nq = m.valid ? (rows + 31) >> 5 : 0;
+        it.orow0 = m.off_e + m.r0;
+        it.tbase = m.bx * TPH;
+        it.e = m.e;
+        return it;
+    };
+    // the wave's two weight tiles of an item: gated = gate tile w and up tile w of the same rows; else two adjacent tiles
+    auto tile0 = [&](const Item& it) __attribute__((always_inline)) {
+        const int t = GATED ? it.tbase + wave : it.tbase + 2 * wave;
+        return t < T_half ? t : T_half - 1;
+    };
+    auto tile1 = [&](const Item& it) __attribute__((always_inline)) {
+        const int t = GATED ? it.tbase + wave : it.tbase + 2 * wave + 1;
+        return (GATED ? T_half : 0) + (t < T_half ? t : T_half - 1);
+    };
+    auto make_rs = [&](const void* base, unsigned bytes) __attribute__((always_inline)) {
         const unsigned long long a = (unsigned long long)base;
         a8w_i32x4 r;
         r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
@@ -209,196 +374,376 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         return r;
     };
     const size_t wbytes = (size_t)T_all * U * 2048;
-    const a8w_i32x4 rs_w = make_rs((const char*)p.w + (size_t)e * wbytes, (unsigned)wbytes);
     const a8w_i32x4 rs_x = make_rs(p.x, (unsigned)((size_t)p.x_rows * (size_t)p.ldx));
     const a8w_i32x4 rs_xs = make_rs(p.xscale, (unsigned)((size_t)p.x_rows * (size_t)p.ld_xscale * 4));
     const int wub = __builtin_amdgcn_readfirstlane((int)(p.w_ustride * 16));
-    const int a_s0 = __builtin_amdgcn_readfirstlane((int)(gt0 * p.w_tstride * 16));
-    const int a_s1 = __builtin_amdgcn_readfirstlane((int)(gt1 * p.w_tstride * 16));
-    const int a_voff = lane * 16;
+    const int wtb = __builtin_amdgcn_readfirstlane((int)(p.w_tstride * 16));
+    const int ldx = p.ldx, ldxs4 = p.ld_xscale * 4, top_k = p.top_k;
 
-    // ---- token pieces: piece q of this wave = token rows 64 q + 8 wave .. + 7, eight 16-byte slots each; the slot
-    // permutation of gemm_tiled.h (x_swizzle) is applied on the SOURCE side, the LDS image stays lane-linear
-    int bvoff[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int pc = q * 512 + tid;
-        const int row = pc >> 3, pslot = pc & 7;
-        const int lslot = pslot ^ x_swizzle<128>(row);
-        const int rr = row < rows ? r0 + row : r0;
-        const int src_row = IS_G1 ? p.sorted_slot[off_e + rr] / p.top_k : off_e + rr;
-        bvoff[q] = src_row * p.ldx + lslot * 16;              // fp8: bytes == elements; < 2 GiB (launcher)
-    }
-    // token-scale pieces (waves 0..3): lane = token 64 wave + lane, 16 bytes = the scales of four K units
-    int svoff = 0;
+    // ---- an item's row table (LDS, kTbl + 2048 * buffer): [256] source row * ldx, then [256] source row * ld_xscale * 4.
+    // Waves 0..3 gather one sorted_slot entry per lane (GEMM1; GEMM2 rows are their own sources) into the landing zone ...
+    auto gather_item = [&](const Item& it) __attribute__((always_inline)) {
+        if constexpr (IS_G1) {
+            if (wave < 4) {
+                const int r = wave * 64 + lane;
+                a8w_dma4_flat(lds0 + kRaw + wave * 256, p.sorted_slot + it.orow0 + (r < it.rows ? r : 0));
+            }
+        }
+    };
+    // ... and, once the entries have landed (two barriers later), store the two pre-multiplied offsets of their rows
+    auto store_table = [&](int buf, const Item& it) __attribute__((always_inline)) {
+        if (wave < 4) {
+            const int r = wave * 64 + lane;
+            int src;
+            if constexpr (IS_G1) {
+                int raw;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(raw) : "v"(lds0 + kRaw + r * 4) : "memory");
+                src = raw / top_k;
+            } else {
+                src = it.orow0 + (r < it.rows ? r : 0);
+            }
+            const int a = lds0 + kTbl + buf * 2048 + r * 4;
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:1024" ::"v"(a), "v"(src * ldx), "v"(src * ldxs4) : "memory");
+        }
+    };
+    // Lane-derived LDS addresses, recomputed from an opaque copy of the thread id wherever they are used: kept as loop
+    // invariants they would live across the epilogue, and the compiler's registers must stay below the fixed map (v40..).
+    //   B operand: lane (g, j) reads token row 16 b + j, 16-byte slots g and 4 + g (swizzled), + 2048 b
+    //   token pieces: piece q of this wave = token rows 64 q + 8 wave .. + 7, eight 16-byte slots each; the slot permutation
+    //     of gemm_tiled.h (x_swizzle, period 16 in the row: the same for every q) is applied on the SOURCE side, the LDS
+    //     image stays lane-linear.  Scale pieces (waves 0..3): lane = token 64 wave + lane, 16 bytes = four K units
+    struct LaneAddr {
+        int vb_lo, vb_hi, vx0, plslot, tb_tok, tb_sc, ws;
+    };
+    auto lane_addr = [&](int t) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(t));
+        const int ln = t & 63, gg = ln >> 4, jj = ln & 15, wv = t >> 6;
+        const int sw = x_swizzle<128>(jj);
+        LaneAddr a;
+        a.vb_lo = lds0 + jj * 128 + ((gg ^ sw) * 16);
+        a.vb_hi = lds0 + jj * 128 + (((4 + gg) ^ sw) * 16);
+        a.vx0 = lds0 + kScBase + jj * 16;                          // + 256 b + kScBuf * ring slot + 4 (u & 3)
+        a.plslot = ((t & 7) ^ x_swizzle<128>(t >> 3)) * 16;
+        a.tb_tok = lds0 + kTbl + (t >> 3) * 4;                     // + 256 q + 2048 * buffer
+        a.tb_sc = lds0 + kTbl + 1024 + ((wv & 3) * 64 + ln) * 4;   // + 2048 * buffer
+        a.ws = lds0 + kWs + wv * 512;                              // + 4096 * buffer + 4 * unit (+ 256: second tile)
+        return a;
+    };
+    // an item's weight-block scales (row 0 of each tile: one block scale per 16-row tile and K unit, prefill_a8w_ok;
+    // lane l <- unit l) into this wave's landing zone of item buffer `buf`
+    auto fetch_ws = [&](const Item& it, int buf) __attribute__((always_inline)) {
+        const int uc = lane < U ? lane : U - 1;
+        const char* sb = (const char*)p.s + ((size_t)it.e * T_all * U + uc) * 64;
+        a8w_dma4_flat(lds0 + kWs + buf * 4096 + wave * 512, sb + (size_t)tile0(it) * U * 64);
+        a8w_dma4_flat(lds0 + kWs + buf * 4096 + wave * 512 + 256, sb + (size_t)tile1(it) * U * 64);
+    };
+
+    Item cur, nxt;
+    Meta pend;
     {
-        const int row = (wave & 3) * 64 + lane;
-        const int rr = row < rows ? r0 + row : r0;
-        const int src_row = IS_G1 ? p.sorted_slot[off_e + rr] / p.top_k : off_e + rr;
-        svoff = src_row * p.ld_xscale * 4;
+        // (three items of metadata through the one landing zone, each waited for: the pipeline has not started)
+        Meta m0 = meta_a(w);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        meta_a_done(m0);
+        meta_b(m0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        meta_b_done(m0);
+        cur = make_item(m0);
+        gather_item(cur);
+        fetch_ws(cur, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        store_table(0, cur);
+        Meta m1 = meta_a(w + stride);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        meta_a_done(m1);
+        meta_b(m1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        meta_b_done(m1);
+        nxt = make_item(m1);
+        gather_item(nxt);
+        fetch_ws(nxt, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        store_table(1, nxt);
+        pend = meta_a(w + 2 * stride);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        meta_a_done(pend);
+        meta_b(pend);
+        // everything above that came from memory is consumed HERE (the compiler's own loads must not be waited for
+        // inside the hand-counted loop)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    const int n_grp = (U + 3) >> 2;
-    // everything above that came from memory is consumed HERE (the compiler's own loads must not be waited for
-    // inside the hand-counted loop)
-    asm volatile("" ::"v"(bvoff[0]), "v"(bvoff[1]), "v"(bvoff[2]), "v"(bvoff[3]), "v"(svoff), "s"(NQ), "s"(a_s0), "s"(a_s1));
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    int it_next = w + 3 * stride;          // the item after `pend`
+    int sbase = 0;                         // scale ring slot of the current item's group 0
+    int tbuf = 0;                          // row table of the current item (the next item's: tbuf ^ 1)
+    int u = 0, gcount = 0;                 // unit inside the current item; units since the start (LDS stage = gcount & 3)
 
-    const int lds0 = (int)(unsigned)(uintptr_t)(LdsPtr)lds;
-    // B operand addresses: lane (g, j) reads token row 16 b + j, 16-byte slots g and 4 + g (swizzled), + 2048 b
-    const int sw = x_swizzle<128>(j);
-    const int vb_lo = lds0 + j * 128 + ((g ^ sw) * 16);
-    const int vb_hi = lds0 + j * 128 + (((4 + g) ^ sw) * 16);
-    const int vx0 = lds0 + kScBase + j * 16;                  // + 256 b + 4096 (group & 1) + 4 (u & 3)
-
-    auto issue_tokens = [&](int u, int q) __attribute__((always_inline)) {
-        const int uu = u < U ? u : U - 1;
-        a8w_dma16(lds0 + (uu & 3) * kStage + q * 8192 + wave * 1024, bvoff[q], rs_x, uu * 128);
+    // loads of the unit three ahead of (cur, u): `far` = it belongs to the next item
+    auto issue_tokens = [&](int q, int toff, int plslot) __attribute__((always_inline)) {
+        const int tu = u + 3;
+        const int st = lds0 + ((gcount + 3) & 3) * kStage + q * 8192 + wave * 1024;
+        const int uu = tu < U ? tu : (nxt.nq ? tu - U : U - 1);          // (no next item: a harmless repeat keeps the counts)
+        a8w_dma16(st, toff + plslot, rs_x, uu * 128);
     };
-    auto issue_scales = [&](int grp) __attribute__((always_inline)) {    // waves 0..3 only (caller)
-        const int gg = grp < n_grp ? grp : n_grp - 1;
-        a8w_dma16(lds0 + kScBase + (gg & 1) * kScBuf + wave * 1024, svoff, rs_xs, gg * 16);
+    auto issue_scales = [&](int tsoff) __attribute__((always_inline)) {       // after the barrier of every unit; waves 0..3
+        const int tu = u + 3;
+        if (tu < U) {
+            if ((tu & 3) == 0) a8w_dma16(lds0 + kScBase + ((sbase + (tu >> 2)) % 3) * kScBuf + wave * 1024, tsoff, rs_xs, (tu >> 2) * 16);
+        } else if (tu == U && nxt.nq) {
+            a8w_dma16(lds0 + kScBase + ((sbase + n_grp) % 3) * kScBuf + wave * 1024, tsoff, rs_xs, 0);
+        }
     };
-    auto issue_a = [&](int u, auto SLOT) __attribute__((always_inline)) {
-        const int uu = u < U ? u : U - 1;
-        a8w_load_a<decltype(SLOT)::v>(a_voff, rs_w, a_s0 + uu * wub, a_s1 + uu * wub);
-    };
-
-    // ---- weight-block scales: lane l <- scale of unit (chunk * 64 + l) of each tile (row 0 of the tile: one block
-    // scale per 16-row tile, prefill_a8w_ok)
-    float wsv0 = 0.f, wsv1 = 0.f;
-    auto load_ws = [&](int chunk) __attribute__((always_inline)) {
-        const int ul = chunk * 64 + lane;
-        const int uc = ul < U ? ul : U - 1;
-        const float* s0 = (const float*)p.s + ((size_t)e * T_all + gt0) * U * 16 + (size_t)uc * 16;
-        const float* s1 = (const float*)p.s + ((size_t)e * T_all + gt1) * U * 16 + (size_t)uc * 16;
-        asm volatile("global_load_dword %0, %2, off\n\t"
-                     "global_load_dword %1, %3, off\n\t"
-                     : "=&v"(wsv0), "=&v"(wsv1)
-                     : "v"(s0), "v"(s1)
-                     : "memory");
+    auto issue_a = [&](auto SLOT) __attribute__((always_inline)) {
+        const int tu = u + 3;
+        const bool far = tu >= U && nxt.nq;
+        const Item& it = far ? nxt : cur;
+        const int uu = tu < U ? tu : (nxt.nq ? tu - U : U - 1);
+        const a8w_i32x4 rs_w = make_rs((const char*)p.w + (size_t)it.e * wbytes, (unsigned)wbytes);
+        a8w_load_a<decltype(SLOT)::v>(lane * 16, rs_w, tile0(it) * wtb + uu * wub, tile1(it) * wtb + uu * wub);
     };
 
-    // ---- prologue
+    // ---- prologue: the pipeline's first three units
     asm volatile("v_mov_b32 v[%c0], 0x7f7f7f7f" ::"i"(kOne) : "memory", A8W_CLOB_TOP);
 #pragma unroll
     for (int i = 0; i < 128; i += 4)
         asm volatile("v_mov_b32 v[%c0+0], 0\n\tv_mov_b32 v[%c0+1], 0\n\tv_mov_b32 v[%c0+2], 0\n\tv_mov_b32 v[%c0+3], 0" ::"i"(kAcc + i) : "memory");
-    load_ws(0);
-    if (wave < 4) issue_scales(0);
+    int ws0, ws1;          // the current unit's two weight-block scales (fp32 bits)
+    int st16 = 0;          // the last epilogue issued >= 16 stores (the ledger's waits of the next three units)
+    {
+        const LaneAddr la = lane_addr(tid);
+        int t[4], ts, w0, w1;
+        asm volatile("ds_read_b32 %0, %7\n\tds_read_b32 %1, %7 offset:256\n\tds_read_b32 %2, %7 offset:512\n\t"
+                     "ds_read_b32 %3, %7 offset:768\n\tds_read_b32 %4, %8\n\tds_read_b32 %5, %9\n\t"
+                     "ds_read_b32 %6, %9 offset:256\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(ts), "=&v"(w0), "=&v"(w1)
+                     : "v"(la.tb_tok), "v"(la.tb_sc), "v"(la.ws)
+                     : "memory");
+        ws0 = __builtin_amdgcn_readfirstlane(w0);
+        ws1 = __builtin_amdgcn_readfirstlane(w1);
+        if (wave < 4) a8w_dma16(lds0 + kScBase + wave * 1024, ts, rs_xs, 0);
+        u = -3, gcount = -3;          // (issue_* address unit u + 3, stage (gcount + 3) & 3)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue_tokens(0, q);
-    issue_a(0, IC<0>{});
+        for (int q = 0; q < 4; ++q) issue_tokens(q, t[q], la.plslot);
+        issue_a(IC<0>{});
+        u = -2, gcount = -2;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue_tokens(1, q);
-    issue_a(1, IC<1>{});
+        for (int q = 0; q < 4; ++q) issue_tokens(q, t[q], la.plslot);
+        issue_a(IC<1>{});
+        u = -1, gcount = -1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue_tokens(2, q);
-    issue_a(2, IC<2>{});
-    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" : "+v"(wsv0), "+v"(wsv1)::"memory");
-    // block 0 of unit 0: B operand and token scale
-    asm volatile("ds_read_b128 v[%c[b]:%c[b]+3], %[lo]\n\t"
-                 "ds_read_b128 v[%c[b]+4:%c[b]+7], %[hi]\n\t"
-                 "ds_read_b32 v[%c[x]], %[xs]\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 :
-                 : [b] "i"(kB), [x] "i"(kX), [lo] "v"(vb_lo), [hi] "v"(vb_hi), [xs] "v"(vx0)
-                 : "memory", A8W_CLOB_B);
+        for (int q = 0; q < 4; ++q) issue_tokens(q, t[q], la.plslot);
+        issue_a(IC<2>{});
+        u = 0, gcount = 0;
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        // block 0 of unit 0: B operand and token scale
+        asm volatile("ds_read_b128 v[%c[b]:%c[b]+3], %[lo]\n\t"
+                     "ds_read_b128 v[%c[b]+4:%c[b]+7], %[hi]\n\t"
+                     "ds_read_b32 v[%c[x]], %[xs]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     :
+                     : [b] "i"(kB), [x] "i"(kX), [lo] "v"(la.vb_lo), [hi] "v"(la.vb_hi), [xs] "v"(la.vx0)
+                     : "memory", A8W_CLOB_B);
+    }
 
-    // ---- one K unit; SLOT = u % 3 (compile time: the A ring is register-indexed)
-    auto unit = [&](int u, auto SLOTC) __attribute__((always_inline)) {
+    // ---- one K unit; SLOT = units-since-start % 3 (compile time: the A ring is register-indexed).  True at an item's end.
+    auto unit = [&](auto SLOTC) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(SLOTC)::v;
-        if (u > 0 && (u & 63) == 0) {        // K > 8192: next 64 weight-block scales (drains the pipeline once)
-            load_ws(u >> 6);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wsv0), "+v"(wsv1)::"memory");
-        }
-        const int ws0 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, wsv0), u & 63);
-        const int ws1 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, wsv1), u & 63);
-        const int st = (u & 3) * kStage, stn = ((u + 1) & 3) * kStage;
-        const int lo_c = vb_lo + st, hi_c = vb_hi + st, lo_n = vb_lo + stn, hi_n = vb_hi + stn;
-        const int xs_c = vx0 + ((u >> 2) & 1) * kScBuf + (u & 3) * 4;
-        const int xs_n = vx0 + (((u + 1) >> 2) & 1) * kScBuf + ((u + 1) & 3) * 4;
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                 // A(u) is in its slot
+        const LaneAddr la = lane_addr(tid);
+        const int st = (gcount & 3) * kStage, stn = ((gcount + 1) & 3) * kStage;
+        const int lo_c = la.vb_lo + st, hi_c = la.vb_hi + st, lo_n = la.vb_lo + stn, hi_n = la.vb_hi + stn;
+        const int xs_c = la.vx0 + ((sbase + (u >> 2)) % 3) * kScBuf + (u & 3) * 4;
+        const int un = u + 1;
+        const int xs_n = un < U ? la.vx0 + ((sbase + (un >> 2)) % 3) * kScBuf + (un & 3) * 4
+                                : la.vx0 + ((sbase + n_grp) % 3) * kScBuf;
+        // next unit's weight-block scales; the row table of the unit three ahead
+        const bool un_far = un >= U && nxt.nq;
+        const int unn = un < U ? un : (nxt.nq ? 0 : U - 1);
+        const int wsaddr = la.ws + (un_far ? tbuf ^ 1 : tbuf) * 4096 + unn * 4;
+        const bool t_far = u + 3 >= U && nxt.nq;
+        const int tsel = (t_far ? tbuf ^ 1 : tbuf) * 2048;
+        int ws0n, ws1n, t[4], ts;
+        // A(u) is in its slot.  (The three units behind an item switch: the epilogue's stores are in the ledger behind
+        // the loads these waits are about -- >= 16 of them when st16 -- and must not be waited for.)
+        const bool late = st16 && u < 3;
+        if (late) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         // (opaque per unit: a loop-invariant q < NQ would be hoisted into sixteen SGPR-pair booleans, which spill)
-        int nq = NQ;
+        int nq = cur.nq;
         asm volatile("" : "+s"(nq));
+        if constexpr (DBG & 2) {
+            ws0n = ws0, ws1n = ws1, ts = 0;
+            t[0] = t[1] = t[2] = t[3] = 0;
+        }
         static_for<8>([&](auto QC) __attribute__((always_inline)) {
             constexpr int q = decltype(QC)::v;
             if (q < nq) {
-                if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q, (q > 0), (2 * q + 1) * 2048, (2 * q + 1) * 256>(lo_c, hi_c, xs_c, ws0, ws1);
                 if constexpr (q == 0) {
+                    if constexpr (!(DBG & 2))
+                        a8w_block0<SLOT, DBG>(lo_c, hi_c, xs_c, ws0, ws1, wsaddr, la.tb_tok + tsel, la.tb_sc + tsel, ws0n, ws1n, t, ts);
                     // tokens(u+1) of THIS wave have landed; after the barrier every wave's have, and nobody reads
-                    // stage (u+3) % 4 = (u-1) % 4 any more
-                    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+                    // stage (gcount+3) % 4 = (gcount-1) % 4 any more
+                    if constexpr (DBG & 64) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // (ablation: no barrier)
+                    else if (late) asm volatile("s_waitcnt vmcnt(28)\n\ts_barrier" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
                     if constexpr (!(DBG & 1))
-                        if ((u & 3) == 1 && wave < 4) issue_scales((u + 3) >> 2);
+                        if (wave < 4) issue_scales(ts);
+                    if (u == 2) {
+                        // two barriers after the item switch: the next item's gathered rows have landed (ledger: sixteen
+                        // loads were issued after them) -> its table; and the pending item's expert is known
+                        if (nxt.nq) store_table(tbuf ^ 1, nxt);
+                        meta_a_done(pend);
+                        meta_b(pend);
+                    }
+                } else {
+                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q, true, (2 * q + 1) * 2048, (2 * q + 1) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
                 }
                 if (q + 1 < nq) {
-                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, (2 * q + 2) * 2048, (2 * q + 2) * 256>(lo_c, hi_c, xs_c, ws0, ws1);
-                    if constexpr (q < 4 && !(DBG & 1)) issue_tokens(u + 3, q);
+                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, (2 * q + 2) * 2048, (2 * q + 2) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
+                    if constexpr (q < 4 && !(DBG & 1)) issue_tokens(q, t[q], la.plslot);
                 } else {
-                    // last block of the unit: prefetch block 0 of unit u+1 (next stage), then the rest of the unit's
+                    // last block of the unit: prefetch block 0 of the next unit (next stage), then the rest of the unit's
                     // loads, then the block's own accumulator update
-                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, 0, 0>(lo_n, hi_n, xs_n, ws0, ws1);
+                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, 0, 0, DBG>(lo_n, hi_n, xs_n, ws0, ws1);
                     if constexpr (!(DBG & 1)) {
                         static_for<4>([&](auto KC) __attribute__((always_inline)) {
-                            if constexpr (decltype(KC)::v >= q) issue_tokens(u + 3, decltype(KC)::v);
+                            if constexpr (decltype(KC)::v >= q) issue_tokens(decltype(KC)::v, t[decltype(KC)::v], la.plslot);
                         });
-                        issue_a(u + 3, IC<SLOT>{});
+                        issue_a(IC<SLOT>{});
                     }
-                    if constexpr (!(DBG & 2)) a8w_flush<2 * q + 1>();
+                    if constexpr (!(DBG & 2)) a8w_flush<2 * q + 1, DBG>();
                 }
             }
         });
         if (dbg_serial) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (debug: serialised units)
+        ws0 = __builtin_amdgcn_readfirstlane(ws0n);
+        ws1 = __builtin_amdgcn_readfirstlane(ws1n);
+        ++gcount;
+        if (gcount >= 12) gcount -= 12;      // (only gcount & 3 and the unroll phase matter)
+        ++u;
+        return u == U;
     };
-    for (int u = 0; u < U; u += 3) {
-        unit(u, IC<0>{});
-        if (u + 1 < U) unit(u + 1, IC<1>{});
-        if (u + 2 < U) unit(u + 2, IC<2>{});
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // trailing (clamped) loads must not outlive the wave
 
-    // ---- epilogue (D layout lane (g, j): rows tile*16 + g*4 + r, token column j of block b)
-    static_for<16>([&](auto BC) __attribute__((always_inline)) {
-        constexpr int b = decltype(BC)::v;
-        if (b < 2 * NQ) {      // (uniform)
-            const int rt = b * 16 + j;
-            f32x4 c0, c1;
-            asm volatile("v_mov_b32 %0, v[%c8+0]\n\tv_mov_b32 %1, v[%c8+1]\n\tv_mov_b32 %2, v[%c8+2]\n\tv_mov_b32 %3, v[%c8+3]\n\t"
-                         "v_mov_b32 %4, v[%c8+4]\n\tv_mov_b32 %5, v[%c8+5]\n\tv_mov_b32 %6, v[%c8+6]\n\tv_mov_b32 %7, v[%c8+7]"
-                         : "=&v"(c0.x), "=&v"(c0.y), "=&v"(c0.z), "=&v"(c0.w), "=&v"(c1.x), "=&v"(c1.y), "=&v"(c1.z), "=&v"(c1.w)
-                         : "i"(kAcc + b * 8));
-            if (rt < rows) {
-                const size_t orow = (size_t)(off_e + r0 + rt);
-                if constexpr (GATED) {
-                    const int n = (tbase + wave) * 16 + g * 4;
-                    if (tbase + wave < p.T_half && n < p.n_real) store_gemm1_frag<ADT, true>(p, c0, c1, orow, n);
-                } else {
-                    static_for<2>([&](auto TC) __attribute__((always_inline)) {
-                        constexpr int t = decltype(TC)::v;
-                        const int tl = tbase + 2 * wave + t;
-                        const int n = tl * 16 + g * 4;
-                        const f32x4 v = t ? c1 : c0;
-                        if (tl < p.T_half && n < p.n_real) {
-                            if constexpr (IS_G1) store_gemm1_frag<ADT, false>(p, v, v, orow, n);
-                            else if (p.y_dt == LKM_DT_F32) store_gemm2_frag(p, v, 0, orow, n);
-                            else {      // the reference's block-fp8 GEMM rounds its output to the activation dtype
-                                unsigned short* o = (unsigned short*)p.out + orow * p.ldo + n;
-                                if (n + 4 <= p.n_real) {
-                                    *(u32x2*)o = u32x2{ActT<ADT>::pack2(v.x, v.y), ActT<ADT>::pack2(v.z, v.w)};
-                                } else {
-                                    if (n + 0 < p.n_real) o[0] = ActT<ADT>::from_f32(v.x);
-                                    if (n + 1 < p.n_real) o[1] = ActT<ADT>::from_f32(v.y);
-                                    if (n + 2 < p.n_real) o[2] = ActT<ADT>::from_f32(v.z);
-                                    if (n + 3 < p.n_real) o[3] = ActT<ADT>::from_f32(v.w);
-                                }
+    // ---- the item's epilogue (D layout lane (g, j): rows tile*16 + g*4 + r, token column j of block b) and the switch to
+    // the next item, whose first units are already in flight
+    int phase = 0;
+    for (;;) {
+        // (one loop header, a switch on the unroll phase: jumping INTO the unrolled body with gotos makes the control flow
+        // irreducible, and the compiler then treats every value that lives across it as divergent)
+        bool end = false;
+        switch (phase) {
+        case 0:
+            end = unit(IC<0>{});
+            if (end) {
+                phase = 1;
+                break;
+            }
+            [[fallthrough]];
+        case 1:
+            end = unit(IC<1>{});
+            if (end) {
+                phase = 2;
+                break;
+            }
+            [[fallthrough]];
+        default:
+            end = unit(IC<2>{});
+            phase = 0;
+            break;
+        }
+        if (!end) continue;
+        {
+            const Item done = cur;
+            const bool more = nxt.nq != 0;
+            {   // store instructions this wave is about to issue: blocks that hold rows x its tiles inside the matrix
+                const int nb = (done.rows + 15) >> 4;
+                const int t0 = GATED ? done.tbase + wave : done.tbase + 2 * wave;
+                const int nt = GATED ? (t0 < T_half && t0 * 16 < p.n_real ? 1 : 0)
+                                     : (t0 < T_half && t0 * 16 < p.n_real ? 1 : 0) + (t0 + 1 < T_half && (t0 + 1) * 16 < p.n_real ? 1 : 0);
+                st16 = nb * nt >= 16;
+            }
+            // (opaque lane coordinates: the compiler must not hoist the epilogue's sixteen row offsets out of the K loop --
+            // it has 39 registers, and a spilled value is a scratch load inside the hand-counted loop)
+            int jj = j, gg = g;
+            asm volatile("" : "+v"(jj), "+v"(gg));
+            if (more) {
+                // the switch first (its gather goes out before the epilogue's stores), the epilogue after
+                sbase = (sbase + n_grp) % 3;
+                tbuf ^= 1;
+                cur = nxt;
+                u = 0;
+                meta_b_done(pend);
+                nxt = make_item(pend);
+                gather_item(nxt);                      // (no such item: repeats item 0's addresses, harmless)
+                fetch_ws(nxt, tbuf ^ 1);
+                pend = meta_a(it_next);
+                it_next += stride;
+            }
+            asm volatile("; A8W_EPILOGUE_BEGIN" ::: "memory");
+            static_for<16>([&](auto BC) __attribute__((always_inline)) {
+                constexpr int b = decltype(BC)::v;
+                if (b < 2 * done.nq) {      // (uniform)
+                    const int rt = b * 16 + jj;
+                    f32x4 c0, c1;
+                    asm volatile("v_mov_b32 %0, v[%c8+0]\n\tv_mov_b32 %1, v[%c8+1]\n\tv_mov_b32 %2, v[%c8+2]\n\tv_mov_b32 %3, v[%c8+3]\n\t"
+                                 "v_mov_b32 %4, v[%c8+4]\n\tv_mov_b32 %5, v[%c8+5]\n\tv_mov_b32 %6, v[%c8+6]\n\tv_mov_b32 %7, v[%c8+7]\n\t"
+                                 "v_mov_b32 v[%c8+0], 0\n\tv_mov_b32 v[%c8+1], 0\n\tv_mov_b32 v[%c8+2], 0\n\tv_mov_b32 v[%c8+3], 0\n\t"
+                                 "v_mov_b32 v[%c8+4], 0\n\tv_mov_b32 v[%c8+5], 0\n\tv_mov_b32 v[%c8+6], 0\n\tv_mov_b32 v[%c8+7], 0"
+                                 : "=&v"(c0.x), "=&v"(c0.y), "=&v"(c0.z), "=&v"(c0.w), "=&v"(c1.x), "=&v"(c1.y), "=&v"(c1.z), "=&v"(c1.w)
+                                 : "i"(kAcc + b * 8)
+                                 : "memory");
+                    if (rt < done.rows) {
+                        const size_t orow = (size_t)(done.orow0 + rt);
+                        if constexpr (GATED) {
+                            const int n = (done.tbase + wave) * 16 + gg * 4;
+                            if (done.tbase + wave < T_half && n < p.n_real) {
+                                if (p.act_type == LKM_ACT_SWIGLUOAI) store_gemm1_frag<ADT, true>(p, c0, c1, orow, n);
+                                else a8w_store_silu_mul<ADT>(p, c0, c1, orow, n);
                             }
+                        } else {
+                            static_for<2>([&](auto TC) __attribute__((always_inline)) {
+                                constexpr int t = decltype(TC)::v;
+                                const int tl = done.tbase + 2 * wave + t;
+                                const int n = tl * 16 + gg * 4;
+                                const f32x4 v = t ? c1 : c0;
+                                if (tl < T_half && n < p.n_real) {
+                                    if constexpr (IS_G1) store_gemm1_frag<ADT, false>(p, v, v, orow, n);
+                                    else if (p.y_dt == LKM_DT_F32) store_gemm2_frag(p, v, 0, orow, n);
+                                    else {      // the reference's block-fp8 GEMM rounds its output to the activation dtype
+                                        unsigned short* o = (unsigned short*)p.out + orow * p.ldo + n;
+                                        if (n + 4 <= p.n_real) {
+                                            *(u32x2*)o = u32x2{ActT<ADT>::pack2(v.x, v.y), ActT<ADT>::pack2(v.z, v.w)};
+                                        } else {
+                                            if (n + 0 < p.n_real) o[0] = ActT<ADT>::from_f32(v.x);
+                                            if (n + 1 < p.n_real) o[1] = ActT<ADT>::from_f32(v.y);
+                                            if (n + 2 < p.n_real) o[2] = ActT<ADT>::from_f32(v.z);
+                                            if (n + 3 < p.n_real) o[3] = ActT<ADT>::from_f32(v.w);
+                                        }
+                                    }
+                                }
+                            });
                         }
-                    });
+                    }
                 }
+            });
+            asm volatile("; A8W_EPILOGUE_END" ::: "memory");
+            if (!more) break;
+            {
+                // Block 0 of the new item's first unit: B operand and token scale, read HERE and not by the old item's last
+                // block -- the compiler's epilogue code is free to use the B / P / x / f registers as temporaries (it
+                // must stay below v78, the E8M0 constant and the A ring: tests/test_a8w_codegen.py), and nothing else of
+                // the fixed map holds a value across the epilogue.  Visible since the barrier of the old item's last unit.
+                const LaneAddr la = lane_addr(tid);
+                asm volatile("ds_read_b128 v[%c[b]:%c[b]+3], %[lo]\n\t"
+                             "ds_read_b128 v[%c[b]+4:%c[b]+7], %[hi]\n\t"
+                             "ds_read_b32 v[%c[x]], %[xs]\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             :
+                             : [b] "i"(kB), [x] "i"(kX), [lo] "v"(la.vb_lo + (gcount & 3) * kStage), [hi] "v"(la.vb_hi + (gcount & 3) * kStage),
+                               [xs] "v"(la.vx0 + (sbase % 3) * kScBuf)
+                             : "memory", A8W_CLOB_B, A8W_CLOB_TOP);
             }
         }
-    });
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // trailing (clamped) loads must not outlive the wave
 #else
     (void)p;
 #endif
@@ -408,7 +753,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
 // multiple of 16), the weight image is tile-major or unit-major with 32-bit offsets, and the operand matrices fit the
 // 2 GiB buffer windows; otherwise the plan stays on gemm_tiled_kernel (pick_cfg asks prefill_a8w_shape_ok first)
 inline bool prefill_a8w_ok(const GemmParams& p) {
-    return p.Kreal % 128 == 0 && p.tile_uniform_scale && p.U >= 1 &&
+    return p.Kreal % 128 == 0 && p.tile_uniform_scale && p.U >= 8 && p.U <= 64 &&      // (the item-boundary pipeline; 64 weight-block scales per tile in the landing zone)
            (size_t)p.x_rows * (size_t)p.ldx < (size_t)0x7fffffff &&
            (size_t)p.x_rows * (size_t)p.ld_xscale * 4 < (size_t)0x7fffffff &&
            (size_t)p.T_half * p.halves * p.U * 2048 < (size_t)0x7fffffff;
@@ -417,20 +762,26 @@ inline bool prefill_a8w_ok(const GemmParams& p) {
 template <int ADT, bool GATED, bool IS_G1, int DBG = 0>
 static int launch_prefill_a8w_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr size_t lds = (size_t)a8w::kLdsBytes;
-    const int TPH = GATED ? 8 : 16;
-    const int RG = ceil_div(p.T_half, TPH);
-    dim3 grid(RG, max_tiles), block(512);
-    GemmParams pp = p;
-    if (p.xcd_map) {
-        pp.xcd_map = RG;
-        grid = dim3(8 * p.xcd_map * RG, 1);      // p.xcd_map = upper bound of the tiles in one XCD's run (host)
+    // persistent: one workgroup per CU (143 KiB of LDS and 256 registers x 512 threads admit exactly one)
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0, v = 0;
+        LKM_HIP_CHECK(hipGetDevice(&dev));
+        LKM_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? (v / 8) * 8 : 256;
+        if (n_cu < 8) n_cu = 8;
     }
+    (void)max_tiles;
+    dim3 grid(n_cu), block(512);
     auto kern = gemm_prefill_a8w_kernel<ADT, GATED, IS_G1, DBG>;
     LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, pp);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, p);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }
+
+// gemm_a8w_dbg.hip: the ablation instantiations (gated GEMM1, bf16)
+int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, int dbg);
 
 template <typename ADTC>
 static bool launch_prefill_a8w_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
@@ -443,8 +794,8 @@ static bool launch_prefill_a8w_if(hipStream_t st, const LaunchCfg& cfg, const Ge
         return true;
     }
     if constexpr (ADT == LKM_DT_BF16) {     // ablation builds: gated GEMM1, bf16 activations only
-        if (is_g1 && gated && (p.dbg & 3)) {
-            *rc = (p.dbg & 1) ? launch_prefill_a8w_t<ADT, true, true, 1>(st, p, max_tiles) : launch_prefill_a8w_t<ADT, true, true, 2>(st, p, max_tiles);
+        if (is_g1 && gated && (p.dbg & 0xfb)) {
+            *rc = launch_prefill_a8w_dbg(st, p, max_tiles, p.dbg & 0xfb);
             return true;
         }
     }

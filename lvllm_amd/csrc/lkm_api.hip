@@ -645,7 +645,8 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         if (tiled == 256 && h->a8) {          // the fp8 x fp8 prefill kernels are the only 256-row variants of the format
             // 9 = round 3 (gemm_prefill_a8w.h: weights straight to registers, tokens through a 4-stage LDS ring, equal
             // token tiles); 8 = round 2 (gemm_prefill_a8.h: both operands through two LDS buffers), kept behind "pf" = 8
-            pf = h->t_pf == 8 ? 8 : 9;
+            // (the round-3 kernel's pipeline runs through item boundaries and needs K loops of at least 8 units)
+            pf = (h->t_pf == 8 || h->U1 < 8 || h->U2 < 8 || h->U1 > 64 || h->U2 > 64) ? 8 : 9;
             waves = 8;
             // The XCD-aware runs (dispatch.hip) stay a knob ("xcd" = 1): on GLM-4.5-Air fp8 prefill they cut GEMM1's
             // L2-miss traffic 5.8 -> 3.55 GB and lift the L2 hit rate 45 -> 66 %, yet the kernel runs 4-6 % SLOWER

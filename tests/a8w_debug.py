@@ -17,9 +17,8 @@ from tests.helpers import make_routing  # noqa: E402
 DEV = "cuda:0"
 
 
-def main():
-    M, E, K, H, I = 3000, 6, 1, 1024, 768
-    gated = True
+def main(M=3000, E=6, K=1, H=1024, I=1024, gated=True):
+    print(f"#### M={M} E={E} K={K} H={H} I={I} gated={gated}")
     g = torch.Generator().manual_seed(1)
     a = (torch.randn((M, H), generator=g) / 10).to(torch.bfloat16)
     w13 = (torch.randn((E, 2 * I, H), generator=g) / 10).to(torch.bfloat16)
@@ -65,6 +64,9 @@ def main():
             print("   bad rows by expert:", {int(e): int(rows[e_of == e].sum()) for e in np.unique(e_of)})
             blk = (pos[rows] // 16)
             print("   bad rows by 16-row block index inside the expert (first 40):", np.bincount(blk)[:40].tolist())
+            first_bad = np.nonzero(rows)[0][:12]
+            print("   first bad tokens (token, expert, pos in expert):", [(int(t), int(e_of[t]), int(pos[t])) for t in first_bad])
+            print("   bad cols by col // 256:", np.bincount(np.nonzero(cols)[0] // 256).tolist())
             print("   bad cols by (col // 16) % 16:", np.bincount((np.nonzero(cols)[0] // 16) % 16, minlength=16).tolist())
             print("   bad cols by col % 16:", np.bincount(np.nonzero(cols)[0] % 16, minlength=16).tolist())
     eng.engine.set_tuning(tiled=0, pf=0, dbg=0, xcd=0)
@@ -72,3 +74,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main(M=12000, E=24, H=1152, I=1280)
+    main(M=12000, E=24, H=1152, I=1280, gated=False)

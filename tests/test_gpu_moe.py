@@ -182,10 +182,13 @@ def test_fp8_w8a8_larger_random():
     np.testing.assert_allclose(out, out16, atol=0.035 * float(np.abs(out16).max()), rtol=0.035)
 
 
-@pytest.mark.parametrize("pf", [9, 8])
 @pytest.mark.parametrize("gated", [True, False])
-@pytest.mark.parametrize("M,E,H,I,xcd", [(600, 4, 512, 384, 0), (1500, 3, 256, 640, 1), (2300, 20, 384, 128, 1),
-                                         (900, 2, 1536, 256, 0)])
+@pytest.mark.parametrize("M,E,H,I,xcd,pf", [
+    (600, 4, 512, 384, 0, 8), (1500, 3, 256, 640, 1, 8), (2300, 20, 384, 128, 1, 8),
+    # round-3 kernel (K loops of >= 8 units): 8 / 8, 12 / 9 and 9 / 10 units, one to ~40 items per workgroup (the
+    # item-boundary pipeline), experts of 1 to 900 rows, padded weight-tile counts (I = 1152: 72 tiles = 4.5 row groups)
+    (700, 3, 1024, 1024, 0, 9), (1500, 5, 1536, 1152, 1, 9), (6000, 24, 1152, 1280, 1, 9), (3000, 7, 1024, 1024, 0, 9),
+    (260, 2, 1024, 1024, 1, 9)])
 def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated, pf):
     """gemm_prefill_a8w.h (pf 9: weights straight to registers, tokens through a 4-stage LDS ring, equal token tiles)
     and gemm_prefill_a8.h (pf 8: both operands through two LDS buffers) -- 256 x 256 tiles on

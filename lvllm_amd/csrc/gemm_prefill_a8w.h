@@ -294,6 +294,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     stride = __builtin_amdgcn_readfirstlane(stride);
     if (w >= n_items) return;
 
+    const size_t wbytes = (size_t)T_all * U * 2048;
+    const int wub = __builtin_amdgcn_readfirstlane((int)(p.w_ustride * 16));
+    const int wtb = __builtin_amdgcn_readfirstlane((int)(p.w_tstride * 16));
     // ---- item descriptors: wave-uniform scalars only
     struct Meta {
         int valid, bx, e, r0, e2, r02, m_e, off_e;
@@ -341,6 +344,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     struct Item {
         int nq;        // 32-row pairs of token blocks that hold rows; 0 = no such item
         int rows, orow0, tbase, e;
+        int wlo, whi;  // the expert's weight image (buffer resource words 0 / 1)
+        int as0, as1;  // byte offsets of this wave's two tiles inside it
     };
     auto make_item = [&](const Meta& m) __attribute__((always_inline)) {
         Item it;
@@ -353,6 +358,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         it.orow0 = m.off_e + m.r0;
         it.tbase = m.bx * TPH;
         it.e = m.e;
+        const unsigned long long wa = (unsigned long long)((const char*)p.w + (size_t)m.e * wbytes);
+        it.wlo = __builtin_amdgcn_readfirstlane((int)(unsigned)wa);
+        it.whi = __builtin_amdgcn_readfirstlane((int)((unsigned)(wa >> 32) & 0xffffu));
+        const int t0 = GATED ? it.tbase + wave : it.tbase + 2 * wave;
+        const int t1 = GATED ? it.tbase + wave : it.tbase + 2 * wave + 1;
+        it.as0 = (t0 < T_half ? t0 : T_half - 1) * wtb;
+        it.as1 = ((GATED ? T_half : 0) + (t1 < T_half ? t1 : T_half - 1)) * wtb;
         return it;
     };
     // the wave's two weight tiles of an item: gated = gate tile w and up tile w of the same rows; else two adjacent tiles
@@ -373,11 +385,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         r.w = 0x00020000;
         return r;
     };
-    const size_t wbytes = (size_t)T_all * U * 2048;
     const a8w_i32x4 rs_x = make_rs(p.x, (unsigned)((size_t)p.x_rows * (size_t)p.ldx));
     const a8w_i32x4 rs_xs = make_rs(p.xscale, (unsigned)((size_t)p.x_rows * (size_t)p.ld_xscale * 4));
-    const int wub = __builtin_amdgcn_readfirstlane((int)(p.w_ustride * 16));
-    const int wtb = __builtin_amdgcn_readfirstlane((int)(p.w_tstride * 16));
     const int ldx = p.ldx, ldxs4 = p.ld_xscale * 4, top_k = p.top_k;
 
     // ---- an item's row table (LDS, kTbl + 2048 * buffer): [256] source row * ldx, then [256] source row * ld_xscale * 4.
@@ -406,8 +415,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
             asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:1024" ::"v"(a), "v"(src * ldx), "v"(src * ldxs4) : "memory");
         }
     };
-    // Lane-derived LDS addresses, recomputed from an opaque copy of the thread id wherever they are used: kept as loop
-    // invariants they would live across the epilogue, and the compiler's registers must stay below the fixed map (v40..).
+    // Lane-derived LDS addresses (loop invariants; the compiler's registers stay below the fixed map in the K loop and
+    // below v78 in the epilogue: tools/scan_a8w_codegen.py).
     //   B operand: lane (g, j) reads token row 16 b + j, 16-byte slots g and 4 + g (swizzled), + 2048 b
     //   token pieces: piece q of this wave = token rows 64 q + 8 wave .. + 7, eight 16-byte slots each; the slot permutation
     //     of gemm_tiled.h (x_swizzle, period 16 in the row: the same for every q) is applied on the SOURCE side, the LDS
@@ -416,7 +425,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         int vb_lo, vb_hi, vx0, plslot, tb_tok, tb_sc, ws;
     };
     auto lane_addr = [&](int t) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(t));
         const int ln = t & 63, gg = ln >> 4, jj = ln & 15, wv = t >> 6;
         const int sw = x_swizzle<128>(jj);
         LaneAddr a;
@@ -473,32 +481,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     int it_next = w + 3 * stride;          // the item after `pend`
-    int sbase = 0;                         // scale ring slot of the current item's group 0
-    int tbuf = 0;                          // row table of the current item (the next item's: tbuf ^ 1)
-    int u = 0, gcount = 0;                 // unit inside the current item; units since the start (LDS stage = gcount & 3)
+    int tbuf = 0;                          // row table / weight scales of the current item (the next item's: tbuf ^ 1)
+    int u = 0;                             // unit inside the current item
+    int stoff = 0;                         // LDS stage of the current unit (byte offset; + kStage mod 4 stages per unit)
+    int xsl = 0;                           // token-scale ring slot of the current unit's group of four
+    int xsl_nxt0 = n_grp % 3;              // ... of the next item's first group
+    const LaneAddr la = lane_addr(tid);
+    auto next3 = [](int v) __attribute__((always_inline)) { return v == 2 ? 0 : v + 1; };
 
-    // loads of the unit three ahead of (cur, u): `far` = it belongs to the next item
-    auto issue_tokens = [&](int q, int toff, int plslot) __attribute__((always_inline)) {
-        const int tu = u + 3;
-        const int st = lds0 + ((gcount + 3) & 3) * kStage + q * 8192 + wave * 1024;
-        const int uu = tu < U ? tu : (nxt.nq ? tu - U : U - 1);          // (no next item: a harmless repeat keeps the counts)
-        a8w_dma16(st, toff + plslot, rs_x, uu * 128);
+    // loads of the unit three ahead of (cur, u); it may belong to the next item
+    auto issue_tokens = [&](int q, int toff, int dma_base, int soff) __attribute__((always_inline)) {
+        a8w_dma16(dma_base + q * 8192, toff + la.plslot, rs_x, soff);
     };
     auto issue_scales = [&](int tsoff) __attribute__((always_inline)) {       // after the barrier of every unit; waves 0..3
         const int tu = u + 3;
         if (tu < U) {
-            if ((tu & 3) == 0) a8w_dma16(lds0 + kScBase + ((sbase + (tu >> 2)) % 3) * kScBuf + wave * 1024, tsoff, rs_xs, (tu >> 2) * 16);
+            if ((tu & 3) == 0) a8w_dma16(lds0 + kScBase + next3(xsl) * kScBuf + wave * 1024, tsoff, rs_xs, (tu >> 2) * 16);
         } else if (tu == U && nxt.nq) {
-            a8w_dma16(lds0 + kScBase + ((sbase + n_grp) % 3) * kScBuf + wave * 1024, tsoff, rs_xs, 0);
+            a8w_dma16(lds0 + kScBase + xsl_nxt0 * kScBuf + wave * 1024, tsoff, rs_xs, 0);
         }
     };
-    auto issue_a = [&](auto SLOT) __attribute__((always_inline)) {
-        const int tu = u + 3;
+    auto issue_a = [&](auto SLOT, int tu) __attribute__((always_inline)) {      // tu: unit index as seen from `cur`
         const bool far = tu >= U && nxt.nq;
-        const Item& it = far ? nxt : cur;
-        const int uu = tu < U ? tu : (nxt.nq ? tu - U : U - 1);
-        const a8w_i32x4 rs_w = make_rs((const char*)p.w + (size_t)it.e * wbytes, (unsigned)wbytes);
-        a8w_load_a<decltype(SLOT)::v>(lane * 16, rs_w, tile0(it) * wtb + uu * wub, tile1(it) * wtb + uu * wub);
+        const int uu = tu < U ? tu : (nxt.nq ? tu - U : U - 1);          // (no next item: a harmless repeat keeps the counts)
+        a8w_i32x4 rs_w;
+        rs_w.x = far ? nxt.wlo : cur.wlo;
+        rs_w.y = far ? nxt.whi : cur.whi;
+        rs_w.z = (int)(unsigned)wbytes;
+        rs_w.w = 0x00020000;
+        a8w_load_a<decltype(SLOT)::v>(lane * 16, rs_w, (far ? nxt.as0 : cur.as0) + uu * wub, (far ? nxt.as1 : cur.as1) + uu * wub);
     };
 
     // ---- prologue: the pipeline's first three units
@@ -509,7 +520,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     int ws0, ws1;          // the current unit's two weight-block scales (fp32 bits)
     int st16 = 0;          // the last epilogue issued >= 16 stores (the ledger's waits of the next three units)
     {
-        const LaneAddr la = lane_addr(tid);
         int t[4], ts, w0, w1;
         asm volatile("ds_read_b32 %0, %7\n\tds_read_b32 %1, %7 offset:256\n\tds_read_b32 %2, %7 offset:512\n\t"
                      "ds_read_b32 %3, %7 offset:768\n\tds_read_b32 %4, %8\n\tds_read_b32 %5, %9\n\t"
@@ -520,19 +530,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         ws0 = __builtin_amdgcn_readfirstlane(w0);
         ws1 = __builtin_amdgcn_readfirstlane(w1);
         if (wave < 4) a8w_dma16(lds0 + kScBase + wave * 1024, ts, rs_xs, 0);
-        u = -3, gcount = -3;          // (issue_* address unit u + 3, stage (gcount + 3) & 3)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) issue_tokens(q, t[q], la.plslot);
-        issue_a(IC<0>{});
-        u = -2, gcount = -2;
+        for (int k = 0; k < 3; ++k) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) issue_tokens(q, t[q], la.plslot);
-        issue_a(IC<1>{});
-        u = -1, gcount = -1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) issue_tokens(q, t[q], la.plslot);
-        issue_a(IC<2>{});
-        u = 0, gcount = 0;
+            for (int q = 0; q < 4; ++q) issue_tokens(q, t[q], lds0 + k * kStage + wave * 1024, k * 128);
+            if (k == 0) issue_a(IC<0>{}, 0);
+            if (k == 1) issue_a(IC<1>{}, 1);
+            if (k == 2) issue_a(IC<2>{}, 2);
+        }
         asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
         // block 0 of unit 0: B operand and token scale
         asm volatile("ds_read_b128 v[%c[b]:%c[b]+3], %[lo]\n\t"
@@ -544,80 +549,89 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                      : "memory", A8W_CLOB_B);
     }
 
-    // ---- one K unit; SLOT = units-since-start % 3 (compile time: the A ring is register-indexed).  True at an item's end.
+    // ---- one K unit; SLOT = units-since-start % 3 (compile time: the A ring is register-indexed), NQ = 32-row pairs of
+    // token blocks (compile time: a unit is straight-line code; a branch per pair cost a tenth of the issue slots).
+    // (what follows block 0 and its barrier; block 0, the barrier and the per-unit hooks do not depend on NQ and stay
+    // outside the switch: 24 copies of them were 100 KB of code)
+    auto body = [&](auto SLOTC, auto NQC, int lo_c, int hi_c, int xs_c, int lo_n, int hi_n, int xs_n, int dma_base, int soff,
+                    const int (&t)[4]) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(SLOTC)::v, NQ = decltype(NQC)::v;
+        static_for<NQ>([&](auto QC) __attribute__((always_inline)) {
+            constexpr int q = decltype(QC)::v;
+            if constexpr (q > 0) {
+                if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q, true, (2 * q + 1) * 2048, (2 * q + 1) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
+            }
+            if constexpr (q + 1 < NQ) {
+                if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, (2 * q + 2) * 2048, (2 * q + 2) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
+                if constexpr (q < 4 && !(DBG & 1)) issue_tokens(q, t[q], dma_base, soff);
+            } else {
+                // last block of the unit: prefetch block 0 of the next unit (next stage), then the rest of the unit's
+                // loads, then the block's own accumulator update
+                if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, 0, 0, DBG>(lo_n, hi_n, xs_n, ws0, ws1);
+                if constexpr (!(DBG & 1)) {
+                    static_for<4>([&](auto KC) __attribute__((always_inline)) {
+                        if constexpr (decltype(KC)::v >= q) issue_tokens(decltype(KC)::v, t[decltype(KC)::v], dma_base, soff);
+                    });
+                    issue_a(IC<SLOT>{}, u + 3);
+                }
+                if constexpr (!(DBG & 2)) a8w_flush<2 * q + 1, DBG>();
+            }
+        });
+    };
     auto unit = [&](auto SLOTC) __attribute__((always_inline)) {
-        constexpr int SLOT = decltype(SLOTC)::v;
-        const LaneAddr la = lane_addr(tid);
-        const int st = (gcount & 3) * kStage, stn = ((gcount + 1) & 3) * kStage;
-        const int lo_c = la.vb_lo + st, hi_c = la.vb_hi + st, lo_n = la.vb_lo + stn, hi_n = la.vb_hi + stn;
-        const int xs_c = la.vx0 + ((sbase + (u >> 2)) % 3) * kScBuf + (u & 3) * 4;
+        const int stn = (stoff + kStage) & (kStages * kStage - 1);
+        const int lo_c = la.vb_lo + stoff, hi_c = la.vb_hi + stoff, lo_n = la.vb_lo + stn, hi_n = la.vb_hi + stn;
+        const int xs_c = la.vx0 + xsl * kScBuf + (u & 3) * 4;
         const int un = u + 1;
-        const int xs_n = un < U ? la.vx0 + ((sbase + (un >> 2)) % 3) * kScBuf + (un & 3) * 4
-                                : la.vx0 + ((sbase + n_grp) % 3) * kScBuf;
-        // next unit's weight-block scales; the row table of the unit three ahead
-        const bool un_far = un >= U && nxt.nq;
-        const int unn = un < U ? un : (nxt.nq ? 0 : U - 1);
-        const int wsaddr = la.ws + (un_far ? tbuf ^ 1 : tbuf) * 4096 + unn * 4;
-        const bool t_far = u + 3 >= U && nxt.nq;
-        const int tsel = (t_far ? tbuf ^ 1 : tbuf) * 2048;
+        const int nxt_ok = nxt.nq ? 1 : 0;
+        const int xs_n = un < U ? la.vx0 + ((un & 3) ? xsl : next3(xsl)) * kScBuf + (un & 3) * 4 : la.vx0 + xsl_nxt0 * kScBuf;
+        // next unit's weight-block scales; the row table and the DMA target / source of the unit three ahead
+        const int unn = un < U ? un : (nxt_ok ? 0 : U - 1);
+        const int wsaddr = la.ws + ((un >= U ? nxt_ok : 0) ^ tbuf) * 4096 + unn * 4;
+        const int tu = u + 3;
+        const int tsel = ((tu >= U ? nxt_ok : 0) ^ tbuf) * 2048;
+        const int dma_base = lds0 + ((stoff + 3 * kStage) & (kStages * kStage - 1)) + wave * 1024;
+        const int soff = (tu < U ? tu : (nxt_ok ? tu - U : U - 1)) * 128;
         int ws0n, ws1n, t[4], ts;
         // A(u) is in its slot.  (The three units behind an item switch: the epilogue's stores are in the ledger behind
         // the loads these waits are about -- >= 16 of them when st16 -- and must not be waited for.)
         const bool late = st16 && u < 3;
         if (late) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        // (opaque per unit: a loop-invariant q < NQ would be hoisted into sixteen SGPR-pair booleans, which spill)
-        int nq = cur.nq;
-        asm volatile("" : "+s"(nq));
+        constexpr int SLOT = decltype(SLOTC)::v;
         if constexpr (DBG & 2) {
             ws0n = ws0, ws1n = ws1, ts = 0;
             t[0] = t[1] = t[2] = t[3] = 0;
+        } else {
+            a8w_block0<SLOT, DBG>(lo_c, hi_c, xs_c, ws0, ws1, wsaddr, la.tb_tok + tsel, la.tb_sc + tsel, ws0n, ws1n, t, ts);
         }
-        static_for<8>([&](auto QC) __attribute__((always_inline)) {
-            constexpr int q = decltype(QC)::v;
-            if (q < nq) {
-                if constexpr (q == 0) {
-                    if constexpr (!(DBG & 2))
-                        a8w_block0<SLOT, DBG>(lo_c, hi_c, xs_c, ws0, ws1, wsaddr, la.tb_tok + tsel, la.tb_sc + tsel, ws0n, ws1n, t, ts);
-                    // tokens(u+1) of THIS wave have landed; after the barrier every wave's have, and nobody reads
-                    // stage (gcount+3) % 4 = (gcount-1) % 4 any more
-                    if constexpr (DBG & 64) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // (ablation: no barrier)
-                    else if (late) asm volatile("s_waitcnt vmcnt(28)\n\ts_barrier" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-                    if constexpr (!(DBG & 1))
-                        if (wave < 4) issue_scales(ts);
-                    if (u == 2) {
-                        // two barriers after the item switch: the next item's gathered rows have landed (ledger: sixteen
-                        // loads were issued after them) -> its table; and the pending item's expert is known
-                        if (nxt.nq) store_table(tbuf ^ 1, nxt);
-                        meta_a_done(pend);
-                        meta_b(pend);
-                    }
-                } else {
-                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q, true, (2 * q + 1) * 2048, (2 * q + 1) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
-                }
-                if (q + 1 < nq) {
-                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, (2 * q + 2) * 2048, (2 * q + 2) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
-                    if constexpr (q < 4 && !(DBG & 1)) issue_tokens(q, t[q], la.plslot);
-                } else {
-                    // last block of the unit: prefetch block 0 of the next unit (next stage), then the rest of the unit's
-                    // loads, then the block's own accumulator update
-                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, 0, 0, DBG>(lo_n, hi_n, xs_n, ws0, ws1);
-                    if constexpr (!(DBG & 1)) {
-                        static_for<4>([&](auto KC) __attribute__((always_inline)) {
-                            if constexpr (decltype(KC)::v >= q) issue_tokens(decltype(KC)::v, t[decltype(KC)::v], la.plslot);
-                        });
-                        issue_a(IC<SLOT>{});
-                    }
-                    if constexpr (!(DBG & 2)) a8w_flush<2 * q + 1, DBG>();
-                }
-            }
-        });
+        // tokens(u+1) of THIS wave have landed; after the barrier every wave's have, and nobody reads the stage behind
+        // the current one any more (the DMA's target)
+        if constexpr (DBG & 64) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // (ablation: no barrier)
+        else if (late) asm volatile("s_waitcnt vmcnt(28)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        if constexpr (!(DBG & 1))
+            if (wave < 4) issue_scales(ts);
+        if (u == 2) {
+            // two barriers after the item switch: the next item's gathered rows have landed (ledger: sixteen loads were
+            // issued after them) -> its table; and the pending item's expert is known
+            if (nxt.nq) store_table(tbuf ^ 1, nxt);
+            meta_a_done(pend);
+            meta_b(pend);
+        }
+#define A8W_CASE(n) case n: body(SLOTC, IC<n>{}, lo_c, hi_c, xs_c, lo_n, hi_n, xs_n, dma_base, soff, t); break;
+        switch (cur.nq) {
+            A8W_CASE(1) A8W_CASE(2) A8W_CASE(3) A8W_CASE(4) A8W_CASE(5) A8W_CASE(6) A8W_CASE(7)
+        default:
+            body(SLOTC, IC<8>{}, lo_c, hi_c, xs_c, lo_n, hi_n, xs_n, dma_base, soff, t);
+            break;
+        }
+#undef A8W_CASE
         if (dbg_serial) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (debug: serialised units)
         ws0 = __builtin_amdgcn_readfirstlane(ws0n);
         ws1 = __builtin_amdgcn_readfirstlane(ws1n);
-        ++gcount;
-        if (gcount >= 12) gcount -= 12;      // (only gcount & 3 and the unroll phase matter)
+        stoff = stn;
+        if ((u & 3) == 3) xsl = next3(xsl);
         ++u;
         return u == U;
     };
@@ -666,7 +680,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
             asm volatile("" : "+v"(jj), "+v"(gg));
             if (more) {
                 // the switch first (its gather goes out before the epilogue's stores), the epilogue after
-                sbase = (sbase + n_grp) % 3;
+                xsl = xsl_nxt0;
+                xsl_nxt0 = (xsl + n_grp) % 3;
                 tbuf ^= 1;
                 cur = nxt;
                 u = 0;
@@ -731,14 +746,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                 // block -- the compiler's epilogue code is free to use the B / P / x / f registers as temporaries (it
                 // must stay below v78, the E8M0 constant and the A ring: tests/test_a8w_codegen.py), and nothing else of
                 // the fixed map holds a value across the epilogue.  Visible since the barrier of the old item's last unit.
-                const LaneAddr la = lane_addr(tid);
                 asm volatile("ds_read_b128 v[%c[b]:%c[b]+3], %[lo]\n\t"
                              "ds_read_b128 v[%c[b]+4:%c[b]+7], %[hi]\n\t"
                              "ds_read_b32 v[%c[x]], %[xs]\n\t"
                              "s_waitcnt lgkmcnt(0)\n\t"
                              :
-                             : [b] "i"(kB), [x] "i"(kX), [lo] "v"(la.vb_lo + (gcount & 3) * kStage), [hi] "v"(la.vb_hi + (gcount & 3) * kStage),
-                               [xs] "v"(la.vx0 + (sbase % 3) * kScBuf)
+                             : [b] "i"(kB), [x] "i"(kX), [lo] "v"(la.vb_lo + stoff), [hi] "v"(la.vb_hi + stoff), [xs] "v"(la.vx0 + xsl * kScBuf)
                              : "memory", A8W_CLOB_B, A8W_CLOB_TOP);
             }
         }

@@ -26,7 +26,10 @@ struct Cfg {
 #define MFMA(P, A, B) \
     "v_mfma_scale_f32_16x16x128_f8f6f4 v[" P ":" P "+3], v[" A ":" A "+7], v[" B ":" B "+7], 0, v[%c[one]], v[%c[one]] op_sel_hi:[0,0,0]\n\t"
 #define FMAC4(ACC, F, P)                                 \
-    ".if %c[fma3]\n\t"                                   \
+    ".if %c[fma3] == 2\n\t"                              \
+    "v_pk_fma_f32 v[" ACC "+0:" ACC "+1], v[" P "+0:" P "+1], v[" F ":" F "+1], v[" ACC "+0:" ACC "+1] op_sel_hi:[1,0,1]\n\t" \
+    "v_pk_fma_f32 v[" ACC "+2:" ACC "+3], v[" P "+2:" P "+3], v[" F ":" F "+1], v[" ACC "+2:" ACC "+3] op_sel_hi:[1,0,1]\n\t" \
+    ".elseif %c[fma3]\n\t"                               \
     "v_fma_f32 v[" ACC "+0], v[" F "], v[" P "+0], v[" ACC "+0]\n\t" \
     "v_fma_f32 v[" ACC "+1], v[" F "], v[" P "+1], v[" ACC "+1]\n\t" \
     "v_fma_f32 v[" ACC "+2], v[" F "], v[" P "+2], v[" ACC "+2]\n\t" \
@@ -43,7 +46,8 @@ __device__ __forceinline__ void block(int vaddr, int ws) {
     constexpr int par = BLK & 1;
     constexpr int BC = par ? B1 : B0, BN = par ? B0 : B1;
     constexpr int PC = P + par * 8, PP = P + (par ^ 1) * 8;
-    constexpr int FC = F + par * 2, FP = F + (par ^ 1) * 2;
+    constexpr int FC = FMA3 == 2 ? F + par * 4 : F + par * 2, FP = FMA3 == 2 ? F + (par ^ 1) * 4 : F + (par ^ 1) * 2;
+    constexpr int FS = FMA3 == 2 ? 2 : 1;      // register distance between the two tiles' scale products
     constexpr int AC = ACC + ((BLK + 15) & 15) * 8;
     asm volatile(
         ".if %c[ds]\n\t"
@@ -53,17 +57,17 @@ __device__ __forceinline__ void block(int vaddr, int ws) {
         ".endif\n\t"
         ".if %c[valu]\n\t"
         "v_mul_f32 v[%c[fc]], %[ws], v[%c[x]]\n\t"
-        "v_mul_f32 v[%c[fc]+1], %[ws], v[%c[x]]\n\t"
+        "v_mul_f32 v[%c[fc]+%c[fs]], %[ws], v[%c[x]]\n\t"
         ".endif\n\t"
         ".if %c[mfma]\n\t" MFMA("%c[pc]", "%c[a]", "%c[bc]") ".endif\n\t"
         ".if %c[valu]\n\t" FMAC4("%c[acc]", "%c[fp]", "%c[pp]") ".endif\n\t"
         ".if %c[mfma]\n\t" MFMA("%c[pc]+4", "%c[a]+8", "%c[bc]") ".endif\n\t"
-        ".if %c[valu]\n\t" FMAC4("%c[acc]+4", "%c[fp]+1", "%c[pp]+4") ".endif\n\t"
+        ".if %c[valu]\n\t" FMAC4("%c[acc]+4", "%c[fp]+%c[fs]", "%c[pp]+4") ".endif\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         :
         : [bn] "i"(BN), [bc] "i"(BC), [pc] "i"(PC), [pp] "i"(PP), [fc] "i"(FC), [fp] "i"(FP), [a] "i"(A), [acc] "i"(AC),
           [one] "i"(ONE), [x] "i"(ONE + 1), [boff] "i"(BLK * 2048), [mfma] "i"(DO_MFMA), [valu] "i"(DO_VALU), [ds] "i"(DO_DS),
-          [fma3] "i"(FMA3), [va] "v"(vaddr), [ws] "s"(ws)
+          [fma3] "i"(FMA3), [fs] "i"(FS), [va] "v"(vaddr), [ws] "s"(ws)
         : "memory", "v255");
 }
 
@@ -138,5 +142,11 @@ int main() {
     run("mfma + valu + lds, P at 58, B at 42/50", probe<80, 42, 50, 58, 128, 76, 74, 1, 1, 1, 0>, 512, 2);
     run("mfma + lds, kernel map", probe<80, 40, 48, 56, 128, 74, 78, 1, 0, 1, 0>, 512, 2);
     run("lds only", probe<80, 40, 48, 56, 128, 74, 78, 0, 0, 1, 0>, 512, 0);
+    //  v_pk_fma_f32 with a lo-broadcast scale pair: f pairs at v64..v71 (P at 48.., B at 32.. would collide: own map)
+    run("valu only, v_pk_fma_f32 (6 VALU / block)", probe<80, 32, 40, 48, 128, 64, 72, 0, 1, 0, 2>, 512, 0);
+    run("mfma + valu(pk)", probe<80, 32, 40, 48, 128, 64, 72, 1, 1, 0, 2>, 512, 2);
+    run("mfma + valu(pk) + lds", probe<80, 32, 40, 48, 128, 64, 72, 1, 1, 1, 2>, 512, 2);
+    run("mfma + valu(pk) + lds, one wave per SIMD", probe<80, 32, 40, 48, 128, 64, 72, 1, 1, 1, 2>, 256, 2);
+    run("mfma + valu + lds, one wave per SIMD", probe<80, 40, 48, 56, 128, 74, 78, 1, 1, 1, 0>, 256, 2);
     return 0;
 }

@@ -130,8 +130,8 @@ __device__ __forceinline__ void a8w_block_t(int vblo, int vbhi, int vxs, int ws0
 // the scalar cache): the weight-block scales of the NEXT unit and the source offsets of the unit's four token pieces
 // and one scale piece (row table).
 template <int SLOT, int DBG>
-__device__ __forceinline__ void a8w_block0(int vblo, int vbhi, int vxs, int ws0, int ws1, int wsaddr, int taddr, int tsaddr,
-                                           int& ws0n, int& ws1n, int (&t)[4], int& ts) {
+__device__ __forceinline__ void a8w_block0(int vblo, int vbhi, int vxs, int ws0, int ws1, int wsaddr, int taddr,
+                                           int& ws0n, int& ws1n, int (&t)[4]) {
     constexpr int A = a8w::kA + SLOT * 16;
     asm volatile(
         A8W_IF(8)
@@ -145,7 +145,6 @@ __device__ __forceinline__ void a8w_block0(int vblo, int vbhi, int vxs, int ws0,
         "ds_read_b32 %[t1], %[taddr] offset:256\n\t"
         "ds_read_b32 %[t2], %[taddr] offset:512\n\t"
         "ds_read_b32 %[t3], %[taddr] offset:768\n\t"
-        "ds_read_b32 %[ts], %[tsaddr]\n\t"
         A8W_IF(16)
         "v_mul_f32 v[%c[fc]], %[ws0], v[%c[xc]]\n\t"
         "v_mul_f32 v[%c[fc]+1], %[ws1], v[%c[xc]]\n\t"
@@ -155,11 +154,10 @@ __device__ __forceinline__ void a8w_block0(int vblo, int vbhi, int vxs, int ws0,
         A8W_MFMA("%c[pc]+4", "%c[a]+8", "%c[bc]")
         A8W_FI
         "s_waitcnt lgkmcnt(0)\n\t"
-        : [ws0n] "=&v"(ws0n), [ws1n] "=&v"(ws1n), [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3]),
-          [ts] "=&v"(ts)
+        : [ws0n] "=&v"(ws0n), [ws1n] "=&v"(ws1n), [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3])
         : [bn] "i"(a8w::kB + 8), [bc] "i"(a8w::kB), [pc] "i"(a8w::kP), [xc] "i"(a8w::kX), [xn] "i"(a8w::kX + 1),
           [fc] "i"(a8w::kF), [a] "i"(A), [one] "i"(a8w::kOne), [dbg] "i"(DBG), [vblo] "v"(vblo), [vbhi] "v"(vbhi),
-          [vxs] "v"(vxs), [ws0] "s"(ws0), [ws1] "s"(ws1), [wsaddr] "v"(wsaddr), [taddr] "v"(taddr), [tsaddr] "v"(tsaddr)
+          [vxs] "v"(vxs), [ws0] "s"(ws0), [ws1] "s"(ws1), [wsaddr] "v"(wsaddr), [taddr] "v"(taddr)
         : "memory", A8W_CLOB_B, A8W_CLOB_TOP);
 }
 
@@ -316,8 +314,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         m.bx = ss % RG;
         const int tn = ti + 1 < n_tiles ? ti + 1 : ti;
         m.e2 = ti + 1 < n_tiles ? 0 : -1;      // (-1: no successor)
-        const int* a = (lane & 1) ? p.tile_r0 : p.tile_e;
-        a += (lane & 2) ? tn : ti;              // lanes 0..3: tile_e[ti], tile_r0[ti], tile_e[tn], tile_r0[tn]
+        int ln = lane;
+        asm volatile("" : "+v"(ln));            // (per-item address arithmetic must not be hoisted out of the item loop: registers)
+        const int* a = (ln & 1) ? p.tile_r0 : p.tile_e;
+        a += (ln & 2) ? tn : ti;                // lanes 0..3: tile_e[ti], tile_r0[ti], tile_e[tn], tile_r0[tn]
         a8w_dma4_flat(lds0 + kStA + wave * 256, a);
         m.e = m.r0 = m.r02 = m.m_e = m.off_e = 0;
         return m;
@@ -331,7 +331,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         m.r02 = __builtin_amdgcn_readfirstlane(v.w);
     };
     auto meta_b = [&](Meta& m) __attribute__((always_inline)) {
-        const int* a = ((lane & 1) ? p.offsets : p.counts) + m.e;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int* a = ((ln & 1) ? p.offsets : p.counts) + m.e;
         a8w_dma4_flat(lds0 + kStB + wave * 256, a);
     };
     auto meta_b_done = [&](Meta& m) __attribute__((always_inline)) {
@@ -394,7 +396,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     auto gather_item = [&](const Item& it) __attribute__((always_inline)) {
         if constexpr (IS_G1) {
             if (wave < 4) {
-                const int r = wave * 64 + lane;
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int r = wave * 64 + ln;
                 a8w_dma4_flat(lds0 + kRaw + wave * 256, p.sorted_slot + it.orow0 + (r < it.rows ? r : 0));
             }
         }
@@ -402,7 +406,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     // ... and, once the entries have landed (two barriers later), store the two pre-multiplied offsets of their rows
     auto store_table = [&](int buf, const Item& it) __attribute__((always_inline)) {
         if (wave < 4) {
-            const int r = wave * 64 + lane;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int r = wave * 64 + ln;
             int src;
             if constexpr (IS_G1) {
                 int raw;
@@ -422,10 +428,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     //     of gemm_tiled.h (x_swizzle, period 16 in the row: the same for every q) is applied on the SOURCE side, the LDS
     //     image stays lane-linear.  Scale pieces (waves 0..3): lane = token 64 wave + lane, 16 bytes = four K units
     struct LaneAddr {
-        int vb_lo, vb_hi, vx0, plslot, tb_tok, tb_sc, ws;
+        int vb_lo, vb_hi, vx0, plslot, tb_tok;
     };
     auto lane_addr = [&](int t) __attribute__((always_inline)) {
-        const int ln = t & 63, gg = ln >> 4, jj = ln & 15, wv = t >> 6;
+        const int ln = t & 63, gg = ln >> 4, jj = ln & 15;
         const int sw = x_swizzle<128>(jj);
         LaneAddr a;
         a.vb_lo = lds0 + jj * 128 + ((gg ^ sw) * 16);
@@ -433,14 +439,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         a.vx0 = lds0 + kScBase + jj * 16;                          // + 256 b + kScBuf * ring slot + 4 (u & 3)
         a.plslot = ((t & 7) ^ x_swizzle<128>(t >> 3)) * 16;
         a.tb_tok = lds0 + kTbl + (t >> 3) * 4;                     // + 256 q + 2048 * buffer
-        a.tb_sc = lds0 + kTbl + 1024 + ((wv & 3) * 64 + ln) * 4;   // + 2048 * buffer
-        a.ws = lds0 + kWs + wv * 512;                              // + 4096 * buffer + 4 * unit (+ 256: second tile)
         return a;
     };
     // an item's weight-block scales (row 0 of each tile: one block scale per 16-row tile and K unit, prefill_a8w_ok;
     // lane l <- unit l) into this wave's landing zone of item buffer `buf`
     auto fetch_ws = [&](const Item& it, int buf) __attribute__((always_inline)) {
-        const int uc = lane < U ? lane : U - 1;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int uc = ln < U ? ln : U - 1;
         const char* sb = (const char*)p.s + ((size_t)it.e * T_all * U + uc) * 64;
         a8w_dma4_flat(lds0 + kWs + buf * 4096 + wave * 512, sb + (size_t)tile0(it) * U * 64);
         a8w_dma4_flat(lds0 + kWs + buf * 4096 + wave * 512 + 256, sb + (size_t)tile1(it) * U * 64);
@@ -482,34 +488,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     }
     int it_next = w + 3 * stride;          // the item after `pend`
     int tbuf = 0;                          // row table / weight scales of the current item (the next item's: tbuf ^ 1)
-    int u = 0;                             // unit inside the current item
     int stoff = 0;                         // LDS stage of the current unit (byte offset; + kStage mod 4 stages per unit)
     int xsl = 0;                           // token-scale ring slot of the current unit's group of four
     int xsl_nxt0 = n_grp % 3;              // ... of the next item's first group
+    // An item occupies Up = 3 * ceil(U / 3) unit POSITIONS: the A ring has three register-indexed slots, so the unit
+    // code exists once per slot and an item must start at slot 0; the Up - U positions behind the last K unit are NULL
+    // units (no multiplication; they keep the barrier cadence and issue their share of the next item's loads).
+    const int Up = ((U + 2) / 3) * 3;
     const LaneAddr la = lane_addr(tid);
     auto next3 = [](int v) __attribute__((always_inline)) { return v == 2 ? 0 : v + 1; };
 
-    // loads of the unit three ahead of (cur, u); it may belong to the next item
+    // the scale piece's source offset (waves 0..3; read when a piece is due: once per four units)
+    auto scale_src = [&](int tsel) __attribute__((always_inline)) {
+        int ln = lane, ts;
+        asm volatile("" : "+v"(ln));
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ts) : "v"(lds0 + kTbl + 1024 + tsel + ((wave & 3) * 64 + ln) * 4) : "memory");
+        return ts;
+    };
+    // loads of the unit three positions ahead
     auto issue_tokens = [&](int q, int toff, int dma_base, int soff) __attribute__((always_inline)) {
         a8w_dma16(dma_base + q * 8192, toff + la.plslot, rs_x, soff);
     };
-    auto issue_scales = [&](int tsoff) __attribute__((always_inline)) {       // after the barrier of every unit; waves 0..3
-        const int tu = u + 3;
-        if (tu < U) {
-            if ((tu & 3) == 0) a8w_dma16(lds0 + kScBase + next3(xsl) * kScBuf + wave * 1024, tsoff, rs_xs, (tu >> 2) * 16);
-        } else if (tu == U && nxt.nq) {
-            a8w_dma16(lds0 + kScBase + xsl_nxt0 * kScBuf + wave * 1024, tsoff, rs_xs, 0);
-        }
-    };
-    auto issue_a = [&](auto SLOT, int tu) __attribute__((always_inline)) {      // tu: unit index as seen from `cur`
-        const bool far = tu >= U && nxt.nq;
-        const int uu = tu < U ? tu : (nxt.nq ? tu - U : U - 1);          // (no next item: a harmless repeat keeps the counts)
+    auto issue_a = [&](auto SLOT, const Item& it, int uu) __attribute__((always_inline)) {
         a8w_i32x4 rs_w;
-        rs_w.x = far ? nxt.wlo : cur.wlo;
-        rs_w.y = far ? nxt.whi : cur.whi;
+        rs_w.x = it.wlo;
+        rs_w.y = it.whi;
         rs_w.z = (int)(unsigned)wbytes;
         rs_w.w = 0x00020000;
-        a8w_load_a<decltype(SLOT)::v>(lane * 16, rs_w, (far ? nxt.as0 : cur.as0) + uu * wub, (far ? nxt.as1 : cur.as1) + uu * wub);
+        a8w_load_a<decltype(SLOT)::v>(lane * 16, rs_w, it.as0 + uu * wub, it.as1 + uu * wub);
     };
 
     // ---- prologue: the pipeline's first three units
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                      "ds_read_b32 %3, %7 offset:768\n\tds_read_b32 %4, %8\n\tds_read_b32 %5, %9\n\t"
                      "ds_read_b32 %6, %9 offset:256\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(ts), "=&v"(w0), "=&v"(w1)
-                     : "v"(la.tb_tok), "v"(la.tb_sc), "v"(la.ws)
+                     : "v"(la.tb_tok), "v"(lds0 + kTbl + 1024 + ((wave & 3) * 64 + lane) * 4), "v"(lds0 + kWs + wave * 512)
                      : "memory");
         ws0 = __builtin_amdgcn_readfirstlane(w0);
         ws1 = __builtin_amdgcn_readfirstlane(w1);
@@ -534,9 +540,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         for (int k = 0; k < 3; ++k) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) issue_tokens(q, t[q], lds0 + k * kStage + wave * 1024, k * 128);
-            if (k == 0) issue_a(IC<0>{}, 0);
-            if (k == 1) issue_a(IC<1>{}, 1);
-            if (k == 2) issue_a(IC<2>{}, 2);
+            if (k == 0) issue_a(IC<0>{}, cur, 0);
+            if (k == 1) issue_a(IC<1>{}, cur, 1);
+            if (k == 2) issue_a(IC<2>{}, cur, 2);
         }
         asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
         // block 0 of unit 0: B operand and token scale
@@ -549,121 +555,130 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                      : "memory", A8W_CLOB_B);
     }
 
-    // ---- one K unit; SLOT = units-since-start % 3 (compile time: the A ring is register-indexed), NQ = 32-row pairs of
-    // token blocks (compile time: a unit is straight-line code; a branch per pair cost a tenth of the issue slots).
-    // (what follows block 0 and its barrier; block 0, the barrier and the per-unit hooks do not depend on NQ and stay
-    // outside the switch: 24 copies of them were 100 KB of code)
-    auto body = [&](auto SLOTC, auto NQC, int lo_c, int hi_c, int xs_c, int lo_n, int hi_n, int xs_n, int dma_base, int soff,
-                    const int (&t)[4]) __attribute__((always_inline)) {
-        constexpr int SLOT = decltype(SLOTC)::v, NQ = decltype(NQC)::v;
-        static_for<NQ>([&](auto QC) __attribute__((always_inline)) {
-            constexpr int q = decltype(QC)::v;
-            if constexpr (q > 0) {
-                if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q, true, (2 * q + 1) * 2048, (2 * q + 1) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
-            }
-            if constexpr (q + 1 < NQ) {
-                if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, (2 * q + 2) * 2048, (2 * q + 2) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
-                if constexpr (q < 4 && !(DBG & 1)) issue_tokens(q, t[q], dma_base, soff);
-            } else {
-                // last block of the unit: prefetch block 0 of the next unit (next stage), then the rest of the unit's
-                // loads, then the block's own accumulator update
-                if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, 0, 0, DBG>(lo_n, hi_n, xs_n, ws0, ws1);
-                if constexpr (!(DBG & 1)) {
-                    static_for<4>([&](auto KC) __attribute__((always_inline)) {
-                        if constexpr (decltype(KC)::v >= q) issue_tokens(decltype(KC)::v, t[decltype(KC)::v], dma_base, soff);
-                    });
-                    issue_a(IC<SLOT>{}, u + 3);
-                }
-                if constexpr (!(DBG & 2)) a8w_flush<2 * q + 1, DBG>();
-            }
-        });
-    };
-    auto unit = [&](auto SLOTC) __attribute__((always_inline)) {
+    // ---- one unit position.  SLOT = position % 3 (the A ring is register-indexed).  KIND: 0 = one of the item's first
+    // three (waits that step over the previous epilogue's stores; the hook that finishes the next item's tables), 1 =
+    // middle (everything it touches belongs to the current item: no selects), 2 = one of the last three (its loads are the
+    // NEXT item's first units; the position may be a null unit).
+    auto unit = [&](auto SLOTC, auto KINDC, int pp) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(SLOTC)::v, KIND = decltype(KINDC)::v;
         const int stn = (stoff + kStage) & (kStages * kStage - 1);
         const int lo_c = la.vb_lo + stoff, hi_c = la.vb_hi + stoff, lo_n = la.vb_lo + stn, hi_n = la.vb_hi + stn;
-        const int xs_c = la.vx0 + xsl * kScBuf + (u & 3) * 4;
-        const int un = u + 1;
+        const int xs_c = la.vx0 + xsl * kScBuf + (pp & 3) * 4;
+        const int un = pp + 1;
+        const int xs_n = la.vx0 + ((un & 3) ? xsl : next3(xsl)) * kScBuf + (un & 3) * 4;
         const int nxt_ok = nxt.nq ? 1 : 0;
-        const int xs_n = un < U ? la.vx0 + ((un & 3) ? xsl : next3(xsl)) * kScBuf + (un & 3) * 4 : la.vx0 + xsl_nxt0 * kScBuf;
-        // next unit's weight-block scales; the row table and the DMA target / source of the unit three ahead
-        const int unn = un < U ? un : (nxt_ok ? 0 : U - 1);
-        const int wsaddr = la.ws + ((un >= U ? nxt_ok : 0) ^ tbuf) * 4096 + unn * 4;
-        const int tu = u + 3;
-        const int tsel = ((tu >= U ? nxt_ok : 0) ^ tbuf) * 2048;
         const int dma_base = lds0 + ((stoff + 3 * kStage) & (kStages * kStage - 1)) + wave * 1024;
-        const int soff = (tu < U ? tu : (nxt_ok ? tu - U : U - 1)) * 128;
-        int ws0n, ws1n, t[4], ts;
+        // next real unit's weight-block scales; row table, source unit of the position three ahead
+        int wsaddr, tsel, soff;
+        if constexpr (KIND == 2) {
+            const int far = un >= U ? nxt_ok : 0;
+            wsaddr = lds0 + kWs + wave * 512 + (far ^ tbuf) * 4096 + (un < U ? un : (nxt_ok ? 0 : U - 1)) * 4;
+            tsel = (nxt_ok ^ tbuf) * 2048;
+            soff = (nxt_ok ? SLOT : U - 1) * 128;               // (the tail's k-th position fetches the next item's unit k)
+        } else {
+            wsaddr = lds0 + kWs + wave * 512 + tbuf * 4096 + un * 4;
+            tsel = tbuf * 2048;
+            const int tu = pp + 3;
+            soff = (tu < U ? tu : U - 1) * 128;                 // (a null position's loads: a harmless repeat)
+        }
+        const bool real = KIND != 2 || pp < U;
+        int ws0n = ws0, ws1n = ws1, t[4];
         // A(u) is in its slot.  (The three units behind an item switch: the epilogue's stores are in the ledger behind
         // the loads these waits are about -- >= 16 of them when st16 -- and must not be waited for.)
-        const bool late = st16 && u < 3;
+        const bool late = KIND == 0 && st16;
         if (late) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        constexpr int SLOT = decltype(SLOTC)::v;
-        if constexpr (DBG & 2) {
-            ws0n = ws0, ws1n = ws1, ts = 0;
-            t[0] = t[1] = t[2] = t[3] = 0;
+        if (real && !(DBG & 2)) {
+            a8w_block0<SLOT, DBG>(lo_c, hi_c, xs_c, ws0, ws1, wsaddr, la.tb_tok + tsel, ws0n, ws1n, t);
+            ws0n = __builtin_amdgcn_readfirstlane(ws0n);       // (scalars from here on: two registers less across the unit)
+            ws1n = __builtin_amdgcn_readfirstlane(ws1n);
         } else {
-            a8w_block0<SLOT, DBG>(lo_c, hi_c, xs_c, ws0, ws1, wsaddr, la.tb_tok + tsel, la.tb_sc + tsel, ws0n, ws1n, t, ts);
+            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\tds_read_b32 %2, %4 offset:512\n\t"
+                         "ds_read_b32 %3, %4 offset:768\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                         : "v"(la.tb_tok + tsel)
+                         : "memory");
         }
         // tokens(u+1) of THIS wave have landed; after the barrier every wave's have, and nobody reads the stage behind
         // the current one any more (the DMA's target)
         if constexpr (DBG & 64) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // (ablation: no barrier)
         else if (late) asm volatile("s_waitcnt vmcnt(28)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-        if constexpr (!(DBG & 1))
-            if (wave < 4) issue_scales(ts);
-        if (u == 2) {
+        if constexpr (!(DBG & 1)) {
+            // token scales: a group of four units is fetched three positions before its first unit
+            if constexpr (KIND == 2) {
+                if (SLOT == 0 && nxt_ok && wave < 4) a8w_dma16(lds0 + kScBase + xsl_nxt0 * kScBuf + wave * 1024, scale_src(tsel), rs_xs, 0);
+            } else {
+                const int tu = pp + 3;
+                if ((tu & 3) == 0 && tu < U && wave < 4)
+                    a8w_dma16(lds0 + kScBase + next3(xsl) * kScBuf + wave * 1024, scale_src(tsel), rs_xs, (tu >> 2) * 16);
+            }
+        }
+        if constexpr (KIND == 0 && SLOT == 2) {
             // two barriers after the item switch: the next item's gathered rows have landed (ledger: sixteen loads were
             // issued after them) -> its table; and the pending item's expert is known
             if (nxt.nq) store_table(tbuf ^ 1, nxt);
             meta_a_done(pend);
             meta_b(pend);
         }
-#define A8W_CASE(n) case n: body(SLOTC, IC<n>{}, lo_c, hi_c, xs_c, lo_n, hi_n, xs_n, dma_base, soff, t); break;
-        switch (cur.nq) {
-            A8W_CASE(1) A8W_CASE(2) A8W_CASE(3) A8W_CASE(4) A8W_CASE(5) A8W_CASE(6) A8W_CASE(7)
-        default:
-            body(SLOTC, IC<8>{}, lo_c, hi_c, xs_c, lo_n, hi_n, xs_n, dma_base, soff, t);
-            break;
+        const int nq = real ? cur.nq : 0;
+        static_for<8>([&](auto QC) __attribute__((always_inline)) {
+            constexpr int q = decltype(QC)::v;
+            if (q < nq) {
+                if constexpr (q > 0) {
+                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q, true, (2 * q + 1) * 2048, (2 * q + 1) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
+                }
+                if (q + 1 < nq) {
+                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, (2 * q + 2) * 2048, (2 * q + 2) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
+                    if constexpr (q < 4 && !(DBG & 1)) issue_tokens(q, t[q], dma_base, soff);
+                } else {
+                    // last block of the unit: prefetch block 0 of the next unit (next stage), then the rest of the unit's
+                    // token pieces (below), then the block's own accumulator update
+                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, 0, 0, DBG>(lo_n, hi_n, xs_n, ws0, ws1);
+                    if constexpr (!(DBG & 1)) {
+                        static_for<4>([&](auto KC) __attribute__((always_inline)) {
+                            if constexpr (decltype(KC)::v >= q) issue_tokens(decltype(KC)::v, t[decltype(KC)::v], dma_base, soff);
+                        });
+                    }
+                    if constexpr (!(DBG & 2)) a8w_flush<2 * q + 1, DBG>();
+                }
+            }
+        });
+        if constexpr (!(DBG & 1)) {
+            if (nq == 0) {      // (a null unit: all four pieces)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) issue_tokens(q, t[q], dma_base, soff);
+            }
+            // A of the position three ahead, into the slot this position has just finished with
+            if constexpr (KIND == 2) {
+                if (nxt_ok) issue_a(IC<SLOT>{}, nxt, SLOT);
+                else issue_a(IC<SLOT>{}, cur, U - 1);
+            } else {
+                const int tu = pp + 3;
+                issue_a(IC<SLOT>{}, cur, tu < U ? tu : U - 1);
+            }
         }
-#undef A8W_CASE
         if (dbg_serial) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (debug: serialised units)
-        ws0 = __builtin_amdgcn_readfirstlane(ws0n);
-        ws1 = __builtin_amdgcn_readfirstlane(ws1n);
+        ws0 = ws0n;
+        ws1 = ws1n;
         stoff = stn;
-        if ((u & 3) == 3) xsl = next3(xsl);
-        ++u;
-        return u == U;
+        if ((pp & 3) == 3) xsl = next3(xsl);
     };
 
-    // ---- the item's epilogue (D layout lane (g, j): rows tile*16 + g*4 + r, token column j of block b) and the switch to
-    // the next item, whose first units are already in flight
-    int phase = 0;
+    // ---- the items: head triple, middle triples, tail triple, then the epilogue (D layout lane (g, j): rows tile*16 +
+    // g*4 + r, token column j of block b) and the switch to the next item, whose first units are already in flight
     for (;;) {
-        // (one loop header, a switch on the unroll phase: jumping INTO the unrolled body with gotos makes the control flow
-        // irreducible, and the compiler then treats every value that lives across it as divergent)
-        bool end = false;
-        switch (phase) {
-        case 0:
-            end = unit(IC<0>{});
-            if (end) {
-                phase = 1;
-                break;
-            }
-            [[fallthrough]];
-        case 1:
-            end = unit(IC<1>{});
-            if (end) {
-                phase = 2;
-                break;
-            }
-            [[fallthrough]];
-        default:
-            end = unit(IC<2>{});
-            phase = 0;
-            break;
+        unit(IC<0>{}, IC<0>{}, 0);
+        unit(IC<1>{}, IC<0>{}, 1);
+        unit(IC<2>{}, IC<0>{}, 2);
+        for (int p0 = 3; p0 + 3 < Up; p0 += 3) {
+            unit(IC<0>{}, IC<1>{}, p0);
+            unit(IC<1>{}, IC<1>{}, p0 + 1);
+            unit(IC<2>{}, IC<1>{}, p0 + 2);
         }
-        if (!end) continue;
+        unit(IC<0>{}, IC<2>{}, Up - 3);
+        unit(IC<1>{}, IC<2>{}, Up - 2);
+        unit(IC<2>{}, IC<2>{}, Up - 1);
         {
             const Item done = cur;
             const bool more = nxt.nq != 0;
@@ -684,7 +699,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                 xsl_nxt0 = (xsl + n_grp) % 3;
                 tbuf ^= 1;
                 cur = nxt;
-                u = 0;
                 meta_b_done(pend);
                 nxt = make_item(pend);
                 gather_item(nxt);                      // (no such item: repeats item 0's addresses, harmless)

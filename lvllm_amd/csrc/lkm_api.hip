@@ -648,11 +648,12 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // (the round-3 kernel's pipeline runs through item boundaries and needs K loops of at least 8 units)
             pf = (h->t_pf == 8 || h->U1 < 8 || h->U2 < 8 || h->U1 > 64 || h->U2 > 64) ? 8 : 9;
             waves = 8;
-            // The XCD-aware runs (dispatch.hip) stay a knob ("xcd" = 1): on GLM-4.5-Air fp8 prefill they cut GEMM1's
-            // L2-miss traffic 5.8 -> 3.55 GB and lift the L2 hit rate 45 -> 66 %, yet the kernel runs 4-6 % SLOWER
-            // (1256 -> 1307, 1195 -> 1269 us on two boxes): it is bound by the round-trip latency of one 66 KiB DMA
-            // burst per CU, not by fabric bandwidth, and co-scheduled siblings wait on the same misses
-            // (profiles/r02_glm_a8_prefill.md)
+            // The XCD-aware runs (dispatch.hip): for the round-2 kernel a knob ("xcd" = 1) -- they cut GEMM1's L2-miss
+            // traffic 5.8 -> 3.55 GB and that kernel ran 4-6 % SLOWER (bound by the round trip of one 66 KiB DMA burst
+            // per CU, profiles/r02_glm_a8_prefill.md).  The round-3 kernel keeps ~190 KiB in flight per CU and IS
+            // sensitive to where its bytes come from: GEMM1 1127 -> 982 us, GEMM2 762 -> 653 us with the runs
+            // (profiles/r03_a8w_*.log), so they are its default ("xcd" = -1 switches them off).
+            if (pf == 9 && h->t_xcd >= 0) pl->xcd1 = pl->xcd2 = 1;
         }
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;

@@ -1,0 +1,246 @@
+"""The reference's OWN lk_moe glue, run unmodified against this repo's `lk_moe` module on the GPU.
+
+oracle/make_ref_glue.py extracts (with `ast`, byte for byte) the methods of the reference's RoutedExperts that hand the
+weights to lk_moe and drive its three entry points -- _get_quant_params, _process_{bf6_fp16, wna16, fp8, mxfp4, nvfp4},
+_initialize_cuda_graph_buffers, _cpu_decode, _cpu_prefill, _gpu_prefill, clean_weights_after_loading,
+global_to_local_expert_ids (vllm/model_executor/layers/fused_moe/routed_experts.py:1332-1342, 1420-1899) -- into
+oracle/_ref/routed_experts_glue.py, a build artifact (git-ignored; it travels to the GPU box like oracle/_ref/*.so).  Here
+they are bound to a stand-in object that holds CPU weight tensors in the layouts the reference's create_weights produce:
+    unquantized   w13_weight [E, 2I, H], w2_weight [E, H, I]                        (unquantized_fused_moe_method.py:98-135)
+    wna16         w13_weight_packed int32 [E, H/8, 2I], w13_weight_scale [E, H/g, 2I]   ("Marlin" shapes,
+                  compressed_tensors_moe_wna16.py:131-230, 239-420: transposed, the glue transposes them back)
+    fp8 block     w13_weight float8_e4m3fn [E, 2I, H], w13_weight_scale_inv fp32 [E, 2I/128, H/128]   (fp8.py:524-668)
+    mxfp4 / nvfp4 w13_weight_packed uint8 [E, 2I, H/2], w13_weight_scale uint8 [E, 2I, H/32 | H/16] (+ global scales)
+What is checked per MOE_* family: the constructor call as the glue makes it (host pointers, transposed-back views, the
+class-static output buffer), the weight tensors deleted right after construction (clean_weights_after_loading: the engine
+must own its copy), _cpu_decode inside a captured graph (the reference always captures it, moe_runner.py:609-614) and
+replayed on new inputs, _cpu_prefill (host pointers) and _gpu_prefill eagerly -- all against the oracle."""
+import enum
+import importlib.util
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import bench
+from oracle import oracle as orc
+from tests.helpers import make_routing, torch_to_bits
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GLUE = Path(__file__).resolve().parents[1] / "oracle" / "_ref" / "routed_experts_glue.py"
+
+
+def _load_glue():
+    if not GLUE.exists():
+        pytest.skip("oracle/_ref/routed_experts_glue.py not built (python oracle/make_ref_glue.py needs /root/reference)")
+    # the one import inside the extracted methods that this image cannot satisfy: an enum of the WNA16 backends
+    name = "vllm.model_executor.layers.fused_moe.oracle.int_wna16"
+    if name not in sys.modules:
+        parts = name.split(".")
+        for i in range(1, len(parts) + 1):
+            sys.modules.setdefault(".".join(parts[:i]), types.ModuleType(".".join(parts[:i])))
+
+        class WNA16MoEBackend(enum.Enum):
+            MARLIN = 0
+            FLASHINFER_TRTLLM = 1
+        sys.modules[name].WNA16MoEBackend = WNA16MoEBackend
+    spec = importlib.util.spec_from_file_location("routed_experts_glue", GLUE)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _QuantMethod:          # what _process_wna16 reads off self.quant_method
+    def __init__(self, group_size):
+        self.group_size, self.num_bits, self.packed_factor = group_size, 4, 8
+
+
+def _stand_in(glue, E, K, H, I, dtype, **weights):
+    for a in ("cuda_graphs", "output_gpu"):      # class statics of the previous family (other hidden size / device)
+        if hasattr(glue.RoutedExperts, a):
+            delattr(glue.RoutedExperts, a)
+
+    class Layer(glue.RoutedExperts):
+        def _ensure_moe_quant_config_init(self):
+            pass
+    s = Layer.__new__(Layer)
+    s.is_gpu_resident_layer = False
+    s.use_ep, s.tp_size, s.tp_rank, s.ep_size, s.ep_rank = False, 1, 0, 1, 0
+    s.has_gate_proj, s.local_num_experts, s.top_k = True, E, K
+    s.hidden_size, s.intermediate_size_per_partition = H, I
+    s.max_num_batched_tokens, s.max_num_seqs, s.max_num_group_batch_size = 2048, 64, 2048 + 128
+    s.activation_type, s.swiglu_alpha, s.swiglu_limit = 0, None, None
+    s.use_gpu_prefill, s.params_dtype, s.check_nan_in_output = True, dtype, True
+    for k, v in weights.items():
+        setattr(s, k, v)
+    return s
+
+
+def _drive(s, E, K, H, I, ref_fn, atol, rtol):
+    """the three entry points as the reference calls them; ref_fn(x_bits, ids, tw) -> fp32 oracle output"""
+    s._initialize_cuda_graph_buffers()
+    s.clean_weights_after_loading()              # the caller's tensors are gone: the engine owns its copy
+    for name in ("w13_weight", "w2_weight", "w13_weight_packed", "w13_weight_scale", "w13_weight_scale_inv"):
+        assert not hasattr(s, name)
+    dt = s.params_dtype
+    gen = torch.Generator().manual_seed(3)
+
+    def inputs(M, seed):
+        x = (torch.randn((M, H), generator=gen) / 8).to(dt)
+        tw, ids = make_routing(M, E, K, seed=seed, drop=0.1)
+        return x, torch.from_numpy(tw), torch.from_numpy(ids)
+
+    def check(out, x, tw, ids, what):
+        ref = ref_fn(torch_to_bits(x), ids.numpy(), tw.numpy())
+        scale = float(np.abs(ref).max())
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=atol * scale, rtol=rtol, err_msg=what)
+
+    # ---- _cpu_decode, captured (static input buffers, the class-static fp32 output buffer) and replayed
+    M = 24
+    xs = torch.zeros((M, H), dtype=dt, device=DEV)
+    tws = torch.zeros((M, K), dtype=torch.float32, device=DEV)
+    idss = torch.zeros((M, K), dtype=torch.int32, device=DEV)
+    x, tw, ids = inputs(M, 1)
+    xs.copy_(x), tws.copy_(tw), idss.copy_(ids)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        s._cpu_decode(xs, tws, idss)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out_static = s._cpu_decode(xs, tws, idss)
+    g.replay()
+    torch.cuda.synchronize()
+    check(out_static, x, tw, ids, "_cpu_decode (captured)")
+    x, tw, ids = inputs(M, 2)
+    xs.copy_(x), tws.copy_(tw), idss.copy_(ids)
+    g.replay()
+    torch.cuda.synchronize()
+    check(out_static, x, tw, ids, "_cpu_decode (replayed on new inputs)")
+    assert out_static.dtype == dt and type(s).output_gpu.dtype == torch.float32
+    # ---- _cpu_prefill (host pointers, blocking) and _gpu_prefill (device pointers, activation dtype)
+    x, tw, ids = inputs(300, 3)
+    check(s._cpu_prefill(x.to(DEV), tw.to(DEV), ids.to(DEV)), x, tw, ids, "_cpu_prefill")
+    check(s._gpu_prefill(x.to(DEV), tw.to(DEV), ids.to(DEV)), x, tw, ids, "_gpu_prefill")
+
+
+def _masters(E, H, I, seed, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    w13 = (torch.randn((E, 2 * I, H), generator=g) / 10).to(dtype)
+    w2 = (torch.randn((E, H, I), generator=g) / 10).to(dtype)
+    return w13, w2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_reference_glue_bf6_fp16(dtype):
+    """MOE_BF16 / MOE_FP16 through RoutedExperts._process_bf6_fp16 (routed_experts.py:1618-1668)"""
+    glue = _load_glue()
+    E, K, H, I = 6, 2, 512, 256
+    w13, w2 = _masters(E, H, I, 1, dtype)
+    odt = orc.BF16 if dtype == torch.bfloat16 else orc.F16
+    a13, a2 = torch_to_bits(w13), torch_to_bits(w2)
+    s = _stand_in(glue, E, K, H, I, dtype, w13_weight=w13, w2_weight=w2)
+    s._process_bf6_fp16()
+    assert type(s.lk_moe).__name__ == ("MOE_BF16" if dtype == torch.bfloat16 else "MOE_FP16")
+    del w13, w2
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=odt, wfmt=orc.W_BF16 if dtype == torch.bfloat16 else orc.W_F16)
+    _drive(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a13, a2, x, ids, tw), 3e-3, 1.5e-2)
+
+
+def test_reference_glue_wna16():
+    """MOE_WNA16 through RoutedExperts._process_wna16 (:1456-1533): the checkpoint's transposed int32 / scale tensors,
+    `.cpu().transpose(1, 2).contiguous().view(torch.uint8)` pointers, group size from _get_quant_params"""
+    glue = _load_glue()
+    E, K, H, I, g = 4, 2, 512, 256, 64
+    w13, w2 = _masters(E, H, I, 2)
+    q13, s13 = bench.quantize_int4(w13.to(DEV), g)
+    q2, s2 = bench.quantize_int4(w2.to(DEV), g)
+    q13, s13, q2, s2 = q13.cpu(), s13.cpu(), q2.cpu(), s2.cpu()
+    # create_weights' shapes: [E, K/8, N] int32 (eight nibbles of consecutive k per word), scales [E, K/g, N]
+    pk = lambda q: q.contiguous().view(torch.int32).transpose(1, 2).contiguous()       # noqa: E731
+    s = _stand_in(glue, E, K, H, I, torch.bfloat16, w13_weight_packed=pk(q13), w2_weight_packed=pk(q2),
+                  w13_weight_scale=s13.transpose(1, 2).contiguous(), w2_weight_scale=s2.transpose(1, 2).contiguous(),
+                  quant_method=_QuantMethod(g))
+    assert s.w13_weight_packed.shape == (E, H // 8, 2 * I) and s.w13_weight_scale.shape == (E, H // g, 2 * I)
+    s._process_wna16("group")
+    assert type(s.lk_moe).__name__ == "MOE_WNA16" and (s.lk_moe_config.groupN, s.lk_moe_config.groupK) == (1, g)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_INT4, groupN=1, groupK=g)
+    a = (q13.numpy(), q2.numpy(), torch_to_bits(s13), torch_to_bits(s2))
+    _drive(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3]), 3e-3, 1.5e-2)
+
+
+def test_reference_glue_fp8_block():
+    """MOE_FP8 through RoutedExperts._process_fp8(block_quant=True) (:1549-1616): float8_e4m3fn weights and the
+    128 x 128 `weight_scale_inv` tensors; lk_moe's fp8 semantics are W8A16 (bf16 activations)"""
+    glue = _load_glue()
+    E, K, H, I = 4, 2, 512, 256
+    w13, w2 = _masters(E, H, I, 3)
+    q13, s13 = bench.quantize_fp8_block(w13.to(DEV))
+    q2, s2 = bench.quantize_fp8_block(w2.to(DEV))
+    q13, s13, q2, s2 = q13.cpu(), s13.cpu(), q2.cpu(), s2.cpu()
+    s = _stand_in(glue, E, K, H, I, torch.bfloat16, w13_weight=q13.view(torch.float8_e4m3fn),
+                  w2_weight=q2.view(torch.float8_e4m3fn), w13_weight_scale_inv=s13, w2_weight_scale_inv=s2)
+    s._process_fp8(True)
+    assert type(s.lk_moe).__name__ == "MOE_FP8" and (s.lk_moe_config.groupN, s.lk_moe_config.groupK) == (128, 128)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128)
+    a = (q13.numpy(), q2.numpy(), s13.numpy(), s2.numpy())
+    _drive(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3]), 3e-3, 1.5e-2)
+
+
+def test_reference_glue_mxfp4():
+    """MOE_MXFP4 through RoutedExperts._process_mxfp4 (:1748-1815): packed E2M1 + E8M0 scales per 32 k"""
+    glue = _load_glue()
+    E, K, H, I = 4, 2, 512, 256
+    w13, w2 = _masters(E, H, I, 4)
+    q13, s13 = bench.quantize_mxfp4(w13.to(DEV))
+    q2, s2 = bench.quantize_mxfp4(w2.to(DEV))
+    q13, s13, q2, s2 = q13.cpu(), s13.cpu(), q2.cpu(), s2.cpu()
+    s = _stand_in(glue, E, K, H, I, torch.bfloat16, w13_weight_packed=q13, w2_weight_packed=q2, w13_weight_scale=s13,
+                  w2_weight_scale=s2)
+    s._process_mxfp4()
+    assert type(s.lk_moe).__name__ == "MOE_MXFP4" and (s.lk_moe_config.groupN, s.lk_moe_config.groupK) == (1, 32)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_MXFP4, groupN=1, groupK=32)
+    a = (q13.numpy(), q2.numpy(), s13.numpy(), s2.numpy())
+    _drive(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3]), 3e-3, 1.5e-2)
+
+
+def test_reference_glue_nvfp4():
+    """MOE_NVFP4 through RoutedExperts._process_nvfp4(need_reciprocal_global_scale=True) (:1674-1744): e4m3 block scales
+    per 16 k and the per-expert global scales, whose reciprocals the glue hands over"""
+    glue = _load_glue()
+    E, K, H, I = 4, 2, 512, 256
+    w13, w2 = _masters(E, H, I, 5)
+    q13, s13, m13 = bench.quantize_nvfp4(w13.to(DEV))
+    q2, s2, m2 = bench.quantize_nvfp4(w2.to(DEV))
+    q13, s13, m13, q2, s2, m2 = q13.cpu(), s13.cpu(), m13.cpu(), q2.cpu(), s2.cpu(), m2.cpu()
+    s = _stand_in(glue, E, K, H, I, torch.bfloat16, w13_weight_packed=q13, w2_weight_packed=q2,
+                  w13_weight_scale=s13.view(torch.float8_e4m3fn), w2_weight_scale=s2.view(torch.float8_e4m3fn),
+                  w13_weight_global_scale=1.0 / m13, w2_weight_global_scale=1.0 / m2)
+    s._process_nvfp4(need_reciprocal_global_scale=True)
+    assert type(s.lk_moe).__name__ == "MOE_NVFP4" and (s.lk_moe_config.groupN, s.lk_moe_config.groupK) == (1, 16)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_NVFP4, groupN=1, groupK=16)
+    g13, g2 = (1.0 / (1.0 / m13)).numpy(), (1.0 / (1.0 / m2)).numpy()       # what the glue computes and passes
+    a = (q13.numpy(), q2.numpy(), s13.numpy(), s2.numpy())
+    _drive(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3], gs13=g13, gs2=g2),
+           3e-3, 1.5e-2)
+
+
+def test_reference_glue_global_to_local_expert_ids():
+    """RoutedExperts.global_to_local_expert_ids (:1332-1342) against ops.global_to_local_expert_ids on the same expert map"""
+    glue = _load_glue()
+    from lvllm_amd import ops
+    E_global, ep, rank = 64, 4, 2
+    _, emap = ops.determine_expert_map(ep, rank, E_global)
+    s = glue.RoutedExperts.__new__(glue.RoutedExperts)
+    s._expert_map = emap
+    rng = np.random.default_rng(0)
+    ids = torch.from_numpy(rng.integers(-1, E_global, (97, 6)).astype(np.int64)).to(DEV)
+    want = s.global_to_local_expert_ids(ids).cpu().numpy()
+    got = ops.global_to_local_expert_ids(ids.to(torch.int32), emap.to(DEV)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)

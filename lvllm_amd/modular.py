@@ -354,3 +354,15 @@ def bind_vllm_base():
             LkmExperts.__init__(self, moe_config, quant_config, max_num_tokens=max_num_tokens or 8192, **kw)
 
     return LkmExpertsModular
+
+
+def bind_vllm_prepare_finalize():
+    """`class LkmPrepareAndFinalizeModular(LkmPrepareAndFinalize, mk.FusedMoEPrepareAndFinalizeModular)` -- the same for
+    the prepare / finalize half (modular_kernel.py:257-418).  Raises ImportError where vLLM is not importable."""
+    from vllm.model_executor.layers.fused_moe import modular_kernel as mk
+
+    class LkmPrepareAndFinalizeModular(LkmPrepareAndFinalize, mk.FusedMoEPrepareAndFinalizeModular):  # type: ignore[misc]
+        pass
+
+    return LkmPrepareAndFinalizeModular
+

@@ -388,9 +388,6 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
                                                 max_batch_size=max(8192, M), num_processes=world, process_id=rank)
     if args.tune:
         eng.engine.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
-    if use_ep and args.ep_mode == "a2a":
-        # the engine sees ep x capacity token records of which ~1/ep carry local ids: plan for the rows that exist
-        eng.engine.set_tuning(valid_den=world)
 
     # synthetic inputs (seed 7): x = randn/10, router logits = randn
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
@@ -428,8 +425,9 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
             def step():
                 eng.forward_logits(x, logits, K, True, **fl)
     else:
-        def local_compute(rows, lids, ws, dt):
-            return eng.forward_rows(rows, ws, lids, out_dtype=dt)
+        def local_compute(rows, lids, ws, dt, valid_den=None):
+            # (a2a mode hands over ep x capacity token records of which ~1/ep carry local ids and says so: valid_den)
+            return eng.forward_rows(rows, ws, lids, out_dtype=dt, valid_den=valid_den)
         ep = ExpertParallelExperts(local_compute, E, H, mode=args.ep_mode,
                                    return_dtype=torch.float32 if args.ep_return == "f32" else None)
 
@@ -541,8 +539,6 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
         # ~10 us on top of the kernel time rocprofv3 reports for the same launch
         PROF_REP = 8
         pout = torch.empty((M, H), dtype=torch.float32, device=dev)
-        if use_ep and args.ep_mode == "a2a":
-            eng.engine.set_tuning(valid_den=0)            # the profiled call below hands over this rank's own rows only
         eng.engine.set_tuning(prof_rep=PROF_REP)
         eng.engine.set_profiling(True)
         acc = {"sort": 0.0, "gemm1": 0.0, "gemm2": 0.0, "combine": 0.0}

@@ -30,6 +30,15 @@ including none.  The fixed-vs-ragged decision is made from that capacity, never 
 path exchanges its sizes and takes any M.  `validate_uniform=True` checks the contract with an all-gather (eager
 debugging aid; it synchronises the host).
 
+Capacity below the worst case.  With group-limited routing (DeepSeek-V3 / GLM: top-k out of `topk_group` of `n_group`
+expert groups, groups laid out rank by rank) a token visits at most topk_group * max(1, ep / n_group) ranks, so a
+destination receives about M * that / ep records from a source of M tokens, not M.  `routing_groups=(n_group,
+topk_group)` makes capacity = ceil(M * ranks_per_token / ep * capacity_slack) the default (BASELINE configs[3]: 0.625 M
+at slack 1.25 -> 0.625 x the bytes on the wire, and the owner's engine scans 0.625 x the record slots).  The pack
+kernel COUNTS what does not fit (it never drops silently); an eager step notices (`check_overflow=True`, one host read)
+and repeats itself at the exact bound, a captured step cannot branch: its caller reads `overflow_count()` after the
+replay and re-runs that step eagerly (`capacity=M`) when it moved.
+
 Placement is the reference's linear map (expert_map_manager.py:62-79).  With EPLB (lvllm_amd/eplb.py) the ids
 handed to forward() are PHYSICAL expert ids and `num_experts` is the number of physical slots: the linear map over
 the slots is exactly the EPLB placement (slot p lives on rank p // (P / ep)); tests/test_eplb.py runs that end to
@@ -47,9 +56,38 @@ from .ops import determine_expert_map
 
 # local_compute(rows [R,H] act dtype (row-strided view), ids int32 [R,Kx], weights fp32 [R,Kx], out_dtype) ->
 # [R,H] contiguous in out_dtype: for every row the weighted sum over the LOCAL experts among its Kx ids (< 0 = skip)
+# A callable that also declares a keyword `valid_den` is told how sparse the records are (ep x capacity slots of which
+# ~1/valid_den carry a local id): the engine plans its tiles for the rows that exist (ops.forward_rows(valid_den=...)).
 LocalCompute = Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.dtype], torch.Tensor]
 # transport(out, inp): equal-split all-to-all over the group on tensors of shape [ep, ...]
 Transport = Callable[[torch.Tensor, torch.Tensor], None]
+
+
+# Exchange buffers: ONE grow-only pool per (device, group), shared by every layer's ExpertParallelExperts -- the layers
+# of a model run one after the other on a stream, so they can exchange through the same memory; a pool that was handed
+# out stays alive (captured graphs replay on its addresses), a larger request allocates a new one.
+_POOLS: dict = {}
+_RETIRED: list = []
+
+
+def _pool(dev, group, name: str, nbytes: int) -> torch.Tensor:
+    key = (str(dev), id(group), name)
+    t = _POOLS.get(key)
+    if t is None or t.numel() < nbytes:
+        if t is not None:
+            _RETIRED.append(t)
+        t = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+        _POOLS[key] = t
+    return t
+
+
+def ranks_per_token(ep: int, n_group: int, topk_group: int, top_k: int | None = None) -> int:
+    """upper bound of the ranks one token's experts live on under group-limited routing with the groups laid out
+    rank by rank (linear placement)"""
+    r = topk_group * max(1, -(-ep // max(n_group, 1)))
+    if top_k is not None:
+        r = min(r, top_k)
+    return max(1, min(ep, r))
 
 
 def owner_of(ids: torch.Tensor, num_experts: int, ep_size: int) -> torch.Tensor:
@@ -65,19 +103,28 @@ def owner_of(ids: torch.Tensor, num_experts: int, ep_size: int) -> torch.Tensor:
     return torch.where(idl < 0, torch.full_like(idl, -1), r)
 
 
+def _capturing(t: torch.Tensor) -> bool:
+    """a host read of the overflow counter is impossible while the step is being captured into a hipGraph"""
+    return bool(t.is_cuda and torch.cuda.is_current_stream_capturing())
+
+
 class ExpertParallelExperts:
     def __init__(self, local_compute: LocalCompute, num_experts: int, hidden_size: int,
                  group: dist.ProcessGroup | None = None, mode: str = "a2a", kernels=None,
                  transport: Transport | None = None, fixed_max_tokens: int = 1024,
                  capacity_tokens: int | None = None, return_dtype: torch.dtype | None = None,
-                 global_ids: bool = False, validate_uniform: bool = False):
+                 global_ids: bool = False, validate_uniform: bool = False,
+                 routing_groups: tuple[int, int] | None = None, capacity_slack: float = 1.25,
+                 check_overflow: bool = False):
         """kernels: namespace with ep_row_bytes / ep_pack_tokens / ep_combine (default lvllm_amd.ops = the HIP
         kernels, no CPU path; the gloo tests inject torch doubles).  transport: equal-split all-to-all (default
         dist.all_to_all_single over `group`).  fixed_max_tokens: largest capacity served by the fixed path.
         capacity_tokens: the group-wide record capacity per destination (default: this step's token count).
         return_dtype: dtype of the partial rows on the way back (default: the activation dtype; torch.float32
         keeps the single-rank fp32 sum exactly).  global_ids: records carry GLOBAL expert ids (for a receiver
-        that applies expert_map itself, modular.LkmPrepareAndFinalize) instead of ids local to the owner."""
+        that applies expert_map itself, modular.LkmPrepareAndFinalize) instead of ids local to the owner.
+        routing_groups = (n_group, topk_group), capacity_slack, check_overflow: the capacity below the worst case and
+        its fallback (module docstring)."""
         if mode not in ("a2a", "ar"):
             raise ValueError(f"unknown EP mode {mode!r} (expected 'a2a' or 'ar')")
         self.local_compute = local_compute
@@ -89,6 +136,15 @@ class ExpertParallelExperts:
         self.return_dtype = return_dtype
         self.global_ids = global_ids
         self.validate_uniform = validate_uniform
+        self.routing_groups = routing_groups
+        self.capacity_slack = capacity_slack
+        self.check_overflow = check_overflow
+        self._overflow_seen = 0              # (device counter value at the last check)
+        import inspect
+        try:
+            self._lc_takes_den = "valid_den" in inspect.signature(local_compute).parameters
+        except (TypeError, ValueError):
+            self._lc_takes_den = False
         self.E, self.H = num_experts, hidden_size
         self.group = group
         self.ep = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -99,39 +155,54 @@ class ExpertParallelExperts:
         self.expert_map = emap if emap is not None else torch.arange(num_experts, dtype=torch.int32)
         base, rem = divmod(num_experts, self.ep)
         self.first_expert = [r * base + min(r, rem) for r in range(self.ep)]
-        self._bufs: dict = {}
+        self._overflow_bufs: dict = {}
         self.last_wire: dict | None = None
 
     def _dist_a2a(self, out: torch.Tensor, inp: torch.Tensor) -> None:
         dist.all_to_all_single(out, inp, group=self.group)
 
     # -------------------------------------------------------------------------------- a2a, fixed
-    def capacity_for(self, M: int, capacity: int | None = None) -> int:
-        cap = capacity if capacity is not None else (self.capacity_tokens if self.capacity_tokens is not None else M)
-        if M > cap:
+    def capacity_for(self, M: int, capacity: int | None = None, K: int | None = None) -> int:
+        """record slots per destination: the explicit `capacity`, else the constructor's `capacity_tokens`, else (with
+        `routing_groups`) the group-limited estimate, else the token count (the exact worst case)"""
+        if capacity is not None:
+            cap = capacity
+        elif self.capacity_tokens is not None:
+            cap = self.capacity_tokens
+        elif self.routing_groups is not None and self.ep > 1:
+            n_group, topk_group = self.routing_groups
+            rpt = ranks_per_token(self.ep, n_group, topk_group, K)
+            cap = min(M, -(-int(M * rpt * self.capacity_slack) // self.ep))
+            return max(cap, 1)
+        else:
+            cap = M
+        if M > cap and self.routing_groups is None:
             raise ValueError(f"{M} tokens exceed the group-wide record capacity {cap}")
         return max(cap, 1)
 
     def _buffers(self, M: int, K: int, cap: int, act_dtype: torch.dtype, ret_dtype: torch.dtype, dev):
-        """persistent per-shape exchange buffers (a captured graph replays on these addresses)"""
-        key = (M, K, cap, act_dtype, ret_dtype, str(dev))
-        b = self._bufs.get(key)
-        if b is None:
-            rowb = self.kernels.ep_row_bytes(self.H, K)
-            b = dict(rowb=rowb,
-                     send=torch.empty((self.ep, cap, rowb), dtype=torch.uint8, device=dev),
-                     recv=torch.empty((self.ep, cap, rowb), dtype=torch.uint8, device=dev),
-                     slot_of=torch.empty((self.ep, M), dtype=torch.int32, device=dev),
-                     overflow=torch.zeros((1,), dtype=torch.int32, device=dev),
-                     back=torch.empty((self.ep, cap, self.H), dtype=ret_dtype, device=dev))
-            self._bufs[key] = b
-        return b
+        """views of the shared exchange pool for this step's shape (a captured graph replays on these addresses: the
+        pool never moves once handed out, and a step's views are prefixes of it)"""
+        rowb = self.kernels.ep_row_bytes(self.H, K)
+        n = self.ep * cap
+        rsz = torch.empty((), dtype=ret_dtype).element_size()
+        send = _pool(dev, self.group, "send", n * rowb)[: n * rowb].view(self.ep, cap, rowb)
+        recv = _pool(dev, self.group, "recv", n * rowb)[: n * rowb].view(self.ep, cap, rowb)
+        back = _pool(dev, self.group, "back", n * self.H * rsz)[: n * self.H * rsz].view(ret_dtype).view(self.ep, cap, self.H)
+        slot_of = _pool(dev, self.group, "slot_of", self.ep * M * 4)[: self.ep * M * 4].view(torch.int32).view(self.ep, M)
+        ov = self._overflow_bufs.get(str(dev))
+        if ov is None:
+            ov = self._overflow_bufs[str(dev)] = torch.zeros((1,), dtype=torch.int32, device=dev)
+        return dict(rowb=rowb, send=send, recv=recv, slot_of=slot_of, overflow=ov, back=back)
 
-    def dispatch_fixed(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor, capacity: int | None = None):
+    def dispatch_fixed(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor, capacity: int | None = None,
+                       return_handle: bool = False):
         """tokens -> owners, ONE collective: (rows [ep*cap, H] act dtype, ids int32 [ep*cap, K], weights fp32
-        [ep*cap, K]) -- row-strided views into the receive buffer; unused record slots carry ids -1."""
+        [ep*cap, K]) -- row-strided views into the receive buffer; unused record slots carry ids -1.  With
+        return_handle the step's state comes back as a fourth value to be passed to combine_fixed (two micro-batches
+        in flight: each keeps its own handle; their buffers must then be distinct -- see `_buffers`)."""
         M, K = ids.shape
-        cap = self.capacity_for(M, capacity)
+        cap = self.capacity_for(M, capacity, K)
         ret = self.return_dtype or hidden.dtype
         b = self._buffers(M, K, cap, hidden.dtype, ret, hidden.device)
         self.kernels.ep_pack_tokens(hidden, tw, ids, self.E, self.ep, cap, b["send"], b["slot_of"], b["overflow"],
@@ -142,37 +213,59 @@ class ExpertParallelExperts:
         rows = rec[:, :H2].view(hidden.dtype)
         rids = rec[:, H2:H2 + 4 * K].view(torch.int32)
         rws = rec[:, H2 + 4 * K:H2 + 8 * K].view(torch.float32)
-        self._last = (b, M, K, cap)
-        return rows, rids, rws
+        handle = (b, M, K, cap)
+        self._last = handle
+        return (rows, rids, rws, handle) if return_handle else (rows, rids, rws)
 
     def combine_fixed(self, y: torch.Tensor, M: int, out_dtype: torch.dtype = torch.float32,
-                      out: torch.Tensor | None = None) -> torch.Tensor:
+                      out: torch.Tensor | None = None, handle=None) -> torch.Tensor:
         """owners -> tokens, ONE collective: y [ep*cap, H] (the owners' weighted partial rows, return dtype) ->
-        [M, H] out_dtype = fixed-order fp32 sum over the ranks a token visited"""
-        b, M_, K, cap = self._last
-        assert M_ == M and y.shape == (self.ep * cap, self.H) and y.dtype == b["back"].dtype, (y.shape, y.dtype)
+        [M, H] out_dtype = fixed-order fp32 sum over the ranks a token visited.  `handle`: what dispatch_fixed
+        returned for THIS step (default: the most recent dispatch)."""
+        b, M_, K, cap = handle if handle is not None else self._last
+        if M_ != M or y.shape != (self.ep * cap, self.H) or y.dtype != b["back"].dtype:
+            raise RuntimeError(f"combine_fixed for {M} tokens / rows {tuple(y.shape)} {y.dtype} does not match its "
+                               f"dispatch ({M_} tokens, capacity {cap}, {b['back'].dtype})")
         self.transport(b["back"], y.view(self.ep, cap, self.H))
         if out is None:
             out = torch.empty((M, self.H), dtype=out_dtype, device=y.device)
         return self.kernels.ep_combine(b["back"], b["slot_of"], out)
 
+    def _local(self, rows, rids, rws, ret):
+        if self._lc_takes_den:
+            return self.local_compute(rows, rids, rws, ret, valid_den=self.ep)
+        return self.local_compute(rows, rids, rws, ret)
+
     def _forward_a2a_fixed(self, hidden, tw, ids, cap: int, out_dtype: torch.dtype, out=None) -> torch.Tensor:
         M, K = ids.shape
-        rows, rids, rws = self.dispatch_fixed(hidden, tw, ids, cap)
+        rows, rids, rws, h = self.dispatch_fixed(hidden, tw, ids, cap, return_handle=True)
+        if self.check_overflow and cap < M and not _capturing(hidden) and self._any_rank_overflowed(hidden.device):
+            # a destination ran out of record slots on some rank: every rank repeats the step at the exact bound
+            return self._forward_a2a_fixed(hidden, tw, ids, M, out_dtype, out)
         ret = self.return_dtype or hidden.dtype
-        y = self.local_compute(rows, rids, rws, ret)
-        return self.combine_fixed(y, M, out_dtype, out)
+        y = self._local(rows, rids, rws, ret)
+        return self.combine_fixed(y, M, out_dtype, out, handle=h)
+
+    def _any_rank_overflowed(self, dev) -> bool:
+        """the overflow decision is collective (a rank that re-ran alone would post mismatched exchanges): the MAX over
+        ranks of `dropped since the last look`, one 4-byte all-reduce and one host read. Eager steps only."""
+        ov = self._overflow_bufs[str(dev)]
+        delta = ov - self._overflow_seen
+        self._overflow_seen = ov.clone()
+        if self.ep > 1 and dist.is_initialized():
+            dist.all_reduce(delta, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(delta.item()) > 0)
 
     def overflow_count(self) -> int:
         """tokens dropped so far for lack of record capacity (only possible with a capacity below the token
         count); reading it synchronises the host."""
-        return int(sum(int(b["overflow"].item()) for b in self._bufs.values()))
+        return int(sum(int(b.item()) for b in self._overflow_bufs.values()))
 
     def wire_bytes(self, M: int, K: int, capacity: int | None = None, act_bytes: int = 2,
                    ret_bytes: int | None = None) -> dict:
         """bytes one rank puts on xGMI per fixed-path step (the blocks for the other ep-1 ranks) next to the
         routed-row bytes of a slot-granular exchange of the same step"""
-        cap = self.capacity_for(M, capacity)
+        cap = self.capacity_for(M, capacity, K)
         rowb = self.kernels.ep_row_bytes(self.H, K)
         rb = act_bytes if ret_bytes is None else ret_bytes
         out_b, back_b = (self.ep - 1) * cap * rowb, (self.ep - 1) * cap * self.H * rb
@@ -218,22 +311,32 @@ class ExpertParallelExperts:
 
     # -------------------------------------------------------------------------------- ar
     def _forward_ar(self, hidden: torch.Tensor, tw: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+        """all ranks see all tokens: ONE all-gather of token records [activations | ids | weights] (the same record the
+        a2a path ships), local experts only, ONE reduce-scatter of the [ep*M, H] partials in the return dtype (the
+        activation dtype by default -- what the reference all-reduces, moe_runner.py:494; return_dtype=float32 keeps the
+        single-rank fp32 sum)"""
         M, K = ids.shape
         dev = hidden.device
         ep = self.ep
-        xs = torch.empty((ep * M, self.H), dtype=hidden.dtype, device=dev)
-        ii = torch.empty((ep * M, K), dtype=torch.int32, device=dev)
-        ww = torch.empty((ep * M, K), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(xs, hidden.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(ii, ids.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(ww, tw.contiguous(), group=self.group)
+        H2 = self.H * 2
+        rowb = H2 + 8 * K
+        rec = torch.empty((M, rowb), dtype=torch.uint8, device=dev)
+        rec[:, :H2].view(hidden.dtype).copy_(hidden)
+        rec[:, H2:H2 + 4 * K].view(torch.int32).copy_(ids)
+        rec[:, H2 + 4 * K:].view(torch.float32).copy_(tw)
+        allrec = torch.empty((ep * M, rowb), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(allrec, rec, group=self.group)
+        xs = allrec[:, :H2].view(hidden.dtype)
+        ii = allrec[:, H2:H2 + 4 * K].view(torch.int32)
+        ww = allrec[:, H2 + 4 * K:].view(torch.float32)
         if self.expert_map.device != dev:               # once, outside any graph capture (the warm-up step)
             self.expert_map = self.expert_map.to(dev)
         emap = self.expert_map
         local = torch.where(ii < 0, torch.full_like(ii, -1),
                             emap[ii.clamp(0, self.E - 1).to(torch.int64)])    # routed_experts.py:1332-1342
-        part = self.local_compute(xs, local.contiguous(), ww, torch.float32)    # [ep*M, H] fp32
-        out = torch.empty((M, self.H), dtype=torch.float32, device=dev)
+        ret = self.return_dtype or hidden.dtype
+        part = self._local(xs, local.contiguous(), ww, ret)                    # [ep*M, H]
+        out = torch.empty((M, self.H), dtype=ret, device=dev)
         dist.reduce_scatter_tensor(out, part.contiguous(), group=self.group)
         return out
 
@@ -257,12 +360,20 @@ class ExpertParallelExperts:
         capacity: see the module docstring (the token count every rank of the group agrees on)."""
         if out is not None:
             out_dtype = out.dtype
+        if self.ep > 1 and self.mode == "a2a" and capacity is None and self.capacity_tokens is None \
+                and self.routing_groups is None and not self.validate_uniform and not getattr(self, "_warned_cap", False):
+            # (ranks with different token counts would post different collective sizes: name the common capacity)
+            import warnings
+            warnings.warn("ExpertParallelExperts: no group-wide capacity given (capacity_tokens / capacity / "
+                          "routing_groups); the rank-local token count is used -- every rank must hold the SAME "
+                          "number of tokens in a step, or pass a common capacity", stacklevel=2)
+            self._warned_cap = True
         if self.ep == 1 and not force_collectives:
             y = self.local_compute(hidden, topk_ids, topk_weights, out_dtype)
             return y if out is None else out.copy_(y)
         M = topk_ids.size(0)
         if self.mode == "a2a":
-            cap = self.capacity_for(M, capacity)
+            cap = self.capacity_for(M, capacity, topk_ids.size(1))
             if self.validate_uniform:
                 self._check_uniform(cap, "record capacity")
             if cap <= self.fixed_max_tokens:

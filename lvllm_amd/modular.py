@@ -243,11 +243,20 @@ class LkmExperts:
             ok = t_.dim() == 2 and (t_.size(1) == 1 or t_.stride(1) == 1) and t_.stride(0) % align == 0
             return t_ if ok else t_.contiguous()
         x, ids, tw = rowwise(hidden_states, 8), rowwise(ids, 1), rowwise(tw, 1)
+        den = getattr(expert_tokens_meta, "valid_den", None)
         if output.is_contiguous() and output.dtype in (torch.float32, hidden_states.dtype):
-            eng.forward_rows(x, tw, ids, out=output)
+            eng.forward_rows(x, tw, ids, out=output, valid_den=den)
         else:
             output.copy_(eng.forward_rows(x, tw, ids, out_dtype=torch.float32 if output.dtype == torch.float32
-                                          else hidden_states.dtype))
+                                          else hidden_states.dtype, valid_den=den))
+
+
+class LkmTokensMeta:
+    """what LkmPrepareAndFinalize.prepare hands to LkmExperts.apply in the `expert_tokens_meta` position"""
+    __slots__ = ("valid_den", "expert_num_tokens", "expert_num_tokens_cpu")
+
+    def __init__(self, valid_den: int):
+        self.valid_den, self.expert_num_tokens, self.expert_num_tokens_cpu = valid_den, None, None
 
 
 class LkmPrepareAndFinalize:
@@ -275,6 +284,7 @@ class LkmPrepareAndFinalize:
                                          fixed_max_tokens=fixed_max_tokens, global_ids=True,
                                          return_dtype=torch.float32)   # the experts' rows return as they are
         self._shape: tuple[int, int] | None = None
+        self._handle = None
 
     # ---- facts (modular_kernel.py:201-246)
     @property
@@ -322,9 +332,18 @@ class LkmPrepareAndFinalize:
                 raise ValueError("apply_router_weight_on_input is only supported for topk=1")
             a1 = (a1.to(torch.float32) * tw).to(a1.dtype)
             tw = torch.ones_like(tw)
-        rows, gids, ws = self._ep.dispatch_fixed(a1.contiguous(), tw.contiguous(), topk_ids.to(torch.int32).contiguous())
+        if self._handle is not None:
+            # one exchange in flight per instance: a second prepare would pack into the buffers the first finalize still
+            # has to read (two micro-batches need two instances with distinct buffer pools) -- fail loudly
+            raise RuntimeError("LkmPrepareAndFinalize.prepare called again before the matching finalize "
+                               "(supports_async() is False: one exchange in flight per instance)")
+        rows, gids, ws, self._handle = self._ep.dispatch_fixed(a1.contiguous(), tw.contiguous(),
+                                                               topk_ids.to(torch.int32).contiguous(), return_handle=True)
         self._shape = (M, K)
-        return rows, None, None, gids, ws
+        # third value = expert_tokens_meta (modular_kernel.py:96-118 carries per-expert counts there; this exchange has
+        # none on the host): it tells LkmExperts.apply how sparse the records are, so the launch plan is made for the
+        # rows that exist (~1/ep of the ep x capacity slots carry a local id)
+        return rows, None, LkmTokensMeta(valid_den=self._ep.ep) if self._ep.ep > 1 else None, gids, ws
 
     # ---- modular_kernel.py:354-376
     def finalize(self, output: torch.Tensor, fused_expert_output: torch.Tensor, topk_weights: torch.Tensor,
@@ -337,7 +356,9 @@ class LkmPrepareAndFinalize:
         if self._shape != (M, K):
             raise RuntimeError(f"finalize for [{M}, {K}] slots without the matching prepare ({self._shape})")
         y = fused_expert_output if fused_expert_output.dtype == torch.float32 else fused_expert_output.to(torch.float32)
-        out = self._ep.combine_fixed(y.contiguous(), M, output.dtype if output.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32)
+        handle, self._handle = self._handle, None
+        out = self._ep.combine_fixed(y.contiguous(), M, output.dtype if output.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32,
+                                     handle=handle)
         if out.data_ptr() != output.data_ptr():
             output.copy_(out)
 

@@ -351,10 +351,11 @@ class RoutedExpertsEngine:
 
     def forward_rows(self, hidden: torch.Tensor, topk_weights: torch.Tensor, topk_ids: torch.Tensor,
                      out: torch.Tensor | None = None, out_dtype: torch.dtype = torch.float32,
-                     id_offset: int = 0) -> torch.Tensor:
+                     id_offset: int = 0, valid_den: int | None = None) -> torch.Tensor:
         """The operator on ROW-STRIDED views (last dimension contiguous), as the expert-parallel exchange hands
         them over: hidden [R,H] act dtype, ids int32 [R,K], weights fp32 [R,K]; `id_offset` is subtracted from
-        ids >= 0 (global -> local under linear placement).  -> [R,H] contiguous, fp32 or the activation dtype."""
+        ids >= 0 (global -> local under linear placement).  valid_den: the caller's records are sparse (expert-parallel
+        exchange: ep x capacity slots, ~1/valid_den of them local).  -> [R,H] contiguous, fp32 or the activation dtype."""
         _need_cuda(hidden, topk_weights, topk_ids)
         R, K = topk_ids.shape
         assert hidden.dtype == self.act_dtype and topk_ids.dtype == torch.int32 and topk_weights.dtype == torch.float32
@@ -366,6 +367,12 @@ class RoutedExpertsEngine:
         assert out.is_contiguous() and out.dtype in (torch.float32, self.act_dtype)
         if R == 0:
             return out
+        vd = int(valid_den or 0)
+        if vd != getattr(self, "_valid_den", 0):
+            # expert-parallel records: ~1 / valid_den of the R x K slots carry a local id -- the launch plan is made for
+            # the rows that exist (host-side hint, lkm_set_tuning "valid_den"); a call without the hint plans densely again
+            self.engine.set_tuning(valid_den=vd)
+            self._valid_den = vd
         self.engine.forward_strided(torch.cuda.current_stream(hidden.device).cuda_stream, R, K, hidden.data_ptr(),
                                     hidden.stride(0) if R > 1 else max(hidden.stride(0), self.H), topk_ids.data_ptr(),
                                     topk_ids.stride(0) if R > 1 else max(topk_ids.stride(0), K), int(id_offset),

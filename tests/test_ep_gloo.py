@@ -75,7 +75,9 @@ def _pf_worker(rank, world, port, q):
         d = orc.MoeDesc(E=n_loc, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
         a, tw, ids = _tokens(rank)
         a1q, a1q_scale, meta, ids_d, w_d = pf.prepare(a, tw, ids, E, emap, False, None, True)
-        assert a1q_scale is None and meta is None and ids_d.shape == (world * M, K) and a1q.shape == (world * M, H)
+        assert a1q_scale is None and meta.valid_den == world and ids_d.shape == (world * M, K) and a1q.shape == (world * M, H)
+        with pytest.raises(RuntimeError, match="before the matching finalize"):   # one exchange in flight per instance
+            pf.prepare(a, tw, ids, E, emap, False, None, True)
         # what LkmExperts.apply does with them: expert_map, then the weighted expert rows (the oracle stands in)
         g = ids_d.contiguous().to(torch.int64)
         lids = torch.where(g >= 0, emap[g.clamp(min=0)].to(torch.int64), torch.full_like(g, -1)).to(torch.int32)
@@ -235,3 +237,94 @@ def test_owner_of_matches_expert_map():
             for r in range(ep):
                 _, emap = orc.expert_map(ep, r, Eg, 0)
                 np.testing.assert_array_equal((own[1:] == r).numpy(), emap >= 0)
+
+
+def _grouped_worker(rank, world, port, slack, skew, q):
+    """group-limited routing (one expert group per rank, every token picks its experts inside `topk_group` groups):
+    the capacity below the worst case, its counted overflow and the eager fallback to the exact bound"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lvllm_amd.ep import ExpertParallelExperts
+        Eg, Kg, Mg, n_group, topk_group = 16, 4, 24, world, 2
+        g = torch.Generator().manual_seed(7)
+        w13 = (torch.randn((Eg, 2 * I, H), generator=g) / 4).to(torch.bfloat16)
+        w2 = (torch.randn((Eg, H, I), generator=g) / 4).to(torch.bfloat16)
+        ep = ExpertParallelExperts(lambda *a: None, Eg, H, mode="a2a", kernels=TorchEpKernels,
+                                   return_dtype=torch.float32, routing_groups=(n_group, topk_group),
+                                   capacity_slack=slack, check_overflow=True)
+        lo, n_loc = ep.first_expert[rank], ep.local_num
+        d = orc.MoeDesc(E=n_loc, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+        seen = []
+
+        def local_compute(x, lids, ws, out_dtype, valid_den=None):
+            seen.append((x.shape[0], valid_den))
+            y = orc.moe(d, torch_to_bits(w13[lo:lo + n_loc]), torch_to_bits(w2[lo:lo + n_loc]),
+                        torch_to_bits(x.contiguous()), lids.contiguous().numpy(), ws.contiguous().numpy())
+            return torch.from_numpy(y).to(out_dtype)
+        ep.local_compute = local_compute
+        ep._lc_takes_den = True
+        # routing: token m picks `topk_group` groups (= ranks) and K experts inside them: spread evenly (12 records per
+        # destination), or every token of the rank (of ONE rank: the decision must still be collective) on groups 0 and 1
+        gr = torch.Generator().manual_seed(50 + rank)
+        per = Eg // n_group
+        ids = torch.empty((Mg, Kg), dtype=torch.int32)
+        for m in range(Mg):
+            skewed = skew == "all" or (skew == "one_rank" and rank == 0)
+            groups = torch.tensor([0, 1]) if skewed else torch.tensor([m % n_group, (m + 1) % n_group])
+            pool = torch.cat([torch.arange(per) + int(gi) * per for gi in groups])
+            ids[m] = pool[torch.randperm(len(pool), generator=gr)[:Kg]].to(torch.int32)
+        tw = torch.rand((Mg, Kg), generator=gr) + 0.1
+        a = (torch.randn((Mg, H), generator=gr) / 2).to(torch.bfloat16)
+        cap = ep.capacity_for(Mg, None, Kg)
+        out = ep.forward(a, tw, ids)
+        wb = ep.wire_bytes(Mg, Kg)
+        dfull = orc.MoeDesc(E=Eg, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+        ref = orc.moe(dfull, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids.numpy(), tw.numpy())
+        q.put((rank, cap, ep.overflow_count(), [s[0] for s in seen], [s[1] for s in seen], wb["dispatch_bytes"],
+               float(np.abs(out.numpy() - ref).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("slack,skew", [(1.25, "none"), (1.0, "one_rank"), (0.5, "all")])
+def test_group_limited_capacity_and_overflow_fallback(slack, skew):
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grouped_worker, args=(r, world, port, slack, skew, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Mg, rowb = 24, TorchEpKernels.ep_row_bytes(H, 4)
+    for rank, cap, ov, rows_seen, dens, disp_bytes, err in res:
+        # ranks per token <= topk_group = 2 of 4 ranks: capacity = ceil(24 * 2 * slack / 4)
+        assert cap == -(-int(Mg * 2 * slack) // world)
+        assert disp_bytes == (world - 1) * cap * rowb
+        assert all(dn == world for dn in dens)              # the engine is told how sparse the records are
+        assert err < 1e-5                                    # the result is exact either way
+        if skew == "none":
+            assert cap == 15 and rows_seen == [world * cap] and ov == 0   # 0.625 x the worst case of 24 record slots
+        else:
+            # some rank had 24 records for a destination with `cap` slots: counted there, agreed by all, and the step ran
+            # once at the exact bound (capacity = tokens) on EVERY rank
+            assert rows_seen == [world * Mg]
+            assert (ov > 0) == (skew == "all" or rank == 0)
+
+
+def test_wire_bytes_of_baseline_config3_with_group_limited_capacity():
+    """BASELINE.json configs[3] (DeepSeek-V3 routing, 8 groups = 8 ranks, top-4 groups, M = 32 tokens per rank): the
+    default capacity with `routing_groups` puts <= 0.63 x the bytes of the worst-case capacity on the wire"""
+    from lvllm_amd.ep import ExpertParallelExperts, ranks_per_token
+    assert ranks_per_token(8, 8, 4, 8) == 4 and ranks_per_token(8, 4, 2) == 4 and ranks_per_token(2, 8, 4) == 2
+    a = ExpertParallelExperts(lambda *x: None, 256, 7168, kernels=TorchEpKernels)
+    b = ExpertParallelExperts(lambda *x: None, 256, 7168, kernels=TorchEpKernels, routing_groups=(8, 4))
+    a.ep = b.ep = 8                        # (no process group here: the accounting only)
+    wa, wb = a.wire_bytes(32, 8), b.wire_bytes(32, 8)
+    assert wa["capacity_tokens"] == 32 and wb["capacity_tokens"] == 20
+    assert wb["dispatch_bytes"] / wa["dispatch_bytes"] == pytest.approx(0.625)
+    assert wb["return_bytes"] / wa["return_bytes"] == pytest.approx(0.625)

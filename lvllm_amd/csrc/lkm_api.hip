@@ -182,29 +182,48 @@ static bool is_device_ptr(const void* p) {
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
-// copy-or-alias: returns a device pointer holding `bytes` of src; *tmp is set if it must be freed
-static int to_device(const void* src, size_t bytes, const void** dev, void** tmp) {
-    *tmp = nullptr;
-    if (is_device_ptr(src)) {
-        *dev = src;
+// one device buffer for host-side sources (lkm_create hands the weights over through it chunk by chunk); everything that
+// uses it is enqueued on the null stream, so the chunks are ordered without events
+struct Staging {
+    void* buf = nullptr;
+    size_t cap = 0, limit = (size_t)256 << 20;
+    Staging() {
+        const char* env = getenv("LKM_STAGE_BYTES");
+        if (env && atoll(env) > 0) limit = (size_t)atoll(env);
+    }
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return LKM_OK;
+        if (buf) {
+            (void)hipStreamSynchronize(nullptr);
+            (void)hipFree(buf);
+            buf = nullptr;
+            cap = 0;
+        }
+        hipError_t e = hipMalloc(&buf, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            buf = nullptr;
+            set_error("hipMalloc(%zu) for weight staging failed: %s", bytes, hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? LKM_E_NOMEM : LKM_E_HIP;
+        }
+        cap = bytes;
         return LKM_OK;
     }
-    void* d = nullptr;
-    hipError_t e = hipMalloc(&d, bytes);
-    if (e != hipSuccess) {
-        set_error("hipMalloc(%zu) for weight staging failed: %s", bytes, hipGetErrorString(e));
-        return LKM_E_NOMEM;
+    int finish() {
+        hipError_t e = hipStreamSynchronize(nullptr);
+        if (buf) (void)hipFree(buf);
+        buf = nullptr;
+        cap = 0;
+        if (e != hipSuccess) {
+            set_error("weight hand-off failed: %s", hipGetErrorString(e));
+            return LKM_E_HIP;
+        }
+        return LKM_OK;
     }
-    e = hipMemcpy(d, src, bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)hipFree(d);
-        set_error("hipMemcpy H2D of weights failed: %s", hipGetErrorString(e));
-        return LKM_E_HIP;
+    ~Staging() {
+        if (buf) (void)finish();
     }
-    *dev = d;
-    *tmp = d;
-    return LKM_OK;
-}
+};
 
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
@@ -368,125 +387,87 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     h->loads = loads;
     RepackDims d13{h->E, h->I, halves, h->interleaved ? 1 : 0, h->H, h->T1_half, h->U1, h->a8 ? 1 : 0, h->unit_major ? 1 : 0};
     RepackDims d2{h->E, h->H, 1, 0, h->I, h->T2, h->U2, h->a8 ? 1 : 0, h->unit_major ? 1 : 0};
+    // hand-off of the caller's tensors: device sources are read in place; host sources pass through ONE
+    // staging buffer of <= LKM_STAGE_BYTES (default 256 MiB, never less than one expert) in chunks of whole experts --
+    // copy, repack, next chunk, all in stream order -- so creation adds at most one chunk to the footprint of the
+    // finished image, and the host waits once, at the end (`staging` synchronises and frees when it goes out of scope).
+    Staging staging;
+    // src: [E][src_pe bytes]; dst: [E][dst_pe bytes]; launch(src chunk, dst chunk, dims with E = experts in the chunk)
+    auto hand_off = [&](const void* src, size_t src_pe, void* dst, size_t dst_pe, RepackDims d, auto&& launch) -> int {
+        if (is_device_ptr(src)) return launch(src, dst, d);
+        size_t per = staging.limit / (src_pe ? src_pe : 1);
+        per = per < 1 ? 1 : (per > (size_t)h->E ? (size_t)h->E : per);
+        int r = staging.reserve(per * src_pe);
+        for (size_t e0 = 0; r == LKM_OK && e0 < (size_t)h->E; e0 += per) {
+            const size_t ne = (size_t)h->E - e0 < per ? (size_t)h->E - e0 : per;
+            hipError_t ce = hipMemcpyAsync(staging.buf, (const char*)src + e0 * src_pe, ne * src_pe, hipMemcpyHostToDevice, nullptr);
+            if (ce != hipSuccess) {
+                set_error("hipMemcpy H2D of %zu weight bytes failed: %s", ne * src_pe, hipGetErrorString(ce));
+                return LKM_E_HIP;
+            }
+            d.E = (int)ne;
+            r = launch(staging.buf, (char*)dst + e0 * dst_pe, d);
+        }
+        return r;
+    };
+    const int wfr = h->ps ? LKM_W_INT4_PS : wf;
     {
-        const size_t n13 = (size_t)h->E * halves * h->I, n2 = (size_t)h->E * h->H;
-        const size_t b13 = n13 * h->H / 2 * wbytes_per_elem_x2(wf);
-        const size_t b2 = n2 * h->I / 2 * wbytes_per_elem_x2(wf);
-        const void* dsrc;
-        void* tmp;
-        LKM_TRY(to_device(w13, b13, &dsrc, &tmp));
-        rc = launch_repack_w(nullptr, h->ps ? LKM_W_INT4_PS : wf, dsrc, h->w13, d13);
-        hipError_t se = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (rc != LKM_OK) return fail(rc);
-        LKM_TRY_HIP(se);
-        LKM_TRY(to_device(w2, b2, &dsrc, &tmp));
-        rc = launch_repack_w(nullptr, h->ps ? LKM_W_INT4_PS : wf, dsrc, h->w2, d2);
-        se = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (rc != LKM_OK) return fail(rc);
-        LKM_TRY_HIP(se);
+        const size_t b13 = (size_t)halves * h->I * h->H / 2 * wbytes_per_elem_x2(wf);     // source bytes per expert
+        const size_t b2 = (size_t)h->H * h->I / 2 * wbytes_per_elem_x2(wf);
+        auto rw = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_w(nullptr, wfr, sp, dp, dd); };
+        LKM_TRY(hand_off(w13, b13, h->w13, w13_vec / h->E * 16, d13, rw));
+        LKM_TRY(hand_off(w2, b2, h->w2, w2_vec / h->E * 16, d2, rw));
     }
     if (h->ps) {     // fp32 scale per (row, 128-k unit), the layout of the fp8 block scales
         const int g = cfg->groupK;
-        const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16;
-        const size_t n2 = (size_t)h->E * h->T2 * h->U2 * 16;
-        LKM_TRY_HIP(hipMalloc(&h->s13, n13 * 4));
-        LKM_TRY_HIP(hipMalloc(&h->s2, n2 * 4));
-        h->weight_bytes += (int64_t)(n13 + n2) * 4;
-        const void* dsrc;
-        void* tmp;
-        LKM_TRY(to_device(w13_scale, (size_t)h->E * halves * h->I * (h->H / g) * 2, &dsrc, &tmp));
-        rc = launch_repack_s_int4ps(nullptr, dsrc, h->s13, d13, g, adt);
-        hipError_t se = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (rc != LKM_OK) return fail(rc);
-        LKM_TRY_HIP(se);
-        LKM_TRY(to_device(w2_scale, (size_t)h->E * h->H * (h->I / g) * 2, &dsrc, &tmp));
-        rc = launch_repack_s_int4ps(nullptr, dsrc, h->s2, d2, g, adt);
-        se = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (rc != LKM_OK) return fail(rc);
-        LKM_TRY_HIP(se);
+        const size_t n13 = (size_t)halves * h->T1_half * h->U1 * 16, n2 = (size_t)h->T2 * h->U2 * 16;   // per expert
+        LKM_TRY_HIP(hipMalloc(&h->s13, h->E * n13 * 4));
+        LKM_TRY_HIP(hipMalloc(&h->s2, h->E * n2 * 4));
+        h->weight_bytes += (int64_t)h->E * (n13 + n2) * 4;
+        auto rs = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4ps(nullptr, sp, dp, dd, g, adt); };
+        LKM_TRY(hand_off(w13_scale, (size_t)halves * h->I * (h->H / g) * 2, h->s13, n13 * 4, d13, rs));
+        LKM_TRY(hand_off(w2_scale, (size_t)h->H * (h->I / g) * 2, h->s2, n2 * 4, d2, rs));
     } else if (wf == LKM_W_INT4_B8) {
         const int g = cfg->groupK;
-        const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16 * h->spu;
-        const size_t n2 = (size_t)h->E * h->T2 * h->U2 * 16 * h->spu;
-        LKM_TRY_HIP(hipMalloc(&h->s13, n13 * 2 + 16));   // +16: the kernels fetch 8 bytes per lane
-        LKM_TRY_HIP(hipMalloc(&h->s2, n2 * 2 + 16));
-        h->weight_bytes += (int64_t)(n13 + n2) * 2;
-        const void* dsrc;
-        void* tmp;
-        LKM_TRY(to_device(w13_scale, (size_t)h->E * halves * h->I * (h->H / g) * 2, &dsrc, &tmp));
-        rc = launch_repack_s_int4(nullptr, dsrc, h->s13, d13, g, h->spu);
-        hipError_t se = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (rc != LKM_OK) return fail(rc);
-        LKM_TRY_HIP(se);
-        LKM_TRY(to_device(w2_scale, (size_t)h->E * h->H * (h->I / g) * 2, &dsrc, &tmp));
-        rc = launch_repack_s_int4(nullptr, dsrc, h->s2, d2, g, h->spu);
-        se = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (rc != LKM_OK) return fail(rc);
-        LKM_TRY_HIP(se);
+        const size_t n13 = (size_t)halves * h->T1_half * h->U1 * 16 * h->spu, n2 = (size_t)h->T2 * h->U2 * 16 * h->spu;
+        LKM_TRY_HIP(hipMalloc(&h->s13, h->E * n13 * 2 + 16));   // +16: the kernels fetch 8 bytes per lane
+        LKM_TRY_HIP(hipMalloc(&h->s2, h->E * n2 * 2 + 16));
+        h->weight_bytes += (int64_t)h->E * (n13 + n2) * 2;
+        auto rs = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4(nullptr, sp, dp, dd, g, h->spu); };
+        LKM_TRY(hand_off(w13_scale, (size_t)halves * h->I * (h->H / g) * 2, h->s13, n13 * 2, d13, rs));
+        LKM_TRY(hand_off(w2_scale, (size_t)h->H * (h->I / g) * 2, h->s2, n2 * 2, d2, rs));
     } else if (wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4) {
         const int g = cfg->groupK, spu = 128 / g;
-        const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16 * spu;
-        const size_t n2 = (size_t)h->E * h->T2 * h->U2 * 16 * spu;
-        LKM_TRY_HIP(hipMalloc(&h->s13, n13));
-        LKM_TRY_HIP(hipMalloc(&h->s2, n2));
-        h->weight_bytes += (int64_t)(n13 + n2);
+        const size_t n13 = (size_t)halves * h->T1_half * h->U1 * 16 * spu, n2 = (size_t)h->T2 * h->U2 * 16 * spu;
+        LKM_TRY_HIP(hipMalloc(&h->s13, h->E * n13));
+        LKM_TRY_HIP(hipMalloc(&h->s2, h->E * n2));
+        h->weight_bytes += (int64_t)h->E * (n13 + n2);
         const int pad = wf == LKM_W_MXFP4 ? 127 : 0x38;   // 1.0 in E8M0 / e4m3fn (the padded weights are 0)
-        const void* dsrc;
-        void* tmp;
-        LKM_TRY(to_device(w13_scale, (size_t)h->E * halves * h->I * (h->H / g), &dsrc, &tmp));
-        rc = launch_repack_s_fp4(nullptr, dsrc, h->s13, d13, g, pad);
-        hipError_t se = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (rc != LKM_OK) return fail(rc);
-        LKM_TRY_HIP(se);
-        LKM_TRY(to_device(w2_scale, (size_t)h->E * h->H * (h->I / g), &dsrc, &tmp));
-        rc = launch_repack_s_fp4(nullptr, dsrc, h->s2, d2, g, pad);
-        se = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (rc != LKM_OK) return fail(rc);
-        LKM_TRY_HIP(se);
+        auto rs = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_fp4(nullptr, sp, dp, dd, g, pad); };
+        LKM_TRY(hand_off(w13_scale, (size_t)halves * h->I * (h->H / g), h->s13, n13, d13, rs));
+        LKM_TRY(hand_off(w2_scale, (size_t)h->H * (h->I / g), h->s2, n2, d2, rs));
         if (wf == LKM_W_NVFP4) {   // per-expert multipliers (NULL = 1.0)
             for (int which = 0; which < 2; ++which) {
                 const void* src = which ? w2_gs : w13_gs;
                 float** dst = which ? &h->gs2 : &h->gs13;
                 if (!src) continue;
-                LKM_TRY(to_device(src, (size_t)h->E * 4, &dsrc, &tmp));
                 LKM_TRY_HIP(hipMalloc(dst, (size_t)h->E * 4));
-                hipError_t ce = hipMemcpy(*dst, dsrc, (size_t)h->E * 4, hipMemcpyDeviceToDevice);
-                if (tmp) (void)hipFree(tmp);
-                LKM_TRY_HIP(ce);
+                LKM_TRY_HIP(hipMemcpyAsync(*dst, src, (size_t)h->E * 4, hipMemcpyDefault, nullptr));
             }
         }
     } else if (wf == LKM_W_FP8_E4M3) {
         const int gN = cfg->groupN, gK = cfg->groupK;
-        const size_t n13 = (size_t)h->E * halves * h->T1_half * h->U1 * 16;
-        const size_t n2 = (size_t)h->E * h->T2 * h->U2 * 16;
-        LKM_TRY_HIP(hipMalloc(&h->s13, n13 * 4));
-        LKM_TRY_HIP(hipMalloc(&h->s2, n2 * 4));
-        h->weight_bytes += (int64_t)(n13 + n2) * 4;
-        const void* dsrc;
-        void* tmp;
-        const size_t src13 = (size_t)h->E * ceil_div(halves * h->I, gN) * ceil_div(h->H, gK) * 4;
-        const size_t src2 = (size_t)h->E * ceil_div(h->H, gN) * ceil_div(h->I, gK) * 4;
-        LKM_TRY(to_device(w13_scale, src13, &dsrc, &tmp));
-        rc = launch_repack_s_fp8(nullptr, dsrc, h->s13, d13, gN, gK);
-        hipError_t se = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (rc != LKM_OK) return fail(rc);
-        LKM_TRY_HIP(se);
-        LKM_TRY(to_device(w2_scale, src2, &dsrc, &tmp));
-        rc = launch_repack_s_fp8(nullptr, dsrc, h->s2, d2, gN, gK);
-        se = hipDeviceSynchronize();
-        if (tmp) (void)hipFree(tmp);
-        if (rc != LKM_OK) return fail(rc);
-        LKM_TRY_HIP(se);
+        const size_t n13 = (size_t)halves * h->T1_half * h->U1 * 16, n2 = (size_t)h->T2 * h->U2 * 16;
+        LKM_TRY_HIP(hipMalloc(&h->s13, h->E * n13 * 4));
+        LKM_TRY_HIP(hipMalloc(&h->s2, h->E * n2 * 4));
+        h->weight_bytes += (int64_t)h->E * (n13 + n2) * 4;
+        const size_t src13 = (size_t)ceil_div(halves * h->I, gN) * ceil_div(h->H, gK) * 4;
+        const size_t src2 = (size_t)ceil_div(h->H, gN) * ceil_div(h->I, gK) * 4;
+        auto rs = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_fp8(nullptr, sp, dp, dd, gN, gK); };
+        LKM_TRY(hand_off(w13_scale, src13, h->s13, n13 * 4, d13, rs));
+        LKM_TRY(hand_off(w2_scale, src2, h->s2, n2 * 4, d2, rs));
     }
+    LKM_TRY(staging.finish());     // the one host wait of the hand-off; the caller may free its tensors after this
 
     // scratch: sized for the larger of the decode batch and one prefill chunk
     size_t chunk = cfg->group_max_len > 0 ? (size_t)cfg->group_max_len : 4224;

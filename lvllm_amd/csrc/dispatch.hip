@@ -106,36 +106,59 @@ __device__ __forceinline__ void sort_slots_body(
     }
     __syncthreads();
 
-    // exclusive scans of cnt[], of the (cnt>0) flags and of the per-expert tile counts
-    int carry_cnt = 0, carry_act = 0, carry_til = 0, maxc = 0;
+    // Row-aware launch order: the active list and the tile list are written heaviest expert first (rows descending, id
+    // ascending among equals).  The streamers take blockIdx.y -> active[], the tile kernels blockIdx -> tile list, so
+    // the workgroups of the experts with the most rows (the longest ones under skewed routing: more token blocks per
+    // weight byte, two row tiles) start first and the light ones fill the tail.  counts / offsets / sorted_slot keep
+    // the stable expert-ascending layout (moe_align_block_size.py:11-103); results do not depend on the order.
+    int32_t* ord = wcnt;                 // [E] (the scatter below initialises wcnt itself)
+    for (int e = tid; e < E; e += THREADS) {
+        const int c = cnt[e];
+        int rk = 0;
+        for (int f = 0; f < E; ++f) {
+            const int cf = cnt[f];
+            rk += (cf > c || (cf == c && f < e)) ? 1 : 0;
+        }
+        ord[rk] = e;
+    }
+    __syncthreads();
+
+    // exclusive scans: cnt[] in expert order (row offsets); the (cnt>0) flags, the per-expert tile counts and cnt[] again in
+    // launch order (active list, tile list, XCD cut keys)
+    int carry_cnt = 0, carry_act = 0, carry_til = 0, carry_ord = 0, maxc = 0;
     for (int base = 0; base < E; base += THREADS) {
         int e = base + tid;
         int c = (e < E) ? cnt[e] : 0;
-        int a = c > 0 ? 1 : 0;
-        int t = (tile_rows > 0 && c > tile_min) ? (c + tile_rows - 1) / tile_rows : 0;
-        int sc = c, sa = a, stl = t;
+        const int eo = (e < E) ? ord[e] : 0;          // the expert at launch position `e`
+        int co = (e < E) ? cnt[eo] : 0;
+        int a = co > 0 ? 1 : 0;
+        int t = (tile_rows > 0 && co > tile_min) ? (co + tile_rows - 1) / tile_rows : 0;
+        int sc = c, sa = a, stl = t, so = co;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            int tc = __shfl_up(sc, d, 64), ta = __shfl_up(sa, d, 64), tt = __shfl_up(stl, d, 64);
+            int tc = __shfl_up(sc, d, 64), ta = __shfl_up(sa, d, 64), tt = __shfl_up(stl, d, 64), to = __shfl_up(so, d, 64);
             if (lane >= d) {
                 sc += tc;
                 sa += ta;
                 stl += tt;
+                so += to;
             }
         }
         if (lane == 63) {
             wsum[wv] = sc;
             wsum[WAVES + wv] = sa;
             wsum[2 * WAVES + wv] = stl;
+            wsum[3 * WAVES + wv] = so;
         }
         __syncthreads();
-        int pc = 0, pa = 0, pt = 0, tot_c = 0, tot_a = 0, tot_t = 0;
+        int pc = 0, pa = 0, pt = 0, po = 0, tot_c = 0, tot_a = 0, tot_t = 0;
         for (int w = 0; w < WAVES; ++w) {
-            int xc = wsum[w], xa = wsum[WAVES + w], xt = wsum[2 * WAVES + w];
+            int xc = wsum[w], xa = wsum[WAVES + w], xt = wsum[2 * WAVES + w], xo = wsum[3 * WAVES + w];
             if (w < wv) {
                 pc += xc;
                 pa += xa;
                 pt += xt;
+                po += xo;
             }
             tot_c += xc;
             tot_a += xa;
@@ -144,21 +167,23 @@ __device__ __forceinline__ void sort_slots_body(
         int ex_c = carry_cnt + pc + sc - c;
         int ex_a = carry_act + pa + sa - a;
         int ex_t = carry_til + pt + stl - t;
+        int ex_o = carry_ord + po + so - co;
         if (e < E) {
             off[e] = ex_c;
             counts[e] = c;
             offsets[e] = ex_c;
-            if (a) active[ex_a] = e;
+            if (a) active[ex_a] = eo;
             for (int i = 0; i < t; ++i) {
-                tile_e[ex_t + i] = e;
-                tile_r0[ex_t + i] = tile_first_row(c, t, i, tile_rows, tile_gran);
-                if (xcd_cap > 0) tkey[ex_t + i] = ex_c + i * tile_rows + (ex_t + i) * tile_rows;
+                tile_e[ex_t + i] = eo;
+                tile_r0[ex_t + i] = tile_first_row(co, t, i, tile_rows, tile_gran);
+                if (xcd_cap > 0) tkey[ex_t + i] = ex_o + i * tile_rows + (ex_t + i) * tile_rows;
             }
         }
         maxc = max(maxc, c);
         carry_cnt += tot_c;
         carry_act += tot_a;
         carry_til += tot_t;
+        carry_ord += tot_c;                      // (both orders sum the same counts)
         __syncthreads();
     }
 #pragma unroll

@@ -160,7 +160,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0, t_fuse = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0, t_fuse = 0, t_tiled2 = 0;
     bool unit_major = false;  // weight image layout (RepackDims::unit_major)
     int loads = 2;            // 16-byte loads per lane per (tile, unit)
     // profiling
@@ -356,6 +356,7 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     int rc = LKM_OK;
     auto fail = [&](int code) {
         lkm_destroy(h);
+        (void)hipGetLastError();     // a failed hipMalloc stays the "last error": the next launch check must not see it
         return code;
     };
 #define LKM_TRY(expr)                        \
@@ -525,7 +526,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
     // ---- which kernels
     // Mixtral bf16: M=64 (16 rows/expert) skinny 537 us vs tiled 570 us; M=128 (32 rows/expert) skinny
     // 714 us vs tiled64 585 us; 64-row tiles beat 128-row tiles up to M=512, 4 waves beat 8.
-    int tiled = 0, split = 0;
+    int tiled = 0, split = 0, g2_only = 0;
     {
         // Tile rows by rows per expert (profiles/r01_tile_thresholds.log, Mixtral shapes, 8 experts):
         // 16-bit weights 48 rows/expert: 64 (507 us vs 604 at 128); 64: 128 (602 vs 746); 96: 128 (628 vs
@@ -572,8 +573,26 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // M=32 196 -> 190, MXFP4 M=32 158 -> 150).  fp8 stays at 64: the DSv3 rank slice loses in GEMM1 (147 ->
         // 160 us) what it gains in GEMM2 (88 -> 85), Mixtral W8A8 M=48 is equal.
         if (tiled == 64 && !split && wf_is_4bit(h->wf) && est_max <= 32) tiled = 32;
+        // fp8 x fp8 with many experts (round 3, with the four-deep weight ring below): the 32-row tile for the DSv3 rank
+        // slice, uniform 266 -> 265 us per step, Zipf (18 of 32 experts hit, the hot one 126 rows) 196 -> 186 (GEMM1 112 ->
+        // 102 us: twice the workgroups on a chip the 64-row grid leaves under-subscribed).  W8A16 keeps 64 rows (uniform 263
+        // vs 266, Zipf 189 vs 200): profiles/r03_mixed_plan_sweep.log
+        if (tiled == 64 && !split && h->a8 && est_max <= 32 && n_act >= 16) tiled = 32;
         if (h->t_tiled > 0) { tiled = h->t_tiled; split = 0; }
         if (h->t_tiled < 0) { tiled = 0; split = 0; }
+        // Mixed plan (streamer formats, an expert may hold more than one token block): GEMM1 stays with the streamer, GEMM2
+        // takes the tile kernel.  A streamer wave re-reads its expert's token rows from the L2 for every weight tile, and
+        // GEMM2's rows are I = 3.5 x H long: with skewed routing the expert that holds most of the rows (Mixtral M=32, Zipf:
+        // 23 of 64) costs 660 KB of L2 reads per 16-row weight tile, where the tile kernel stages the rows through LDS once
+        // per four waves.  Mixtral M=32, step us, streamer GEMM2 -> tile GEMM2: bf16 uniform 455 -> 461, Zipf 477 -> 460;
+        // fp8-W8A8 uniform 257 -> 255, Zipf 289 -> 266 (32-row tiles); bf16 M=20 / 24 gain nothing and pay the tile list
+        // (+4 us), so the rule starts where two full token blocks are likely (profiles/r03_zipf_launch_order_sweep.log,
+        // r03_mixed_plan_sweep.log).  "tiled2" = -1 switches it off, n > 0 forces n-row GEMM2 tiles.
+        if (!tiled && !split && (w16 || h->wf == LKM_W_FP8_E4M3) && est_max >= 24 && h->t_tiled2 >= 0 && h->t_tiled >= 0 &&
+            h->t_fuse == 0)            // ("fuse" = +-1 asks for the streamer GEMM2 with / without the combine folded in)
+            g2_only = w16 ? 64 : 32;
+        if (!tiled && !split && h->t_tiled2 > 0) g2_only = h->t_tiled2;
+        if (g2_only) tiled = g2_only;
     }
     pl->split_rows = split;
     // XCD-aware work mapping (gemm_tiled.h; the workgroups that share a token tile or a weight panel run on
@@ -610,6 +629,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // fp8 with a short K loop (DSv3: I = 2048 = 16 units): four resident waves beat the deeper ring,
             // GEMM2 W8A16 91.3 -> 83.9 us, W8A8 90.8 -> 88.4
             if (h->wf == LKM_W_FP8_E4M3 && h->U2 <= 32) pd2 = 2;
+            if (h->wf == LKM_W_FP8_E4M3 && tiled == 32) pd1 = pd2 = 4;      // (the 32-row tile has the registers for it)
             // int4 / NVFP4 with two GEMM2 tiles per wave: the decoders are VALU-heavy, the resident wave is worth
             // more than the deeper ring (int4 GEMM2 92 -> 84.5 us, NVFP4 80.4 -> 78.6; MXFP4 LOSES: 67.5 -> 72.7)
             if (w4_64 && h->wf != LKM_W_MXFP4) pd2 = 2;
@@ -656,7 +676,8 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         }
         pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves, pd1, pf};
         pl->t2 = LaunchCfg{nt2, tiled / 16, 1, sk2, tiled, waves, pd2, pf};
-        if (!split) return;
+        if (g2_only) pl->t1 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
+        if (!split && !g2_only) return;
     }
     // ---- skinny geometry (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4;
     // otherwise nt*tb<=8)
@@ -692,6 +713,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
     const size_t y_rows = h->arena->y_elems / h->H;
     while (sk > 1 && (size_t)sk * n_slots > y_rows) sk /= 2;
     pl->s2 = LaunchCfg{nt2, tb, 1, sk, 0, 0, 0, 0};
+    if (g2_only) pl->s2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
 }
 
 // the no-scatter decode path (run_chunk): at most four tokens, streamer geometry of one tile / one token block per wave
@@ -1200,6 +1222,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "sk2")) h->t_sk2 = value;
     else if (!strcmp(key, "tbmax")) h->t_tb = value;
     else if (!strcmp(key, "tiled")) h->t_tiled = value;
+    else if (!strcmp(key, "tiled2")) h->t_tiled2 = value;
     else if (!strcmp(key, "waves")) h->t_waves = value;
     else if (!strcmp(key, "pd1")) h->t_pd1 = value;
     else if (!strcmp(key, "pd2")) h->t_pd2 = value;

@@ -51,9 +51,12 @@ def main():
     assert ep16.overflow_count() == 0
     print(f"a2a-bf16 eager OK (max rel {err:.2e})", flush=True)
 
-    epar = ExpertParallelExperts(local, E, H, mode="ar")
+    epar = ExpertParallelExperts(local, E, H, mode="ar", return_dtype=torch.float32)
     got = epar.forward(x, tw, ids, force_collectives=True)
     assert torch.equal(got, want)
+    # default: the partial sums are reduced in the activation dtype (what the reference all-reduces, moe_runner.py:494)
+    got16 = ExpertParallelExperts(local, E, H, mode="ar").forward(x, tw, ids, force_collectives=True)
+    assert got16.dtype == torch.bfloat16 and torch.equal(got16, eng.prefill(x, tw, ids))
     print("ar eager OK", flush=True)
 
     # ---- capture: router top-k + pack + all-to-all + grouped GEMMs + all-to-all + combine in ONE graph

@@ -100,18 +100,22 @@ def test_forward_routed_equals_router_then_forward(M, E, K, scoring, bias, group
     rsf = 2.5 if grouped else 1.0
     if grouped:
         kw.update(num_expert_group=grouped[0], topk_group=grouped[1], routed_scaling_factor=rsf)
-    out_d, w_d, ids_d = eng.forward_logits(x, logits.to(DEV), K, True, **kw)      # default plan: router + sort fused
-    eng.engine.set_tuning(fuse=1)                                               # + GEMM2 + combine fused
-    out, w, ids = eng.forward_logits(x, logits.to(DEV), K, True, **kw)
-    assert torch.equal(out_d.view(torch.int32), out.view(torch.int32)) and torch.equal(ids_d, ids) and torch.equal(w_d, w)
+    # every plan: the default one (router + sort fused; GEMM2 may be the tile kernel), the streamer GEMM2 with the combine
+    # folded in (fuse=1) and without (fuse=-1).  The two streamer plans also agree with each other bit for bit.
     if grouped:
         w0, i0 = ops.grouped_topk(x, logits.to(DEV), K, True, grouped[0], grouped[1], scoring, rsf, kw["e_score_correction_bias"])
     else:
         w0, i0 = ops.topk_softmax(logits.to(DEV), K, True, kw["e_score_correction_bias"], scoring, rsf)
-    eng.engine.set_tuning(fuse=-1)
-    base = eng.forward_rows(x, w0, i0)
-    assert torch.equal(ids, i0) and torch.equal(w.view(torch.int32), w0.view(torch.int32))
-    assert torch.equal(out.view(torch.int32), base.view(torch.int32)), eng.engine.describe()
+    outs = {}
+    for fuse in (0, 1, -1):
+        eng.engine.set_tuning(fuse=fuse)
+        out, w, ids = eng.forward_logits(x, logits.to(DEV), K, True, **kw)
+        base = eng.forward_rows(x, w0, i0)
+        assert torch.equal(ids, i0) and torch.equal(w.view(torch.int32), w0.view(torch.int32))
+        assert torch.equal(out.view(torch.int32), base.view(torch.int32)), (fuse, eng.engine.describe())
+        outs[fuse] = out
+    assert torch.equal(outs[1].view(torch.int32), outs[-1].view(torch.int32))
+    torch.testing.assert_close(outs[0], outs[1], atol=1e-4, rtol=1e-4)
     # the router against the oracle
     sc = 0 if scoring == "softmax" else 1
     if grouped:

@@ -56,7 +56,7 @@ def test_engines_of_deepseek_v3_size_until_the_gpu_is_full(monkeypatch):
         np.testing.assert_array_equal(eng.decode(x, tw, ids).cpu().numpy(), first)
 
     # a host-sourced engine fits where image + one staging chunk fit (2.8 GB image, < 2 x that free)
-    del engines[-1]
+    del engines[-1], eng
     torch.cuda.empty_cache()
     Es = 64
     h13, h2 = w13[:Es].cpu(), w2[:Es].cpu()

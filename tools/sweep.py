@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--g1", default="1:1:1,1:2:1,2:1:1,2:2:1,1:2:2,1:4:1,4:1:1", help="nt1:tb:kw list")
     ap.add_argument("--g2", default="1:1,1:2,1:4,2:1,2:2,2:4,2:8,4:2,4:4", help="nt2:sk list")
     ap.add_argument("--M", type=int, default=0)
+    ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--cfgs", default="", help="';'-separated tuning sets 'k=v,k=v' measured as whole steps (replaces --g1/--g2)")
     args = ap.parse_args()
     wl = dict(WORKLOADS[args.workload])
@@ -35,6 +36,8 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(7)
     x = (torch.randn((M, H), generator=gen, device=dev) / 10).to(torch.bfloat16)
     logits = torch.randn((M, E), generator=gen, device=dev)
+    if args.routing == "zipf":      # log-popularity bias p(e) ~ 1/(e+1), as bench.py
+        logits = logits + torch.log(1.0 / torch.arange(1, E + 1, device=dev, dtype=torch.float32))[None, :]
     tw, ids = ops.topk_softmax(logits, K, True)
     e_act = int(torch.unique(ids).numel())
     g1_bytes, g2_bytes = e_act * 2 * I * H * bpe, e_act * H * I * bpe
@@ -52,7 +55,8 @@ def main():
                 acc[k] += p[k] / args.reps
         return acc
 
-    print(f"# {args.workload} M={M} e_act={e_act} g1={g1_bytes/1e9:.3f} GB g2={g2_bytes/1e9:.3f} GB")
+    print(f"# rows per expert: {torch.bincount(ids.flatten().long(), minlength=E).tolist()}")
+    print(f"# {args.workload} {args.routing} M={M} e_act={e_act} g1={g1_bytes/1e9:.3f} GB g2={g2_bytes/1e9:.3f} GB")
     if args.cfgs:
         keys = ("nt1", "nt2", "kw1", "sk2", "tbmax", "tiled", "waves", "hybrid", "pd1", "pd2", "xcd", "pf", "direct", "valid_den", "dbg")
         for spec in args.cfgs.split(";"):

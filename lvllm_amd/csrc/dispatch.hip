@@ -562,6 +562,62 @@ int launch_sort(hipStream_t st, const int32_t* ids_ptr, int top_k, int ids_ld, i
     return LKM_OK;
 }
 
+// ------------------------------------------------------------------ item list of the fp8 x fp8 prefill kernel
+// The persistent prefill kernel (gemm_prefill_a8w.h) walks a list of (token tile, row group) items; the workgroups of one
+// XCD take consecutive list positions at the same time.  What runs at the same time should share its operands in that
+// XCD's L2: the expert's token tiles that multiply the SAME weight row group are adjacent in the list (one read of the
+// 1 MB weight panel from the fabric serves all of them), the row groups of an expert follow each other (its token tiles
+// stay in the L2 while the expert lasts).  With the tile-major order (all row groups of a tile, then the next tile) the
+// sharers of a weight panel were eleven positions apart, usually in different rounds of the 32 workgroups: GLM-4.5-Air
+// GEMM1 pulled 3.6 GB through the fabric for 1.75 GB of operands, and the kernel's data movement alone (no MFMA) took
+// 640 us of its 955 (profiles/r03_a8w_item_order.md).
+__global__ __launch_bounds__(256) void build_items_kernel(const int32_t* __restrict__ tile_e, const int32_t* __restrict__ tile_r0,
+                                                          const int32_t* __restrict__ counts, const int32_t* __restrict__ offsets,
+                                                          const int32_t* __restrict__ meta, int xcd_parts, int rg1, int rg2,
+                                                          int32_t* __restrict__ items1, int32_t* __restrict__ items2) {
+    const int n_tiles = meta[3];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    int lo = 0, hi = n_tiles;
+    if (xcd_parts) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int f = meta[8 + c], l = meta[9 + c];
+            if (t >= f && t < l) {
+                lo = f;
+                hi = l;
+            }
+        }
+    }
+    const int e = tile_e[t], r0 = tile_r0[t];
+    int a = t, b = t + 1;
+    while (a > lo && tile_e[a - 1] == e) --a;
+    while (b < hi && tile_e[b] == e) ++b;
+    const int T = b - a, j = t - a;
+    int rows = (t + 1 < n_tiles && tile_e[t + 1] == e) ? tile_r0[t + 1] - r0 : counts[e] - r0;
+    rows = rows > 256 ? 256 : (rows < 1 ? 1 : rows);
+    const int orow0 = offsets[e] + r0;
+    for (int which = 0; which < 2; ++which) {
+        const int rg_n = which ? rg2 : rg1;
+        int32_t* items = which ? items2 : items1;
+        if (!items) continue;
+        for (int rg = 0; rg < rg_n; ++rg) {
+            const size_t pos = (size_t)a * rg_n + (size_t)rg * T + j;
+            *(int4*)(items + pos * 4) = make_int4(e, orow0, rows, rg);
+        }
+    }
+}
+
+int launch_build_items(hipStream_t st, const int32_t* tile_e, const int32_t* tile_r0, const int32_t* counts,
+                       const int32_t* offsets, const int32_t* meta, int xcd_parts, int rg1, int rg2, int max_tiles,
+                       int32_t* items1, int32_t* items2) {
+    if (max_tiles <= 0) return LKM_OK;
+    hipLaunchKernelGGL(build_items_kernel, dim3((unsigned)ceil_div(max_tiles, 256)), dim3(256), 0, st, tile_e, tile_r0, counts,
+                       offsets, meta, xcd_parts, rg1, rg2, items1, items2);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
 // ------------------------------------------------------------------ dynamic 1x128 fp8 activation quant
 // per_token_group_quant_fp8 (csrc/libtorch_stable/quantization/w8a8/fp8/per_token_group_quant.cu:100;
 // spec tests/kernels/quant_utils.py:157-180): s = max(amax,1e-10)/448, q = clamp(x/s, +-448) -> e4m3fn.

@@ -16,6 +16,13 @@ int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, i
         LKM_A8W_DBG_CASE(2 | 64)       // data movement without the barrier
         LKM_A8W_DBG_CASE(1 | 2)        // neither: prologue + epilogue + the loop's own bookkeeping and barriers
         LKM_A8W_DBG_CASE(1 | 2 | 64)
+        LKM_A8W_DBG_CASE(128)          // the whole kernel, blocks do not wait for their LDS reads
+        LKM_A8W_DBG_CASE(1 | 128)
+        LKM_A8W_DBG_CASE(8)            // the whole kernel without: LDS reads / VALU / MFMA / barrier
+        LKM_A8W_DBG_CASE(16)
+        LKM_A8W_DBG_CASE(32)
+        LKM_A8W_DBG_CASE(64)
+        LKM_A8W_DBG_CASE(8 | 16)
 #undef LKM_A8W_DBG_CASE
     default:
         set_error("fp8 W8A8 prefill kernel: ablation dbg=%d not built", dbg);

@@ -82,7 +82,7 @@ typedef __attribute__((ext_vector_type(4))) int a8w_i32x4;
 // accumulators.  SLOT: A ring slot of the unit.  HASPREV: block b-1 of the same unit exists.  The prefetch address is
 // the caller's: (same stage, block b+1) or (next stage, block 0).
 // DBG (ablations, assembler conditionals): 8 = no LDS reads, 16 = no VALU (scale products, accumulator updates),
-// 32 = no MFMA
+// 32 = no MFMA, 128 = the block does not wait for its LDS reads
 #define A8W_IF(bit) ".if (%c[dbg] & " #bit ") == 0\n\t"
 #define A8W_FI ".endif\n\t"
 template <int SLOT, int B, bool HASPREV, int BOFF, int XOFF, int DBG>
@@ -116,7 +116,9 @@ __device__ __forceinline__ void a8w_block_t(int vblo, int vbhi, int vxs, int ws0
         ".if %c[hasprev] && ((%c[dbg] & 16) == 0)\n\t"
         A8W_FMAC4("%c[acc]+4", "%c[fp]+1", "%c[pp]+4")
         A8W_FI
+        A8W_IF(128)
         "s_waitcnt lgkmcnt(0)\n\t"
+        A8W_FI
         :
         : [bn] "i"(BN), [bc] "i"(BC), [pc] "i"(PC), [pp] "i"(PP), [xc] "i"(XC), [xn] "i"(XN), [fc] "i"(FC),
           [fp] "i"(FP), [a] "i"(A), [acc] "i"(ACC), [one] "i"(a8w::kOne), [boff] "i"(BOFF), [xoff] "i"(XOFF),
@@ -275,9 +277,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     constexpr int TPH = GATED ? 8 : 16;                       // tiles per half taken by one item
     const int RG = __builtin_amdgcn_readfirstlane((T_half + TPH - 1) / TPH);
     const int n_tiles = __builtin_amdgcn_readfirstlane(p.meta[3]);
-    // ---- this workgroup's items: position s of its part's list = (tile first + s / RG, row group s % RG), s = w, w +
-    // stride, ...  With the XCD-aware runs (dispatch.hip xcd_cut) a part is one XCD's run of tiles and its workgroups
-    // the ones the dispatcher places there (block b -> XCD b % 8: a speed assumption, never a correctness one)
+    // ---- this workgroup's items: positions s = w, w + stride, ... of its part of the item list (p.items, built by
+    // dispatch.hip build_items_kernel: {expert, first output row, rows, row group} per item, an expert's token tiles of one
+    // row group adjacent).  With the XCD-aware runs (dispatch.hip xcd_cut) a part is one XCD's run of tiles x the row
+    // groups, and its workgroups the ones the dispatcher places there (block b -> XCD b % 8: a speed assumption, never a
+    // correctness one)
     int first = 0, n_c = n_tiles, w = blockIdx.x, stride = gridDim.x;
     if (p.xcd_map) {
         const int c = blockIdx.x & 7;
@@ -297,51 +301,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     const int wtb = __builtin_amdgcn_readfirstlane((int)(p.w_tstride * 16));
     // ---- item descriptors: wave-uniform scalars only
     struct Meta {
-        int valid, bx, e, r0, e2, r02, m_e, off_e;
+        int valid, bx, e, orow0, rows;
     };
     const int lds0 = (int)(unsigned)(uintptr_t)(LdsPtr)lds;
-    // Metadata of the item two ahead, in two dependent stages of 4-byte LDS-DMA (behind the asm blocks' "memory" clobbers
-    // and the epilogue's stores the compiler cannot keep such loads scalar, and a load it issues itself is waited for with
-    // vmcnt(0): the whole pipeline; a register destination written by an asm load is copied around by the register
-    // allocator before the data lands).  Stage A at an item switch: the tile-list entry and its successor -> this wave's
-    // landing zone; stage B two barriers later: the expert's row count and offset; both read back with a plain LDS read
-    // after the ledger says they have landed.
+    const int item0 = __builtin_amdgcn_readfirstlane(first * RG);
+    // Metadata of the item two ahead: its 16-byte record by 4-byte LDS-DMA into this wave's landing zone at an item switch
+    // (behind the asm blocks' "memory" clobbers and the epilogue's stores the compiler cannot keep such loads scalar, and a
+    // load it issues itself is waited for with vmcnt(0): the whole pipeline; a register destination written by an asm
+    // load is copied around by the register allocator before the data lands), read back with a plain LDS read at the
+    // next switch, a whole item later.
     auto meta_a = [&](int s) __attribute__((always_inline)) {
         Meta m;
         m.valid = s < n_items;
         const int ss = m.valid ? s : 0;
-        const int ti = first + ss / RG;
-        m.bx = ss % RG;
-        const int tn = ti + 1 < n_tiles ? ti + 1 : ti;
-        m.e2 = ti + 1 < n_tiles ? 0 : -1;      // (-1: no successor)
         int ln = lane;
         asm volatile("" : "+v"(ln));            // (per-item address arithmetic must not be hoisted out of the item loop: registers)
-        const int* a = (ln & 1) ? p.tile_r0 : p.tile_e;
-        a += (ln & 2) ? tn : ti;                // lanes 0..3: tile_e[ti], tile_r0[ti], tile_e[tn], tile_r0[tn]
-        a8w_dma4_flat(lds0 + kStA + wave * 256, a);
-        m.e = m.r0 = m.r02 = m.m_e = m.off_e = 0;
+        a8w_dma4_flat(lds0 + kStA + wave * 256, p.items + (size_t)(item0 + ss) * 4 + (ln & 3));
+        m.bx = m.e = m.orow0 = m.rows = 0;
         return m;
     };
     auto meta_a_done = [&](Meta& m) __attribute__((always_inline)) {      // (landed: caller's ledger)
         a8w_i32x4 v;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds0 + kStA + wave * 256) : "memory");
         m.e = __builtin_amdgcn_readfirstlane(v.x);
-        m.r0 = __builtin_amdgcn_readfirstlane(v.y);
-        if (m.e2 != -1) m.e2 = __builtin_amdgcn_readfirstlane(v.z);
-        m.r02 = __builtin_amdgcn_readfirstlane(v.w);
-    };
-    auto meta_b = [&](Meta& m) __attribute__((always_inline)) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int* a = ((ln & 1) ? p.offsets : p.counts) + m.e;
-        a8w_dma4_flat(lds0 + kStB + wave * 256, a);
-    };
-    auto meta_b_done = [&](Meta& m) __attribute__((always_inline)) {
-        int c, o;
-        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:4\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(c), "=&v"(o) : "v"(lds0 + kStB + wave * 256) : "memory");
-        m.m_e = __builtin_amdgcn_readfirstlane(c);
-        m.off_e = __builtin_amdgcn_readfirstlane(o);
+        m.orow0 = __builtin_amdgcn_readfirstlane(v.y);
+        m.rows = __builtin_amdgcn_readfirstlane(v.z);
+        m.bx = __builtin_amdgcn_readfirstlane(v.w);
     };
     struct Item {
         int nq;        // 32-row pairs of token blocks that hold rows; 0 = no such item
@@ -351,13 +336,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     };
     auto make_item = [&](const Meta& m) __attribute__((always_inline)) {
         Item it;
-        int rows = m.m_e - m.r0;
-        if (m.e2 == m.e) rows = m.r02 - m.r0;
-        if (rows > 256) rows = 256;
-        if (rows < 1) rows = 1;
+        const int rows = m.rows;
         it.rows = rows;
         it.nq = m.valid ? (rows + 31) >> 5 : 0;
-        it.orow0 = m.off_e + m.r0;
+        it.orow0 = m.orow0;
         it.tbase = m.bx * TPH;
         it.e = m.e;
         const unsigned long long wa = (unsigned long long)((const char*)p.w + (size_t)m.e * wbytes);
@@ -459,9 +441,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         Meta m0 = meta_a(w);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         meta_a_done(m0);
-        meta_b(m0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        meta_b_done(m0);
         cur = make_item(m0);
         gather_item(cur);
         fetch_ws(cur, 0);
@@ -470,18 +449,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         Meta m1 = meta_a(w + stride);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         meta_a_done(m1);
-        meta_b(m1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        meta_b_done(m1);
         nxt = make_item(m1);
         gather_item(nxt);
         fetch_ws(nxt, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         store_table(1, nxt);
         pend = meta_a(w + 2 * stride);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        meta_a_done(pend);
-        meta_b(pend);
         // everything above that came from memory is consumed HERE (the compiler's own loads must not be waited for
         // inside the hand-counted loop)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -616,10 +589,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         }
         if constexpr (KIND == 0 && SLOT == 2) {
             // two barriers after the item switch: the next item's gathered rows have landed (ledger: sixteen loads were
-            // issued after them) -> its table; and the pending item's expert is known
+            // issued after them) -> its table
             if (nxt.nq) store_table(tbuf ^ 1, nxt);
-            meta_a_done(pend);
-            meta_b(pend);
         }
         const int nq = real ? cur.nq : 0;
         static_for<8>([&](auto QC) __attribute__((always_inline)) {
@@ -699,7 +670,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                 xsl_nxt0 = (xsl + n_grp) % 3;
                 tbuf ^= 1;
                 cur = nxt;
-                meta_b_done(pend);
+                meta_a_done(pend);                     // (its record landed a whole item ago)
                 nxt = make_item(pend);
                 gather_item(nxt);                      // (no such item: repeats item 0's addresses, harmless)
                 fetch_ws(nxt, tbuf ^ 1);

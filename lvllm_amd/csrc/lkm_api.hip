@@ -41,6 +41,8 @@ struct Arena {
     size_t tile_cap = 0;
     int32_t* hist = nullptr;                         // multi-workgroup sort: [chunks][E]
     size_t hist_cap = 0;
+    int32_t* items = nullptr;                        // fp8 x fp8 prefill kernel: the two GEMMs' item lists (launch_build_items)
+    size_t items_cap = 0;
     unsigned char *xq = nullptr, *aq = nullptr;   // W8A8: fp8 activations (tokens / intermediate rows)
     float *xqs = nullptr, *aqs = nullptr;         //       and their 1x128 scales
     size_t xq_n = 0, aq_n = 0, xqs_n = 0, aqs_n = 0;
@@ -67,7 +69,7 @@ static int grow(T*& ptr, size_t& have, size_t want, std::vector<void*>& retired)
 }
 
 static int arena_reserve(int device, int E, size_t slots, size_t act_elems, size_t y_elems,
-                         size_t xq_n, size_t xqs_n, size_t aq_n, size_t aqs_n, Arena** out) {
+                         size_t xq_n, size_t xqs_n, size_t aq_n, size_t aqs_n, size_t items_n, Arena** out) {
     std::lock_guard<std::mutex> lk(g_arena_mu);
     LKM_REQUIRE(device >= 0 && device < 64, "device ordinal %d out of range", device);
     Arena& a = g_arenas[device];
@@ -125,6 +127,7 @@ static int arena_reserve(int device, int E, size_t slots, size_t act_elems, size
     if (xqs_n && (rc = grow(a.xqs, a.xqs_n, xqs_n, a.retired)) != LKM_OK) return rc;
     if (aq_n && (rc = grow(a.aq, a.aq_n, aq_n, a.retired)) != LKM_OK) return rc;
     if (aqs_n && (rc = grow(a.aqs, a.aqs_n, aqs_n, a.retired)) != LKM_OK) return rc;
+    if (items_n && (rc = grow(a.items, a.items_cap, items_n, a.retired)) != LKM_OK) return rc;
     *out = &a;
     return LKM_OK;
 }
@@ -234,6 +237,12 @@ static size_t wbytes_per_elem_x2(int wf) {  // bytes per 2 elements
     case LKM_W_FP8_E4M3: return 2;
     default: return 1;
     }
+}
+
+// row groups per token tile of the fp8 x fp8 prefill kernel (gemm_prefill_a8w.h: an item takes 8 gate + 8 up tiles of a
+// gated GEMM1, 16 tiles otherwise)
+static int a8w_row_groups(const LkmEngine* h, int gemm) {
+    return gemm == 1 ? ceil_div(h->T1_half, h->gated ? 8 : 16) : ceil_div(h->T2, 16);
 }
 
 extern "C" int lkm_abi_version(void) { return LKM_ABI_VERSION; }
@@ -481,9 +490,11 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     {
         const size_t kb1 = ceil_div(h->H, 128), kb2 = ceil_div(h->I, 128);
         const bool xs = h->a8 || h->ps;       // per-(row, 128-k) scalars: activation scales / activation sums
+        // the fp8 x fp8 prefill kernel's item lists: (256-row token tiles of the largest chunk) x (row groups of GEMM1 + GEMM2)
+        const size_t items_n = h->a8 ? (slots / 256 + (size_t)h->E + 8) * (size_t)(a8w_row_groups(h, 1) + a8w_row_groups(h, 2)) * 4 : 0;
         LKM_TRY(arena_reserve(h->device, h->E, slots, slots * h->ld_act, y_rows * h->H,
                               h->a8 ? cap * h->H : 0, xs ? cap * kb1 : 0, h->a8 ? slots * h->I : 0,
-                              xs ? slots * kb2 : 0, &h->arena));
+                              xs ? slots * kb2 : 0, items_n, &h->arena));
     }
     for (auto& e : h->ev) LKM_TRY_HIP(hipEventCreate(&e));
     *out = h;
@@ -803,6 +814,17 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
                          a->hist_cap, xcd_cap);
         if (rc != LKM_OK) return rc;
     }
+    const int32_t *items1 = nullptr, *items2 = nullptr;
+    if (pl.t1.pf == 9 && pl.t2.pf == 9 && !direct) {
+        // the round-3 fp8 x fp8 prefill kernel walks its own item lists (dispatch.hip build_items_kernel)
+        const int rg1 = a8w_row_groups(h, 1), rg2 = a8w_row_groups(h, 2);
+        LKM_REQUIRE((size_t)max_tiles * (size_t)(rg1 + rg2) * 4 <= a->items_cap, "prefill item lists: %d tiles exceed the arena", max_tiles);
+        items1 = a->items;
+        items2 = a->items + (size_t)max_tiles * rg1 * 4;
+        rc = launch_build_items(st, a->tile_e, a->tile_r0, a->counts, a->offsets, a->meta,
+                                xcd_cap && (h->t_xcd > 0 || pl.xcd1) ? 1 : 0, rg1, rg2, max_tiles, a->items, a->items + (size_t)max_tiles * rg1 * 4);
+        if (rc != LKM_OK) return rc;
+    }
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[1], st));
     // weights are read once per step when an expert's rows fit one token tile
     const int stream_nt = tile_rows && !pl.split_rows
@@ -837,6 +859,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.sorted_slot = a->sorted_slot;
     p1.tile_e = a->tile_e;
     p1.tile_r0 = a->tile_r0;
+    p1.items = items1;
     p1.max_rows = pl.split_rows;
     p1.stream_nt = stream_nt;
     p1.out = a->act;
@@ -904,6 +927,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.sorted_slot = a->sorted_slot;
     p2.tile_e = a->tile_e;
     p2.tile_r0 = a->tile_r0;
+    p2.items = items2;
     p2.max_rows = pl.split_rows;
     p2.stream_nt = stream_nt;
     p2.out = a->y;

@@ -24,6 +24,14 @@ int launch_repack_s_fp4(hipStream_t st, const void* src, void* dst, const Repack
                         int pad);
 
 // ---- dispatch.hip
+// Work list of the round-3 fp8 x fp8 prefill kernel: for each of the two GEMMs (rg1 / rg2 row groups per token tile),
+// every (token tile, row group) item as {expert, offsets[e] + first row, rows, row group}, ordered inside each part of the
+// tile list (one XCD's run, or the whole list) expert by expert, and inside an expert row group by row group with the
+// expert's token tiles adjacent.  max_tiles sizes the launch; the lists hold max_tiles * rg records each.
+int launch_build_items(hipStream_t st, const int32_t* tile_e, const int32_t* tile_r0, const int32_t* counts,
+                       const int32_t* offsets, const int32_t* meta, int xcd_parts, int rg1, int rg2, int max_tiles,
+                       int32_t* items1, int32_t* items2);
+
 // slot i = column i % top_k of token i / top_k in an [M][ids_ld] array; id_offset is subtracted from ids >= 0
 int launch_sort(hipStream_t st, const int32_t* ids, int top_k, int ids_ld, int id_offset, int n_slots, int E,
                 int32_t* counts, int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot, int32_t* active,
@@ -83,6 +91,9 @@ struct GemmParams {
     const int32_t* sorted_slot;
     const int32_t* tile_e;   // tiled kernels: work list of (expert, first row) token tiles
     const int32_t* tile_r0;
+    const int32_t* items;    // fp8 x fp8 prefill kernel (gemm_prefill_a8w.h): its own work list, one 16-byte record
+                             // {expert, first output row, rows, row group} per (token tile, row group) item in launch
+                             // order (dispatch.hip build_items_kernel)
     int max_rows;            // skinny kernels: skip experts with more rows than this (0 = no limit);
                              // they are handled by the tiled kernels of the same step (hybrid dispatch)
     int stream_nt;           // 1: weights are read once (decode) -> nontemporal loads

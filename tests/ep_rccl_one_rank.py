@@ -55,7 +55,8 @@ def main():
     got = epar.forward(x, tw, ids, force_collectives=True)
     assert torch.equal(got, want)
     # default: the partial sums are reduced in the activation dtype (what the reference all-reduces, moe_runner.py:494)
-    got16 = ExpertParallelExperts(local, E, H, mode="ar").forward(x, tw, ids, force_collectives=True)
+    got16 = ExpertParallelExperts(local, E, H, mode="ar").forward(x, tw, ids, force_collectives=True,
+                                                                  out_dtype=torch.bfloat16)
     assert got16.dtype == torch.bfloat16 and torch.equal(got16, eng.prefill(x, tw, ids))
     print("ar eager OK", flush=True)
 

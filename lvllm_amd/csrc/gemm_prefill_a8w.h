@@ -69,13 +69,23 @@ typedef __attribute__((ext_vector_type(4))) int a8w_i32x4;
 #define A8W_CLOB_B "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55"
 #define A8W_CLOB_TOP "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
+// (the plain 128-k MFMA, both operands e4m3: the MX-scaled form with both scale operands 1.0 computes the same bits but is
+// two instructions -- v_mfma_ld_scale_b32 + the MFMA -- 16 bytes and one more issue slot per MFMA)
 #define A8W_MFMA(P, A, B) \
-    "v_mfma_scale_f32_16x16x128_f8f6f4 v[" P ":" P "+3], v[" A ":" A "+7], v[" B ":" B "+7], 0, v[%c[one]], v[%c[one]] op_sel_hi:[0,0,0]\n\t"
+    "v_mfma_f32_16x16x128_f8f6f4 v[" P ":" P "+3], v[" A ":" A "+7], v[" B ":" B "+7], 0\n\t"
 #define A8W_FMAC4(ACC, F, P)                            \
     "v_fmac_f32 v[" ACC "+0], v[" F "], v[" P "+0]\n\t" \
     "v_fmac_f32 v[" ACC "+1], v[" F "], v[" P "+1]\n\t" \
     "v_fmac_f32 v[" ACC "+2], v[" F "], v[" P "+2]\n\t" \
     "v_fmac_f32 v[" ACC "+3], v[" F "], v[" P "+3]\n\t"
+
+#define A8W_MUL4(ACC, F, P)                            \
+    "v_mul_f32 v[" ACC "+0], v[" F "], v[" P "+0]\n\t" \
+    "v_mul_f32 v[" ACC "+1], v[" F "], v[" P "+1]\n\t" \
+    "v_mul_f32 v[" ACC "+2], v[" F "], v[" P "+2]\n\t" \
+    "v_mul_f32 v[" ACC "+3], v[" F "], v[" P "+3]\n\t"
+// accumulator update: += in general, = in an item's first K unit (OPT bit 0: the accumulators are never zeroed)
+#define A8W_ACC4(ACC, F, P) ".if %c[first]\n\t" A8W_MUL4(ACC, F, P) ".else\n\t" A8W_FMAC4(ACC, F, P) ".endif\n\t"
 
 // One 16-token block of one K unit: prefetch the next block's B operand and token scale, form this block's two scale
 // products, multiply both weight tiles, and -- between the MFMAs -- add the PREVIOUS block's partial sums into its
@@ -85,7 +95,9 @@ typedef __attribute__((ext_vector_type(4))) int a8w_i32x4;
 // 32 = no MFMA, 128 = the block does not wait for its LDS reads
 #define A8W_IF(bit) ".if (%c[dbg] & " #bit ") == 0\n\t"
 #define A8W_FI ".endif\n\t"
-template <int SLOT, int B, bool HASPREV, int BOFF, int XOFF, int DBG>
+// OPT: bit 0 = the unit is the item's first (accumulators are assigned, not added to), bit 1 = both weight tiles share one
+// block scale (GEMM2 and the plain GEMM1: two adjacent 16-row tiles of one 128-row scale block) -> one scale product
+template <int SLOT, int B, bool HASPREV, int BOFF, int XOFF, int DBG, int OPT>
 __device__ __forceinline__ void a8w_block_t(int vblo, int vbhi, int vxs, int ws0, int ws1) {
     constexpr int par = B & 1, npar = par ^ 1;
     constexpr int BC = a8w::kB + par * 8, BN = a8w::kB + npar * 8;
@@ -102,27 +114,29 @@ __device__ __forceinline__ void a8w_block_t(int vblo, int vbhi, int vxs, int ws0
         A8W_FI
         A8W_IF(16)
         "v_mul_f32 v[%c[fc]], %[ws0], v[%c[xc]]\n\t"
+        ".if %c[same] == 0\n\t"
         "v_mul_f32 v[%c[fc]+1], %[ws1], v[%c[xc]]\n\t"
+        ".endif\n\t"
         A8W_FI
         A8W_IF(32)
         A8W_MFMA("%c[pc]", "%c[a]", "%c[bc]")
         A8W_FI
         ".if %c[hasprev] && ((%c[dbg] & 16) == 0)\n\t"
-        A8W_FMAC4("%c[acc]", "%c[fp]", "%c[pp]")
+        A8W_ACC4("%c[acc]", "%c[fp]", "%c[pp]")
         A8W_FI
         A8W_IF(32)
         A8W_MFMA("%c[pc]+4", "%c[a]+8", "%c[bc]")
         A8W_FI
         ".if %c[hasprev] && ((%c[dbg] & 16) == 0)\n\t"
-        A8W_FMAC4("%c[acc]+4", "%c[fp]+1", "%c[pp]+4")
+        A8W_ACC4("%c[acc]+4", "%c[fp1]", "%c[pp]+4")
         A8W_FI
         A8W_IF(128)
         "s_waitcnt lgkmcnt(0)\n\t"
         A8W_FI
         :
         : [bn] "i"(BN), [bc] "i"(BC), [pc] "i"(PC), [pp] "i"(PP), [xc] "i"(XC), [xn] "i"(XN), [fc] "i"(FC),
-          [fp] "i"(FP), [a] "i"(A), [acc] "i"(ACC), [one] "i"(a8w::kOne), [boff] "i"(BOFF), [xoff] "i"(XOFF),
-          [hasprev] "i"(HASPREV ? 1 : 0), [dbg] "i"(DBG),
+          [fp] "i"(FP), [fp1] "i"(FP + ((OPT & 2) ? 0 : 1)), [a] "i"(A), [acc] "i"(ACC), [boff] "i"(BOFF), [xoff] "i"(XOFF),
+          [hasprev] "i"(HASPREV ? 1 : 0), [dbg] "i"(DBG), [first] "i"(OPT & 1), [same] "i"((OPT >> 1) & 1),
           [vblo] "v"(vblo), [vbhi] "v"(vbhi), [vxs] "v"(vxs), [ws0] "s"(ws0), [ws1] "s"(ws1)
         : "memory", A8W_CLOB_B, A8W_CLOB_TOP);
 }
@@ -131,7 +145,7 @@ __device__ __forceinline__ void a8w_block_t(int vblo, int vbhi, int vxs, int ws0
 // and complete at the asm's end (lgkmcnt(0)), all from LDS (a scalar load here would park every later lgkmcnt(0) behind
 // the scalar cache): the weight-block scales of the NEXT unit and the source offsets of the unit's four token pieces
 // and one scale piece (row table).
-template <int SLOT, int DBG>
+template <int SLOT, int DBG, int OPT>
 __device__ __forceinline__ void a8w_block0(int vblo, int vbhi, int vxs, int ws0, int ws1, int wsaddr, int taddr,
                                            int& ws0n, int& ws1n, int (&t)[4]) {
     constexpr int A = a8w::kA + SLOT * 16;
@@ -149,7 +163,9 @@ __device__ __forceinline__ void a8w_block0(int vblo, int vbhi, int vxs, int ws0,
         "ds_read_b32 %[t3], %[taddr] offset:768\n\t"
         A8W_IF(16)
         "v_mul_f32 v[%c[fc]], %[ws0], v[%c[xc]]\n\t"
+        ".if %c[same] == 0\n\t"
         "v_mul_f32 v[%c[fc]+1], %[ws1], v[%c[xc]]\n\t"
+        ".endif\n\t"
         A8W_FI
         A8W_IF(32)
         A8W_MFMA("%c[pc]", "%c[a]", "%c[bc]")
@@ -158,23 +174,23 @@ __device__ __forceinline__ void a8w_block0(int vblo, int vbhi, int vxs, int ws0,
         "s_waitcnt lgkmcnt(0)\n\t"
         : [ws0n] "=&v"(ws0n), [ws1n] "=&v"(ws1n), [t0] "=&v"(t[0]), [t1] "=&v"(t[1]), [t2] "=&v"(t[2]), [t3] "=&v"(t[3])
         : [bn] "i"(a8w::kB + 8), [bc] "i"(a8w::kB), [pc] "i"(a8w::kP), [xc] "i"(a8w::kX), [xn] "i"(a8w::kX + 1),
-          [fc] "i"(a8w::kF), [a] "i"(A), [one] "i"(a8w::kOne), [dbg] "i"(DBG), [vblo] "v"(vblo), [vbhi] "v"(vbhi),
+          [fc] "i"(a8w::kF), [a] "i"(A), [dbg] "i"(DBG), [same] "i"((OPT >> 1) & 1), [vblo] "v"(vblo), [vbhi] "v"(vbhi),
           [vxs] "v"(vxs), [ws0] "s"(ws0), [ws1] "s"(ws1), [wsaddr] "v"(wsaddr), [taddr] "v"(taddr)
         : "memory", A8W_CLOB_B, A8W_CLOB_TOP);
 }
 
 // the accumulator update of a unit's LAST block (its MFMAs were the last two instructions of the matrix pipe: 16 wait
 // states cover the 11 an 8-pass result needs before a VALU may read it)
-template <int B, int DBG>
+template <int B, int DBG, int OPT>
 __device__ __forceinline__ void a8w_flush() {
     if constexpr (DBG & 16) return;
     constexpr int par = B & 1;
     constexpr int PP = a8w::kP + par * 8, FP = a8w::kF + par * 2, ACC = a8w::kAcc + B * 8;
     asm volatile("s_nop 15\n\t"
-                 A8W_FMAC4("%c[acc]", "%c[fp]", "%c[pp]")
-                 A8W_FMAC4("%c[acc]+4", "%c[fp]+1", "%c[pp]+4")
+                 A8W_ACC4("%c[acc]", "%c[fp]", "%c[pp]")
+                 A8W_ACC4("%c[acc]+4", "%c[fp1]", "%c[pp]+4")
                  :
-                 : [acc] "i"(ACC), [fp] "i"(FP), [pp] "i"(PP)
+                 : [acc] "i"(ACC), [fp] "i"(FP), [fp1] "i"(FP + ((OPT & 2) ? 0 : 1)), [pp] "i"(PP), [first] "i"(OPT & 1)
                  : "memory", A8W_CLOB_TOP);
 }
 
@@ -492,10 +508,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     };
 
     // ---- prologue: the pipeline's first three units
-    asm volatile("v_mov_b32 v[%c0], 0x7f7f7f7f" ::"i"(kOne) : "memory", A8W_CLOB_TOP);
-#pragma unroll
-    for (int i = 0; i < 128; i += 4)
-        asm volatile("v_mov_b32 v[%c0+0], 0\n\tv_mov_b32 v[%c0+1], 0\n\tv_mov_b32 v[%c0+2], 0\n\tv_mov_b32 v[%c0+3], 0" ::"i"(kAcc + i) : "memory");
     int ws0, ws1;          // the current unit's two weight-block scales (fp32 bits)
     int st16 = 0;          // the last epilogue issued >= 16 stores (the ledger's waits of the next three units)
     {
@@ -534,6 +546,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     // NEXT item's first units; the position may be a null unit).
     auto unit = [&](auto SLOTC, auto KINDC, int pp) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(SLOTC)::v, KIND = decltype(KINDC)::v;
+        // the item's first unit assigns the accumulators (they are never zeroed); two tiles of one scale block share the product
+        constexpr int OPT = ((KIND == 0 && SLOT == 0) ? 1 : 0) | (GATED ? 0 : 2);
         const int stn = (stoff + kStage) & (kStages * kStage - 1);
         const int lo_c = la.vb_lo + stoff, hi_c = la.vb_hi + stoff, lo_n = la.vb_lo + stn, hi_n = la.vb_hi + stn;
         const int xs_c = la.vx0 + xsl * kScBuf + (pp & 3) * 4;
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         if (late) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         if (real && !(DBG & 2)) {
-            a8w_block0<SLOT, DBG>(lo_c, hi_c, xs_c, ws0, ws1, wsaddr, la.tb_tok + tsel, ws0n, ws1n, t);
+            a8w_block0<SLOT, DBG, OPT>(lo_c, hi_c, xs_c, ws0, ws1, wsaddr, la.tb_tok + tsel, ws0n, ws1n, t);
             ws0n = __builtin_amdgcn_readfirstlane(ws0n);       // (scalars from here on: two registers less across the unit)
             ws1n = __builtin_amdgcn_readfirstlane(ws1n);
         } else {
@@ -597,21 +611,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
             constexpr int q = decltype(QC)::v;
             if (q < nq) {
                 if constexpr (q > 0) {
-                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q, true, (2 * q + 1) * 2048, (2 * q + 1) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
+                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q, true, (2 * q + 1) * 2048, (2 * q + 1) * 256, DBG, OPT>(lo_c, hi_c, xs_c, ws0, ws1);
                 }
                 if (q + 1 < nq) {
-                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, (2 * q + 2) * 2048, (2 * q + 2) * 256, DBG>(lo_c, hi_c, xs_c, ws0, ws1);
+                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, (2 * q + 2) * 2048, (2 * q + 2) * 256, DBG, OPT>(lo_c, hi_c, xs_c, ws0, ws1);
                     if constexpr (q < 4 && !(DBG & 1)) issue_tokens(q, t[q], dma_base, soff);
                 } else {
                     // last block of the unit: prefetch block 0 of the next unit (next stage), then the rest of the unit's
                     // token pieces (below), then the block's own accumulator update
-                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, 0, 0, DBG>(lo_n, hi_n, xs_n, ws0, ws1);
+                    if constexpr (!(DBG & 2)) a8w_block_t<SLOT, 2 * q + 1, true, 0, 0, DBG, OPT>(lo_n, hi_n, xs_n, ws0, ws1);
                     if constexpr (!(DBG & 1)) {
                         static_for<4>([&](auto KC) __attribute__((always_inline)) {
                             if constexpr (decltype(KC)::v >= q) issue_tokens(decltype(KC)::v, t[decltype(KC)::v], dma_base, soff);
                         });
                     }
-                    if constexpr (!(DBG & 2)) a8w_flush<2 * q + 1, DBG>();
+                    if constexpr (!(DBG & 2)) a8w_flush<2 * q + 1, DBG, OPT>();
                 }
             }
         });
@@ -684,9 +698,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                     const int rt = b * 16 + jj;
                     f32x4 c0, c1;
                     asm volatile("v_mov_b32 %0, v[%c8+0]\n\tv_mov_b32 %1, v[%c8+1]\n\tv_mov_b32 %2, v[%c8+2]\n\tv_mov_b32 %3, v[%c8+3]\n\t"
-                                 "v_mov_b32 %4, v[%c8+4]\n\tv_mov_b32 %5, v[%c8+5]\n\tv_mov_b32 %6, v[%c8+6]\n\tv_mov_b32 %7, v[%c8+7]\n\t"
-                                 "v_mov_b32 v[%c8+0], 0\n\tv_mov_b32 v[%c8+1], 0\n\tv_mov_b32 v[%c8+2], 0\n\tv_mov_b32 v[%c8+3], 0\n\t"
-                                 "v_mov_b32 v[%c8+4], 0\n\tv_mov_b32 v[%c8+5], 0\n\tv_mov_b32 v[%c8+6], 0\n\tv_mov_b32 v[%c8+7], 0"
+                                 "v_mov_b32 %4, v[%c8+4]\n\tv_mov_b32 %5, v[%c8+5]\n\tv_mov_b32 %6, v[%c8+6]\n\tv_mov_b32 %7, v[%c8+7]"
                                  : "=&v"(c0.x), "=&v"(c0.y), "=&v"(c0.z), "=&v"(c0.w), "=&v"(c1.x), "=&v"(c1.y), "=&v"(c1.z), "=&v"(c1.w)
                                  : "i"(kAcc + b * 8)
                                  : "memory");

@@ -352,6 +352,16 @@ def mfma_peak_tf(wl):
     return MFMA_PEAK_TF["fp8" if (wl["fmt"] == "fp8" and wl.get("fp8_mode")) else "bf16"]
 
 
+def kernel_source_hash() -> str:
+    """hash of the HIP sources the kernels are built from (profiles/hbm_traffic.json records the one its PMC pass ran on)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "lvllm_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def roof_fields(flops, bytes_, ms, peak_tf):
     """the two rooflines of one kernel side by side (BASELINE.json's metric names the MFMA roofline, the decode
     kernels are HBM-bound): achieved TFLOP/s and GB/s, their fractions of the dense MFMA peak and of the 8 TB/s HBM
@@ -567,27 +577,30 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
         g1_ms = max(prof_ms["gemm1"], 1e-6)
         g1_flops = 4.0 * rows * H * I                                # gate + up projections of every routed row
         both = roof_fields(g1_flops, g1_bytes, g1_ms, mfma_peak_tf(wl))
+        traffic, stale = None, None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
+        if tf.exists():
+            try:
+                tj = json.loads(tf.read_text())
+                traffic = tj.get(name, {}).get("gemm1_bytes_per_launch")
+                stale = tj.get("kernel_source_hash") != kernel_source_hash()
+            except Exception:
+                traffic = None
+        tsrc = (None if traffic is None else
+                "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE pass of this workload (tools/update_hbm_traffic.py), "
+                "gfx950-corrected (x2); not re-read in this run -- traffic_stale says whether the kernel sources have changed "
+                "since that pass")
         if prefill:     # MFMA-bound regime: the roofline of the dominant kernel is flops against the dense MFMA peak
             peak = mfma_peak_tf(wl)
             ach = g1_flops / (g1_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "gemm1 (grouped, tiled)", "achieved": round(ach, 1), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "algorithmic_flops": g1_flops}
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "traffic_stale": stale, "algorithmic_bytes": g1_bytes, "algorithmic_flops": g1_flops}
         else:
             achieved = g1_bytes / (g1_ms * 1e-3) / 1e9               # (a rank whose experts got no row: 0)
-            traffic = None
-            tf = ROOT / "profiles" / "hbm_traffic.json"
-            if tf.exists():
-                try:
-                    traffic = json.loads(tf.read_text()).get(name, {}).get("gemm1_bytes_per_launch")
-                except Exception:
-                    traffic = None
             roofline = {"bound": "hbm", "kernel": "gemm1_act_kernel", "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": traffic,
-                        "traffic_source": None if traffic is None else
-                        "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE pass of this workload, gfx950-corrected "
-                        "(x2), committed with the kernel it measured -- static, NOT re-read in this run",
-                        "algorithmic_bytes": g1_bytes}
+                        "traffic": traffic, "traffic_source": tsrc, "traffic_stale": stale, "algorithmic_bytes": g1_bytes}
         roofline.update(both)       # mfma_frac, hbm_frac, roof = min(MFMA, AI x HBM), frac_of_roof: both rooflines, always
         step_fl = roof_fields(layer_flops, layer_bytes, ms_per_step, mfma_peak_tf(wl))
         roofline.update({

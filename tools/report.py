@@ -54,16 +54,20 @@ def main():
                 continue
             raw.append(j)
             rf, lay, km = j["roofline"], j["roofline"]["layer"], j["roofline"]["kernel_ms"]
-            # prefill workloads report their dominant kernel in TFLOP/s: show the weight bytes / time here all the same
-            g1 = rf["achieved"] if rf["unit"] == "GB/s" else lay["weight_bytes"] * 2 / 3 / (km["gemm1"] * 1e-3) / 1e9
+            stp = rf.get("step", {})
+            # the same columns as the bench line's `roofline` (bench.py roof_fields): the dominant kernel against both peaks
+            # and against roof = min(MFMA peak, AI x HBM peak), then the whole step against the same two peaks
             rows.append(
                 f"| {name} | {routing} | {j['ms_per_step']*1e3:.1f} | {j['value']:.0f} | {lay['routed_rows']} / {lay['experts_hit']} | "
                 f"{km['sort']*1e3:.1f} / {km['gemm1']*1e3:.1f} / {km['gemm2']*1e3:.1f} / {km['combine']*1e3:.1f} | "
-                f"{g1:.0f} ({g1/80:.1f} %) | {lay['GBps_over_step']:.0f} ({lay['GBps_over_step']/80:.1f} %) | "
-                f"{lay['TFLOPs_over_step']:.1f} ({lay['TFLOPs_over_step']/mfma_peak*100:.2f} %) | {j['config']['geometry'].split('|',2)[2].strip()} |")
+                f"{rf['GBps']:.0f} ({rf['hbm_frac']*100:.1f} %) | {rf['tflops']:.1f} ({rf['mfma_frac']*100:.2f} % of {rf['mfma_peak_tflops']/1e3:.1f} PF) | "
+                f"{rf['roof_tflops']:.0f} ({rf['roof_bound']}) | {rf['frac_of_roof']:.3f} | "
+                f"{lay['GBps_over_step']:.0f} ({stp.get('hbm_frac', 0)*100:.1f} %) | {lay['TFLOPs_over_step']:.1f} ({stp.get('mfma_frac', 0)*100:.2f} %) | "
+                f"{stp.get('frac_of_roof', 0):.3f} | {j['config']['geometry'].split('|',2)[2].strip()} |")
     hdr = ("| config | routing | step µs (graph, incl. router) | tokens/s | routed rows / experts hit | "
-           "kernel µs sort / gemm1 / gemm2 / combine (HIP events) | GEMM1 GB/s (% of 8 TB/s) | layer weight GB/s over the whole step (%) | "
-           "layer TFLOP/s (% of 2.5 PF bf16 MFMA) | geometry |\n|---|---|---|---|---|---|---|---|---|---|")
+           "kernel µs sort / gemm1 / gemm2 / combine (HIP events) | GEMM1 GB/s (hbm_frac of 8 TB/s) | GEMM1 TFLOP/s (mfma_frac of the dense peak) | "
+           "roof TFLOP/s = min(MFMA, AI x HBM) (bound) | GEMM1 frac_of_roof | step: weight GB/s (hbm_frac) | step: TFLOP/s (mfma_frac) | "
+           "step frac_of_roof | geometry |\n|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     if ONLY is not None and (OUT / "report.md").exists():
         key = lambda line: tuple(c.strip() for c in line.split("|")[1:3])
         fresh = {key(r): r for r in rows}

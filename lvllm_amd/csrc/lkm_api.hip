@@ -588,7 +588,9 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // slice, uniform 266 -> 265 us per step, Zipf (18 of 32 experts hit, the hot one 126 rows) 196 -> 186 (GEMM1 112 ->
         // 102 us: twice the workgroups on a chip the 64-row grid leaves under-subscribed).  W8A16 keeps 64 rows (uniform 263
         // vs 266, Zipf 189 vs 200): profiles/r03_mixed_plan_sweep.log
-        if (tiled == 64 && !split && h->a8 && est_max <= 32 && n_act >= 16) tiled = 32;
+        if (tiled == 64 && !split && h->a8 && est_max <= 32 && n_act >= 16 &&
+            (long long)n_act * ((h->T1_half + 3) / 4) <= 4096)      // (an under-subscribed grid only: all 256 DSv3 experts on one GPU
+            tiled = 32;                                             //  under Zipf routing LOSE 10 %, 840 -> 927 us, uniform equal)
         if (h->t_tiled > 0) { tiled = h->t_tiled; split = 0; }
         if (h->t_tiled < 0) { tiled = 0; split = 0; }
         // Mixed plan (streamer formats, an expert may hold more than one token block): GEMM1 stays with the streamer, GEMM2

@@ -50,7 +50,8 @@ def test_engines_of_deepseek_v3_size_until_the_gpu_is_full(monkeypatch):
     with pytest.raises(_clib.LkmError) as ei:
         RoutedExpertsEngine(w13, w2, **kw)
     assert ei.value.code == _clib.E_NOMEM, ei.value
-    assert abs(_free() - before) < 64 << 20                                  # the failed attempt left nothing behind
+    assert _free() > before - (64 << 20)                                     # the failed attempt left nothing behind (the runtime may
+                                                                             # hand back deferred frees of its own: more is fine)
     # every engine created so far holds the same image and still answers with the same bits
     for eng in (engines[0], engines[-1]):
         np.testing.assert_array_equal(eng.decode(x, tw, ids).cpu().numpy(), first)

@@ -17,7 +17,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from bench import EXTRA_EP, EXTRA_N1, HEADLINE, kernel_source_hash  # noqa: E402
 
-OUT = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out"
+OUT = (Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out").resolve()
 
 
 def gemm_of(kernel: str):

@@ -75,10 +75,19 @@ def _pool(dev, group, name: str, nbytes: int) -> torch.Tensor:
     t = _POOLS.get(key)
     if t is None or t.numel() < nbytes:
         if t is not None:
-            _RETIRED.append(t)
+            _RETIRED.append(t)                      # (a captured graph may still replay on it)
+            nbytes = max(nbytes, t.numel() * 3 // 2)   # geometric growth: a rising batch size retires O(log) pools
         t = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
         _POOLS[key] = t
     return t
+
+
+def release_retired_exchange_buffers() -> int:
+    """drop the pools that were outgrown (call when no captured graph that used them will be replayed again); returns
+    the bytes released"""
+    n = sum(t.numel() for t in _RETIRED)
+    _RETIRED.clear()
+    return n
 
 
 def ranks_per_token(ep: int, n_group: int, topk_group: int, top_k: int | None = None) -> int:

@@ -23,6 +23,8 @@ int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, i
         LKM_A8W_DBG_CASE(32)
         LKM_A8W_DBG_CASE(64)
         LKM_A8W_DBG_CASE(8 | 16)
+        LKM_A8W_DBG_CASE(256)          // timing of the three synchronisation points (printed by two waves)
+        LKM_A8W_DBG_CASE(256 | 1)
 #undef LKM_A8W_DBG_CASE
     default:
         set_error("fp8 W8A8 prefill kernel: ablation dbg=%d not built", dbg);

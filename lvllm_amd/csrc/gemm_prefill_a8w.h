@@ -127,6 +127,7 @@ __device__ __forceinline__ void a8w_block_t(int vblo, int vbhi, int vxs, int ws0
         A8W_IF(32)
         A8W_MFMA("%c[pc]+4", "%c[a]+8", "%c[bc]")
         A8W_FI
+
         ".if %c[hasprev] && ((%c[dbg] & 16) == 0)\n\t"
         A8W_ACC4("%c[acc]+4", "%c[fp1]", "%c[pp]+4")
         A8W_FI
@@ -544,6 +545,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     // three (waits that step over the previous epilogue's stores; the hook that finishes the next item's tables), 1 =
     // middle (everything it touches belongs to the current item: no selects), 2 = one of the last three (its loads are the
     // NEXT item's first units; the position may be a null unit).
+    // DBG 256 (development): cycles this wave spends at the unit's three synchronisation points -- the wait for its weight
+    // loads, the wait for its token pieces, the barrier -- summed over the kernel; one wave prints them at the end
+    unsigned t_top = 0, t_mid = 0, t_bar = 0;
+    auto now = [&]() __attribute__((always_inline)) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return (unsigned)t;
+    };
+    unsigned t_start = 0;
+    if constexpr (DBG & 256) t_start = now();
     auto unit = [&](auto SLOTC, auto KINDC, int pp) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(SLOTC)::v, KIND = decltype(KINDC)::v;
         // the item's first unit assigns the accumulators (they are never zeroed); two tiles of one scale block share the product
@@ -573,8 +584,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         // A(u) is in its slot.  (The three units behind an item switch: the epilogue's stores are in the ledger behind
         // the loads these waits are about -- >= 16 of them when st16 -- and must not be waited for.)
         const bool late = KIND == 0 && st16;
+        unsigned tt0 = 0;
+        if constexpr (DBG & 256) tt0 = now();
         if (late) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if constexpr (DBG & 256) t_top += now() - tt0;
         if (real && !(DBG & 2)) {
             a8w_block0<SLOT, DBG, OPT>(lo_c, hi_c, xs_c, ws0, ws1, wsaddr, la.tb_tok + tsel, ws0n, ws1n, t);
             ws0n = __builtin_amdgcn_readfirstlane(ws0n);       // (scalars from here on: two registers less across the unit)
@@ -588,7 +602,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         }
         // tokens(u+1) of THIS wave have landed; after the barrier every wave's have, and nobody reads the stage behind
         // the current one any more (the DMA's target)
-        if constexpr (DBG & 64) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // (ablation: no barrier)
+        if constexpr (DBG & 256) {
+            const unsigned a0 = now();
+            if (late) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            const unsigned a1 = now();
+            asm volatile("s_barrier" ::: "memory");
+            t_mid += a1 - a0;
+            t_bar += now() - a1;
+        } else if constexpr (DBG & 64) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // (ablation: no barrier)
         else if (late) asm volatile("s_waitcnt vmcnt(28)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
         if constexpr (!(DBG & 1)) {
@@ -754,6 +776,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // trailing (clamped) loads must not outlive the wave
+    if constexpr (DBG & 256) {
+        const unsigned tot = now() - t_start;
+        if ((blockIdx.x == 8 || blockIdx.x == 77) && lane == 0 && (wave == 0 || wave == 5))
+            printf("a8w wg %d wave %d: total %u ticks, wait weights %u, wait tokens %u, barrier %u\n", (int)blockIdx.x, wave, tot, t_top, t_mid, t_bar);
+    }
 #else
     (void)p;
 #endif
@@ -804,8 +831,8 @@ static bool launch_prefill_a8w_if(hipStream_t st, const LaunchCfg& cfg, const Ge
         return true;
     }
     if constexpr (ADT == LKM_DT_BF16) {     // ablation builds: gated GEMM1, bf16 activations only
-        if (is_g1 && gated && (p.dbg & 0xfb)) {
-            *rc = launch_prefill_a8w_dbg(st, p, max_tiles, p.dbg & 0xfb);
+        if (is_g1 && gated && (p.dbg & 0x1fb)) {
+            *rc = launch_prefill_a8w_dbg(st, p, max_tiles, p.dbg & 0x1fb);
             return true;
         }
     }

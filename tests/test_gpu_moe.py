@@ -191,8 +191,8 @@ def test_fp8_w8a8_larger_random():
     (260, 2, 1024, 1024, 1, 9)])
 def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated, pf):
     """gemm_prefill_a8w.h (pf 9: weights straight to registers, tokens through a 4-stage LDS ring, equal token tiles)
-    and gemm_prefill_a8.h (pf 8: both operands through two LDS buffers) -- 256 x 256 tiles on
-    v_mfma_scale_f32_16x16x128_f8f6f4 with unit E8M0 scales, block scales applied to each instruction's fp32 result --
+    and gemm_prefill_a8.h (pf 8: both operands through two LDS buffers) -- 256 x 256 tiles on the 128-k fp8 MFMA (pf 9:
+    v_mfma_f32_16x16x128_f8f6f4; pf 8: its MX-scaled form with unit scales), block scales applied to each instruction's fp32 result --
     against the oracle and against the legacy-fp8-MFMA tiled kernel: ragged tiles, 1 to 12 K units (fewer than the
     pipeline depth, not a multiple of the register ring), padded weight-tile counts, with and without the XCD runs"""
     from lvllm_amd import _clib
@@ -223,6 +223,36 @@ def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated, pf):
     eng.engine.set_tuning(tiled=128, xcd=-1)
     close(out, _run_decode(eng, a, tw, ids), 4e-3, 1e-2)
     eng.engine.set_tuning(tiled=0, xcd=0, pf=0)
+
+
+@pytest.mark.parametrize("dtype,act", [(torch.float16, 0), (torch.bfloat16, 1), (torch.float16, 1)])
+def test_fp8_w8a8_prefill_kernel_fp16_and_swigluoai(dtype, act):
+    """the round-3 prefill kernel's other instantiations: fp16 activations (its own translation unit) and the
+    interleaved swigluoai epilogue (activation_kernels.cu:401-440), through decode AND through gpu_prefill (activation-
+    dtype output, chunked: two chunks of different plans)"""
+    from lvllm_amd import _clib
+    M, E, K, H, I = 2600, 6, 2, 1024, 1152
+    odt = orc.F16 if dtype == torch.float16 else orc.BF16
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, dtype, seed=77 + act, drop=0.05, skew=0.5)
+    q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+    q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+    eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dtype, fmt="fp8",
+               w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128,
+               fp8_mode=_clib.FP8_W8A8, activation_type=act, max_batch_size=2048, group_max_len=2048)
+    eng.engine.set_tuning(tiled=256)
+    out = _run_decode(eng, a, tw, ids)
+    assert "tm=256" in eng.engine.describe() and "pf=9" in eng.engine.describe(), eng.engine.describe()
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=odt, wfmt=orc.W_FP8, groupN=128, groupK=128, round_gemm1=True, w8a8=True,
+                    activation=orc.ACT_SILU if act == 0 else orc.ACT_SWIGLUOAI)
+    ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    scale = float(np.abs(ref).max())
+    bad = np.abs(out - ref) > 1e-2 * scale + 2e-2 * np.abs(ref)
+    assert bad.mean() < 1e-4, f"{bad.sum()} of {bad.size} elements differ"
+    np.testing.assert_allclose(out, ref, atol=0.035 * scale, rtol=0.035)
+    # gpu_prefill: the same rows in the activation dtype, 2600 tokens in chunks of 2048 + 552
+    pre = eng.prefill(a.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV))
+    assert pre.dtype == dtype
+    np.testing.assert_allclose(pre.float().cpu().numpy(), ref, atol=0.035 * scale, rtol=0.035)
 
 
 def _rand_case(M, E, K, H, I, dtype, seed, gated=True, drop=0.0, skew=0.0):

@@ -1,6 +1,7 @@
 // gemm_prefill_a8w.h -- per-expert grouped GEMMs for the prefill regime, fp8 weights x fp8 activations (W8A8, the
 // in-tree block-fp8 semantics: fused_moe.py:298-610, native_w8a8_block_matmul tests/kernels/quant_utils.py:91-154),
-// round-3 kernel: 256 weight rows x up to 256 tokens per workgroup on v_mfma_scale_f32_16x16x128_f8f6f4.
+// round-3 kernel: PERSISTENT workgroups (one per CU) walking a device-built list of items = 256 weight rows x up to 256
+// tokens x all of K, on v_mfma_f32_16x16x128_f8f6f4 (one instruction per 16-token block, 16-row tile and 128-k block).
 //
 // What round 2's kernel (gemm_prefill_a8.h) was bound by: ONE 66 KiB LDS-DMA burst in flight per CU (both operands
 // through two LDS buffers), waves of a SIMD released in phase by a per-unit barrier, operand reads scheduled by the
@@ -10,12 +11,15 @@
 //     3-slot register ring (2 units = 8 KiB per wave in flight while a third is multiplied);
 //   * TOKENS go through a 4-stage LDS ring (32 KiB per 128-k unit), filled by LDS-DMA two to three units ahead, read
 //     as B operands by all eight waves (a wave multiplies its two tiles by EVERY 16-token block of the tile);
-//   * token scales ride in 16-byte pieces (4 units per token) into a 2 x 4 KiB LDS ring; weight-block scales sit in
-//     two registers per wave (lane l = unit l) and reach the multiplier by v_readlane;
+//   * token scales ride in 16-byte pieces (4 units per token) into a 3 x 4 KiB LDS ring; an item's weight-block scales
+//     and its row table (source row offsets) are fetched by LDS-DMA while the previous item runs and read from LDS;
 //   * every load, DMA, wait and barrier of the K loop is issued from inline asm with hand-counted vmcnt (a load the
 //     compiler can see next to an LDS-DMA turns each of its waits into vmcnt(0)); ~190 KiB in flight per CU;
-//   * the K loop's operands live in a FIXED register map (v40..v255, below) that the compiler never allocates
-//     (amdgpu_num_vgpr caps it at v0..v39), so values that arrive asynchronously are never copied early;
+//   * the K loop's operands live in a FIXED register map (v40..v255, below) that the compiler never allocates: every asm
+//     statement of the loop names the registers it owns as clobbers and tools/scan_a8w_codegen.py checks the generated
+//     code (amdgpu_num_vgpr is ignored below ~57 registers), so values that arrive asynchronously are never copied early;
+//   * the pipeline does not drain between items: the last three unit positions of an item fetch the first three units
+//     of the next one, whose record / row table / scales arrived earlier the same way;
 //   * ONE barrier per unit, placed after the first token block: a wave's MFMAs never wait for it (they need only
 //     their own A slot and B operands prefetched before the barrier), it only gates the DMA issue;
 //   * the accumulator update acc += (ws * xs) * partial of block b runs between the MFMAs of block b + 1, plain
@@ -30,7 +34,7 @@
 //   v56..v71   P[2][2]   MFMA results of block parity x tile (4 each)
 //   v72..v73   x[2]      token scale of the current / next block
 //   v74..v77   f[2][2]   ws * xs of block parity x tile
-//   v78        E8M0 1.0 x 4 (scale operand of the MFMA), v79 spare
+//   v78..v79   spare (v78 held the E8M0 unit scale while the MFMA was the MX-scaled form: two instructions per MFMA)
 //   v80..v127  A ring    slot s: tile 0 = v[80+16s .. +7], tile 1 = v[88+16s .. +7]
 //   v128..v255 acc       block b, tile t: v[128 + 8b + 4t .. +3]
 //
@@ -51,8 +55,8 @@ constexpr int kB = 40, kP = 56, kX = 72, kF = 74, kOne = 78, kA = 80, kAcc = 128
 constexpr int kStage = 256 * 128, kStages = 4;
 constexpr int kScBase = kStage * kStages, kScBuf = 256 * 16;
 constexpr int kTbl = kScBase + 3 * kScBuf;               // two row tables (current / next item) of 2 KiB
-constexpr int kStA = kTbl + 2 * 2048;                    // per-wave landing zones of the item metadata (2 x 8 x 256 B)
-constexpr int kStB = kStA + 2048;
+constexpr int kStA = kTbl + 2 * 2048;                    // per-wave landing zones of the next item's record (8 x 256 B)
+constexpr int kStB = kStA + 2048;                        // (unused since the item records carry the expert's row offset)
 constexpr int kRaw = kStB + 2048;                        // 256 gathered sorted_slot entries of the next item
 constexpr int kWs = kRaw + 1024;                         // weight-block scales: [2 items][8 waves][2 tiles][64 units] fp32
 constexpr int kLdsBytes = kWs + 2 * 8 * 512;             // 160 768: four token stages, three token-scale groups, two row
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
             {
                 // Block 0 of the new item's first unit: B operand and token scale, read HERE and not by the old item's last
                 // block -- the compiler's epilogue code is free to use the B / P / x / f registers as temporaries (it
-                // must stay below v78, the E8M0 constant and the A ring: tests/test_a8w_codegen.py), and nothing else of
+                // must stay below v78, under the A ring: tests/test_a8w_codegen.py), and nothing else of
                 // the fixed map holds a value across the epilogue.  Visible since the barrier of the old item's last unit.
                 asm volatile("ds_read_b128 v[%c[b]:%c[b]+3], %[lo]\n\t"
                              "ds_read_b128 v[%c[b]+4:%c[b]+7], %[hi]\n\t"

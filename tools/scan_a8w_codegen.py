@@ -4,7 +4,7 @@ hand-written K loop relies on.  The loop keeps its operands in a fixed register 
 touch -- clang's amdgpu_num_vgpr is ignored below ~57 registers, so this is verified on the assembly instead:
 
   * outside the inline-asm statements, no instruction writes a VGPR >= 40 -- except between the A8W_EPILOGUE_BEGIN / _END
-    markers, where the limit is v78 (nothing of v40..v77 is live across an item's epilogue; v78 = the MFMA scale constant,
+    markers, where the limit is v78 (nothing of v40..v77 is live across an item's epilogue; v78..v79 spare,
     v80.. = the weight ring with loads in flight, v128.. = the accumulators the epilogue itself reads through asm);
   * no scratch (a spill is a vector-memory operation inside the hand-counted vmcnt ledger);
   * no compiler-issued s_waitcnt vmcnt / vector load between the first and the last s_barrier of a kernel.

@@ -320,6 +320,43 @@ def test_hybrid_dispatch_skewed_routing(M, E, K, H, I, skew):
     np.testing.assert_allclose(_run_decode(eng, a, tw, ids), out, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("fmt,M,E,K,H,I,skew", [("bf16", 32, 8, 2, 512, 1024, 2.0), ("bf16", 32, 16, 4, 256, 384, 0.0),
+                                               ("fp8a8", 32, 8, 2, 512, 384, 2.0), ("fp8", 32, 8, 2, 256, 512, 3.0)])
+def test_mixed_plan_and_launch_order_under_skewed_routing(fmt, M, E, K, H, I, skew):
+    """round 3: from two likely token blocks per expert on, GEMM1 runs on the streamer and GEMM2 on the tile kernel (the
+    streamer re-reads an expert's token rows from the L2 per weight tile); the sort hands both kernels their experts
+    heaviest first.  Against the oracle, against the all-streamer plan ("tiled2" = -1; same 64-k / 128-k partial sums,
+    different kernels), through decode and through the routed entry point, uniform and Zipf-like routing."""
+    from lvllm_amd import _clib
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=M + E, skew=skew, drop=0.05)
+    if fmt == "bf16":
+        eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+        ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+        atol, rtol = ATOL, RTOL
+    else:
+        q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+        q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+        a8 = fmt == "fp8a8"
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
+                   w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128,
+                   fp8_mode=_clib.FP8_W8A8 if a8 else _clib.FP8_W8A16)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128, round_gemm1=a8, w8a8=a8)
+        ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+        atol, rtol = (1e-2 * float(np.abs(ref).max()), 2e-2) if a8 else (ATOL * max(1.0, float(np.abs(ref).max())), RTOL)
+    out = _run_decode(eng, a, tw, ids)
+    desc = eng.engine.describe()
+    assert "skinny g1 nt=1" in desc and "g2 nt=0 tb=0" in desc and "tiled g1 nt=0, g2 nt=" in desc, desc      # the mixed plan
+    np.testing.assert_allclose(out, ref, atol=atol, rtol=rtol, err_msg=desc)
+    dead = (ids < 0).all(axis=1)
+    assert (out[dead] == 0).all()
+    eng.engine.set_tuning(tiled2=-1)
+    base = _run_decode(eng, a, tw, ids)
+    assert "g2 nt=0 tb=0" not in eng.engine.describe()
+    np.testing.assert_allclose(out, base, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4)
+    eng.engine.set_tuning(tiled2=0)
+
+
 @pytest.mark.parametrize("fmt", ["int4", "fp8"])
 def test_quantised_tiled_path(fmt):
     M, E, K, H, I = 160, 4, 2, 256, 256

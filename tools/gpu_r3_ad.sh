@@ -1,4 +1,4 @@
 #!/bin/bash
 set -u
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_moe.py -m gpu -q -x --timeout 600 -k "fp16_and_swigluoai" 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_gpu_moe.py -m gpu -q --timeout 600 -k "mixed_plan" 2>&1 | tail -25

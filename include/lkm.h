@@ -261,6 +261,17 @@ int lkm_ep_combine(void* stream, const void* back, int32_t back_dtype, const int
 int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots, int32_t E, int32_t* counts,
                    int32_t* offsets, int32_t* sorted_slot, int32_t* pos_of_slot);
 
+/*
+ * Dynamic per-token-group fp8 quantisation of activation rows, group = 128 columns: the operator the in-tree block-fp8
+ * path applies to both GEMM inputs (per_token_group_quant_fp8, model_executor/layers/quantization/utils/fp8_utils.py:
+ * 533-660, csrc/libtorch_stable/quantization/w8a8/fp8/per_token_group_quant.cu:100; spec tests/kernels/quant_utils.py:
+ * 157-180): scale = max(amax, 1e-10) / 448, q = clamp(x / scale, +-448) -> e4m3fn.  x [rows][ld_x] (16-bit, dtype
+ * x_dtype, cols a multiple of 8), q [rows][cols] bytes, scales fp32 [rows][ceil(cols / 128)] (row-major).  The engine
+ * runs the same kernel on its W8A8 inputs; exposed so that the bytes can be checked against the reference arithmetic.
+ */
+int lkm_per_token_group_quant_fp8(void* stream, const void* x, int32_t x_dtype, int64_t ld_x, int32_t rows, int32_t cols,
+                                  void* q, float* scales);
+
 /* -------------------------------------------------------------------------------------------
  * Introspection / measurement.
  */

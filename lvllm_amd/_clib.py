@@ -78,6 +78,8 @@ _SIGS = {
                                      C.c_void_p, C.c_void_p]),
     "lkm_ep_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32, C.c_void_p, C.c_int32]),
+    "lkm_per_token_group_quant_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                              C.c_void_p, C.c_void_p]),
     "lkm_sort_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "lkm_last_error": (C.c_char_p, []),

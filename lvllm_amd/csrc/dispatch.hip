@@ -644,62 +644,101 @@ int launch_build_items(hipStream_t st, const int32_t* tile_e, const int32_t* til
 // Sixteen lanes per (row, 128-element group), eight elements (one 16-byte load, one 8-byte store) per lane:
 // four groups per wavefront.  (One wavefront per group with 4-byte loads ran at ~2 TB/s on the 276 MB of a
 // GLM-4.5-Air prefill intermediate.)
-template <int ADT>
+// x / s, correctly rounded, for the quantiser's operands (s = amax / 448 >= 2.2e-13 is normal, |x| <= amax so |x / s| <=
+// 448: none of the range handling of the general division sequence -- v_div_scale, v_div_fmas, v_div_fixup -- can
+// trigger): the reciprocal is refined ONCE per group and each quotient takes the two remainder corrections of the
+// IEEE sequence, five operations instead of ten.  Quotients below 2^-10 round to fp8 zero whatever their last bits are.
+// The kernel was VALU-bound on its eight divisions per lane (3.9 TB/s); bit-exactness of the bytes against x / s in
+// IEEE arithmetic: tests/test_gpu_quant.py.
+struct DivBy {
+    float s, r;
+};
+__device__ __forceinline__ DivBy make_div_by(float s) {
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float e = __builtin_fmaf(-s, r0, 1.0f);
+    return DivBy{s, __builtin_fmaf(e, r0, r0)};
+}
+__device__ __forceinline__ float div_by(float x, const DivBy& d) {
+    const float q0 = x * d.r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d.s, x), d.r, q0);
+    // (the corrections turn -0 / s into +0: the sign of the quotient is the sign of x)
+    return __builtin_copysignf(__builtin_fmaf(__builtin_fmaf(-q1, d.s, x), d.r, q1), x);
+}
+
+template <int ADT, int UNR>
 __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const unsigned short* __restrict__ src,
                                                              int ld_src, int R, int K,
                                                              unsigned char* __restrict__ dst,
                                                              float* __restrict__ scales) {
 #pragma clang fp contract(off)
+    // UNR groups per sixteen lanes, their loads issued together (one group per sixteen lanes kept 16 bytes per lane in
+    // flight: 3.7 TB/s on the GLM-4.5-Air prefill intermediate)
     const int KB = (K + 127) / 128;
-    const long long gid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
-    if (gid >= (long long)R * KB) return;          // whole 16-lane groups leave together
-    const int row = (int)(gid / KB), kb = (int)(gid % KB), sub = threadIdx.x & 15;
-    const int k = kb * 128 + sub * 8;
-    float v[8];
-    const bool in = k < K;                          // K % 8 == 0: a chunk is fully inside or fully outside
-    if (in) {
-        const u32x4 raw = *(const u32x4*)(src + (size_t)row * ld_src + k);
+    const long long total = (long long)R * KB;
+    const long long g0 = (((long long)blockIdx.x * 256 + threadIdx.x) >> 4) * UNR;
+    if (g0 >= total) return;          // whole 16-lane groups leave together
+    const int sub = threadIdx.x & 15;
+    u32x4 raw[UNR];
+    bool in[UNR], live[UNR];
+    int row[UNR], kb[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const long long gid = g0 + u;
+        live[u] = gid < total;
+        const long long gg = live[u] ? gid : g0;
+        row[u] = (int)(gg / KB);
+        kb[u] = (int)(gg % KB);
+        const int k = kb[u] * 128 + sub * 8;
+        in[u] = k < K;                          // K % 8 == 0: a chunk is fully inside or fully outside
+        raw[u] = u32x4{0u, 0u, 0u, 0u};
+        if (in[u]) raw[u] = *(const u32x4*)(src + (size_t)row[u] * ld_src + k);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        float v[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[2 * i] = ActT<ADT>::to_f32((unsigned short)(raw[i] & 0xffffu));
-            v[2 * i + 1] = ActT<ADT>::to_f32((unsigned short)(raw[i] >> 16));
+            v[2 * i] = in[u] ? ActT<ADT>::to_f32((unsigned short)(raw[u][i] & 0xffffu)) : 0.0f;
+            v[2 * i + 1] = in[u] ? ActT<ADT>::to_f32((unsigned short)(raw[u][i] >> 16)) : 0.0f;
         }
-    } else {
+        float amax = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = 0.0f;
+        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+        if (amax < 1e-10f) amax = 1e-10f;
+        const float s = amax / 448.0f;
+        if (in[u] && live[u]) {
+            float q[8];
+            const DivBy d = make_div_by(s);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = fminf(fmaxf(div_by(v[i], d), -448.0f), 448.0f);
+            u32x2 o;
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+            o.x = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], pk, true);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], 0, false);
+            o.y = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], pk, true);
+            *(u32x2*)(dst + (size_t)row[u] * K + kb[u] * 128 + sub * 8) = o;
+        }
+        if (sub == 0 && live[u]) scales[(size_t)row[u] * KB + kb[u]] = s;
     }
-    float amax = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
-#pragma unroll
-    for (int m = 8; m > 0; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
-    if (amax < 1e-10f) amax = 1e-10f;
-    const float s = amax / 448.0f;
-    if (in) {
-        float q[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = fminf(fmaxf(v[i] / s, -448.0f), 448.0f);
-        u32x2 o;
-        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
-        o.x = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], pk, true);
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], 0, false);
-        o.y = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], pk, true);
-        *(u32x2*)(dst + (size_t)row * K + k) = o;
-    }
-    if (sub == 0) scales[(size_t)row * KB + kb] = s;
 }
 
 int launch_quant_fp8_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, void* dst,
                           float* scales) {
     if (R <= 0) return LKM_OK;
-    const long long groups = (long long)R * ((K + 127) / 128);      // 16 lanes each, 16 groups per block
-    dim3 grid((unsigned)((groups + 15) / 16)), block(256);
-    if (adt == LKM_DT_BF16)
-        hipLaunchKernelGGL(quant_fp8_rows_kernel<LKM_DT_BF16>, grid, block, 0, st, (const unsigned short*)src,
-                           ld_src, R, K, (unsigned char*)dst, scales);
-    else
-        hipLaunchKernelGGL(quant_fp8_rows_kernel<LKM_DT_F16>, grid, block, 0, st, (const unsigned short*)src,
-                           ld_src, R, K, (unsigned char*)dst, scales);
+    const long long groups = (long long)R * ((K + 127) / 128);      // 16 lanes each, 16 x UNR groups per block
+    // four groups per sixteen lanes once the matrix is large enough to fill the chip that way
+    const bool wide = groups >= 4 * 16 * 4096;
+    const int unr = wide ? 4 : 1;
+    dim3 grid((unsigned)((groups + 16 * unr - 1) / (16 * unr))), block(256);
+    if (adt == LKM_DT_BF16) {
+        if (wide) hipLaunchKernelGGL((quant_fp8_rows_kernel<LKM_DT_BF16, 4>), grid, block, 0, st, (const unsigned short*)src, ld_src, R, K, (unsigned char*)dst, scales);
+        else hipLaunchKernelGGL((quant_fp8_rows_kernel<LKM_DT_BF16, 1>), grid, block, 0, st, (const unsigned short*)src, ld_src, R, K, (unsigned char*)dst, scales);
+    } else {
+        if (wide) hipLaunchKernelGGL((quant_fp8_rows_kernel<LKM_DT_F16, 4>), grid, block, 0, st, (const unsigned short*)src, ld_src, R, K, (unsigned char*)dst, scales);
+        else hipLaunchKernelGGL((quant_fp8_rows_kernel<LKM_DT_F16, 1>), grid, block, 0, st, (const unsigned short*)src, ld_src, R, K, (unsigned char*)dst, scales);
+    }
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

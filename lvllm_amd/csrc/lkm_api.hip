@@ -1167,6 +1167,15 @@ extern "C" int lkm_prefill_host(LkmHandle h, int32_t num_tokens, int32_t top_k,
     return LKM_OK;
 }
 
+extern "C" int lkm_per_token_group_quant_fp8(void* stream, const void* x, int32_t x_dtype, int64_t ld_x, int32_t rows,
+                                             int32_t cols, void* q, float* scales) {
+    LKM_REQUIRE(x && q && scales, "lkm_per_token_group_quant_fp8: null pointer");
+    LKM_REQUIRE(x_dtype == LKM_DT_BF16 || x_dtype == LKM_DT_F16, "lkm_per_token_group_quant_fp8: 16-bit activations only");
+    LKM_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && ld_x >= cols && ld_x % 8 == 0 && ld_x <= 0x7fffffffLL,
+                "lkm_per_token_group_quant_fp8: rows=%d cols=%d ld=%lld (cols and ld multiples of 8)", rows, cols, (long long)ld_x);
+    return launch_quant_fp8_rows((hipStream_t)stream, x, (int)ld_x, x_dtype, rows, cols, q, scales);
+}
+
 extern "C" int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots, int32_t E,
                               int32_t* counts, int32_t* offsets, int32_t* sorted_slot,
                               int32_t* pos_of_slot) {

@@ -255,6 +255,20 @@ def ep_combine(back: torch.Tensor, slot_of: torch.Tensor, out: torch.Tensor) -> 
     return out
 
 
+def per_token_group_quant_fp8(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """x [rows, cols] bf16 / fp16 (row stride a multiple of 8) -> (q uint8 [rows, cols] e4m3fn bytes, scales fp32
+    [rows, ceil(cols / 128)]): per_token_group_quant_fp8 with groups of 128 (fp8_utils.py:533-660), the quantiser the
+    W8A8 engines run on their inputs."""
+    _need_cuda(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.bfloat16, torch.float16)
+    rows, cols = x.shape
+    q = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((rows, -(-cols // 128)), dtype=torch.float32, device=x.device)
+    _clib.check(_clib.lib().lkm_per_token_group_quant_fp8(_stream(x), _ptr(x), _DT[x.dtype], x.stride(0), rows, cols,
+                                                          _ptr(q), _ptr(sc)))
+    return q, sc
+
+
 def sort_slots(topk_ids: torch.Tensor, num_experts: int):
     """Stable counting sort of the M*K slots by expert.
     -> counts [E], offsets [E+1], sorted_slot [M*K] (tail -1), pos_of_slot [M*K] (-1 = skipped)."""

@@ -1,0 +1,55 @@
+"""The activation quantiser of the W8A8 path (per_token_group_quant_fp8 with groups of 128, fp8_utils.py:533-660; spec
+tests/kernels/quant_utils.py:157-180) against its arithmetic in IEEE fp32 on the CPU: scale = max(amax, 1e-10) / 448,
+q = clamp(x / scale, +-448) -> e4m3fn (round to nearest even).  BIT-EXACT: bytes and scales.  The kernel divides with a
+shared refined reciprocal and two remainder corrections per element instead of the general division sequence; this is the
+test that says the two agree on every element (millions of random values, all-zero groups, values at the clamp, tiny
+and huge magnitudes, ragged column counts, strided rows)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref(x32: np.ndarray):
+    rows, cols = x32.shape
+    kb = -(-cols // 128)
+    pad = np.zeros((rows, kb * 128), np.float32)
+    pad[:, :cols] = x32
+    g = pad.reshape(rows, kb, 128)
+    amax = np.maximum(np.abs(g).max(axis=2), np.float32(1e-10)).astype(np.float32)
+    s = (amax / np.float32(448.0)).astype(np.float32)
+    q = np.clip((g / s[:, :, None]).astype(np.float32), np.float32(-448.0), np.float32(448.0))
+    return orc.f32_to_fp8(q.reshape(rows, kb * 128)[:, :cols].copy()), s
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,cols,kind", [(4096, 4096, "randn"), (777, 1408, "randn"), (64, 136, "randn"), (3, 8, "randn"),
+                                            (2048, 2048, "wide"), (512, 1024, "edge"), (40000, 512, "randn")])
+def test_per_token_group_quant_is_bit_exact(rows, cols, kind, dtype):
+    from lvllm_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    if kind == "randn":
+        x = torch.randn((rows, cols), generator=g) * (torch.rand((rows, 1), generator=g) * 4 + 0.01)
+    elif kind == "wide":     # magnitudes over the whole range of the dtype, row by row
+        x = torch.randn((rows, cols), generator=g) * torch.exp2(torch.randint(-14 if dtype == torch.float16 else -60, 15, (rows, 1), generator=g).float())
+    else:                    # zero groups, single spikes, values equal to +-amax, denormal-sized groups
+        x = torch.randn((rows, cols), generator=g)
+        x[::7] = 0.0
+        x[1::7, ::128] = 1000.0
+        x[2::7] = torch.sign(x[2::7]) * 3.0
+        x[3::7] *= 1e-12 if dtype == torch.bfloat16 else 1e-6
+    x = x.clamp(-6.0e4, 6.0e4).to(dtype)                    # (finite in fp16: an infinite input has no defined quantisation)
+    ld = cols + 24                                            # rows strided like the engine's intermediate
+    buf = torch.zeros((rows, ld), dtype=dtype)
+    buf[:, :cols] = x
+    xd = buf.to(DEV)[:, :cols]
+    q, s = ops.per_token_group_quant_fp8(xd)
+    q_ref, s_ref = _ref(x.float().numpy())
+    np.testing.assert_array_equal(s.cpu().numpy().view(np.int32), s_ref.view(np.int32))
+    got = q.cpu().numpy()
+    bad = np.flatnonzero(got.ravel() != q_ref.ravel())
+    assert bad.size == 0, (bad.size, got.ravel()[bad[:5]], q_ref.ravel()[bad[:5]], x.float().numpy().ravel()[bad[:5]])

@@ -705,6 +705,12 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         long long waves = (long long)n_act * (h->T1_half / nt1);
         while (kw < 8 && waves * kw < kMinWaves && h->U1 / (kw * 2) >= 2) kw *= 2;
     }
+    // 16-bit weights, waves that may hold two token blocks (a hot expert under skewed routing does): four waves per
+    // workgroup split K and reduce through LDS -- a quarter of the wave length, so the slow two-block waves of the hot
+    // expert stop setting the tail.  Mixtral bf16 M=32 through bench.py (graph, alternating): uniform 440.6 -> 439.4 us,
+    // Zipf 455.9 -> 448.6-449.7 (kw 2: 452; kw 8: 467-470): profiles/r03_streamer_kw_ab.log
+    // (fp8 x fp8, Mixtral M=32: GEMM1 153.3 -> 148.7 us uniform, 157.7 -> 154.1 Zipf)
+    if ((h->wf == LKM_W_BF16 || h->wf == LKM_W_F16 || h->a8) && h->gated && tb >= 2 && kw < 4 && h->U1 >= 32) kw = 4;
     if (h->t_kw1 > 0) kw = h->t_kw1;
     pl->s1 = LaunchCfg{nt1, tb, kw, 1, 0, 0, 0, 0};
     // sub-16-bit weights: two tiles per wave halve the token-operand loads per weight byte

@@ -1,0 +1,12 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+echo "== pytest"; timeout 1800 python -m pytest tests/test_gpu_moe.py tests/test_gpu_fused_step.py tests/test_gpu_fullsize.py tests/test_gpu_ep.py -m gpu -q -x --timeout 900 2>&1 | tail -3
+for i in 1 2; do
+for w in mixtral8x7b_bf16_decode_m32 mixtral8x7b_fp8w8a8_decode_m32; do
+for t in "" "kw1=1" "kw1=4"; do
+for r in uniform zipf; do
+timeout 300 python bench.py --workload $w --no-extras --no-cpu-baseline --steps 200 --warmup 20 --routing $r ${t:+--tune $t} 2>/dev/null | grep '^{' | python -c "
+import json,sys; j=json.loads(sys.stdin.read()); print('$i $w tune=[$t] $r step us', round(j['ms_per_step']*1e3,1), j['roofline']['kernel_ms'])"
+done; done; done; done | tee gpurun_out/r3_aj.log

@@ -71,10 +71,13 @@ WORKLOADS = {
     "glm45air_fp8w8a8_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=1, prefill=True),
 }
 HEADLINE = "mixtral8x7b_bf16_decode_m32"
-EXTRA_N1 = ["mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128", "mixtral8x7b_int4g128_fast_decode_m128",
-            # BASELINE.json configs[4] (the MFMA-bound grouped GEMM) and the headline workload under Zipf routing
-            # ("uniform and Zipf"; methodology benchmarks/kernels/benchmark_moe.py:96-333)
-            "glm45air_fp8w8a8_prefill_m8192", ("mixtral8x7b_bf16_decode_m32", "zipf")]
+EXTRA_N1 = [# the headline workload under Zipf routing first, in the thermal state the headline itself ran in (after the
+            # prefill workload the same kernels measure 1-3 % slower): SURVEY 8d "uniform and Zipf"; methodology
+            # benchmarks/kernels/benchmark_moe.py:96-333
+            ("mixtral8x7b_bf16_decode_m32", "zipf"),
+            "mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128", "mixtral8x7b_int4g128_fast_decode_m128",
+            # BASELINE.json configs[4] (the MFMA-bound grouped GEMM)
+            "glm45air_fp8w8a8_prefill_m8192"]
 EXTRA_EP = "dsv3_fp8w8a8_ep_decode_b256"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp8": 5000.0}   # dense, MI355X_MICROARCH.md

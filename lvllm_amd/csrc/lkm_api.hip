@@ -603,7 +603,8 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // r03_mixed_plan_sweep.log).  "tiled2" = -1 switches it off, n > 0 forces n-row GEMM2 tiles.
         if (!tiled && !split && (w16 || h->wf == LKM_W_FP8_E4M3) && est_max >= 24 && h->t_tiled2 >= 0 && h->t_tiled >= 0 &&
             h->t_fuse == 0)            // ("fuse" = +-1 asks for the streamer GEMM2 with / without the combine folded in)
-            g2_only = w16 ? 64 : 32;
+            g2_only = 32;          // (the rule only holds while an expert cannot exceed 32 rows: one 32-row tile each; against
+                                   //  64-row tiles no measurable difference, profiles/r03_headline_gemm2_ab.log)
         if (!tiled && !split && h->t_tiled2 > 0) g2_only = h->t_tiled2;
         if (g2_only) tiled = g2_only;
     }

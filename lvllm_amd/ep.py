@@ -165,6 +165,7 @@ class ExpertParallelExperts:
         base, rem = divmod(num_experts, self.ep)
         self.first_expert = [r * base + min(r, rem) for r in range(self.ep)]
         self._overflow_bufs: dict = {}
+        self._uniform_checked: set = set()
         self.last_wire: dict | None = None
 
     def _dist_a2a(self, out: torch.Tensor, inp: torch.Tensor) -> None:
@@ -369,14 +370,15 @@ class ExpertParallelExperts:
         capacity: see the module docstring (the token count every rank of the group agrees on)."""
         if out is not None:
             out_dtype = out.dtype
-        if self.ep > 1 and self.mode == "a2a" and capacity is None and self.capacity_tokens is None \
-                and self.routing_groups is None and not self.validate_uniform and not getattr(self, "_warned_cap", False):
-            # (ranks with different token counts would post different collective sizes: name the common capacity)
-            import warnings
-            warnings.warn("ExpertParallelExperts: no group-wide capacity given (capacity_tokens / capacity / "
-                          "routing_groups); the rank-local token count is used -- every rank must hold the SAME "
-                          "number of tokens in a step, or pass a common capacity", stacklevel=2)
-            self._warned_cap = True
+        if self.ep > 1 and capacity is None and self.capacity_tokens is None and self.routing_groups is None \
+                and not self.validate_uniform and not _capturing(hidden):
+            # no group-wide capacity was named: the rank-local token count sizes the collectives, so ranks with different
+            # counts would post mismatched exchanges (a hang or silent corruption).  Checked ONCE per new token count,
+            # outside any capture (one small all-gather): fail loudly instead (ADVICE r2).
+            M0 = topk_ids.size(0)
+            if M0 not in self._uniform_checked:
+                self._check_uniform(M0, "token count (no common capacity was given)")
+                self._uniform_checked.add(M0)
         if self.ep == 1 and not force_collectives:
             y = self.local_compute(hidden, topk_ids, topk_weights, out_dtype)
             return y if out is None else out.copy_(y)

@@ -328,3 +328,40 @@ def test_wire_bytes_of_baseline_config3_with_group_limited_capacity():
     assert wa["capacity_tokens"] == 32 and wb["capacity_tokens"] == 20
     assert wb["dispatch_bytes"] / wa["dispatch_bytes"] == pytest.approx(0.625)
     assert wb["return_bytes"] / wa["return_bytes"] == pytest.approx(0.625)
+
+
+def _unequal_no_capacity_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lvllm_amd.ep import ExpertParallelExperts
+        ep = ExpertParallelExperts(lambda *a: None, E, H, mode="a2a", kernels=TorchEpKernels)
+        Mr = 8 + rank                                  # ranks disagree on the token count and name no common capacity
+        a = torch.zeros((Mr, H), dtype=torch.bfloat16)
+        ids = torch.zeros((Mr, K), dtype=torch.int32)
+        tw = torch.ones((Mr, K))
+        try:
+            ep.forward(a, tw, ids)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unequal_token_counts_without_a_common_capacity_fail_loudly():
+    """rank-local token counts size the collectives when no capacity is named; ranks that disagree are told so
+    (one all-gather per new token count, outside capture) instead of hanging in mismatched exchanges"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unequal_no_capacity_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        assert "different token count" in res[rank] and "[8, 9]" in res[rank], res

@@ -212,6 +212,7 @@ class ExpertParallelExperts:
         return_handle the step's state comes back as a fourth value to be passed to combine_fixed (two micro-batches
         in flight: each keeps its own handle; their buffers must then be distinct -- see `_buffers`)."""
         M, K = ids.shape
+        self._ensure_uniform(M, capacity, hidden)
         cap = self.capacity_for(M, capacity, K)
         ret = self.return_dtype or hidden.dtype
         b = self._buffers(M, K, cap, hidden.dtype, ret, hidden.device)
@@ -350,6 +351,15 @@ class ExpertParallelExperts:
         dist.reduce_scatter_tensor(out, part.contiguous(), group=self.group)
         return out
 
+    def _ensure_uniform(self, M: int, capacity, like: torch.Tensor) -> None:
+        """no group-wide capacity was named: the rank-local token count sizes the collectives, so ranks with different
+        counts would post mismatched exchanges (a hang or silent corruption).  Checked ONCE per new token count, outside
+        any capture (one small all-gather): fail loudly instead."""
+        if self.ep > 1 and capacity is None and self.capacity_tokens is None and self.routing_groups is None \
+                and not self.validate_uniform and not _capturing(like) and M not in self._uniform_checked:
+            self._check_uniform(M, "token count (no common capacity was given)")
+            self._uniform_checked.add(M)
+
     def _check_uniform(self, value: int, what: str) -> None:
         t = torch.tensor([value], dtype=torch.int64)
         if dist.is_initialized() and dist.get_backend(self.group) != "gloo":
@@ -370,15 +380,7 @@ class ExpertParallelExperts:
         capacity: see the module docstring (the token count every rank of the group agrees on)."""
         if out is not None:
             out_dtype = out.dtype
-        if self.ep > 1 and capacity is None and self.capacity_tokens is None and self.routing_groups is None \
-                and not self.validate_uniform and not _capturing(hidden):
-            # no group-wide capacity was named: the rank-local token count sizes the collectives, so ranks with different
-            # counts would post mismatched exchanges (a hang or silent corruption).  Checked ONCE per new token count,
-            # outside any capture (one small all-gather): fail loudly instead (ADVICE r2).
-            M0 = topk_ids.size(0)
-            if M0 not in self._uniform_checked:
-                self._check_uniform(M0, "token count (no common capacity was given)")
-                self._uniform_checked.add(M0)
+        self._ensure_uniform(topk_ids.size(0), capacity, hidden)
         if self.ep == 1 and not force_collectives:
             y = self.local_compute(hidden, topk_ids, topk_weights, out_dtype)
             return y if out is None else out.copy_(y)

@@ -26,6 +26,7 @@ from __future__ import annotations
 import argparse
 import gc
 import json
+import math
 import os
 import socket
 import subprocess
@@ -365,6 +366,10 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def prefill_like(wl) -> bool:
+    return bool(wl.get("prefill"))
+
+
 def roof_fields(flops, bytes_, ms, peak_tf):
     """the two rooflines of one kernel side by side (BASELINE.json's metric names the MFMA roofline, the decode
     kernels are HBM-bound): achieved TFLOP/s and GB/s, their fractions of the dense MFMA peak and of the 8 TB/s HBM
@@ -508,6 +513,27 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
             graph, launch = None, "eager"
     run = (lambda: graph.replay()) if graph is not None else step
 
+    # ---- pre-roll: untimed steps through the launch path that is about to be timed, so that the GPU has been busy for
+    # ~30 ms when it reaches the opening barrier.  After an idle stretch (graph capture: milliseconds of host work) the
+    # clocks need about that long to settle, and a 20-step region of a 0.25-0.45 ms step would otherwise measure the ramp:
+    # Mixtral bf16 M=32 at K = 20: 450 us without, 432-437 with 50 steps of pre-roll, 432 over 2000 steps; int4 M=128:
+    # 292 against 246 (profiles/r03_timed_region_length.log).  At least W steps, at most 200; the count is reported
+    # (`config.preroll_steps`).  The timed region itself is untouched: exactly K steps between two barriers.
+    preroll = 0
+    if os.environ.get("LKM_BENCH_NO_PREROLL") != "1":
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            run()
+        barrier()
+        est = max((time.perf_counter() - t0) / 3, 1e-5)
+        preroll = int(min(200, max(warmup, 1, math.ceil(0.03 / est))))
+        if ctx["dist"]:      # (every rank the same count: the steps contain collectives)
+            pr = torch.tensor([preroll], device=dev)
+            dist.all_reduce(pr, op=dist.ReduceOp.MAX)
+            preroll = int(pr.item())
+        for _ in range(preroll):
+            run()
     # ---- timed region: exactly `steps` steps, barrier + synchronize on both sides
     barrier()
     t0 = time.perf_counter()
@@ -523,6 +549,22 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
     tokens_per_s = M * world / (dt / steps)
     if wd is not None:
         wd.disarm()
+
+    # ---- the same step over a longer run (reported next to the line's value, never instead of it): right after the
+    # synchronisation that opens a timed region the GPU clocks ramp for a few milliseconds, which a 20-step region of a
+    # 0.44 ms step carries in full (Mixtral bf16 M=32, one box: 450 us at K = 20, 436 at K = 200, 432 at K = 2000:
+    # profiles/r03_timed_region_length.log)
+    long_run = None
+    LONG = 400
+    if steps < LONG and not prefill_like(wl) and not use_ep:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(LONG):
+            run()
+        barrier()
+        long_run = {"steps": LONG, "ms_per_step": round((time.perf_counter() - t0) / LONG * 1e3, 4),
+                    "what": "the same captured step, one longer timed region (the clock ramp after the opening "
+                            "synchronisation weighs less); `value` above is the K-step region the contract asks for"}
 
     # ---- optional: cold-cache variant.  Not part of the timed steps above.
     cold_ms = None
@@ -628,7 +670,7 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
                           f"grouped {rt['scoring']}+bias top-{K} of {rt['topk_group']}/{rt['n_group']} groups x{rt['routed_scaling']}",
                           "routing": routing,
                           "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}",
-                          "launch": launch, "geometry": eng.engine.describe()},
+                          "launch": launch, "preroll_steps": preroll, "geometry": eng.engine.describe()},
                "roofline": roofline}
         if ep is not None and args.ep_mode == "a2a":
             rb = 4 if args.ep_return == "f32" else 2
@@ -637,6 +679,8 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
                                              return_dtype="fp32" if rb == 4 else "bf16")
         if cold_ms is not None:
             res["ms_per_step_cold"] = round(cold_ms, 4)     # events around each step, caches evicted before it
+        if long_run is not None:
+            res["long_run"] = long_run
         if with_cpu and world == 1 and oracle_in is not None:
             gpu_out = eng.decode(x, tw, ids).cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(name, wl, oracle_in, masters, x, tw, ids, gpu_out, args.cpu_seconds)
@@ -761,6 +805,8 @@ def main():
         }
         if "ms_per_step_cold" in head:
             line["ms_per_step_cold"] = head["ms_per_step_cold"]
+        if "long_run" in head:
+            line["long_run"] = head["long_run"]
         if extras:
             line["extra"] = extras
         return line

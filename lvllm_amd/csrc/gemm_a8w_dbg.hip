@@ -2,7 +2,21 @@
 // bf16 activations only: tuning key "dbg" selects one; results are wrong by construction, only the time is read.
 #include "gemm_prefill_a8w.h"
 namespace lkm {
-int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, int dbg) {
+int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, int dbg, bool gemm2) {
+    if (gemm2) {
+        switch (dbg) {
+#define LKM_A8W_DBG_CASE(D) case D: return launch_prefill_a8w_t<LKM_DT_BF16, false, false, D>(st, p, max_tiles);
+            LKM_A8W_DBG_CASE(1)
+            LKM_A8W_DBG_CASE(2)
+            LKM_A8W_DBG_CASE(1 | 2)
+            LKM_A8W_DBG_CASE(512)          // no epilogue
+            LKM_A8W_DBG_CASE(1 | 2 | 512)
+#undef LKM_A8W_DBG_CASE
+        default:
+            set_error("fp8 W8A8 prefill kernel: GEMM2 ablation dbg=%d not built", dbg);
+            return LKM_E_INVALID;
+        }
+    }
     switch (dbg) {
 #define LKM_A8W_DBG_CASE(D) case D: return launch_prefill_a8w_t<LKM_DT_BF16, true, true, D>(st, p, max_tiles);
         LKM_A8W_DBG_CASE(1)            // compute skeleton: no loads / DMA in the K loop
@@ -25,6 +39,8 @@ int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, i
         LKM_A8W_DBG_CASE(8 | 16)
         LKM_A8W_DBG_CASE(256)          // timing of the three synchronisation points (printed by two waves)
         LKM_A8W_DBG_CASE(256 | 1)
+        LKM_A8W_DBG_CASE(512)          // no epilogue
+        LKM_A8W_DBG_CASE(1 | 2 | 512)
 #undef LKM_A8W_DBG_CASE
     default:
         set_error("fp8 W8A8 prefill kernel: ablation dbg=%d not built", dbg);

@@ -65,6 +65,10 @@ constexpr int kLdsBytes = kWs + 2 * 8 * 512;             // 160 768: four token 
 
 typedef __attribute__((ext_vector_type(4))) int a8w_i32x4;
 
+#ifndef LKM_A8W_WIDE_EPI
+#define LKM_A8W_WIDE_EPI 2      // 16-byte epilogue stores: 1 = GEMM2, 2 = GEMM2 and the gated GEMM1 (0: the 8-byte stores of the first version)
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // clobber lists: tell the compiler (for the kernel descriptor's register count) which fixed registers the asm owns
 // clobber lists: every fixed register is named in the asm statements of the K loop, so that the compiler neither counts
@@ -246,7 +250,7 @@ __device__ __forceinline__ void a8w_dma4_flat(int lds_addr, const void* addr) {
 // (activation_kernels.cu:57-75: gate and up rounded to the activation dtype by the GEMM, T(silu_f32(g)) * u); only
 // the last bit of the fp32 sigmoid differs, far inside the operator's tolerance (tests/kernels/moe/test_block_fp8.py).
 template <int ADT>
-__device__ __forceinline__ void a8w_store_silu_mul(const GemmParams& p, const f32x4& gate, const f32x4& upv, size_t out_row, int n) {
+__device__ __forceinline__ u32x2 a8w_silu_mul(const GemmParams& p, const f32x4& gate, const f32x4& upv) {
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -258,19 +262,37 @@ __device__ __forceinline__ void a8w_store_silu_mul(const GemmParams& p, const f3
         const float sg = a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * -1.44269504088896341f));
         v[r] = p.round_gemm1 ? ActT<ADT>::to_f32(ActT<ADT>::from_f32(sg)) * up : sg * up;
     }
+    return u32x2{ActT<ADT>::pack2(v[0], v[1]), ActT<ADT>::pack2(v[2], v[3])};
+}
+template <int ADT>
+__device__ __forceinline__ void a8w_store_silu_mul(const GemmParams& p, const f32x4& gate, const f32x4& upv, size_t out_row, int n) {
+    const u32x2 o2 = a8w_silu_mul<ADT>(p, gate, upv);
     unsigned short* o = (unsigned short*)p.out + out_row * p.ldo + n;
     if (n + 4 <= p.n_real) {
-        *(u32x2*)o = u32x2{ActT<ADT>::pack2(v[0], v[1]), ActT<ADT>::pack2(v[2], v[3])};
+        *(u32x2*)o = o2;
     } else {
+        const unsigned short h[4] = {(unsigned short)o2.x, (unsigned short)(o2.x >> 16), (unsigned short)o2.y, (unsigned short)(o2.y >> 16)};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (n + r < p.n_real) o[r] = ActT<ADT>::from_f32(v[r]);
+            if (n + r < p.n_real) o[r] = h[r];
     }
+}
+
+// Two lanes 16 apart hold neighbouring 8-byte pieces of an output row: lane (g, j) columns 4 g .. 4 g + 3 of row j.
+// v_permlane16_swap_b32 (odd 16-lane rows of the first operand <-> even rows of the second) turns two such pieces per
+// lane -- `a` and `b`, of two different rows (GEMM1: two token blocks) or two different tiles (GEMM2) -- into ONE 16-byte
+// piece per lane: even g keeps its `a` and receives g + 1's `a` (columns 4 g .. 4 g + 7 of a's row / tile), odd g
+// receives g - 1's `b` and keeps its own (columns 4 (g - 1) .. 4 g + 3 of b's).  Half the store instructions, 64
+// contiguous bytes per row and instruction instead of 32: the epilogue is store-issue bound.
+__device__ __forceinline__ u32x4 a8w_pair16(const u32x2& a, const u32x2& b) {
+    const u32x2 lo = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    return u32x4{lo.x, hi.x, lo.y, hi.y};
 }
 
 // DBG (development ablations, results wrong by construction): 1 = no loads / DMA inside the K loop (compute skeleton),
 // 2 = no token blocks (data movement + barriers only), 8 / 16 / 32 = blocks without LDS reads / VALU / MFMA, 64 = no
-// per-unit barrier.  Tuning key "dbg"; bit 4 (serialised units) is a run-time flag.  The ablation kernels live in
+// per-unit barrier, 512 = the epilogue computes nothing and stores nothing.  Tuning key "dbg"; bit 4 (serialised units) is a run-time flag.  The ablation kernels live in
 // their own translation unit (gemm_a8w_dbg.hip).
 //
 // PERSISTENT: the grid is one workgroup per CU; a workgroup walks its share of the (token tile, weight row group) items
@@ -393,6 +415,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     const a8w_i32x4 rs_x = make_rs(p.x, (unsigned)((size_t)p.x_rows * (size_t)p.ldx));
     const a8w_i32x4 rs_xs = make_rs(p.xscale, (unsigned)((size_t)p.x_rows * (size_t)p.ld_xscale * 4));
     const int ldx = p.ldx, ldxs4 = p.ld_xscale * 4, top_k = p.top_k;
+    const float rcp_top_k = p.rcp_top_k;
 
     // ---- an item's row table (LDS, kTbl + 2048 * buffer): [256] source row * ldx, then [256] source row * ld_xscale * 4.
     // Waves 0..3 gather one sorted_slot entry per lane (GEMM1; GEMM2 rows are their own sources) into the landing zone ...
@@ -416,7 +439,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
             if constexpr (IS_G1) {
                 int raw;
                 asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(raw) : "v"(lds0 + kRaw + r * 4) : "memory");
-                src = raw / top_k;
+                // slot -> token: raw / top_k through a SCALAR float reciprocal (the compiler's integer division keeps its
+                // magic number in a vector register across the whole kernel, and the K loop has none to spare); exact
+                // for slot numbers below 2^22 (prefill_a8w_ok): the quotient is off by at most one before the correction
+                src = (int)((float)raw * rcp_top_k);
+                const int rem = raw - src * top_k;
+                src += (rem >= top_k ? 1 : 0) - (rem < 0 ? 1 : 0);
             } else {
                 src = it.orow0 + (r < it.rows ? r : 0);
             }
@@ -561,6 +589,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     if constexpr (DBG & 256) t_start = now();
     auto unit = [&](auto SLOTC, auto KINDC, int pp) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(SLOTC)::v, KIND = decltype(KINDC)::v;
+        // (a tail position is a kernel-wide constant, Up - 3 + SLOT: opaque, or the compiler hoists the lane addresses that
+        // depend on it out of the item loop into vector registers the K loop does not have)
+        if constexpr (KIND == 2) asm volatile("" : "+s"(pp));
         // the item's first unit assigns the accumulators (they are never zeroed); two tiles of one scale block share the product
         constexpr int OPT = ((KIND == 0 && SLOT == 0) ? 1 : 0) | (GATED ? 0 : 2);
         const int stn = (stoff + kStage) & (kStages * kStage - 1);
@@ -702,6 +733,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
             }
             // (opaque lane coordinates: the compiler must not hoist the epilogue's sixteen row offsets out of the K loop --
             // it has 39 registers, and a spilled value is a scratch load inside the hand-counted loop)
+            // (from here to A8W_EPILOGUE_END the compiler may use v40..v77: nothing of the fixed map below the A ring is live
+            // across an item switch -- block 0 of the next unit re-reads its B operand and token scale behind the epilogue)
+            asm volatile("; A8W_EPILOGUE_BEGIN" ::: "memory");
             int jj = j, gg = g;
             asm volatile("" : "+v"(jj), "+v"(gg));
             if (more) {
@@ -717,18 +751,61 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                 pend = meta_a(it_next);
                 it_next += stride;
             }
-            asm volatile("; A8W_EPILOGUE_BEGIN" ::: "memory");
+            auto read_acc = [&](auto BC, f32x4& c0, f32x4& c1) __attribute__((always_inline)) {
+                asm volatile("v_mov_b32 %0, v[%c8+0]\n\tv_mov_b32 %1, v[%c8+1]\n\tv_mov_b32 %2, v[%c8+2]\n\tv_mov_b32 %3, v[%c8+3]\n\t"
+                             "v_mov_b32 %4, v[%c8+4]\n\tv_mov_b32 %5, v[%c8+5]\n\tv_mov_b32 %6, v[%c8+6]\n\tv_mov_b32 %7, v[%c8+7]"
+                             : "=&v"(c0.x), "=&v"(c0.y), "=&v"(c0.z), "=&v"(c0.w), "=&v"(c1.x), "=&v"(c1.y), "=&v"(c1.z), "=&v"(c1.w)
+                             : "i"(kAcc + decltype(BC)::v * 8)
+                             : "memory");
+            };
+            // 16-byte stores (a8w_pair16) where this wave's tiles lie whole inside the matrix and the output is 16-bit
+            bool wide = false;
+            if constexpr (LKM_A8W_WIDE_EPI >= 2 && GATED) {
+                wide = done.tbase + wave < T_half && (done.tbase + wave + 1) * 16 <= p.n_real && p.act_type != LKM_ACT_SWIGLUOAI &&
+                       (p.ldo & 7) == 0;
+            } else if constexpr (LKM_A8W_WIDE_EPI && !IS_G1) {
+                wide = done.tbase + 2 * wave + 1 < T_half && (done.tbase + 2 * wave + 2) * 16 <= p.n_real && p.y_dt != LKM_DT_F32 &&
+                       (p.ldo & 7) == 0;
+            }
+            if (wide && !(DBG & 512)) {
+                const int godd = gg & 1, gcol = (gg & ~1) * 4;
+                static_for<8>([&](auto QC) __attribute__((always_inline)) {
+                    constexpr int q = decltype(QC)::v;
+                    if (q < done.nq) {      // (uniform)
+                        if constexpr (GATED) {
+                            // blocks 2 q and 2 q + 1 of the wave's one output tile: even g stores the first's row, odd g the second's
+                            f32x4 c0, c1;
+                            read_acc(IC<2 * q>{}, c0, c1);
+                            const u32x2 oa = a8w_silu_mul<ADT>(p, c0, c1);
+                            read_acc(IC<2 * q + 1>{}, c0, c1);
+                            const u32x2 ob = a8w_silu_mul<ADT>(p, c0, c1);
+                            const u32x4 piece = a8w_pair16(oa, ob);
+                            const int rt = (2 * q + godd) * 16 + jj;
+                            if (rt < done.rows)
+                                *(u32x4*)((unsigned short*)p.out + (size_t)(done.orow0 + rt) * p.ldo + (done.tbase + wave) * 16 + gcol) = piece;
+                        } else {
+                            // the wave's two adjacent tiles of one block: even g stores into the first, odd g into the second
+                            static_for<2>([&](auto HC) __attribute__((always_inline)) {
+                                constexpr int b = 2 * q + decltype(HC)::v;
+                                f32x4 c0, c1;
+                                read_acc(IC<b>{}, c0, c1);
+                                const u32x4 piece = a8w_pair16(u32x2{ActT<ADT>::pack2(c0.x, c0.y), ActT<ADT>::pack2(c0.z, c0.w)},
+                                                               u32x2{ActT<ADT>::pack2(c1.x, c1.y), ActT<ADT>::pack2(c1.z, c1.w)});
+                                const int rt = b * 16 + jj;
+                                if (rt < done.rows)
+                                    *(u32x4*)((unsigned short*)p.out + (size_t)(done.orow0 + rt) * p.ldo + (done.tbase + 2 * wave + godd) * 16 + gcol) = piece;
+                            });
+                        }
+                    }
+                });
+            } else
             static_for<16>([&](auto BC) __attribute__((always_inline)) {
                 constexpr int b = decltype(BC)::v;
                 if (b < 2 * done.nq) {      // (uniform)
                     const int rt = b * 16 + jj;
                     f32x4 c0, c1;
-                    asm volatile("v_mov_b32 %0, v[%c8+0]\n\tv_mov_b32 %1, v[%c8+1]\n\tv_mov_b32 %2, v[%c8+2]\n\tv_mov_b32 %3, v[%c8+3]\n\t"
-                                 "v_mov_b32 %4, v[%c8+4]\n\tv_mov_b32 %5, v[%c8+5]\n\tv_mov_b32 %6, v[%c8+6]\n\tv_mov_b32 %7, v[%c8+7]"
-                                 : "=&v"(c0.x), "=&v"(c0.y), "=&v"(c0.z), "=&v"(c0.w), "=&v"(c1.x), "=&v"(c1.y), "=&v"(c1.z), "=&v"(c1.w)
-                                 : "i"(kAcc + b * 8)
-                                 : "memory");
-                    if (rt < done.rows) {
+                    read_acc(BC, c0, c1);
+                    if (rt < done.rows && !(DBG & 512)) {
                         const size_t orow = (size_t)(done.orow0 + rt);
                         if constexpr (GATED) {
                             const int n = (done.tbase + wave) * 16 + gg * 4;
@@ -794,7 +871,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
 // multiple of 16), the weight image is tile-major or unit-major with 32-bit offsets, and the operand matrices fit the
 // 2 GiB buffer windows; otherwise the plan stays on gemm_tiled_kernel (pick_cfg asks prefill_a8w_shape_ok first)
 inline bool prefill_a8w_ok(const GemmParams& p) {
-    return p.Kreal % 128 == 0 && p.tile_uniform_scale && p.U >= 8 && p.U <= 64 &&      // (the item-boundary pipeline; 64 weight-block scales per tile in the landing zone)
+    return p.Kreal % 128 == 0 && p.tile_uniform_scale && p.U >= 8 && p.U <= 64 && (size_t)p.x_rows * (size_t)(p.top_k > 0 ? p.top_k : 1) < ((size_t)1 << 22) &&      // (the item-boundary pipeline; 64 weight-block scales per tile in the landing zone)
            (size_t)p.x_rows * (size_t)p.ldx < (size_t)0x7fffffff &&
            (size_t)p.x_rows * (size_t)p.ld_xscale * 4 < (size_t)0x7fffffff &&
            (size_t)p.T_half * p.halves * p.U * 2048 < (size_t)0x7fffffff;
@@ -821,8 +898,8 @@ static int launch_prefill_a8w_t(hipStream_t st, const GemmParams& p, int max_til
     return LKM_OK;
 }
 
-// gemm_a8w_dbg.hip: the ablation instantiations (gated GEMM1, bf16)
-int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, int dbg);
+// gemm_a8w_dbg.hip: the ablation instantiations (bf16: gated GEMM1, or GEMM2 when the tuning value carries bit 1024)
+int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, int dbg, bool gemm2);
 
 template <typename ADTC>
 static bool launch_prefill_a8w_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
@@ -834,9 +911,9 @@ static bool launch_prefill_a8w_if(hipStream_t st, const LaunchCfg& cfg, const Ge
         *rc = LKM_E_INVALID;
         return true;
     }
-    if constexpr (ADT == LKM_DT_BF16) {     // ablation builds: gated GEMM1, bf16 activations only
-        if (is_g1 && gated && (p.dbg & 0x1fb)) {
-            *rc = launch_prefill_a8w_dbg(st, p, max_tiles, p.dbg & 0x1fb);
+    if constexpr (ADT == LKM_DT_BF16) {     // ablation builds: bf16 activations only; bit 1024 = of GEMM2 instead of the gated GEMM1
+        if ((p.dbg & 0x3fb) && ((p.dbg & 0x400) ? !is_g1 : (is_g1 && gated))) {
+            *rc = launch_prefill_a8w_dbg(st, p, max_tiles, p.dbg & 0x3fb, !is_g1);
             return true;
         }
     }

@@ -861,6 +861,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.ld_xscale = kb1;
     p1.round_gemm1 = h->a8 ? 1 : 0;
     p1.top_k = K;
+    p1.rcp_top_k = 1.0f / (float)K;
     p1.counts = a->counts;
     p1.offsets = a->offsets;
     p1.active = a->active;
@@ -929,6 +930,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.xscale = a->aqs;
     p2.ld_xscale = kb2;
     p2.top_k = K;
+    p2.rcp_top_k = 1.0f / (float)K;
     p2.counts = a->counts;
     p2.offsets = a->offsets;
     p2.active = a->active;

@@ -79,6 +79,7 @@ struct GemmParams {
     const void* x;  // GEMM1: hidden [M][H] ; GEMM2: act [rows][ldx]
     int ldx;        // row stride of x in elements
     int top_k;      // GEMM1: slot -> token = slot / top_k
+    float rcp_top_k;  // 1 / top_k (the fp8 prefill kernel divides through it: gemm_prefill_a8w.h store_table)
     const float* xscale;  // W8A8: per (token row, 128-k block) activation scales, row stride ld_xscale
     int ld_xscale;
     int round_gemm1;      // 1: round GEMM1 outputs to the act dtype before the activation (in-tree GPU

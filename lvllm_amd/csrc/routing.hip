@@ -315,6 +315,7 @@ extern "C" int lkm_router_gemm_topk(void* stream, const void* x, int32_t x_dtype
         gp.ldx = H;
         gp.x_rows = M;
         gp.top_k = 1;
+        gp.rcp_top_k = 1.0f;
         gp.meta = meta;
         gp.counts = meta + 4;
         gp.offsets = meta + 5;

@@ -684,21 +684,7 @@ int launch_build_items(hipStream_t st, const int32_t* tile_e, const int32_t* til
 // IEEE sequence, five operations instead of ten.  Quotients below 2^-10 round to fp8 zero whatever their last bits are.
 // The kernel was VALU-bound on its eight divisions per lane (3.9 TB/s); bit-exactness of the bytes against x / s in
 // IEEE arithmetic: tests/test_gpu_quant.py.
-struct DivBy {
-    float s, r;
-};
-__device__ __forceinline__ DivBy make_div_by(float s) {
-    const float r0 = __builtin_amdgcn_rcpf(s);
-    const float e = __builtin_fmaf(-s, r0, 1.0f);
-    return DivBy{s, __builtin_fmaf(e, r0, r0)};
-}
-__device__ __forceinline__ float div_by(float x, const DivBy& d) {
-    const float q0 = x * d.r;
-    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d.s, x), d.r, q0);
-    // (the corrections turn -0 / s into +0: the sign of the quotient is the sign of x)
-    return __builtin_copysignf(__builtin_fmaf(__builtin_fmaf(-q1, d.s, x), d.r, q1), x);
-}
-
+// (DivBy / make_div_by / div_by: lkm_common.h -- shared with the fused quantisation of gemm_prefill_a8w.h)
 template <int ADT, int UNR>
 __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const unsigned short* __restrict__ src,
                                                              int ld_src, int R, int K,

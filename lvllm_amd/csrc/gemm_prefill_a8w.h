@@ -59,7 +59,8 @@ constexpr int kStA = kTbl + 2 * 2048;                    // per-wave landing zon
 constexpr int kStB = kStA + 2048;                        // (unused since the item records carry the expert's row offset)
 constexpr int kRaw = kStB + 2048;                        // 256 gathered sorted_slot entries of the next item
 constexpr int kWs = kRaw + 1024;                         // weight-block scales: [2 items][8 waves][2 tiles][64 units] fp32
-constexpr int kLdsBytes = kWs + 2 * 8 * 512;             // 160 768: four token stages, three token-scale groups, two row
+constexpr int kRmax = kWs + 2 * 8 * 512;                 // row maxima of the fused output quantisation: [2 halves][256 rows] u32
+constexpr int kLdsBytes = kRmax + 2048;                  // 162 816: four token stages, three token-scale groups, two row
                                                          // tables, the landing zones, the weight-block scales
 }  // namespace a8w
 
@@ -415,6 +416,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
     const a8w_i32x4 rs_x = make_rs(p.x, (unsigned)((size_t)p.x_rows * (size_t)p.ldx));
     const a8w_i32x4 rs_xs = make_rs(p.xscale, (unsigned)((size_t)p.x_rows * (size_t)p.ld_xscale * 4));
     const int ldx = p.ldx, ldxs4 = p.ld_xscale * 4, top_k = p.top_k;
+    // fused 1 x 128 fp8 quantisation of the gated GEMM1's output (the W8A8 intermediate): p.out_q / p.out_qs instead of p.out
+    const bool fq = GATED && __builtin_amdgcn_readfirstlane(p.out_q != nullptr ? 1 : 0) != 0;
     const float rcp_top_k = p.rcp_top_k;
 
     // ---- an item's row table (LDS, kTbl + 2048 * buffer): [256] source row * ldx, then [256] source row * ld_xscale * 4.
@@ -504,6 +507,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         store_table(1, nxt);
         pend = meta_a(w + 2 * stride);
+        if constexpr (GATED) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + kRmax + tid * 4), "v"(0) : "memory");      // (row maxima: 512 words)
         // everything above that came from memory is consumed HERE (the compiler's own loads must not be waited for
         // inside the hand-counted loop)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
 
     // ---- prologue: the pipeline's first three units
     int ws0, ws1;          // the current unit's two weight-block scales (fp32 bits)
-    int st16 = 0;          // the last epilogue issued >= 16 stores (the ledger's waits of the next three units)
+    int st_cls = 0;        // store instructions of the last epilogue: 2 = at least 16, 1 = at least 8 (the ledger's waits of the next three units)
     {
         int t[4], ts, w0, w1;
         asm volatile("ds_read_b32 %0, %7\n\tds_read_b32 %1, %7 offset:256\n\tds_read_b32 %2, %7 offset:512\n\t"
@@ -617,11 +621,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         const bool real = KIND != 2 || pp < U;
         int ws0n = ws0, ws1n = ws1, t[4];
         // A(u) is in its slot.  (The three units behind an item switch: the epilogue's stores are in the ledger behind
-        // the loads these waits are about -- >= 16 of them when st16 -- and must not be waited for.)
-        const bool late = KIND == 0 && st16;
+        // the loads these waits are about -- at least 16 (8) of them when st_cls is 2 (1) -- and must not be waited for.
+        // (Counting FEWER stores than were issued only makes a wait stricter; counting more would let it pass with a
+        // load outstanding.)
+        const bool late = KIND == 0 && st_cls == 2, late8 = KIND == 0 && st_cls == 1;
         unsigned tt0 = 0;
         if constexpr (DBG & 256) tt0 = now();
         if (late) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (late8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         if constexpr (DBG & 256) t_top += now() - tt0;
         if (real && !(DBG & 2)) {
@@ -640,6 +647,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         if constexpr (DBG & 256) {
             const unsigned a0 = now();
             if (late) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+            else if (late8) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             const unsigned a1 = now();
             asm volatile("s_barrier" ::: "memory");
@@ -647,6 +655,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
             t_bar += now() - a1;
         } else if constexpr (DBG & 64) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // (ablation: no barrier)
         else if (late) asm volatile("s_waitcnt vmcnt(28)\n\ts_barrier" ::: "memory");
+        else if (late8) asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
         if constexpr (!(DBG & 1)) {
             // token scales: a group of four units is fetched three positions before its first unit
@@ -657,6 +666,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                 if ((tu & 3) == 0 && tu < U && wave < 4)
                     a8w_dma16(lds0 + kScBase + next3(xsl) * kScBuf + wave * 1024, scale_src(tsel), rs_xs, (tu >> 2) * 16);
             }
+        }
+        if constexpr (GATED && KIND == 0 && SLOT == 0) {
+            // one barrier after the item switch: every wave has read the previous item's row maxima (fused output
+            // quantisation) -> clear them for this item's epilogue, a whole item away
+            if (fq) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + kRmax + tid * 4), "v"(0) : "memory");
         }
         if constexpr (KIND == 0 && SLOT == 2) {
             // two barriers after the item switch: the next item's gathered rows have landed (ledger: sixteen loads were
@@ -724,12 +738,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
         {
             const Item done = cur;
             const bool more = nxt.nq != 0;
-            {   // store instructions this wave is about to issue: blocks that hold rows x its tiles inside the matrix
+            // 16-byte stores (a8w_pair16) where this wave's tiles lie whole inside the matrix and the output is 16-bit
+            bool wide = false;
+            if constexpr (LKM_A8W_WIDE_EPI >= 2 && GATED) {
+                wide = done.tbase + wave < T_half && (done.tbase + wave + 1) * 16 <= p.n_real && p.act_type != LKM_ACT_SWIGLUOAI &&
+                       (p.ldo & 7) == 0;
+            } else if constexpr (LKM_A8W_WIDE_EPI && !IS_G1) {
+                wide = done.tbase + 2 * wave + 1 < T_half && (done.tbase + 2 * wave + 2) * 16 <= p.n_real && p.y_dt != LKM_DT_F32 &&
+                       (p.ldo & 7) == 0;
+            }
+            {   // store INSTRUCTIONS this wave is about to issue (one with no active lane is branched over): 8-byte stores =
+                // blocks that hold rows x its tiles inside the matrix; 16-byte stores = one per 32-row pair of blocks
+                // (gated GEMM1: two blocks of one tile) or one per block (GEMM2: both tiles)
                 const int nb = (done.rows + 15) >> 4;
                 const int t0 = GATED ? done.tbase + wave : done.tbase + 2 * wave;
                 const int nt = GATED ? (t0 < T_half && t0 * 16 < p.n_real ? 1 : 0)
                                      : (t0 < T_half && t0 * 16 < p.n_real ? 1 : 0) + (t0 + 1 < T_half && (t0 + 1) * 16 < p.n_real ? 1 : 0);
-                st16 = nb * nt >= 16;
+                // (fused quantisation: one 8-byte store per pair, plus one scale store on wave q of pair q)
+                const int st_n = (DBG & 512) ? 0 : wide ? (GATED ? done.nq + ((fq && wave < done.nq) ? 1 : 0) : nb) : nb * nt;
+                st_cls = st_n >= 16 ? 2 : st_n >= 8 ? 1 : 0;
             }
             // (opaque lane coordinates: the compiler must not hoist the epilogue's sixteen row offsets out of the K loop --
             // it has 39 registers, and a spilled value is a scratch load inside the hand-counted loop)
@@ -758,16 +785,85 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                              : "i"(kAcc + decltype(BC)::v * 8)
                              : "memory");
             };
-            // 16-byte stores (a8w_pair16) where this wave's tiles lie whole inside the matrix and the output is 16-bit
-            bool wide = false;
-            if constexpr (LKM_A8W_WIDE_EPI >= 2 && GATED) {
-                wide = done.tbase + wave < T_half && (done.tbase + wave + 1) * 16 <= p.n_real && p.act_type != LKM_ACT_SWIGLUOAI &&
-                       (p.ldo & 7) == 0;
-            } else if constexpr (LKM_A8W_WIDE_EPI && !IS_G1) {
-                wide = done.tbase + 2 * wave + 1 < T_half && (done.tbase + 2 * wave + 2) * 16 <= p.n_real && p.y_dt != LKM_DT_F32 &&
-                       (p.ldo & 7) == 0;
-            }
-            if (wide && !(DBG & 512)) {
+            if (GATED && fq && !(DBG & 512)) {
+                // ---- gated GEMM1 with the intermediate's 1 x 128 fp8 quantisation fused in (per_token_group_quant_fp8,
+                // dispatch.hip quant_fp8_rows_kernel: same operations on the same bf16 / f16 values, bit-identical
+                // bytes and scales).  An item is 256 rows x ONE 128-column group: wave w holds columns 16 w .. 16 w + 15.
+                // Per half of the item (four 32-row pairs; the packed outputs of a half are 16 registers): row maxima
+                // of the wave's 16 columns -> ds_max_u32 into the half's 256 words -> barrier -> every wave reads the
+                // row's maximum over the 128 columns, quantises its eight values and stores eight bytes; wave q of pair q
+                // also stores the scale.  The host enables this only where every wave's tile lies inside the matrix
+                // (I % 128 == 0: all eight waves take this path and meet at the barriers).
+                if constexpr (GATED) {
+#pragma clang fp contract(off)
+                    const int godd = gg & 1, gcol = (gg & ~1) * 4;
+                    const int col = (done.tbase + wave) * 16 + gcol;
+                    const int qgrp = done.tbase >> 3;                 // the 128-column group (TPH = 8 tiles)
+                    int rbase = lds0 + kRmax;                         // (a plain local: the nested generic lambdas capture it)
+                    static_for<2>([&](auto HC) __attribute__((always_inline)) {
+                        constexpr int hf = decltype(HC)::v;
+                        if (hf * 4 < done.nq) {      // (uniform over the workgroup)
+                            u32x4 piece[4];
+                            static_for<4>([&](auto QC) __attribute__((always_inline)) {
+                                constexpr int qq = decltype(QC)::v, q = hf * 4 + qq;
+                                if (q < done.nq) {
+                                    f32x4 c0, c1;
+                                    read_acc(IC<2 * q>{}, c0, c1);
+                                    const u32x2 oa = a8w_silu_mul<ADT>(p, c0, c1);
+                                    read_acc(IC<2 * q + 1>{}, c0, c1);
+                                    const u32x2 ob = a8w_silu_mul<ADT>(p, c0, c1);
+                                    piece[qq] = a8w_pair16(oa, ob);
+                                    float am = 0.0f;
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) {
+                                        am = fmaxf(am, fabsf(ActT<ADT>::to_f32((unsigned short)(piece[qq][i] & 0xffffu))));
+                                        am = fmaxf(am, fabsf(ActT<ADT>::to_f32((unsigned short)(piece[qq][i] >> 16))));
+                                    }
+                                    // (lane ^ 32 = the other eight columns of the same row)
+                                    // (the elements through scalars: __builtin_bit_cast of a vector ELEMENT reads element 0)
+                                    const unsigned ab = __builtin_bit_cast(unsigned, am);
+                                    const u32x2 sw = __builtin_amdgcn_permlane32_swap(ab, ab, false, false);
+                                    const unsigned sw0 = sw.x, sw1 = sw.y;
+                                    am = fmaxf(__builtin_bit_cast(float, sw0), __builtin_bit_cast(float, sw1));
+                                    const int rt = (2 * q + godd) * 16 + jj;
+                                    const int ra = rbase + hf * 1024 + rt * 4;
+                                    const unsigned amb = __builtin_bit_cast(unsigned, am);
+                                    if (gg < 2) asm volatile("ds_max_u32 %0, %1" ::"v"(ra), "v"(amb) : "memory");
+                                }
+                            });
+                            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                            static_for<4>([&](auto QC) __attribute__((always_inline)) {
+                                constexpr int qq = decltype(QC)::v, q = hf * 4 + qq;
+                                if (q < done.nq) {
+                                    const int rt = (2 * q + godd) * 16 + jj;
+                                    const int ra = rbase + hf * 1024 + rt * 4;
+                                    unsigned mb;
+                                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(mb) : "v"(ra) : "memory");
+                                    float amax = __builtin_bit_cast(float, mb);
+                                    if (amax < 1e-10f) amax = 1e-10f;
+                                    const float sc = amax / 448.0f;
+                                    const DivBy d = make_div_by(sc);
+                                    float qv[8];
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) {
+                                        qv[2 * i] = fminf(fmaxf(div_by(ActT<ADT>::to_f32((unsigned short)(piece[qq][i] & 0xffffu)), d), -448.0f), 448.0f);
+                                        qv[2 * i + 1] = fminf(fmaxf(div_by(ActT<ADT>::to_f32((unsigned short)(piece[qq][i] >> 16)), d), -448.0f), 448.0f);
+                                    }
+                                    u32x2 o;
+                                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(qv[0], qv[1], 0, false);
+                                    o.x = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(qv[2], qv[3], pk, true);
+                                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(qv[4], qv[5], 0, false);
+                                    o.y = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(qv[6], qv[7], pk, true);
+                                    if (rt < done.rows) {
+                                        *(u32x2*)(p.out_q + (size_t)(done.orow0 + rt) * p.ldo + col) = o;
+                                        if (gg < 2 && wave == (q & 7)) p.out_qs[(size_t)(done.orow0 + rt) * p.ld_qs + qgrp] = sc;
+                                    }
+                                }
+                            });
+                        }
+                    });
+                }
+            } else if (wide && !(DBG & 512)) {
                 const int godd = gg & 1, gcol = (gg & ~1) * 4;
                 static_for<8>([&](auto QC) __attribute__((always_inline)) {
                     constexpr int q = decltype(QC)::v;

@@ -163,7 +163,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0, t_fuse = 0, t_tiled2 = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0, t_fuse = 0, t_tiled2 = 0, t_fuseq = 0;
     bool unit_major = false;  // weight image layout (RepackDims::unit_major)
     int loads = 2;            // 16-byte loads per lane per (tile, unit)
     // profiling
@@ -862,6 +862,16 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.round_gemm1 = h->a8 ? 1 : 0;
     p1.top_k = K;
     p1.rcp_top_k = 1.0f / (float)K;
+    // The gated GEMM1 of the fp8 prefill kernel quantises its own output (the 1 x 128 groups of the W8A8 intermediate:
+    // one item = 256 rows x one group) where every 128-column group is whole: no 16-bit intermediate, no quantiser launch.
+    // Tuning key "fuseq" = -1 keeps the separate pass (same bytes: tests/test_gpu_moe.py).
+    const bool fuse_q = h->a8 && h->gated && !direct && pl.t1.tiled == 256 && pl.t1.pf == 9 && h->I % 128 == 0 && h->ld_act % 8 == 0 &&
+                        h->cfg.activation_type != LKM_ACT_SWIGLUOAI && h->t_fuseq >= 0 && !(h->t_dbg & 0x3fb);
+    if (fuse_q) {
+        p1.out_q = (unsigned char*)a->aq;
+        p1.out_qs = a->aqs;
+        p1.ld_qs = kb2;
+    }
     p1.counts = a->counts;
     p1.offsets = a->offsets;
     p1.active = a->active;
@@ -917,7 +927,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.U = h->U2;
     p2.Kreal = h->I;
     p2.n_real = h->H;
-    if (h->a8) {   // re-quantise the intermediate (per_token_group_quant of act_out, test_block_fp8.py:128)
+    if (h->a8 && !fuse_q) {   // re-quantise the intermediate (per_token_group_quant of act_out, test_block_fp8.py:128)
         rc = launch_quant_fp8_rows(st, a->act, h->ld_act, h->adt, (int)n_slots, h->I, a->aq, a->aqs);
         if (rc != LKM_OK) return rc;
     }
@@ -1267,6 +1277,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "tbmax")) h->t_tb = value;
     else if (!strcmp(key, "tiled")) h->t_tiled = value;
     else if (!strcmp(key, "tiled2")) h->t_tiled2 = value;
+    else if (!strcmp(key, "fuseq")) h->t_fuseq = value;
     else if (!strcmp(key, "waves")) h->t_waves = value;
     else if (!strcmp(key, "pd1")) h->t_pd1 = value;
     else if (!strcmp(key, "pd2")) h->t_pd2 = value;

@@ -258,6 +258,26 @@ struct WGeom<LKM_W_NVFP4> {
     static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
 };
 
+// ---- x / s, correctly rounded, for the 1 x 128 fp8 activation quantiser's operands (dispatch.hip quant_fp8_rows_kernel,
+// gemm_prefill_a8w.h fused epilogue): s = amax / 448 >= 2.2e-13 is normal and |x| <= amax, so |x / s| <= 448 and none of the
+// range handling of the general division sequence can trigger; the reciprocal is refined ONCE per group and each quotient
+// takes the two remainder corrections of the IEEE sequence.  Bit-exactness against x / s: tests/test_gpu_quant.py.
+struct DivBy {
+    float s, r;
+};
+__device__ __forceinline__ DivBy make_div_by(float s) {
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float e = __builtin_fmaf(-s, r0, 1.0f);
+    return DivBy{s, __builtin_fmaf(e, r0, r0)};
+}
+__device__ __forceinline__ float div_by(float x, const DivBy& d) {
+    const float q0 = x * d.r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, d.s, x), d.r, q0);
+    // (the corrections turn -0 / s into +0: the sign of the quotient is the sign of x)
+    return __builtin_copysignf(__builtin_fmaf(__builtin_fmaf(-q1, d.s, x), d.r, q1), x);
+}
+
+
 inline bool wf_is_4bit(int wf) { return wf == LKM_W_INT4_B8 || wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4; }
 inline int wf_unitk(int wf) { return (wf == LKM_W_BF16 || wf == LKM_W_F16) ? 64 : 128; }
 inline int wf_loads(int wf) { return wf_is_4bit(wf) ? 1 : 2; }

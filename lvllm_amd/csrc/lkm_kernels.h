@@ -101,6 +101,11 @@ struct GemmParams {
     // outputs
     void* out;  // GEMM1: act [rows][ldo] act dtype ; GEMM2: y [SK][sk_stride] fp32
     int ldo;
+    // gated GEMM1 of the fp8 prefill kernel with the intermediate's 1 x 128 quantisation fused in (else null): e4m3 bytes
+    // [rows][ldo] and scales [rows][ld_qs] instead of `out`
+    unsigned char* out_q;
+    float* out_qs;
+    int ld_qs;
     size_t sk_stride;  // GEMM2: elements between split-K slabs
     int SK;            // GEMM2: number of K splits
     int groups;        // tile groups per expert = T_half / NT

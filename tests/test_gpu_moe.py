@@ -225,7 +225,7 @@ def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated, pf):
     eng.engine.set_tuning(tiled=0, xcd=0, pf=0)
 
 
-@pytest.mark.parametrize("dtype,act", [(torch.float16, 0), (torch.bfloat16, 1), (torch.float16, 1)])
+@pytest.mark.parametrize("dtype,act", [(torch.float16, 0), (torch.bfloat16, 0), (torch.bfloat16, 1), (torch.float16, 1)])
 def test_fp8_w8a8_prefill_kernel_fp16_and_swigluoai(dtype, act):
     """the round-3 prefill kernel's other instantiations: fp16 activations (its own translation unit) and the
     interleaved swigluoai epilogue (activation_kernels.cu:401-440), through decode AND through gpu_prefill (activation-
@@ -249,6 +249,11 @@ def test_fp8_w8a8_prefill_kernel_fp16_and_swigluoai(dtype, act):
     bad = np.abs(out - ref) > 1e-2 * scale + 2e-2 * np.abs(ref)
     assert bad.mean() < 1e-4, f"{bad.sum()} of {bad.size} elements differ"
     np.testing.assert_allclose(out, ref, atol=0.035 * scale, rtol=0.035)
+    # SiLU: GEMM1 quantised its own output (1 x 128 groups in the epilogue); the separate quantiser pass gives the same bits
+    eng.engine.set_tuning(fuseq=-1)
+    out_sep = _run_decode(eng, a, tw, ids)
+    assert np.array_equal(out, out_sep)
+    eng.engine.set_tuning(fuseq=0)
     # gpu_prefill: the same rows in the activation dtype, 2600 tokens in chunks of 2048 + 552
     pre = eng.prefill(a.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV))
     assert pre.dtype == dtype

@@ -641,6 +641,13 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
             roofline = {"bound": "mfma", "kernel": "gemm1 (grouped, tiled)", "achieved": round(ach, 1), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                         "traffic_stale": stale, "algorithmic_bytes": g1_bytes, "algorithmic_flops": g1_flops}
+            # the second GEMM of the step against the same peak (2 * rows * I * H flops), and what the GEMM1 launch also does
+            g2_ms = max(prof_ms.get("gemm2", 0.0), 1e-6)
+            roofline["gemm2"] = {"achieved": round(2.0 * rows * H * I / (g2_ms * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+                                 "frac": round(2.0 * rows * H * I / (g2_ms * 1e-3) / 1e12 / peak, 4)}
+            if wl.get("fp8_mode") == 1 and wl.get("fmt") == "fp8":
+                roofline["kernel_includes"] = ("gated SiLU and the 1 x 128 fp8 quantisation of the intermediate in GEMM1's epilogue "
+                                               "(a separate 37-us pass until late round 3); the GEMM2 bracket holds GEMM2 only")
         else:
             achieved = g1_bytes / (g1_ms * 1e-3) / 1e9               # (a rank whose experts got no row: 0)
             roofline = {"bound": "hbm", "kernel": "gemm1_act_kernel", "achieved": round(achieved, 1),

@@ -22,9 +22,10 @@ MFMA = {
     1: "v_mfma_f32_16x16x32_bf16 %[acc{a}], %[A4], %[B4], %[acc{a}]",
     2: "v_mfma_f32_32x32x16_bf16 %[big{b}], %[A4], %[B4], %[big{b}]",
     3: "v_mfma_f32_16x16x128_f8f6f4 %[acc{a}], %[A8], %[B8], %[acc{a}]",
+    4: "v_mfma_f32_32x32x64_f8f6f4 %[big{b}], %[A8], %[B8], %[big{b}]",
 }
-MFMA_NAME = {0: "-", 1: "16x16x32 bf16", 2: "32x32x16 bf16", 3: "16x16x128 fp8"}
-MFMA_CYC = {1: 16, 2: 32, 3: 32}          # nominal pipe cycles per instruction
+MFMA_NAME = {0: "-", 1: "16x16x32 bf16", 2: "32x32x16 bf16", 3: "16x16x128 fp8", 4: "32x32x64 fp8"}
+MFMA_CYC = {1: 16, 2: 32, 3: 32, 4: 64}          # nominal pipe cycles per instruction
 
 VALU = {
     "fma": "v_fma_f32 %[t{j}], %[t{j}], %[c], %[c]",
@@ -156,6 +157,8 @@ def main():
         add(0, 4, op, new=True)
         add(1, 2, op, new=True)
         add(2, 5, op, new=True)
+    for k in (0, 8, 10, 12, 13, 14, 16):
+        add(4, k, new=True)
     for op in ("pkfma", "fma"):          # 4 or 8 MFMAs back to back, then their VALU
         for cl in (4, 8, 16):
             add(1, 2, op, cl=cl, new=True)

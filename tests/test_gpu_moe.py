@@ -254,6 +254,19 @@ def test_fp8_w8a8_prefill_kernel_fp16_and_swigluoai(dtype, act):
     out_sep = _run_decode(eng, a, tw, ids)
     assert np.array_equal(out, out_sep)
     eng.engine.set_tuning(fuseq=0)
+    if act == 0:
+        # ... also where rows of the intermediate hold NaN / Inf / nothing but zeros (the quantiser's maximum drops NaN, its
+        # clamp turns a NaN quotient into -448: whatever the separate pass makes of such a row, the epilogue makes the same)
+        a_bad = a.clone()
+        a_bad[3, 5] = float("nan")
+        a_bad[40, :] = float("inf")
+        a_bad[41, 7] = float("-inf")
+        a_bad[100:110, :] = 0
+        o_f = _run_decode(eng, a_bad, tw, ids)
+        eng.engine.set_tuning(fuseq=-1)
+        o_s = _run_decode(eng, a_bad, tw, ids)
+        eng.engine.set_tuning(fuseq=0)
+        assert np.array_equal(o_f, o_s, equal_nan=True)
     # gpu_prefill: the same rows in the activation dtype, 2600 tokens in chunks of 2048 + 552
     pre = eng.prefill(a.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV))
     assert pre.dtype == dtype

@@ -20,19 +20,27 @@ def test_generated_code_keeps_the_fixed_register_map(tmp_path):
     if not Path(hipcc).exists():
         pytest.skip("hipcc not available")
     sys.path.insert(0, str(ROOT))
+    from concurrent.futures import ThreadPoolExecutor
     from lvllm_amd import build
-    asm = tmp_path / "gemm_tiled_fp8a8_bf16.s"
     flags = [f for f in build.FLAGS if f != "-fPIC"]
-    r = subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", "-o", str(asm),
-                        str(ROOT / "lvllm_amd" / "csrc" / "gemm_tiled_fp8a8_bf16.hip")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    s = subprocess.run([sys.executable, str(ROOT / "tools" / "scan_a8w_codegen.py"), str(asm)], capture_output=True, text=True)
-    assert s.returncode == 0, s.stdout[-4000:] + s.stderr[-2000:]
-    assert "3 kernels, 0 violations" in s.stdout, s.stdout[-2000:]
-    # the three instantiations (gated GEMM1, plain GEMM1, GEMM2) use no scratch and the whole register file
-    text = asm.read_text(errors="ignore")
-    names = re.findall(r"^(_ZN3lkm23gemm_prefill_a8w_kernel\S*):", text, flags=re.M)
-    assert len(names) == 3
-    for n in names:
-        m = re.search(re.escape(n) + r":.*?; ScratchSize: (\d+)", text, flags=re.S)
-        assert m and m.group(1) == "0", (n, m and m.group(1))
+
+    def compile_tu(name):
+        asm = tmp_path / f"{name}.s"
+        r = subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", "-o", str(asm),
+                            str(ROOT / "lvllm_amd" / "csrc" / f"{name}.hip")], capture_output=True, text=True)
+        return name, asm, r
+    # both activation dtypes (their own translation units), compiled side by side
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        built = list(ex.map(compile_tu, ["gemm_tiled_fp8a8_bf16", "gemm_tiled_fp8a8_f16"]))
+    for name, asm, r in built:
+        assert r.returncode == 0, r.stderr[-2000:]
+        s = subprocess.run([sys.executable, str(ROOT / "tools" / "scan_a8w_codegen.py"), str(asm)], capture_output=True, text=True)
+        assert s.returncode == 0, name + "\n" + s.stdout[-4000:] + s.stderr[-2000:]
+        assert "3 kernels, 0 violations" in s.stdout, name + "\n" + s.stdout[-2000:]
+        # the three instantiations (gated GEMM1, plain GEMM1, GEMM2) use no scratch and the whole register file
+        text = asm.read_text(errors="ignore")
+        names = re.findall(r"^(_ZN3lkm23gemm_prefill_a8w_kernel\S*):", text, flags=re.M)
+        assert len(names) == 3
+        for n in names:
+            m = re.search(re.escape(n) + r":.*?; ScratchSize: (\d+)", text, flags=re.S)
+            assert m and m.group(1) == "0", (n, m and m.group(1))

@@ -865,7 +865,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     // The gated GEMM1 of the fp8 prefill kernel quantises its own output (the 1 x 128 groups of the W8A8 intermediate:
     // one item = 256 rows x one group) where every 128-column group is whole: no 16-bit intermediate, no quantiser launch.
     // Tuning key "fuseq" = -1 keeps the separate pass (same bytes: tests/test_gpu_moe.py).
-    const bool fuse_q = h->a8 && h->gated && !direct && pl.t1.tiled == 256 && pl.t1.pf == 9 && h->I % 128 == 0 && h->ld_act % 8 == 0 &&
+    const bool fuse_q = h->a8 && h->gated && !direct && pl.t1.tiled == 256 && pl.t1.pf == 9 && !pl.s1.tb && !pl.split_rows &&      // (every row of the intermediate comes from that kernel)
+                         h->I % 128 == 0 && h->ld_act % 8 == 0 &&
                         h->cfg.activation_type != LKM_ACT_SWIGLUOAI && h->t_fuseq >= 0 && !(h->t_dbg & 0x3fb);
     if (fuse_q) {
         p1.out_q = (unsigned char*)a->aq;

@@ -24,6 +24,11 @@
 //     their own A slot and B operands prefetched before the barrier), it only gates the DMA issue;
 //   * the accumulator update acc += (ws * xs) * partial of block b runs between the MFMAs of block b + 1, plain
 //     v_fmac_f32 (packed fp32 next to MFMAs is slower on this chip);
+//   * the epilogue stores 16 bytes per lane: two lanes 16 apart exchange their 8-byte pieces of two tiles (GEMM2) or two
+//     token blocks (gated GEMM1) with v_permlane16_swap_b32 (a8w_pair16) -- half the store instructions, 64 contiguous
+//     bytes per row -- and the gated GEMM1 quantises its own output where the host asks for it (GemmParams::out_q: an item
+//     is 256 rows x exactly one 1 x 128 group of the W8A8 intermediate; row maxima through ds_max_u32, one barrier per
+//     half item, the quantiser's own arithmetic: bit-identical to the separate pass, tests/test_gpu_moe.py);
 //   * ragged experts: the sort cuts an expert's rows into EQUAL tiles in 32-row steps (dispatch.hip, tile_gran), the
 //     kernel runs exactly the 32-row pairs that hold rows (GLM-4.5-Air: 512 +- 22 rows = 3 x 176 instead of
 //     256 + 256 + a 64-row stub that still streams every weight byte).

@@ -59,10 +59,49 @@ def body(mf, k, op, cl=1):
     return "\\n\\t".join(lines)
 
 
+def quantum_body(layout, gated=True, quanta=8):
+    """One K unit's worth of the fp8 prefill kernel's block stream, per QUANTUM = 32 tokens x 32 weight rows x 128 k
+    (128 matrix-pipe cycles either way).  layout 16: today's blocks -- per 16-token block 2 B-operand reads + 1 scale read,
+    the scale products, 2 MFMAs 16x16x128 with the previous block's 2 x 4 accumulator updates between them, one lgkmcnt
+    wait; layout 32: one 32-token block -- 4 B-operand reads + 1 scale read, the scale products, 2 chained MFMAs 32x32x64
+    with the previous block's 16 accumulator updates between / behind them, one wait.  (The updates read registers that
+    no MFMA of the stream writes: issue cost only, as in the kernel, where they read the PREVIOUS block's results.)"""
+    L = []
+    j = 0
+    def valu(n):
+        nonlocal j
+        for _ in range(n):
+            L.append(VALU["fma"].format(j=j % 8, q=j % 4))
+            j += 1
+    for _ in range(quanta):
+        if layout == 16:
+            for blk in range(2):
+                L.append("ds_read_b128 %[acc2], %[la] offset:" + str(blk * 2048))
+                L.append("ds_read_b128 %[acc3], %[la] offset:" + str(blk * 2048 + 1024))
+                L.append("ds_read_b32 %[t7], %[la] offset:8192")
+                valu(2 if gated else 1)
+                L.append(MFMA[3].format(a=0))
+                valu(4)
+                L.append(MFMA[3].format(a=1))
+                valu(4)
+                L.append("s_waitcnt lgkmcnt(0)")
+        else:
+            for k in range(4):
+                L.append("ds_read_b128 %[acc" + str(k) + "], %[la] offset:" + str(k * 1024))
+            L.append("ds_read_b32 %[t7], %[la] offset:8192")
+            valu(2 if gated else 1)
+            L.append("v_mfma_f32_32x32x64_f8f6f4 %[big0], %[A8], %[B8], 0")
+            valu(8)
+            L.append("v_mfma_f32_32x32x64_f8f6f4 %[big0], %[A8], %[B8], %[big0]")
+            valu(8)
+            L.append("s_waitcnt lgkmcnt(0)")
+    return "\\n\\t".join(L)
+
+
 OPERANDS = """: [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [acc3] "+v"(acc[3]), [big0] "+v"(big[0]), [big1] "+v"(big[1]),
               [t0] "+v"(t[0]), [t1] "+v"(t[1]), [t2] "+v"(t[2]), [t3] "+v"(t[3]), [t4] "+v"(t[4]), [t5] "+v"(t[5]), [t6] "+v"(t[6]), [t7] "+v"(t[7]),
               [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3])
-            : [A4] "v"(a4), [B4] "v"(b4), [A8] "v"(a8), [B8] "v"(b8), [c] "v"(c), [pc] "v"(pc)"""
+            : [A4] "v"(a4), [B4] "v"(b4), [A8] "v"(a8), [B8] "v"(b8), [c] "v"(c), [pc] "v"(pc), [la] "v"(la)"""
 
 HEAD = r"""
 #include <hip/hip_runtime.h>
@@ -84,6 +123,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     for (int i = 0; i < 8; ++i) t[i] = in[256 + lane][i & 3] + i; \
     for (int i = 0; i < 4; ++i) p[i] = u32x2{in[320 + lane][i], in[320 + lane][(i + 1) & 3]}; \
     unsigned c = in[384 + lane].x; u32x2 pc = u32x2{in[384 + lane].y, in[384 + lane].z}; \
+    __shared__ u32x4 ldsbuf[640]; \
+    ldsbuf[threadIdx.x & 511] = in[lane]; ldsbuf[512 + (threadIdx.x & 127)] = in[64 + lane]; \
+    const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ldsbuf + lane * 16; \
     __syncthreads(); \
     const long long t0 = __builtin_readcyclecounter();
 #define EPILOGUE \
@@ -105,6 +147,19 @@ __global__ __launch_bounds__(1024) void {name}(const u32x4* __restrict__ in, flo
     for (int it = 0; it < iters; ++it) {{
         asm volatile("{body(mf, k, op, cl)}"
             {OPERANDS});
+    }}
+    EPILOGUE
+}}
+"""
+
+
+def custom_kernel(name, body_text):
+    return f"""
+__global__ __launch_bounds__(1024) void {name}(const u32x4* __restrict__ in, float* __restrict__ out, long long* __restrict__ cyc, int iters) {{
+    PROLOGUE
+    for (int it = 0; it < iters; ++it) {{
+        asm volatile("{body_text}"
+            {OPERANDS} : "memory");
     }}
     EPILOGUE
 }}
@@ -166,6 +221,12 @@ def main():
     src = [HEAD]
     for name, mf, k, op, split, cl in cases:
         src.append(split_kernel(name, mf, k, op) if split else kernel(name, mf, k, op, cl))
+    customs = [("q16g", "block stream, 16-token blocks (today), gated: 4 MFMA 16x16x128 + 20 VALU + 6 ds_read per quantum", quantum_body(16, True)),
+               ("q16p", "block stream, 16-token blocks (today), one scale: 4 MFMA 16x16x128 + 18 VALU + 6 ds_read per quantum", quantum_body(16, False)),
+               ("q32g", "block stream, 32-token blocks, gated: 2 MFMA 32x32x64 + 18 VALU + 5 ds_read per quantum", quantum_body(32, True)),
+               ("q32p", "block stream, 32-token blocks, one scale: 2 MFMA 32x32x64 + 17 VALU + 5 ds_read per quantum", quantum_body(32, False))]
+    for name, what, body_text in customs:
+        src.append(custom_kernel("k_" + name, body_text))
     src.append(r"""
 struct Case { const char* what; void (*fn)(const u32x4*, float*, long long*, int); int mf, k, split; };
 int main() {
@@ -174,6 +235,8 @@ int main() {
     CK(hipMemset(in, 0x3c, 448 * 16));
     const Case cases[] = {
 """)
+    for name, what, body_text in customs:
+        src.append(f'        {{"{what}", k_{name}, -1, 0, 0}},\n')
     for name, mf, k, op, split, cl in cases:
         what = (f"split: wave A {MFMA_NAME[mf]} only | wave B {k} {op} per group" if split
                 else f"{MFMA_NAME[mf]:14s} + {k:2d} {op}" + (f" (clusters of {cl} MFMAs)" if cl > 1 else ""))
@@ -192,7 +255,7 @@ int main() {
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
             long long c[16]; CK(hipMemcpy(c, cyc, sizeof(c), hipMemcpyDeviceToHost));
-            const double n = (double)iters * groups;
+            const double n = (double)iters * (cs.mf < 0 ? 8 : groups);      // (block streams: 8 quanta per asm block)
             // per SIMD: wps waves each ran n groups (split: one wave the MFMAs, one the VALU of n groups)
             const double ns_group = ms * 1e6 / n / (cs.split ? 1 : wps);
             printf("%%-62s %%d waves/SIMD  %%7.2f ns per group per SIMD   wave0 %%6.1f  last wave %%6.1f ticks/group\n", cs.what, wps, ns_group,

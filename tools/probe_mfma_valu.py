@@ -6,9 +6,13 @@ hipcc and runs it on the GPU of the box:
   * MFMA only / VALU only / one MFMA followed by K VALU instructions, for the 16x16x32 bf16, 32x32x16 bf16 and
     16x16x128 f8f6f4 MFMAs and for the VALU instructions the 4-bit decoders and the fp8 prefill kernel are made of;
   * one to three waves per SIMD running the same stream;
-  * two waves per SIMD with the roles split: one wave only MFMAs, its partner only VALU.
+  * two waves per SIMD with the roles split: one wave only MFMAs, its partner only VALU;
+  * clusters of MFMAs followed by their VALU instead of the interleave;
+  * the fp8 prefill kernel's block stream (gemm_prefill_a8w.h: LDS reads, scale products, MFMAs, accumulator updates, the
+    lgkmcnt wait) per quantum of 32 tokens x 32 weight rows x 128 k, in today's 16-token layout (16x16x128 MFMAs) and in a
+    32-token layout on the 32x32x64 MFMA (quantum_body).
 Output: ns per group (one MFMA + K VALU) per SIMD, and the same in cycles at the clock the MFMA-only stream implies.
-  python tools/probe_mfma_valu.py [out.log]
+  python tools/probe_mfma_valu.py [out.log] [--quick] [--build-only]
 """
 import subprocess
 import sys

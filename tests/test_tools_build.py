@@ -26,7 +26,7 @@ def test_instruction_stream_probe_builds():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("src", ["probe_int4_unit.hip", "probe_mfma_issue.hip"])
+@pytest.mark.parametrize("src", ["probe_int4_unit.hip", "probe_mfma_issue.hip", "probe_mfma_layout.hip"])
 def test_kernel_probes_build(src, tmp_path):
     if not (ROOT / "tools" / src).exists():
         pytest.skip(f"{src} not in this tree")

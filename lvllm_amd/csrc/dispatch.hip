@@ -325,6 +325,11 @@ __global__ __launch_bounds__(kChunk) void sort_hist_kernel(const SlotIds ids, in
     for (int e = threadIdx.x; e < E; e += kChunk) hist[(size_t)blockIdx.x * E + e] = smem[e];
 }
 
+// (Launch order, ADVICE r3: the heaviest-expert-first order of `active` / the tile list exists in the single-workgroup sort
+// only -- decode batches, where one hot expert's workgroups set the tail of a 100-us launch.  This multi-workgroup path
+// (> 4096 slots: prefill chunks) emits expert-ascending lists on purpose: its consumers are the 128/256-row tile kernels,
+// whose grids run many rounds, and the fp8 prefill kernel, which re-orders the tiles into its own item list
+// (build_items_kernel).  Results do not depend on either order.)
 __global__ __launch_bounds__(1024) void sort_scan_kernel(int n_chunks, int E, int32_t* __restrict__ hist,
                                                         int32_t* __restrict__ counts,
                                                         int32_t* __restrict__ offsets,

@@ -22,6 +22,19 @@ int launch_gemm2_tiled_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParam
 int launch_gemm1_tiled_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
 int launch_gemm2_tiled_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 
+// round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h: cfg.pf == 5; gemm_w4e.h, loader wave: cfg.pf == 6);
+// false = not taken (shape / variant)
+#define LKM_DECL_W4X(SUFFIX) bool launch_w4x_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, bool, bool, int, int*);
+LKM_DECL_W4X(int4_bf16) LKM_DECL_W4X(int4_f16)
+#undef LKM_DECL_W4X
+static bool launch_w4x(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
+                       int max_tiles, int* rc) {
+    if (cfg.pf != 5 && cfg.pf != 6) return false;
+    if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_w4x_int4_bf16(st, cfg, p, gated, is_g1, max_tiles, rc);
+    if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_w4x_int4_f16(st, cfg, p, gated, is_g1, max_tiles, rc);
+    return false;
+}
+
 int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                  bool gated, int max_active) {
     if (max_active <= 0 || p.groups <= 0) return LKM_OK;
@@ -87,6 +100,10 @@ int launch_gemm2_direct(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, c
 int launch_gemm1_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                        bool gated, int max_tiles) {
     if (max_tiles <= 0) return LKM_OK;
+    {
+        int rc = LKM_OK;
+        if (launch_w4x(st, wf, adt, cfg, p, gated, true, max_tiles, &rc)) return rc;
+    }
     if (wf == LKM_W_BF16 && adt == LKM_DT_BF16) return launch_gemm1_tiled_bf16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_F16 && adt == LKM_DT_F16) return launch_gemm1_tiled_f16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_gemm1_tiled_int4_bf16(st, cfg, p, gated, max_tiles);
@@ -108,6 +125,10 @@ int launch_gemm1_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, co
 int launch_gemm2_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                        int max_tiles) {
     if (max_tiles <= 0) return LKM_OK;
+    {
+        int rc = LKM_OK;
+        if (launch_w4x(st, wf, adt, cfg, p, false, false, max_tiles, &rc)) return rc;
+    }
     if (wf == LKM_W_BF16 && adt == LKM_DT_BF16) return launch_gemm2_tiled_bf16(st, cfg, p, max_tiles);
     if (wf == LKM_W_F16 && adt == LKM_DT_F16) return launch_gemm2_tiled_f16(st, cfg, p, max_tiles);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_gemm2_tiled_int4_bf16(st, cfg, p, max_tiles);

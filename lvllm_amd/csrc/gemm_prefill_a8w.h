@@ -971,8 +971,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
 // usable when K is a whole number of 128-byte units, every 16-row weight tile has ONE block scale per K unit (groupN a
 // multiple of 16), the weight image is tile-major or unit-major with 32-bit offsets, and the operand matrices fit the
 // 2 GiB buffer windows; otherwise the plan stays on gemm_tiled_kernel (pick_cfg asks prefill_a8w_shape_ok first)
-inline bool prefill_a8w_ok(const GemmParams& p) {
-    return p.Kreal % 128 == 0 && p.tile_uniform_scale && p.U >= 8 && p.U <= 64 && (size_t)p.x_rows * (size_t)(p.top_k > 0 ? p.top_k : 1) < ((size_t)1 << 22) &&      // (the item-boundary pipeline; 64 weight-block scales per tile in the landing zone)
+inline bool prefill_a8w_ok(const GemmParams& p, bool is_g1 = true) {
+    // (the slot -> token division through a float reciprocal is exact below 2^22 slots and only GEMM1 divides: its rows are
+    // gathered through sorted_slot; GEMM2 reads the expert-sorted intermediate row by row -- ADVICE r3)
+    const bool slots_ok = !is_g1 || (size_t)p.x_rows * (size_t)(p.top_k > 0 ? p.top_k : 1) < ((size_t)1 << 22);
+    return p.Kreal % 128 == 0 && p.tile_uniform_scale && p.U >= 8 && p.U <= 64 && slots_ok &&      // (the item-boundary pipeline; 64 weight-block scales per tile in the landing zone)
            (size_t)p.x_rows * (size_t)p.ldx < (size_t)0x7fffffff &&
            (size_t)p.x_rows * (size_t)p.ld_xscale * 4 < (size_t)0x7fffffff &&
            (size_t)p.T_half * p.halves * p.U * 2048 < (size_t)0x7fffffff;
@@ -1007,8 +1010,8 @@ static bool launch_prefill_a8w_if(hipStream_t st, const LaunchCfg& cfg, const Ge
                                   int max_tiles, int* rc, ADTC) {
     constexpr int ADT = ADTC::v;
     if (cfg.tiled != 256 || cfg.pf != 9) return false;
-    if (!prefill_a8w_ok(p)) {
-        set_error("fp8 W8A8 prefill kernel: shape not eligible (K %% 128, scale granularity or 2 GiB windows)");
+    if (!prefill_a8w_ok(p, is_g1)) {
+        set_error("fp8 W8A8 prefill kernel: shape not eligible (K %% 128, scale granularity, 2^22 slots or 2 GiB windows)");
         *rc = LKM_E_INVALID;
         return true;
     }

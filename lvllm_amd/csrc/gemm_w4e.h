@@ -1,0 +1,334 @@
+// gemm_w4e.h -- gemm_w4x.h's math (32x32x16 MFMA, a lane decodes one weight row of a 4-bit format) with a LOADER wave:
+// tuning key "pf" = 6.
+//
+// Measured on gemm_w4x_kernel (profiles/r04_w4x_ablations.log; Mixtral int4 M=128 GEMM1, 140-156 us by box): the data
+// movement alone -- weights + scales + token staging + fragment reads, no decode, no MFMA -- takes 111 us (one K unit of
+// prefetch x 12 waves = 24 KiB in flight per CU against ~1.4 us of loaded latency), the arithmetic alone 96 us, and the two
+// overlap by a quarter.  A wave that also computes has no registers for a deeper ring.  Here wave 0 of a workgroup ONLY moves
+// data: weights, scales and token rows of K unit u+S-1 go to an S-deep LDS ring by LDS-DMA (no register per byte in flight;
+// 1-2 slots = 24-48 KiB in flight per workgroup, two workgroups per CU), and the NC consumer waves never touch global
+// memory inside the K loop: they read their two 1-KiB weight pieces, their scale and the token fragments from the slot,
+// decode and multiply.  One s_barrier per unit means "slot u has landed and everybody is done with slot u-1":
+//   loader, unit u:   s_waitcnt vmcnt(slots that may stay in flight x IPU) -> barrier -> DMA of unit u+S-1 (stage of u-1)
+//   consumer, unit u: barrier -> ds_read (weights, scale, token fragments) -> decode -> MFMA
+// LDS slot: [TM token rows x 256 B; the 16-byte slots XOR-swizzled on the SOURCE side, the LDS image is lane-linear]
+//           [NC x (lo tile 1 KiB, hi tile 1 KiB), lane-linear as in HBM][NC x 2 x aux bytes of the (tile, unit), dense].
+// The loader's waits are counted (vector memory retires in order): every slot is exactly IPU DMA instructions, so IPU is a
+// template parameter of the K loop and no other vector-memory instruction exists in the loader's loop.
+#pragma once
+#include "gemm_w4x.h"
+
+namespace lkm {
+
+template <int N>
+__device__ __forceinline__ void w4e_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WF, int ADT, int CB, int NC, bool GATED, bool IS_G1, int S, int DECV>
+__global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef Dec<WF, ADT> D;
+    typedef __attribute__((address_space(3))) void* LdsPtr;
+    static_assert(D::LOADS == 1 && D::UNITK == 128 && !D::A8 && !D::XS && !D::UNIT_SCALE, "4-bit formats decoded per row");
+    static_assert(S >= 3, "ring: the slot being read, the slot in flight, the slot being refilled");
+    constexpr int TM = 32 * CB, ROWB = 256;
+    constexpr int XBYTES = TM * ROWB, WBYTES = NC * 2048;
+    constexpr int AUXMAX = 128;                                  // scale bytes per (tile, unit): int4 32*spu, MXFP4 64, NVFP4 128
+    constexpr int WOFF = XBYTES, AOFF = XBYTES + WBYTES, STAGE = AOFF + NC * 2 * AUXMAX;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int ti = blockIdx.y, bx = blockIdx.x;
+    if (ti >= p.meta[3]) return;
+    const int e = p.tile_e[ti], r0 = p.tile_r0[ti];
+    const int m_e = p.counts[e], off_e = p.offsets[e];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0 = loader, 1..NC = consumers
+    const bool pairs = IS_G1 && GATED;                          // gate tile + its up tile; else two consecutive tiles
+    const int T_all = p.T_half * p.halves;
+    const int sk = IS_G1 ? 0 : blockIdx.z;
+    const int u0 = IS_G1 ? 0 : (int)((long long)sk * p.U / p.SK);
+    const int U = IS_G1 ? p.U : (int)((long long)(sk + 1) * p.U / p.SK) - u0;
+    const int k_base = u0 * 128;
+    const int auxB = D::aux_step(p.spu), adw = auxB / 4;         // scale bytes / dwords per (tile, unit)
+    const int rows_here = m_e - r0 < TM ? m_e - r0 : TM;
+    const bool two_blocks = CB == 2 && rows_here > 32;           // 32-token column blocks that hold rows (workgroup-uniform)
+
+    if (wave == 0) {
+        // ================================================================== loader
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)p.w + (size_t)e * p.w_estride * 16), 0, (int)0xffffffffu, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)D::aux_ptr(p.s, (size_t)e * T_all * p.U, 0, p.spu), 0, (int)0xffffffffu, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((const char*)p.x + (size_t)k_base * 2), 0, (int)0xffffffffu, 0x00020000);
+        auto tile_of = [&](int c, int t2) __attribute__((always_inline)) {
+            const int grp = bx * NC + c;
+            const bool on = (pairs ? grp : 2 * grp) < p.T_half;   // a consumer past the padded tile count streams tile 0
+            return on ? (pairs ? (t2 ? p.T_half + grp : grp) : 2 * grp + t2) : 0;
+        };
+        // weights: (consumer c, tile t2) -> one lane-linear 1-KiB DMA
+        int woff[NC][2];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+                woff[c][t2] = __builtin_amdgcn_readfirstlane((int)((tile_of(c, t2) * p.w_tstride + (long long)u0 * p.w_ustride) * 16));
+        const int wstep = (int)(p.w_ustride * 16);
+        // scales: dword dw = (c*2 + t2) * adw + w of the slot's dense aux area; instruction k moves dwords k*64 .. k*64+63,
+        // the lanes past the last dword of the last instruction are masked off
+        constexpr int AIMAX = (NC * 2 * AUXMAX / 4 + 63) / 64;
+        const int n_adw = NC * 2 * adw;
+        int av[AIMAX];
+#pragma unroll
+        for (int k = 0; k < AIMAX; ++k) {
+            const int dw = (k * 64 + lane) % n_adw;
+            const int ct = dw / adw, w = dw % adw;
+            av[k] = (int)(((long long)tile_of(ct >> 1, ct & 1) * p.U + u0) * auxB) + w * 4;
+        }
+        // tokens: instruction d moves rows d*4 .. d*4+3 (lane L: row d*4 + L/16, physical slot L%16 = logical ^ (row%16))
+        constexpr int XI = TM / 4;
+        int xv[XI];
+#pragma unroll
+        for (int d = 0; d < XI; ++d) {
+            const int row = d * 4 + (lane >> 4), pslot = lane & 15;
+            const int lslot = pslot ^ (row & 15);
+            const int r = r0 + row;
+            const int rr = r < m_e ? r : r0;
+            const int src = IS_G1 ? p.sorted_slot[off_e + rr] / p.top_k : off_e + rr;
+            xv[d] = (int)((unsigned)src * (unsigned)p.ldx * 2u + (unsigned)lslot * 16u);
+        }
+        auto run_loader = [&](auto CBC, auto AIC) __attribute__((always_inline)) {
+            constexpr int CBR = decltype(CBC)::v, AIR = decltype(AIC)::v;
+            constexpr int XIR = CBR * 8;
+            constexpr int IPU = XIR + 2 * NC + AIR;              // DMA instructions per slot: the counted waits rely on it
+            static_assert((S - 2) * IPU < 64, "vmcnt range");      // (launch_w4e_if refuses the variants that would not fit)
+            auto dma = [&](int u) __attribute__((always_inline)) {
+                char* base = lds + (u % S) * STAGE;
+#pragma unroll
+                for (int d = 0; d < XIR; ++d)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LdsPtr)(base + d * 1024), 16, xv[d], u * ROWB, 0, 0);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + WOFF + (c * 2 + t2) * 1024), 16, lane * 16,
+                                                                 woff[c][t2] + u * wstep, 0, 2);
+#pragma unroll
+                for (int k = 0; k < AIR; ++k)
+                    if (k * 64 + lane < n_adw)      // (partial exec on the last instruction; every instruction has >= 1 lane)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (LdsPtr)(base + AOFF + k * 256), 4, av[k], u * auxB, 0, 0);
+            };
+#pragma unroll
+            for (int s = 0; s < S - 1; ++s)
+                if (s < U) dma(s);
+            for (int u = 0; u < U; ++u) {
+                const int younger = U - 1 - u;                    // slots issued after slot u
+                if (younger >= S - 2) w4e_wait_vmcnt<(S - 2) * IPU>();
+                else if (S > 3 && younger == 1) w4e_wait_vmcnt<IPU>();
+                else w4e_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + S - 1 < U) dma(u + S - 1);
+            }
+            w4e_wait_vmcnt<0>();
+        };
+        static_assert(S <= 4, "the tail waits above cover S = 3, 4");
+        const int air = (n_adw + 63) / 64;          // instructions that carry at least one dword (the waits count exactly these)
+        auto run_l = [&](auto CBC) __attribute__((always_inline)) {
+            bool done = false;
+            static_for<AIMAX>([&](auto KC) __attribute__((always_inline)) {
+                constexpr int k = decltype(KC)::v + 1;
+                // (scale dwords per (tile, unit) are 8, 16 or 32 for every format: only those instruction counts exist)
+                constexpr bool possible = k == (NC * 16 + 63) / 64 || k == (NC * 32 + 63) / 64 || k == (NC * 64 + 63) / 64;
+                if constexpr (possible && (S - 2) * (CB * 8 + 2 * NC + k) < 64) {
+                    if (!done && air == k) {
+                        done = true;
+                        run_loader(CBC, IC<k>{});
+                    }
+                }
+            });
+        };
+        if constexpr (CB == 2) {
+            if (two_blocks) run_l(IC<2>{});
+            else run_l(IC<1>{});
+        } else {
+            run_l(IC<1>{});
+        }
+        return;
+    }
+
+    // ====================================================================== consumers
+    const int cw = wave - 1;                                     // consumer index = 32-row group inside the workgroup
+    const int j = lane & 31, h = lane >> 5, i16 = lane & 15, sel = (lane >> 4) & 1;
+    const int grp = bx * NC + cw;
+    const bool wave_on = (pairs ? grp : 2 * grp) < p.T_half;
+    const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
+    // weight pieces of lane (tile sel, row i16, half h): old lanes (2h + q, i16) of the tile's 1-KiB block
+    const int wlds = WOFF + (cw * 2 + sel) * 1024 + ((2 * h) * 16 + i16) * 16;
+    // this lane's scales inside the (tile, unit) block: what Dec<>::aux_ptr adds for lane and spu
+    const int alds = AOFF + (cw * 2 + sel) * auxB + (int)(size_t)D::aux_ptr((const void*)0, 0, lane, p.spu);
+    int baddr[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) baddr[s][q] = j * ROWB + (((s * 4 + 2 * h + q) ^ (j & 15)) * 16);
+
+    f32x16 acc[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+    auto run_c = [&](auto CBC, auto HC) __attribute__((always_inline)) {
+        constexpr int CBR = decltype(CBC)::v;
+        constexpr bool HOIST = decltype(HC)::v != 0;            // int4, one scale group per unit: multipliers once per unit
+        for (int u = 0; u < U; ++u) {
+            __builtin_amdgcn_s_barrier();
+            if (!wave_on) continue;
+            const char* sb = lds + (u % S) * STAGE;
+            u32x4 w[2][1];
+            w[0][0] = *(const u32x4*)(sb + wlds);
+            w[1][0] = *(const u32x4*)(sb + wlds + 256);
+            typename D::Aux aux;
+            if constexpr (WF == LKM_W_INT4_B8) {
+                // aligned reads of what Dec<>::load_aux_at fetches with one unaligned 8-byte load (spu 1 / 2 / 4 scales)
+                if constexpr (HOIST) aux.raw = u32x2{(unsigned)*(const unsigned short*)(sb + alds), 0u};
+                else if (p.spu == 2) aux.raw = u32x2{*(const unsigned*)(sb + alds), 0u};
+                else aux.raw = *(const u32x2*)(sb + alds);
+            } else {
+                D::load_aux_at(aux, sb + alds);
+            }
+            typename Dec<LKM_W_INT4_B8, ADT>::Mult mu;
+            float s512 = 0.f, m8 = 0.f;
+            if constexpr (HOIST) {
+                mu = Dec<LKM_W_INT4_B8, ADT>::mult(aux, 0, 0);
+                s512 = mu.s512.x;
+                m8 = mu.m8.x;
+            }
+            auto dec = [&](int s_, int q_) __attribute__((always_inline)) {
+                if constexpr (HOIST && DECV == 1) return int4_frag_plain<ADT>(w[q_][0][s_], s512, m8);
+                else if constexpr (HOIST) return D::frag_m(w[q_], s_, mu);
+                else return D::frag(w[q_], aux, s_, dparam);
+            };
+            // (measured, profiles/r04_w4e_schedule_ab.log: issuing all 16 fragment reads of the unit up front and fencing
+            // every k-step so that the MFMAs stay one decode apart -- 146 registers -- runs GEMM1 166 us against 144 for
+            // the compiler's own just-in-time reads below)
+            u32x4 bf[2][2][CBR];                                 // [parity of s][q][column block]
+            auto ldb = [&](int s_) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int c = 0; c < CBR; ++c) bf[s_ & 1][q][c] = *(const u32x4*)(sb + c * 32 * ROWB + baddr[s_][q]);
+            };
+            ldb(0);
+            u32x4 a = dec(0, 0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int s_ = t >> 1, q_ = t & 1;
+                if (q_ == 0 && s_ + 1 < 4) ldb(s_ + 1);
+                u32x4 an = a;
+                if (t + 1 < 8) an = dec((t + 1) >> 1, (t + 1) & 1);
+#pragma unroll
+                for (int c = 0; c < CBR; ++c) acc[c] = Mfma32<ADT>::run(a, bf[s_ & 1][q_][c], acc[c]);
+                a = an;
+            }
+        }
+    };
+    auto run = [&](auto CBC) __attribute__((always_inline)) {
+        if constexpr (WF == LKM_W_INT4_B8) {
+            if (p.spu <= 1) return run_c(CBC, IC<1>{});
+        }
+        run_c(CBC, IC<0>{});
+    };
+    if constexpr (CB == 2) {
+        if (two_blocks) run(IC<2>{});
+        else run(IC<1>{});
+    } else {
+        run(IC<1>{});
+    }
+
+    // epilogue: as gemm_w4x_kernel (D layout of the 32x32 MFMA)
+    if (!wave_on) return;
+    static_for<CB>([&](auto CC) __attribute__((always_inline)) {
+        constexpr int c = decltype(CC)::v;
+        const int r_tok = r0 + c * 32 + j;
+        if (r_tok < m_e) {
+            static_for<2>([&](auto RC) __attribute__((always_inline)) {
+                constexpr int rr = decltype(RC)::v;
+                const f32x4 lo = {acc[c][rr * 4 + 0], acc[c][rr * 4 + 1], acc[c][rr * 4 + 2], acc[c][rr * 4 + 3]};
+                const f32x4 hi = {acc[c][8 + rr * 4 + 0], acc[c][8 + rr * 4 + 1], acc[c][8 + rr * 4 + 2], acc[c][8 + rr * 4 + 3]};
+                const int nsub = rr * 8 + h * 4;
+                if constexpr (IS_G1 && GATED) {
+                    const int n = grp * 16 + nsub;
+                    if (n < p.n_real) store_gemm1_frag<ADT, true>(p, lo, hi, (size_t)(off_e + r_tok), n);
+                } else if constexpr (IS_G1) {
+                    const int n0 = (2 * grp) * 16 + nsub, n1 = n0 + 16;
+                    if (n0 < p.n_real) store_gemm1_frag<ADT, false>(p, lo, lo, (size_t)(off_e + r_tok), n0);
+                    if (n1 < p.n_real) store_gemm1_frag<ADT, false>(p, hi, hi, (size_t)(off_e + r_tok), n1);
+                } else {
+                    const int n0 = (2 * grp) * 16 + nsub, n1 = n0 + 16;
+                    if (n0 < p.n_real) store_gemm2_frag(p, lo, sk, (size_t)(off_e + r_tok), n0);
+                    if (n1 < p.n_real) store_gemm2_frag(p, hi, sk, (size_t)(off_e + r_tok), n1);
+                }
+            });
+        }
+    });
+#else
+    (void)p;
+#endif
+}
+
+template <int WF, int ADT, int CB, int NC, bool GATED, bool IS_G1, int S, int DECV>
+static int launch_w4e_t(hipStream_t st, const GemmParams& p, int max_tiles) {
+    constexpr size_t lds = (size_t)S * (CB * 32 * 256 + NC * 2048 + NC * 2 * 128);
+    const int groups = (IS_G1 && GATED) ? p.T_half : p.T_half / 2;
+    dim3 grid(ceil_div(groups, NC), max_tiles, IS_G1 ? 1 : p.SK), block((NC + 1) * 64);
+    auto kern = gemm_w4e_kernel<WF, ADT, CB, NC, GATED, IS_G1, S, DECV>;
+    if (lds > 64 * 1024) LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, p);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
+// cfg.pf == 6 selects the kernel; cfg.tiled 32 / 64 -> one / two token column blocks; cfg.pd = ring depth S (3 / 4);
+// p.dbg & 1 (int4): the packed-fp32-free decoder
+template <int WF, int ADT>
+static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1, int max_tiles, int* rc) {
+    if (cfg.pf != 6 || (cfg.tiled != 32 && cfg.tiled != 64) || !w4x_ok(p)) return false;
+    // built: four consumer waves, ring depth 3 (7 / 8 / 14 consumers and depth 4 measured and dropped:
+    // profiles/r04_w4e_schedule_ab.log, r04_w4x_batch_sweep.log)
+    const int cb = cfg.tiled / 32, s = 3, nc = 4;
+    const int decv = (WF == LKM_W_INT4_B8 && (p.dbg & 1)) ? 1 : 0;
+    // the loader's counted waits need (S - 2) x (DMA instructions per slot) < 64
+    const int aux_b = WF == LKM_W_INT4_B8 ? 32 * p.spu : (WF == LKM_W_MXFP4 ? 64 : 128);      // = Dec<>::aux_step (device side)
+    const int air = (nc * 2 * aux_b / 4 + 63) / 64;
+    if ((s - 2) * (cb * 8 + 2 * nc + air) >= 64) return false;
+#define LKM_W4E_1(CB_, NC_, G_, IS1_, S_, DV_)                                                      \
+    if (cb == CB_ && nc == NC_ && s == S_ && decv == DV_) {                                          \
+        *rc = launch_w4e_t<WF, ADT, CB_, NC_, G_, IS1_, S_, DV_>(st, p, max_tiles);                  \
+        return true;                                                                                 \
+    }
+#define LKM_W4E_DV(CB_, G_, IS1_, S_)                                                               \
+    LKM_W4E_1(CB_, 4, G_, IS1_, S_, 0)                                                               \
+    if constexpr (WF == LKM_W_INT4_B8) { LKM_W4E_1(CB_, 4, G_, IS1_, S_, 1) }
+#define LKM_W4E_ALL(G_, IS1_) LKM_W4E_DV(1, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 3)
+    if (is_g1 && gated) { LKM_W4E_ALL(true, true) }
+    else if (is_g1) { LKM_W4E_ALL(false, true) }
+    else { LKM_W4E_ALL(false, false) }
+#undef LKM_W4E_ALL
+#undef LKM_W4E_DV
+#undef LKM_W4E_1
+    return false;
+}
+
+// one launcher per (format, dtype) translation unit: "pf" = 6 -> the loader / consumer kernel, 5 -> gemm_w4x_kernel
+#define LKM_DEFINE_W4X_LAUNCHER(SUFFIX, WF, ADT)                                                              \
+    bool launch_w4x_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1, \
+                             int max_tiles, int* rc) {                                                        \
+        if (launch_w4e_if<WF, ADT>(st, cfg, p, gated, is_g1, max_tiles, rc)) return true;                     \
+        return launch_w4x_if<WF, ADT>(st, cfg, p, gated, is_g1, max_tiles, rc);                               \
+    }
+
+}  // namespace lkm

@@ -557,7 +557,8 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // 256 x 256 tiles, one v_mfma_scale_f32_16x16x128_f8f6f4 per 128-k block) where the shape qualifies
             // (the kernels address tokens, token scales and an expert's weights through 2 GiB buffer windows; a chunk
             // that does not fit them keeps the 128-row tiles instead of failing the step: prefill_a8w_ok)
-            const bool win_ok = (size_t)M * (size_t)h->H < (size_t)0x7fffffff &&
+            const bool win_ok = n_slots < ((size_t)1 << 22) &&            // (prefill_a8w_ok: GEMM1's slot -> token division)
+                                (size_t)M * (size_t)h->H < (size_t)0x7fffffff &&
                                 n_slots * (size_t)h->ld_act < (size_t)0x7fffffff &&
                                 (size_t)h->T1_half * (h->gated ? 2 : 1) * h->U1 * 2048 < (size_t)0x7fffffff &&
                                 (size_t)h->T2 * h->U2 * 2048 < (size_t)0x7fffffff;
@@ -657,6 +658,10 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         if (wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && waves == 4 && !split && h->t_pf == 4 &&
             h->H % 128 == 0 && h->I % 128 == 0)
             pf = 4;
+        // round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h), "pf" = 5
+        const bool w4x = wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && !split && (h->t_pf == 5 || h->t_pf == 6) &&
+                         h->H % 128 == 0 && h->I % 128 == 0;
+        if (w4x) pf = h->t_pf;                  // (6: with a loader wave per workgroup, gemm_w4e.h; "pd" = ring depth 3 / 4)
         if (tiled == 256 && h->a8) {          // the fp8 x fp8 prefill kernels are the only 256-row variants of the format
             // 9 = round 3 (gemm_prefill_a8w.h: weights straight to registers, tokens through a 4-stage LDS ring, equal
             // token tiles); 8 = round 2 (gemm_prefill_a8.h: both operands through two LDS buffers), kept behind "pf" = 8
@@ -676,8 +681,9 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // tile -- Mixtral EP=8: 64 of them; slabs are summed by combine_kernel.  Not with the hybrid plan
         // (the skinny GEMM2 shares the slab layout and runs sk = 1 there) nor with the prefill kernel.
         int sk2 = 1;
-        if (!split && !pf) {
-            const long long wg = (long long)n_act * ((avg_rows + tiled - 1) / tiled) * ((h->T2 + waves * nt2 - 1) / (waves * nt2));
+        if (!split && (!pf || pf == 5 || pf == 6)) {
+            const int tpw = pf >= 5 ? 2 : nt2;     // weight tiles per wave
+            const long long wg = (long long)n_act * ((avg_rows + tiled - 1) / tiled) * ((h->T2 + waves * tpw - 1) / (waves * tpw));
             // 4-bit weights: a workgroup's K loop is latency-bound, so more and shorter ones pay up to 4 slabs
             // (Mixtral M=128, 512 workgroups at sk 1: GEMM2 int4 107 -> 95 us, NVFP4 100 -> 86, MXFP4 88 -> 75);
             // 16-bit and fp8 lose with any split once the grid covers the chip (bf16 154 -> 163, fp8 90 -> 95)

@@ -63,15 +63,26 @@ LocalCompute = Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.dtype],
 Transport = Callable[[torch.Tensor, torch.Tensor], None]
 
 
-# Exchange buffers: ONE grow-only pool per (device, group), shared by every layer's ExpertParallelExperts -- the layers
-# of a model run one after the other on a stream, so they can exchange through the same memory; a pool that was handed
-# out stays alive (captured graphs replay on its addresses), a larger request allocates a new one.
+# Exchange buffers: ONE grow-only pool per (device, group, pool tag), shared by every layer's ExpertParallelExperts with
+# that tag -- the layers of a model run one after the other on a stream, so they can exchange through the same memory; a
+# pool that was handed out stays alive (captured graphs replay on its addresses), a larger request allocates a new one.
+# Two micro-batches in flight (overlapped layers / dual-batch overlap on two streams) need two pools: give their
+# ExpertParallelExperts different `pool_tag`s.  A pool remembers whether a dispatch is waiting for its combine and refuses a
+# second dispatch until then (the guard used to be per instance while the memory is per pool).
 _POOLS: dict = {}
 _RETIRED: list = []
+_POOL_GROUPS: dict = {}      # id(group) -> group: pins the object, so the id in a pool key cannot be reused by a new group
+_IN_FLIGHT: dict = {}        # (device, id(group), tag) -> description of the dispatch that has not been combined yet
 
 
-def _pool(dev, group, name: str, nbytes: int) -> torch.Tensor:
-    key = (str(dev), id(group), name)
+def _pool_key(dev, group, tag: str) -> tuple:
+    if group is not None:
+        _POOL_GROUPS[id(group)] = group
+    return (str(dev), id(group), tag)
+
+
+def _pool(dev, group, name: str, nbytes: int, tag: str = "") -> torch.Tensor:
+    key = _pool_key(dev, group, tag) + (name,)
     t = _POOLS.get(key)
     if t is None or t.numel() < nbytes:
         if t is not None:
@@ -80,6 +91,16 @@ def _pool(dev, group, name: str, nbytes: int) -> torch.Tensor:
         t = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
         _POOLS[key] = t
     return t
+
+
+def release_group_exchange_buffers(group) -> None:
+    """forget every pool of a process group that is being destroyed (its id may then be reused)"""
+    gid = id(group)
+    for k in [k for k in _POOLS if k[1] == gid]:
+        del _POOLS[k]
+    for k in [k for k in _IN_FLIGHT if k[1] == gid]:
+        del _IN_FLIGHT[k]
+    _POOL_GROUPS.pop(gid, None)
 
 
 def release_retired_exchange_buffers() -> int:
@@ -124,7 +145,7 @@ class ExpertParallelExperts:
                  capacity_tokens: int | None = None, return_dtype: torch.dtype | None = None,
                  global_ids: bool = False, validate_uniform: bool = False,
                  routing_groups: tuple[int, int] | None = None, capacity_slack: float = 1.25,
-                 check_overflow: bool = False):
+                 check_overflow: bool | None = None, pool_tag: str = ""):
         """kernels: namespace with ep_row_bytes / ep_pack_tokens / ep_combine (default lvllm_amd.ops = the HIP
         kernels, no CPU path; the gloo tests inject torch doubles).  transport: equal-split all-to-all (default
         dist.all_to_all_single over `group`).  fixed_max_tokens: largest capacity served by the fixed path.
@@ -133,7 +154,12 @@ class ExpertParallelExperts:
         keeps the single-rank fp32 sum exactly).  global_ids: records carry GLOBAL expert ids (for a receiver
         that applies expert_map itself, modular.LkmPrepareAndFinalize) instead of ids local to the owner.
         routing_groups = (n_group, topk_group), capacity_slack, check_overflow: the capacity below the worst case and
-        its fallback (module docstring)."""
+        its fallback (module docstring).  check_overflow defaults to True whenever routing_groups is given: an eager
+        step then never returns rows with dropped contributions (one 8-byte all-reduce + host read per step); a step
+        being captured cannot branch and only counts -- its caller MUST read overflow_count() after the replay.
+        check_overflow=False is the explicit opt-in to count silently in eager steps too.
+        pool_tag: which exchange-buffer pool of the (device, group) this instance uses (two micro-batches in flight
+        need two tags)."""
         if mode not in ("a2a", "ar"):
             raise ValueError(f"unknown EP mode {mode!r} (expected 'a2a' or 'ar')")
         self.local_compute = local_compute
@@ -147,7 +173,8 @@ class ExpertParallelExperts:
         self.validate_uniform = validate_uniform
         self.routing_groups = routing_groups
         self.capacity_slack = capacity_slack
-        self.check_overflow = check_overflow
+        self.check_overflow = (routing_groups is not None) if check_overflow is None else bool(check_overflow)
+        self.pool_tag = pool_tag
         self._overflow_seen = 0              # (device counter value at the last check)
         import inspect
         try:
@@ -196,10 +223,10 @@ class ExpertParallelExperts:
         rowb = self.kernels.ep_row_bytes(self.H, K)
         n = self.ep * cap
         rsz = torch.empty((), dtype=ret_dtype).element_size()
-        send = _pool(dev, self.group, "send", n * rowb)[: n * rowb].view(self.ep, cap, rowb)
-        recv = _pool(dev, self.group, "recv", n * rowb)[: n * rowb].view(self.ep, cap, rowb)
-        back = _pool(dev, self.group, "back", n * self.H * rsz)[: n * self.H * rsz].view(ret_dtype).view(self.ep, cap, self.H)
-        slot_of = _pool(dev, self.group, "slot_of", self.ep * M * 4)[: self.ep * M * 4].view(torch.int32).view(self.ep, M)
+        send = _pool(dev, self.group, "send", n * rowb, self.pool_tag)[: n * rowb].view(self.ep, cap, rowb)
+        recv = _pool(dev, self.group, "recv", n * rowb, self.pool_tag)[: n * rowb].view(self.ep, cap, rowb)
+        back = _pool(dev, self.group, "back", n * self.H * rsz, self.pool_tag)[: n * self.H * rsz].view(ret_dtype).view(self.ep, cap, self.H)
+        slot_of = _pool(dev, self.group, "slot_of", self.ep * M * 4, self.pool_tag)[: self.ep * M * 4].view(torch.int32).view(self.ep, M)
         ov = self._overflow_bufs.get(str(dev))
         if ov is None:
             ov = self._overflow_bufs[str(dev)] = torch.zeros((1,), dtype=torch.int32, device=dev)
@@ -215,7 +242,13 @@ class ExpertParallelExperts:
         self._ensure_uniform(M, capacity, hidden)
         cap = self.capacity_for(M, capacity, K)
         ret = self.return_dtype or hidden.dtype
+        pkey = _pool_key(hidden.device, self.group, self.pool_tag)
+        if pkey in _IN_FLIGHT:
+            raise RuntimeError(f"exchange pool {self.pool_tag!r} already holds a dispatch that was not combined "
+                               f"({_IN_FLIGHT[pkey]}); two micro-batches in flight need instances with different pool_tag")
+        _IN_FLIGHT[pkey] = f"{M} tokens, capacity {cap}"
         b = self._buffers(M, K, cap, hidden.dtype, ret, hidden.device)
+        b["pool_key"] = pkey
         self.kernels.ep_pack_tokens(hidden, tw, ids, self.E, self.ep, cap, b["send"], b["slot_of"], b["overflow"],
                                     self.global_ids)
         self.transport(b["recv"], b["send"])
@@ -237,6 +270,7 @@ class ExpertParallelExperts:
         if M_ != M or y.shape != (self.ep * cap, self.H) or y.dtype != b["back"].dtype:
             raise RuntimeError(f"combine_fixed for {M} tokens / rows {tuple(y.shape)} {y.dtype} does not match its "
                                f"dispatch ({M_} tokens, capacity {cap}, {b['back'].dtype})")
+        _IN_FLIGHT.pop(b.get("pool_key"), None)
         self.transport(b["back"], y.view(self.ep, cap, self.H))
         if out is None:
             out = torch.empty((M, self.H), dtype=out_dtype, device=y.device)
@@ -247,25 +281,43 @@ class ExpertParallelExperts:
             return self.local_compute(rows, rids, rws, ret, valid_den=self.ep)
         return self.local_compute(rows, rids, rws, ret)
 
-    def _forward_a2a_fixed(self, hidden, tw, ids, cap: int, out_dtype: torch.dtype, out=None) -> torch.Tensor:
+    def abandon_dispatch(self, handle=None) -> None:
+        """give up a dispatch without combining it (error paths, the overflow re-run): frees its pool for the next one"""
+        b = (handle if handle is not None else self._last)[0]
+        _IN_FLIGHT.pop(b.get("pool_key"), None)
+
+    def _forward_a2a_fixed(self, hidden, tw, ids, cap: int, out_dtype: torch.dtype, out=None, trimmed: bool = False) -> torch.Tensor:
+        """trimmed: this step's capacity may be below what a destination can receive.  The flag is formed from
+        group-agreed values only (forward()), so either every rank looks at the overflow counters or none does."""
         M, K = ids.shape
         rows, rids, rws, h = self.dispatch_fixed(hidden, tw, ids, cap, return_handle=True)
-        if self.check_overflow and cap < M and not _capturing(hidden) and self._any_rank_overflowed(hidden.device):
-            # a destination ran out of record slots on some rank: every rank repeats the step at the exact bound
-            return self._forward_a2a_fixed(hidden, tw, ids, M, out_dtype, out)
+        if self.check_overflow and trimmed and not _capturing(hidden):
+            over, m_max = self._any_rank_overflowed(hidden.device, M)
+            if over:
+                # a destination ran out of record slots on some rank: every rank repeats the step at the exact bound of
+                # the LARGEST token count in the group (a rank-local M would post mismatched exchanges)
+                self.abandon_dispatch(h)
+                return self._forward_a2a_fixed(hidden, tw, ids, max(m_max, 1), out_dtype, out, trimmed=False)
         ret = self.return_dtype or hidden.dtype
-        y = self._local(rows, rids, rws, ret)
+        try:
+            y = self._local(rows, rids, rws, ret)
+        except BaseException:
+            self.abandon_dispatch(h)
+            raise
         return self.combine_fixed(y, M, out_dtype, out, handle=h)
 
-    def _any_rank_overflowed(self, dev) -> bool:
+    def _any_rank_overflowed(self, dev, M: int = 0):
         """the overflow decision is collective (a rank that re-ran alone would post mismatched exchanges): the MAX over
-        ranks of `dropped since the last look`, one 4-byte all-reduce and one host read. Eager steps only."""
+        ranks of (`dropped since the last look`, token count), one 8-byte all-reduce and one host read.  Eager steps
+        only.  -> (overflowed anywhere, largest token count of the group)"""
         ov = self._overflow_bufs[str(dev)]
-        delta = ov - self._overflow_seen
+        delta = (ov - self._overflow_seen).to(torch.int32).reshape(1)
         self._overflow_seen = ov.clone()
+        pair = torch.cat([delta, torch.tensor([M], dtype=torch.int32, device=delta.device)])
         if self.ep > 1 and dist.is_initialized():
-            dist.all_reduce(delta, op=dist.ReduceOp.MAX, group=self.group)
-        return bool(int(delta.item()) > 0)
+            dist.all_reduce(pair, op=dist.ReduceOp.MAX, group=self.group)
+        vals = pair.tolist()
+        return bool(vals[0] > 0), int(vals[1])
 
     def overflow_count(self) -> int:
         """tokens dropped so far for lack of record capacity (only possible with a capacity below the token
@@ -352,10 +404,11 @@ class ExpertParallelExperts:
         return out
 
     def _ensure_uniform(self, M: int, capacity, like: torch.Tensor) -> None:
-        """no group-wide capacity was named: the rank-local token count sizes the collectives, so ranks with different
-        counts would post mismatched exchanges (a hang or silent corruption).  Checked ONCE per new token count, outside
-        any capture (one small all-gather): fail loudly instead."""
-        if self.ep > 1 and capacity is None and self.capacity_tokens is None and self.routing_groups is None \
+        """no group-wide capacity was named: the rank-local token count sizes the collectives -- directly, or through the
+        group-limited estimate of `routing_groups` -- so ranks with different counts would post mismatched
+        exchanges (a hang or silent corruption).  Checked ONCE per new token count, outside any capture (one small
+        all-gather): fail loudly instead."""
+        if self.ep > 1 and capacity is None and self.capacity_tokens is None \
                 and not self.validate_uniform and not _capturing(like) and M not in self._uniform_checked:
             self._check_uniform(M, "token count (no common capacity was given)")
             self._uniform_checked.add(M)
@@ -390,7 +443,12 @@ class ExpertParallelExperts:
             if self.validate_uniform:
                 self._check_uniform(cap, "record capacity")
             if cap <= self.fixed_max_tokens:
-                return self._forward_a2a_fixed(hidden, topk_weights, topk_ids, cap, out_dtype, out)
+                # may a destination receive more records than it has slots?  From group-agreed values only: a capacity
+                # derived from M is below the worst case iff cap < M (M is then uniform, _ensure_uniform); a NAMED common
+                # capacity under group-limited routing may be below some rank's token count, which this rank cannot know
+                named = capacity is not None or self.capacity_tokens is not None
+                trimmed = (self.routing_groups is not None) if named else cap < M
+                return self._forward_a2a_fixed(hidden, topk_weights, topk_ids, cap, out_dtype, out, trimmed=trimmed)
             y = self._forward_a2a(hidden, topk_weights, topk_ids)
         else:
             if self.validate_uniform:

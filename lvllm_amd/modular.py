@@ -277,12 +277,15 @@ class LkmPrepareAndFinalize:
     prefill-sized batches; use `ExpertParallelExperts.forward` (ragged path) there."""
 
     def __init__(self, num_experts: int, hidden_size: int, group=None, kernels=None, transport=None,
-                 capacity_tokens: int | None = None, fixed_max_tokens: int = 1024):
+                 capacity_tokens: int | None = None, fixed_max_tokens: int = 1024, pool_tag: str = ""):
         from .ep import ExpertParallelExperts
+        # pool_tag: the exchange-buffer pool of the (device, group) this instance packs into; two micro-batches in
+        # flight (dual-batch overlap) = two instances with different tags (lvllm_amd/ep.py: _pool)
         self._ep = ExpertParallelExperts(lambda *a: None, num_experts, hidden_size, group=group, mode="a2a",
                                          kernels=kernels, transport=transport, capacity_tokens=capacity_tokens,
                                          fixed_max_tokens=fixed_max_tokens, global_ids=True,
-                                         return_dtype=torch.float32)   # the experts' rows return as they are
+                                         return_dtype=torch.float32,   # the experts' rows return as they are
+                                         pool_tag=pool_tag)
         self._shape: tuple[int, int] | None = None
         self._handle = None
 
@@ -334,7 +337,8 @@ class LkmPrepareAndFinalize:
             tw = torch.ones_like(tw)
         if self._handle is not None:
             # one exchange in flight per instance: a second prepare would pack into the buffers the first finalize still
-            # has to read (two micro-batches need two instances with distinct buffer pools) -- fail loudly
+            # has to read (two micro-batches need two instances with different `pool_tag`s; the pool itself refuses a
+            # second dispatch too, lvllm_amd/ep.py) -- fail loudly
             raise RuntimeError("LkmPrepareAndFinalize.prepare called again before the matching finalize "
                                "(supports_async() is False: one exchange in flight per instance)")
         rows, gids, ws, self._handle = self._ep.dispatch_fixed(a1.contiguous(), tw.contiguous(),

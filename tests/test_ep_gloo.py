@@ -365,3 +365,124 @@ def test_unequal_token_counts_without_a_common_capacity_fail_loudly():
         assert p.exitcode == 0
     for rank in range(world):
         assert "different token count" in res[rank] and "[8, 9]" in res[rank], res
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r3
+def _unequal_routing_groups_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lvllm_amd.ep import ExpertParallelExperts
+        ep = ExpertParallelExperts(lambda *a: None, E, H, mode="a2a", kernels=TorchEpKernels, routing_groups=(world, 1))
+        Mr = 8 + 4 * rank          # the group-limited capacity is derived from the rank-local token count: 8 vs 12 tokens
+        a = torch.zeros((Mr, H), dtype=torch.bfloat16)
+        ids = torch.zeros((Mr, K), dtype=torch.int32)
+        tw = torch.ones((Mr, K))
+        try:
+            ep.forward(a, tw, ids)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unequal_token_counts_with_routing_groups_fail_loudly():
+    """`routing_groups` derives the record capacity from the rank-local token count, so the uniformity check
+    must stay on (ranks with different counts would size send / recv / back differently and evaluate the overflow
+    re-run differently: mismatched collectives)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unequal_routing_groups_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        assert "different token count" in res[rank] and "[8, 12]" in res[rank], res
+
+
+def _named_capacity_overflow_worker(rank, world, port, q):
+    """a NAMED common capacity below some rank's token count under group-limited routing: the overflow decision and the
+    capacity of the re-run must come from group-agreed values (the largest token count of the group), whatever the
+    rank-local count is"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lvllm_amd.ep import ExpertParallelExperts
+        Eg, Kg, n_group = 8, 2, world
+        g = torch.Generator().manual_seed(7)
+        w13 = (torch.randn((Eg, 2 * I, H), generator=g) / 4).to(torch.bfloat16)
+        w2 = (torch.randn((Eg, H, I), generator=g) / 4).to(torch.bfloat16)
+        ep = ExpertParallelExperts(lambda *a: None, Eg, H, mode="a2a", kernels=TorchEpKernels, return_dtype=torch.float32,
+                                   routing_groups=(n_group, 1))           # check_overflow defaults to True with routing_groups
+        assert ep.check_overflow
+        lo, n_loc = ep.first_expert[rank], ep.local_num
+        d = orc.MoeDesc(E=n_loc, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+        seen = []
+
+        def local_compute(x, lids, ws, out_dtype, valid_den=None):
+            seen.append(x.shape[0])
+            y = orc.moe(d, torch_to_bits(w13[lo:lo + n_loc]), torch_to_bits(w2[lo:lo + n_loc]),
+                        torch_to_bits(x.contiguous()), lids.contiguous().numpy(), ws.contiguous().numpy())
+            return torch.from_numpy(y).to(out_dtype)
+        ep.local_compute = local_compute
+        ep._lc_takes_den = True
+        Mr = 20 if rank == 0 else 6                     # rank 0 sends all 20 tokens to rank 1's experts: 20 records > 8 slots
+        gr = torch.Generator().manual_seed(90 + rank)
+        per = Eg // world
+        ids = (torch.randint(0, per, (Mr, Kg), generator=gr) + per * (1 if rank == 0 else rank)).to(torch.int32)
+        tw = torch.rand((Mr, Kg), generator=gr) + 0.1
+        a = (torch.randn((Mr, H), generator=gr) / 2).to(torch.bfloat16)
+        out = ep.forward(a, tw, ids, capacity=8)
+        dfull = orc.MoeDesc(E=Eg, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+        ref = orc.moe(dfull, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids.numpy(), tw.numpy())
+        q.put((rank, seen, ep.overflow_count(), float(np.abs(out.numpy() - ref).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_named_capacity_overflow_reruns_at_the_group_maximum():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_named_capacity_overflow_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, seen, ov, err in res:
+        assert seen == [world * 20], (rank, seen)       # ONE expert pass, at the group's largest token count, on every rank
+        assert (ov > 0) == (rank == 0) and err < 1e-5
+
+
+def test_exchange_pool_in_flight_guard_and_pool_tags():
+    """the exchange buffers are per (device, group, pool tag), not per instance -- two instances on one pool
+    must not both have a dispatch in flight; different tags give independent memory"""
+    from lvllm_amd import ep as epm
+    def copy(out, inp):
+        out.copy_(inp)
+    mk = lambda tag: epm.ExpertParallelExperts(lambda *a: None, E, H, mode="a2a", kernels=TorchEpKernels, transport=copy,
+                                               return_dtype=torch.float32, pool_tag=tag)
+    a, tw, ids = _tokens(0)
+    ids = ids.clamp(min=0)
+    x, y, z = mk(""), mk(""), mk("mb1")
+    rows, rids, rws, hx = x.dispatch_fixed(a, tw, ids, return_handle=True)
+    with pytest.raises(RuntimeError, match="already holds a dispatch"):
+        y.dispatch_fixed(a, tw, ids)                     # same pool: refused until x combined
+    rows_z, _, _, hz = z.dispatch_fixed(a, tw, ids, return_handle=True)       # another tag: its own memory
+    assert rows_z.data_ptr() != rows.data_ptr() and torch.equal(rows_z, rows)
+    fake = torch.zeros((x.ep * hx[3], H), dtype=torch.float32)
+    x.combine_fixed(fake, a.size(0), handle=hx)
+    z.combine_fixed(fake, a.size(0), handle=hz)
+    r2 = y.dispatch_fixed(a, tw, ids, return_handle=True)                      # free again
+    y.abandon_dispatch(r2[3])
+    x.dispatch_fixed(a, tw, ids)
+    x.abandon_dispatch()

@@ -434,7 +434,7 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
                 eng.forward_rows(x, tw, ids, out=out)
         else:
             # decode: routing + scatter metadata in one launch (lkm_forward_routed; --tune fuse=-1 gives the five-launch
-            # step back, fuse=1 also folds the combine into GEMM2; same bits in all three)
+            # step back; same bits)
             fl = dict(scoring_func=rt.get("scoring", "softmax"), e_score_correction_bias=bias, out=out)
             if rt["kind"] == "grouped":
                 fl.update(num_expert_group=rt["n_group"], topk_group=rt["topk_group"],

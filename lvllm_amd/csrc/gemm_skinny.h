@@ -880,130 +880,6 @@ __global__ __launch_bounds__(1024) void gemm2_direct_kernel(GemmParams p, int K)
     }
 }
 
-// ------------------------------------------------------------------ GEMM2 + combine, few active experts
-// grid = tile groups; block = up to 16 waves: work item (active expert a, K slice s) = a * SK + s goes to wave
-// item % waves, streams its rows of W2 against the expert's routed rows exactly like gemm2_kernel and leaves the
-// fp32 partials in LDS at the row's SORTED position; the workgroup then forms
-//   out[m][n] = sum_k w[m,k] * sum_s partial[s][pos(m,k)][n]
-// in the order of combine_kernel (s ascending, then k ascending): bit-identical to gemm2_kernel + combine_kernel,
-// one launch and no y round trip.  LDS: SK * (M*K) * NT * 64 bytes (the launcher bounds it).  MAXW = 8 waves (256
-// VGPRs each) for every (NT, TB) <= (2, 2); 16 waves (128 VGPRs) only for NT = TB = 1, the variants that fit.
-template <int WF, int ADT, int NT, int TB, int MAXW>
-__global__ __launch_bounds__(64 * MAXW) void gemm2_combine_kernel(GemmParams p) {
-#pragma clang fp contract(off)
-    typedef Dec<WF, ADT> D;
-    typedef typename std::conditional<ADT == LKM_DT_BF16, bf16_out, f16_out>::type ActOut;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [SK][M*K][NT*16]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int g = lane >> 4, j = lane & 15;
-    const int SK = p.SK, K = p.top_k;
-    const int n_slots = p.comb_M * K;
-    const int tile0 = blockIdx.x * NT;
-    const int n_items = p.meta[0] * SK;
-    const int aux_step = D::aux_step(p.spu), wstep = (int)p.w_ustride;
-    // this thread's output of the epilogue: its sorted positions and routing weights are fetched NOW, under the weight
-    // stream, so that nothing but LDS reads stands between the last MFMA and the store
-    constexpr int Q = NT * 4;   // f32x4 columns of a row of this tile group
-    constexpr int PK = 4;
-    int ppos[PK];
-    float pw[PK];
-#pragma unroll
-    for (int k = 0; k < PK; ++k) {
-        ppos[k] = -1;
-        pw[k] = 0.0f;
-        if ((int)threadIdx.x < p.comb_M * Q && k < K) {
-            const int m = threadIdx.x / Q;
-            ppos[k] = p.comb_pos[m * K + k];
-            pw[k] = p.direct_w[(size_t)m * p.comb_tw_ld + k];
-        }
-    }
-    for (int item = wave; item < n_items; item += nwaves) {
-        const int ai = item / SK, sk = item % SK;
-        const int e = p.active[ai];
-        const int m_e = p.counts[e], off_e = p.offsets[e];
-        const u32x4* wp[NT];
-        const char* auxp[NT];
-        size_t tlv[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const size_t tl = (size_t)e * p.T_half + tile0 + t;
-            tlv[t] = tl;
-            wp[t] = (const u32x4*)p.w + (size_t)e * p.w_estride + (size_t)(tile0 + t) * p.w_tstride + lane;
-            auxp[t] = D::aux_ptr(p.s, tl * p.U, lane, p.spu);
-        }
-        float wsu[NT][2] = {};
-        constexpr bool WSU = false;      // (128-register kernels: the per-row scale loads stay)
-        (void)tlv;
-        const int u0 = (int)((long long)sk * p.U / SK), u1 = (int)((long long)(sk + 1) * p.U / SK);
-        const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
-        for (int sb = 0; sb < m_e; sb += 16 * TB) {
-            const int rows = min(m_e - sb, 16 * TB);
-            const int ntb = (rows + 15) >> 4;
-            constexpr int XB = D::A8 ? 1 : 2;
-            const unsigned char* xp[TB];
-            const float* xsp[TB];
-#pragma unroll
-            for (int b = 0; b < TB; ++b) {
-                const int r = sb + b * 16 + j;
-                const size_t row = (size_t)(off_e + (r < m_e ? r : 0));
-                xp[b] = (const unsigned char*)p.x + row * p.ldx * XB;
-                xsp[b] = p.xscale + row * p.ld_xscale;
-            }
-            f32x4 acc[NT][TB];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int b = 0; b < TB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            LKM_STREAM_RUN(NT, TB, acc, wp, auxp, aux_step, wstep, dparam, xp, xsp, u0, u1, p.Kreal, lane, ntb);
-#pragma unroll
-            for (int b = 0; b < TB; ++b) {
-                const int r_tok = sb + b * 16 + j;
-                if (b < ntb && r_tok < m_e) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        *(f32x4*)(red + ((size_t)sk * n_slots + off_e + r_tok) * (NT * 16) + t * 16 + g * 4) = acc[t][b];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < p.comb_M * Q; idx += blockDim.x) {
-        const int m = idx / Q, q = idx % Q;
-        const int n = tile0 * 16 + q * 4;
-        if (n >= p.n_real) continue;
-        const bool pre = idx == (int)threadIdx.x;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < K; ++k) {
-            int pos;
-            float w;
-            if (pre && k < PK) {
-                pos = k == 0 ? ppos[0] : (k == 1 ? ppos[1] : (k == 2 ? ppos[2] : ppos[3]));   // static indices: registers
-                w = k == 0 ? pw[0] : (k == 1 ? pw[1] : (k == 2 ? pw[2] : pw[3]));
-            } else {
-                pos = p.comb_pos[m * K + k];
-                w = pos >= 0 ? p.direct_w[(size_t)m * p.comb_tw_ld + k] : 0.0f;
-            }
-            if (pos < 0) continue;
-            const float* yp = red + (size_t)pos * (NT * 16) + q * 4;
-            f32x4 v = *(const f32x4*)yp;
-            for (int s = 1; s < SK; ++s) v += *(const f32x4*)(yp + (size_t)s * n_slots * (NT * 16));
-            acc += w * v;
-        }
-        const size_t o = (size_t)m * p.ldo + n;
-        if (n + 4 <= p.n_real) {
-            if (p.direct_out_dt == LKM_DT_F32) store4<float>((float*)p.out + o, acc);
-            else store4<ActOut>((ActOut*)p.out + o, acc);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < p.n_real) {
-                    if (p.direct_out_dt == LKM_DT_F32) store1<float>((float*)p.out + o + r, acc[r]);
-                    else store1<ActOut>((ActOut*)p.out + o + r, acc[r]);
-                }
-        }
-    }
-}
-
 template <int WF, int ADT>
 static int launch_g2_direct_t(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, int K) {
     const int waves = K * p.SK;
@@ -1064,28 +940,6 @@ static int launch_g1_t(hipStream_t st, const GemmParams& p, bool gated, int kw, 
 
 template <int WF, int ADT, int NT, int TB>
 static int launch_g2_t(hipStream_t st, const GemmParams& p, int max_active) {
-    if (p.comb_pos) {
-        const int items = max_active * p.SK;
-        const size_t lds = (size_t)p.SK * p.comb_M * p.top_k * NT * 16 * sizeof(float);
-        LKM_REQUIRE(lds <= 65536, "gemm2+combine: %zu bytes of LDS for M*K=%d rows", lds, p.comb_M * p.top_k);
-        if constexpr (NT == 1 && TB == 1) {
-            if (items > 8) {
-                hipLaunchKernelGGL((gemm2_combine_kernel<WF, ADT, 1, 1, 16>), dim3(p.groups),
-                                   dim3(64 * (items < 16 ? items : 16)), lds, st, p);
-                LKM_HIP_CHECK(hipGetLastError());
-                return LKM_OK;
-            }
-        }
-        if constexpr (NT <= 2 && TB <= 2) {
-            hipLaunchKernelGGL((gemm2_combine_kernel<WF, ADT, NT, TB, 8>), dim3(p.groups),
-                               dim3(64 * (items < 8 ? items : 8)), lds, st, p);
-            LKM_HIP_CHECK(hipGetLastError());
-            return LKM_OK;
-        } else {
-            set_error("gemm2+combine: variant nt=%d tb=%d is not built", NT, TB);
-            return LKM_E_INVALID;
-        }
-    }
     dim3 grid(ceil_div(p.groups * p.SK, 4), max_active), block(256);
     if constexpr (NT * TB <= 8) {
         if (use_unit_scales<WF>(p)) hipLaunchKernelGGL((gemm2_kernel<WF, ADT, NT, TB, WF == LKM_W_FP8_A8>), grid, block, 0, st, p);

@@ -499,15 +499,7 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
 template <typename ADTC>
 static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
                               int max_tiles, int* rc, ADTC);
-// 4-bit formats, 32/64-row tiles: the LDS-DMA ring kernel (gemm_w4dma.h)
-template <int WF, int ADT>
-static bool launch_w4dma_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
-                            int max_tiles, int* rc);
-// fp8 x fp8, 256-row tiles: the MX-scaled-MFMA prefill kernel (gemm_prefill_a8.h)
-template <typename ADTC>
-static bool launch_prefill_a8_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
-                                 int max_tiles, int* rc, ADTC);
-// ... round 3: weights straight to registers, tokens through a 4-stage LDS ring (gemm_prefill_a8w.h)
+// fp8 x fp8, 256-row tiles: weights straight to registers, tokens through a 4-stage LDS ring (gemm_prefill_a8w.h)
 template <typename ADTC>
 static bool launch_prefill_a8w_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
                                   int max_tiles, int* rc, ADTC);
@@ -546,11 +538,6 @@ struct W4Only {
         if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
             int rc = LKM_OK;                                                                          \
             if (launch_prefill_a8w_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc; \
-            if (launch_prefill_a8_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc; \
-        }                                                                                             \
-        if constexpr (W4Only<WF_>::value) {                                                           \
-            int rc = LKM_OK;                                                                          \
-            if (launch_w4dma_if<WF_, ADT_>(st, cfg, p, gated, true, max_tiles, &rc)) return rc;       \
         }                                                                                             \
         if (gated) {                                                                                  \
             LKM_TILED_CASE(2, 4, 1, true, true)                                                       \
@@ -582,11 +569,6 @@ struct W4Only {
         if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
             int rc = LKM_OK;                                                                          \
             if (launch_prefill_a8w_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;\
-            if (launch_prefill_a8_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;\
-        }                                                                                             \
-        if constexpr (W4Only<WF_>::value) {                                                           \
-            int rc = LKM_OK;                                                                          \
-            if (launch_w4dma_if<WF_, ADT_>(st, cfg, p, false, false, max_tiles, &rc)) return rc;      \
         }                                                                                             \
         LKM_TILED_CASE(2, 4, 1, false, false)                                                         \
         LKM_TILED_CASE(4, 4, 1, false, false)                                                         \

@@ -1,5 +1,5 @@
 // gemm_tiled_int4ps_f16.hip -- LDS-staged tiled grouped GEMMs, uint4b8 weights in the fast mode (scale on partial sums).
-#include "gemm_w4dma.h"
+#include "gemm_tiled.h"
 namespace lkm {
 LKM_DEFINE_TILED_LAUNCHERS(int4ps_f16, LKM_W_INT4_PS, LKM_DT_F16)
 }  // namespace lkm

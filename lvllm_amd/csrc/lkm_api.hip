@@ -164,7 +164,6 @@ struct LkmEngine {
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
     int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0, t_fuse = 0, t_tiled2 = 0, t_fuseq = 0;
-    bool unit_major = false;  // weight image layout (RepackDims::unit_major)
     int loads = 2;            // 16-byte loads per lane per (tile, unit)
     // profiling
     bool prof = false;
@@ -386,17 +385,9 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     LKM_TRY_HIP(hipMalloc(&h->w2, w2_vec * 16));
     h->weight_bytes = (int64_t)(w13_vec + w2_vec) * 16;
 
-    // weight image layout (GemmParams::w_*stride): tile-major; LKM_W_UNIT_MAJOR=1 in the environment stores all tiles'
-    // unit-u chunks contiguously instead (development A/B: a synthetic stream reads that order 3-10 % faster,
-    // tools/probe_stream.hip, but the kernels gain nothing consistent: streamers -2 %, tile kernels +2-3 %,
-    // profiles/r02_weight_layout_ab.log)
-    {
-        const char* env = getenv("LKM_W_UNIT_MAJOR");
-        h->unit_major = env && env[0] == '1';
-    }
     h->loads = loads;
-    RepackDims d13{h->E, h->I, halves, h->interleaved ? 1 : 0, h->H, h->T1_half, h->U1, h->a8 ? 1 : 0, h->unit_major ? 1 : 0};
-    RepackDims d2{h->E, h->H, 1, 0, h->I, h->T2, h->U2, h->a8 ? 1 : 0, h->unit_major ? 1 : 0};
+    RepackDims d13{h->E, h->I, halves, h->interleaved ? 1 : 0, h->H, h->T1_half, h->U1, h->a8 ? 1 : 0};
+    RepackDims d2{h->E, h->H, 1, 0, h->I, h->T2, h->U2, h->a8 ? 1 : 0};
     // hand-off of the caller's tensors: device sources are read in place; host sources pass through ONE
     // staging buffer of <= LKM_STAGE_BYTES (default 256 MiB, never less than one expert) in chunks of whole experts --
     // copy, repack, next chunk, all in stream order -- so creation adds at most one chunk to the footprint of the
@@ -553,8 +544,8 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // are formed four token blocks at a time and the kernel fits its registers (GLM-4.5-Air prefill
             // 3677 -> 3179 us with two GEMM2 tiles per wave; Mixtral M=2048 1996 -> 1820; M=512 equal)
             if (h->a8 && avg_rows >= 192) tiled = 128;
-            // ... and from there on the MX-scaled-MFMA prefill kernel (gemm_prefill_a8.h: both operands by LDS-DMA,
-            // 256 x 256 tiles, one v_mfma_scale_f32_16x16x128_f8f6f4 per 128-k block) where the shape qualifies
+            // ... and from there on the persistent prefill kernel (gemm_prefill_a8w.h: 256 x 256 items, one plain
+            // v_mfma_f32_16x16x128_f8f6f4 per 128-k block) where the shape qualifies
             // (the kernels address tokens, token scales and an expert's weights through 2 GiB buffer windows; a chunk
             // that does not fit them keeps the 128-row tiles instead of failing the step: prefill_a8w_ok)
             const bool win_ok = n_slots < ((size_t)1 << 22) &&            // (prefill_a8w_ok: GEMM1's slot -> token division)
@@ -563,6 +554,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
                                 (size_t)h->T1_half * (h->gated ? 2 : 1) * h->U1 * 2048 < (size_t)0x7fffffff &&
                                 (size_t)h->T2 * h->U2 * 2048 < (size_t)0x7fffffff;
             if (h->a8 && avg_rows >= 192 && h->t_pf >= 0 && h->H % 128 == 0 && h->I % 128 == 0 &&
+                h->U1 >= 8 && h->U2 >= 8 && h->U1 <= 64 && h->U2 <= 64 &&
                 h->cfg.groupN % 16 == 0 && h->cfg.groupK == 128 && win_ok)
                 tiled = 256;
         } else if (h->wf == LKM_W_FP8_E4M3 && M >= 48) {
@@ -651,22 +643,17 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         }
         if (tiled == 128 && waves == 4) pd1 = pd2 = 4;   // EP=8 Mixtral rank: 154 vs 229 us at 2/2
         int pf = (tiled == 256 && h->t_pf > 0 && !wf_is_4bit(h->wf)) ? h->t_pf : 0;
-        // 4-bit formats at 32/64-row tiles: the LDS-DMA ring kernel (gemm_w4dma.h) is an opt-in knob ("pf" = 4): three
-        // to four times the bytes in flight per CU, and no faster -- Mixtral M=128 GEMM1 int4 150 -> 183-193 us, MXFP4
-        // 112 -> 118 (108 at depth 3), NVFP4 145 -> 168, int4 fast mode 149 -> 150-157 (profiles/r02_w4dma_sweep.log):
-        // the 4-bit decode kernels are not bound by bytes in flight
-        if (wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && waves == 4 && !split && h->t_pf == 4 &&
-            h->H % 128 == 0 && h->I % 128 == 0)
-            pf = 4;
+        // (round 2's LDS-DMA ring kernel for the 4-bit formats, "pf" = 4, was removed in round 4: three to four times the
+        // bytes in flight per CU and no faster, profiles/r02_w4dma_sweep.log)
         // round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h), "pf" = 5
         const bool w4x = wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && !split && (h->t_pf == 5 || h->t_pf == 6) &&
                          h->H % 128 == 0 && h->I % 128 == 0;
         if (w4x) pf = h->t_pf;                  // (6: with a loader wave per workgroup, gemm_w4e.h; "pd" = ring depth 3 / 4)
         if (tiled == 256 && h->a8) {          // the fp8 x fp8 prefill kernels are the only 256-row variants of the format
-            // 9 = round 3 (gemm_prefill_a8w.h: weights straight to registers, tokens through a 4-stage LDS ring, equal
-            // token tiles); 8 = round 2 (gemm_prefill_a8.h: both operands through two LDS buffers), kept behind "pf" = 8
-            // (the round-3 kernel's pipeline runs through item boundaries and needs K loops of at least 8 units)
-            pf = (h->t_pf == 8 || h->U1 < 8 || h->U2 < 8 || h->U1 > 64 || h->U2 > 64) ? 8 : 9;
+            // 9 = gemm_prefill_a8w.h (weights straight to registers, tokens through a 4-stage LDS ring, equal token tiles);
+            // round 2's kernel ("pf" = 8: both operands through two LDS buffers) was removed in round 4 -- K loops outside
+            // the 8..64 units the item-boundary pipeline needs keep the 128-row tiles (the rule that picks 256 above)
+            pf = 9;
             waves = 8;
             // The XCD-aware runs (dispatch.hip): for the round-2 kernel a knob ("xcd" = 1) -- they cut GEMM1's L2-miss
             // traffic 5.8 -> 3.55 GB and that kernel ran 4-6 % SLOWER (bound by the round trip of one 66 KiB DMA burst
@@ -850,7 +837,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p1.w = h->w13;
     p1.s = h->s13;
     p1.spu = h->spu;
-    set_w_layout(p1, h->T1_half * (h->gated ? 2 : 1), h->U1, h->loads, h->unit_major);
+    set_w_layout(p1, h->T1_half * (h->gated ? 2 : 1), h->U1, h->loads);
     p1.gs = h->gs13;
     p1.xcd_map = (h->t_xcd > 0 || pl.xcd1) ? xcd_cap : 0;
     p1.tile_uniform_scale = h->cfg.groupN > 0 && h->cfg.groupN % 16 == 0;
@@ -923,7 +910,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.w = h->w2;
     p2.s = h->s2;
     p2.spu = h->spu;
-    set_w_layout(p2, h->T2, h->U2, h->loads, h->unit_major);
+    set_w_layout(p2, h->T2, h->U2, h->loads);
     p2.gs = h->gs2;
     p2.xcd_map = (h->t_xcd > 0 || pl.xcd2) ? xcd_cap : 0;
     p2.tile_uniform_scale = p1.tile_uniform_scale;
@@ -991,22 +978,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
                  M, K, pl.s1.kw, sk_direct);
         return LKM_OK;
     }
-    // few active experts (Mixtral-class decode): GEMM2 and the top-k combine in one launch -- the waves of a workgroup
-    // take the (expert, K slice) items of one tile group and sum through LDS in combine_kernel's order.  Bit-identical,
-    // one launch fewer, and not faster: Mixtral bf16 M=32 GEMM2 137.6 -> 142.9 us against a 2.8 us combine kernel
-    // (eight experts' streams per CU instead of four adjacent tiles of one; profiles/r02_decode_fusion.md)
-    const bool fuse2 = pl.s2.tb && !pl.t2.tiled && !pl.split_rows && pl.s2.nt <= 2 && pl.s2.tb <= 2 &&
-                       max_active * sk <= ((pl.s2.nt == 1 && pl.s2.tb == 1) ? 16 : 8) &&
-                       (size_t)sk * n_slots * pl.s2.nt * 64 <= 65536 &&
-                       y_dt == LKM_DT_F32 && h->t_fuse >= 1;   // opt-in (tuning key fuse = 1): measured 2.7 us SLOWER than the two launches
-    if (fuse2) {
-        p2.comb_pos = a->pos_of_slot;
-        p2.comb_M = M;
-        p2.comb_tw_ld = (int)il.tw_ld;
-        p2.direct_w = tw;
-        p2.direct_out_dt = out_dt;
-        p2.out = out;
-    }
+    // (GEMM2 + top-k combine in one launch for few active experts -- round 2's gemm2_combine_kernel, tuning key "fuse" = 1
+    // -- was bit-identical and 2.7 us SLOWER than the two launches (profiles/r02_decode_fusion.md); removed in round 4)
     for (int r = 0; r < rep; ++r) {
         if (pl.s2.tb) {
             p2.groups = h->T2 / pl.s2.nt;
@@ -1020,18 +993,16 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     }
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
 
-    if (!fuse2) {
-        rc = launch_combine(st, a->y, y_dt, sk, p2.sk_stride, a->pos_of_slot, tw, (int)il.tw_ld, M, K, h->H, out, out_dt);
-        if (rc != LKM_OK) return rc;
-    }
+    rc = launch_combine(st, a->y, y_dt, sk, p2.sk_stride, a->pos_of_slot, tw, (int)il.tw_ld, M, K, h->H, out, out_dt);
+    if (rc != LKM_OK) return rc;
     if (prof) {
         LKM_HIP_CHECK(hipEventRecord(h->ev[4], st));
         h->prof_valid = true;
     }
     snprintf(h->last_desc, sizeof(h->last_desc),
-             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2%s nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d pd=%d/%d split=%d pf=%d xcd=%d/%d | nt_loads=%d",
+             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2 nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d pd=%d/%d split=%d pf=%d xcd=%d/%d | nt_loads=%d",
              M, K, pl.s1.tb ? "skinny" : "", pl.t1.tiled ? (pl.s1.tb ? "+tiled" : "tiled") : "", pl.s1.nt,
-             pl.s1.tb, pl.s1.kw, fuse2 ? "+combine" : "", pl.s2.nt, pl.s2.tb, pl.s2.sk, pl.t1.nt, pl.t2.nt, tile_rows, pl.t1.waves,
+             pl.s1.tb, pl.s1.kw, pl.s2.nt, pl.s2.tb, pl.s2.sk, pl.t1.nt, pl.t2.nt, tile_rows, pl.t1.waves,
              pl.t1.pd, pl.t2.pd, pl.split_rows, pl.t1.pf, p1.xcd_map ? 1 : 0, p2.xcd_map ? 1 : 0, stream_nt);
     return LKM_OK;
 }

@@ -12,7 +12,6 @@ struct RepackDims {
     int K;                               // source K (elements)
     int T_half, U;                       // dest tiles per half, units
     int a8;                              // fp8 only: k mapping for fp8 activations (W8A8)
-    int unit_major;                      // weight image: [e][unit][tile] instead of [e][tile][unit] (GemmParams::w_*stride)
 };
 int launch_repack_w(hipStream_t st, int wf, const void* src, void* dst, const RepackDims& d);
 int launch_repack_s_int4(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group,
@@ -64,9 +63,9 @@ struct GemmParams {
     const void* w;
     const void* s;
     // weight addressing, in 16-byte vectors per lane group of 64: vector of (expert e, tile t, unit u, load l) =
-    // e * w_estride + t * w_tstride + u * w_ustride + l * 64 + lane.  Two layouts (RepackDims::unit_major):
-    // tile-major (a tile's units contiguous) and unit-major (all tiles' unit-u chunks contiguous: what the chip reads
-    // at one moment is one contiguous region)
+    // e * w_estride + t * w_tstride + u * w_ustride + l * 64 + lane.  The image is tile-major (a tile's units contiguous;
+    // the unit-major alternative of round 2 -- measured no faster, profiles/r02_weight_layout_ab.log -- was removed in
+    // round 4, the kernels keep addressing through the three strides)
     long long w_estride, w_tstride, w_ustride;
     int spu;     // int4: scales per 128-k unit (1,2,4)
     const float* gs;   // NVFP4: per-expert f32 multiplier [E] (NULL = 1)
@@ -116,11 +115,6 @@ struct GemmParams {
     int direct_out_dt;           // LKM_DT_* of `out` in the direct GEMM2
     int direct_E, direct_id_off; // direct mode: local expert count and the offset subtracted from ids >= 0
                                  // (an id outside [0, E) after that is not local, like -1)
-    // GEMM2 + combine in one launch (skinny streamer, few active experts: gemm2_combine_kernel): non-null comb_pos
-    // switches it on; `out` is then the layer output [comb_M][ldo] of dtype direct_out_dt, direct_w the routing
-    // weights [comb_M][comb_tw_ld]
-    const int32_t* comb_pos;     // pos_of_slot [comb_M * top_k]
-    int comb_M, comb_tw_ld;
     // single-token decode through lkm_forward_routed: the direct GEMM1 routes the one row itself (every workgroup, on
     // its first wavefront: ~2 us under the start of the weight stream instead of a router launch and its gap);
     // workgroup (0, 0) also stores the ids / weights for GEMM2 and the caller (direct_ids / direct_w point at them)
@@ -137,10 +131,10 @@ struct GemmParams {
     int act_type;
     float alpha, limit;
 };
-inline void set_w_layout(GemmParams& p, int T_all, int U, int loads, bool unit_major) {
+inline void set_w_layout(GemmParams& p, int T_all, int U, int loads) {
     p.w_estride = (long long)T_all * U * loads * 64;
-    p.w_tstride = unit_major ? (long long)loads * 64 : (long long)U * loads * 64;
-    p.w_ustride = unit_major ? (long long)T_all * loads * 64 : (long long)loads * 64;
+    p.w_tstride = (long long)U * loads * 64;
+    p.w_ustride = (long long)loads * 64;
 }
 struct LaunchCfg {
     int nt, tb, kw, sk;
@@ -148,7 +142,8 @@ struct LaunchCfg {
                  // else token-tile rows (64 / 128): token operand staged through LDS
     int waves;   // tiled: waves per workgroup (4 / 8)
     int pd;      // tiled: weight register stages (2 / 4; prefetch distance pd-1 K units)
-    int pf;      // 256-row tiles, 16-bit weights: 8 = the LDS-DMA prefill kernel (gemm_prefill.h, opt-in)
+    int pf;      // 256-row tiles: 16-bit weights 8 = the LDS-DMA prefill kernel (gemm_prefill.h, opt-in), fp8 x fp8 9 = gemm_prefill_a8w.h;
+                 // 4-bit formats at 32/64-row tiles: 5 / 6 = the 32x32-MFMA kernels (gemm_w4x.h / gemm_w4e.h)
 };
 int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p,
                  bool gated, int max_active);

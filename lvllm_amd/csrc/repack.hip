@@ -94,12 +94,7 @@ __global__ __launch_bounds__(256) void repack_w_kernel(const uint8_t* __restrict
     o.y = out[1];
     o.z = out[2];
     o.w = out[3];
-    size_t dv = v;
-    if (d.unit_major) {
-        const size_t T_all = (size_t)d.halves * d.T_half;
-        dv = ((((size_t)e * d.U + u) * T_all + tile) * G::LOADS + ld) * 64 + lane;
-    }
-    dst[dv] = o;
+    dst[v] = o;
 }
 
 // int4 group scales: src act-dtype [E][N][K/g]  ->  dst [E][tile][unit][16 rows][SPU] (same dtype)

@@ -308,7 +308,7 @@ extern "C" int lkm_router_gemm_topk(void* stream, const void* x, int32_t x_dtype
         gp.T_half = bp.T;
         gp.halves = 1;
         gp.U = bp.U;
-        set_w_layout(gp, bp.T, bp.U, wf_loads(wf), false);
+        set_w_layout(gp, bp.T, bp.U, wf_loads(wf));
         gp.Kreal = H;
         gp.n_real = E;
         gp.x = x;

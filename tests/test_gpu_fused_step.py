@@ -46,37 +46,6 @@ def _engine(fmt, E, K, H, I, dtype, seed):
     raise AssertionError(fmt)
 
 
-@pytest.mark.parametrize("fmt,M,E,K,H,I", [
-    ("bf16", 32, 8, 2, 4096, 512), ("bf16", 32, 8, 2, 512, 1024), ("bf16", 2, 8, 2, 256, 128), ("bf16", 7, 4, 4, 384, 200), ("bf16", 64, 8, 2, 136, 72),
-    ("bf16", 40, 16, 2, 256, 256), ("bf16", 300, 8, 2, 256, 128), ("bf16", 20, 6, 3, 128, 64),
-    ("int4", 24, 8, 2, 512, 256), ("fp8", 32, 8, 2, 512, 512), ("fp8a8", 32, 8, 2, 512, 512), ("fp8a8", 9, 4, 2, 256, 384),
-])
-def test_gemm2_combine_fused_equals_two_launches(fmt, M, E, K, H, I):
-    """fuse=-1 (GEMM2 -> y -> combine) against fuse=1 (one launch); both output dtypes; ragged routing with empty experts
-    and -1 (non-local) ids; a global-id offset as the expert-parallel receiver uses it."""
-    eng = _engine(fmt, E, K, H, I, torch.bfloat16, seed=M + E)
-    g = torch.Generator().manual_seed(M)
-    a = (torch.randn((M, H), generator=g) / 10).to(torch.bfloat16).to(DEV)
-    n_fused = 0
-    for skew, drop, off in [(0.0, 0.0, 0), (1.5, 0.2, 0), (0.0, 0.1, 3)]:
-        tw, ids = make_routing(M, E, K, seed=M * 3 + E, skew=skew, drop=drop)
-        ids_g = np.where(ids >= 0, ids + off, ids).astype(np.int32)
-        twd, idd = torch.from_numpy(tw).to(DEV), torch.from_numpy(ids_g).to(DEV)
-        for odt in (torch.float32, torch.bfloat16):
-            eng.engine.set_tuning(fuse=1)          # opt-in: GEMM2 + combine in one launch
-            got = eng.forward_rows(a, twd, idd, out_dtype=odt, id_offset=off).cpu()
-            desc = eng.engine.describe()
-            n_fused += "g2+combine" in desc
-            eng.engine.set_tuning(fuse=-1)
-            base = eng.forward_rows(a, twd, idd, out_dtype=odt, id_offset=off).cpu()
-            d2 = eng.engine.describe()
-            assert "g2+combine" not in d2 or "direct" in d2      # (one to four tokens take the no-scatter path either way)
-            assert torch.equal(got.view(torch.int16 if odt == torch.bfloat16 else torch.int32),
-                               base.view(torch.int16 if odt == torch.bfloat16 else torch.int32)), (desc, skew, drop, off)
-    if H == 4096:      # Mixtral-like: 256 output tiles per expert, no split-K -> the fused launch must be the plan
-        assert n_fused > 0, "the planner never chose the fused GEMM2 + combine: " + desc
-
-
 @pytest.mark.parametrize("M,E,K,scoring,bias,grouped", [
     (32, 8, 2, "softmax", False, None), (2, 8, 2, "softmax", False, None), (17, 64, 6, "sigmoid", True, None),
     (128, 8, 2, "softmax", False, None), (5, 128, 8, "softmax", False, None), (64, 16, 4, "sigmoid", False, None),
@@ -100,22 +69,21 @@ def test_forward_routed_equals_router_then_forward(M, E, K, scoring, bias, group
     rsf = 2.5 if grouped else 1.0
     if grouped:
         kw.update(num_expert_group=grouped[0], topk_group=grouped[1], routed_scaling_factor=rsf)
-    # every plan: the default one (router + sort fused; GEMM2 may be the tile kernel), the streamer GEMM2 with the combine
-    # folded in (fuse=1) and without (fuse=-1).  The two streamer plans also agree with each other bit for bit.
+    # both plans: the default one (router + sort in one launch; GEMM2 may be the tile kernel) and the five-launch step with
+    # the streamer GEMM2 (fuse=-1).  (Round 2's GEMM2 + combine launch, fuse=1, was measured slower and removed in round 4.)
     if grouped:
         w0, i0 = ops.grouped_topk(x, logits.to(DEV), K, True, grouped[0], grouped[1], scoring, rsf, kw["e_score_correction_bias"])
     else:
         w0, i0 = ops.topk_softmax(logits.to(DEV), K, True, kw["e_score_correction_bias"], scoring, rsf)
     outs = {}
-    for fuse in (0, 1, -1):
+    for fuse in (0, -1):
         eng.engine.set_tuning(fuse=fuse)
         out, w, ids = eng.forward_logits(x, logits.to(DEV), K, True, **kw)
         base = eng.forward_rows(x, w0, i0)
         assert torch.equal(ids, i0) and torch.equal(w.view(torch.int32), w0.view(torch.int32))
         assert torch.equal(out.view(torch.int32), base.view(torch.int32)), (fuse, eng.engine.describe())
         outs[fuse] = out
-    assert torch.equal(outs[1].view(torch.int32), outs[-1].view(torch.int32))
-    torch.testing.assert_close(outs[0], outs[1], atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(outs[0], outs[-1], atol=1e-4, rtol=1e-4)
     # the router against the oracle
     sc = 0 if scoring == "softmax" else 1
     if grouped:
@@ -136,7 +104,6 @@ def test_forward_routed_in_graph_and_bf16_out():
     x = (torch.randn((M, H), generator=g) / 10).to(torch.bfloat16).to(DEV)
     logits = torch.randn((M, E), generator=g, dtype=torch.float32).to(DEV)
     out = torch.empty((M, H), dtype=torch.bfloat16, device=DEV)
-    eng.engine.set_tuning(fuse=1)
     eager, w_e, i_e = eng.forward_logits(x, logits, K, True, out_dtype=torch.bfloat16)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())

@@ -183,18 +183,16 @@ def test_fp8_w8a8_larger_random():
 
 
 @pytest.mark.parametrize("gated", [True, False])
-@pytest.mark.parametrize("M,E,H,I,xcd,pf", [
-    (600, 4, 512, 384, 0, 8), (1500, 3, 256, 640, 1, 8), (2300, 20, 384, 128, 1, 8),
-    # round-3 kernel (K loops of >= 8 units): 8 / 8, 12 / 9 and 9 / 10 units, one to ~40 items per workgroup (the
-    # item-boundary pipeline), experts of 1 to 900 rows, padded weight-tile counts (I = 1152: 72 tiles = 4.5 row groups)
-    (700, 3, 1024, 1024, 0, 9), (1500, 5, 1536, 1152, 1, 9), (6000, 24, 1152, 1280, 1, 9), (3000, 7, 1024, 1024, 0, 9),
-    (260, 2, 1024, 1024, 1, 9)])
-def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated, pf):
-    """gemm_prefill_a8w.h (pf 9: weights straight to registers, tokens through a 4-stage LDS ring, equal token tiles)
-    and gemm_prefill_a8.h (pf 8: both operands through two LDS buffers) -- 256 x 256 tiles on the 128-k fp8 MFMA (pf 9:
-    v_mfma_f32_16x16x128_f8f6f4; pf 8: its MX-scaled form with unit scales), block scales applied to each instruction's fp32 result --
-    against the oracle and against the legacy-fp8-MFMA tiled kernel: ragged tiles, 1 to 12 K units (fewer than the
-    pipeline depth, not a multiple of the register ring), padded weight-tile counts, with and without the XCD runs"""
+@pytest.mark.parametrize("M,E,H,I,xcd", [
+    # K loops of >= 8 units: 8 / 8, 12 / 9 and 9 / 10 units, one to ~40 items per workgroup (the item-boundary
+    # pipeline), experts of 1 to 900 rows, padded weight-tile counts (I = 1152: 72 tiles = 4.5 row groups)
+    (700, 3, 1024, 1024, 0), (1500, 5, 1536, 1152, 1), (6000, 24, 1152, 1280, 1), (3000, 7, 1024, 1024, 0),
+    (260, 2, 1024, 1024, 1)])
+def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated):
+    """gemm_prefill_a8w.h (weights straight to registers, tokens through a 4-stage LDS ring, equal token tiles): 256 x 256
+    items on the 128-k fp8 MFMA (v_mfma_f32_16x16x128_f8f6f4), block scales applied to each instruction's fp32 result --
+    against the oracle and against the legacy-fp8-MFMA tiled kernel: ragged tiles, 8 to 12 K units (not a multiple of the
+    register ring), padded weight-tile counts, with and without the XCD runs"""
     from lvllm_amd import _clib
     K = 2
     a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=M, gated=gated, drop=0.05, skew=0.5)
@@ -203,9 +201,9 @@ def test_fp8_w8a8_prefill_kernel_scaled_mfma(M, E, H, I, xcd, gated, pf):
     eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
                w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128,
                fp8_mode=_clib.FP8_W8A8, has_gate_proj=gated, activation_type=0 if gated else 2, max_batch_size=4096)
-    eng.engine.set_tuning(tiled=256, xcd=1 if xcd else -1, pf=8 if pf == 8 else 0)
+    eng.engine.set_tuning(tiled=256, xcd=1 if xcd else -1)
     out = _run_decode(eng, a, tw, ids)
-    assert "tm=256" in eng.engine.describe() and f"pf={pf}" in eng.engine.describe(), eng.engine.describe()
+    assert "tm=256" in eng.engine.describe() and "pf=9" in eng.engine.describe(), eng.engine.describe()
     d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128, round_gemm1=True,
                     w8a8=True, has_gate=gated, activation=orc.ACT_SILU if gated else orc.ACT_RELU2)
     ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
@@ -1017,22 +1015,3 @@ def test_modular_experts_top1_preweighted_and_fp8_quant_config():
     want = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=ATOL, rtol=RTOL)
     assert LkmQuant.from_vllm(QC(), torch.bfloat16).fp8_mode == _clib.FP8_W8A16
-
-
-@pytest.mark.parametrize("fmt,M", [("bf16", 20), ("bf16", 200), ("int4", 24), ("int4", 150), ("fp8a8", 40), ("fp8a8", 600)])
-def test_unit_major_weight_image_is_bit_identical(fmt, M, monkeypatch):
-    """LKM_W_UNIT_MAJOR=1 (read by lkm_create) stores the weight image [expert][unit][tile] instead of
-    [expert][tile][unit]; every kernel addresses it through GemmParams::w_*stride, so streamer, tile and prefill paths
-    must give the same bits in both layouts."""
-    from tests.test_gpu_fused_step import _engine
-    E, K, H, I = 4, 2, 512, 384
-    g = torch.Generator().manual_seed(M)
-    a = (torch.randn((M, H), generator=g) / 10).to(torch.bfloat16).to(DEV)
-    tw, ids = make_routing(M, E, K, seed=M, skew=0.5, drop=0.1)
-    twd, idd = torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)
-    monkeypatch.delenv("LKM_W_UNIT_MAJOR", raising=False)
-    base = _engine(fmt, E, K, H, I, torch.bfloat16, seed=3).forward_rows(a, twd, idd).cpu()
-    monkeypatch.setenv("LKM_W_UNIT_MAJOR", "1")
-    eng = _engine(fmt, E, K, H, I, torch.bfloat16, seed=3)
-    got = eng.forward_rows(a, twd, idd).cpu()
-    assert torch.equal(got.view(torch.int32), base.view(torch.int32)), eng.engine.describe()

@@ -367,27 +367,46 @@ class LkmPrepareAndFinalize:
             output.copy_(out)
 
 
-def bind_vllm_base():
+def _mk_module(mk=None):
+    if mk is not None:
+        return mk
+    from vllm.model_executor.layers.fused_moe import modular_kernel
+    return modular_kernel
+
+
+def bind_vllm_base(mk=None):
     """`class LkmExpertsModular(LkmExperts, mk.FusedMoEExpertsModular)` for registration inside LvLLM
     (e.g. through the kernel-selection table of the fused-MoE layer, or @PluggableLayer.register_oot around RoutedExperts, custom_op.py:47-101).
-    Raises ImportError where vLLM is not importable."""
-    from vllm.model_executor.layers.fused_moe import modular_kernel as mk
+    `mk`: the reference's modular_kernel module (default: imported from vLLM; raises ImportError where vLLM is not
+    importable -- the GPU tests pass the module that oracle/make_ref_glue.py cuts out of the reference tree)."""
+    mk = _mk_module(mk)
+    noop = getattr(mk, "TopKWeightAndReduceNoOP", None)
 
     class LkmExpertsModular(LkmExperts, mk.FusedMoEExpertsModular):  # type: ignore[misc]
         def __init__(self, moe_config, quant_config, max_num_tokens=None, num_dispatchers=None, **kw):
             mk.FusedMoEExpertsModular.__init__(self, moe_config, quant_config, max_num_tokens, num_dispatchers)
             LkmExperts.__init__(self, moe_config, quant_config, max_num_tokens=max_num_tokens or 8192, **kw)
 
+        @staticmethod
+        def activation_format():
+            return mk.FusedMoEActivationFormat.Standard
+
+        def finalize_weight_and_reduce_impl(self):
+            if noop is not None:
+                return noop()
+            return LkmExperts.finalize_weight_and_reduce_impl(self)
+
     return LkmExpertsModular
 
 
-def bind_vllm_prepare_finalize():
+def bind_vllm_prepare_finalize(mk=None):
     """`class LkmPrepareAndFinalizeModular(LkmPrepareAndFinalize, mk.FusedMoEPrepareAndFinalizeModular)` -- the same for
     the prepare / finalize half (modular_kernel.py:257-418).  Raises ImportError where vLLM is not importable."""
-    from vllm.model_executor.layers.fused_moe import modular_kernel as mk
+    mk = _mk_module(mk)
 
     class LkmPrepareAndFinalizeModular(LkmPrepareAndFinalize, mk.FusedMoEPrepareAndFinalizeModular):  # type: ignore[misc]
-        pass
+        @property
+        def activation_format(self):
+            return mk.FusedMoEActivationFormat.Standard
 
     return LkmPrepareAndFinalizeModular
-

@@ -7,6 +7,7 @@ Checks, each printed as "<tag> OK":
                   communication_op.py:12-14), bit-identical on one rank
   a2a captured    the a2a step recorded in a hipGraph AFTER the communicator exists, replayed on new inputs
   layer ar        RoutedExpertsLayer with an expert_map + the "ar" reduction of its output
+  reference FusedMoEKernel   the reference's own modular driver (oracle/_ref/modular_kernel_glue.py) over the bound classes
 Exits through os._exit: tearing down a communicator that a live graph still references has hung before."""
 import os
 import sys
@@ -119,6 +120,31 @@ def main():
     torch.cuda.synchronize()
     assert torch.equal(mout, want2), float((mout - want2).abs().max())
     print("modular prepare/apply/finalize OK", flush=True)
+
+    # ---- the same sequence owned by the REFERENCE's FusedMoEKernel (modular_kernel.py:1096-1525, 1588-1726; cut out of the
+    # reference tree by oracle/make_ref_glue.py) over the real one-rank RCCL group: bound classes, workspace allocation,
+    # prepare -> apply -> finalize, the output in the activation dtype
+    glue = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "modular_kernel_glue.py")
+    if os.path.exists(glue):
+        import importlib.util
+        import types
+        spec = importlib.util.spec_from_file_location("modular_kernel_glue", glue)
+        mk = importlib.util.module_from_spec(spec)
+        sys.modules["modular_kernel_glue"] = mk
+        spec.loader.exec_module(mk)
+        from lvllm_amd import modular
+        Experts, PF = modular.bind_vllm_base(mk), modular.bind_vllm_prepare_finalize(mk)
+
+        class QC:
+            a1_scale = a2_scale = w1_scale = w2_scale = block_shape = quant_dtype = None
+        cfg = types.SimpleNamespace(moe_parallel_config=types.SimpleNamespace(dp_size=1, use_ep=True))
+        kern = mk.FusedMoEKernel(PF(E, H, pool_tag="refkernel"), Experts(cfg, QC()))
+        kout = kern.apply(x2, w13, w2, tw2, ids2, mk.MoEActivation.SILU, E, None, False)
+        torch.cuda.synchronize()
+        assert kout.dtype == torch.bfloat16 and torch.equal(kout, want2.to(torch.bfloat16)), float((kout.float() - want2).abs().max())
+        print("reference FusedMoEKernel OK", flush=True)
+    else:
+        print("reference FusedMoEKernel SKIPPED (oracle/_ref/modular_kernel_glue.py not built)", flush=True)
     sys.stdout.flush()
     os._exit(0)
 

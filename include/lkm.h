@@ -84,7 +84,14 @@ typedef struct LkmConfig {
     int32_t group_min_len;    /* idem                                        */
     int32_t group_max_len;    /* prefill chunk length (:1323-1330)           */
     int32_t groupN;           /* quant block shape (rows)                    */
-    int32_t groupK;           /* quant block shape (K)                       */
+    int32_t groupK;           /* quant block shape (K).  The reference hands over ONE value for both GEMMs, the maximum of
+                               * w13's and w2's (routed_experts.py:1440-1453).  Rule: the scale group of a GEMM is
+                               * min(groupK, that GEMM's K) -- groupK >= K means one group per weight row, the scale array
+                               * of that GEMM is [E, N / groupN, ceil(K / groupK)].  Per-channel checkpoints
+                               * (_process_fp8(False), :1381-1383: scales [E, N, 1]; _process_wna16("channel")) therefore
+                               * arrive as groupN = 1, groupK = max(hidden, intermediate) and are accepted (round 4).
+                               * fp8: groupK a multiple of 128 or covering the whole K; int4: 32, 64, 128, a multiple of
+                               * 128 dividing K, or the whole K (itself a multiple of 128). */
     int32_t activation_type;  /* LKM_ACT_*                                   */
     float swiglu_alpha;
     float swiglu_limit;

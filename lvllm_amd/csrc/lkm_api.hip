@@ -304,11 +304,20 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     const bool gated = cfg->has_gate_proj != 0;
     LKM_REQUIRE(!(gated && cfg->activation_type == LKM_ACT_RELU2), "lkm_create: relu2 experts are non-gated (has_gate_proj must be 0)");
     LKM_REQUIRE(!(!gated && cfg->activation_type != LKM_ACT_RELU2), "lkm_create: non-gated experts support activation_type 2 (relu2) only");
+    // groupK >= K of a GEMM means ONE scale group per weight row of that GEMM: the reference hands over
+    // max(groupK of w13, groupK of w2) (routed_experts.py:1440-1453), so per-channel scales -- _process_fp8(False) for
+    // CompressedTensorsW8A8Fp8MoEMethod (:1381-1383, scales [E, N, 1]) and _process_wna16("channel") -- arrive as
+    // groupN = 1, groupK = max(hidden, intermediate).  The group of each GEMM is therefore min(groupK, its K).
+    const int gk13 = cfg->groupK > cfg->hidden_size ? cfg->hidden_size : cfg->groupK;             // GEMM1: K = hidden
+    const int gk2 = cfg->groupK > cfg->intermediate_size ? cfg->intermediate_size : cfg->groupK;   // GEMM2: K = intermediate
     if (wf == LKM_W_FP8_E4M3) {
         LKM_REQUIRE(cfg->fp8_mode == LKM_FP8_W8A16 || cfg->fp8_mode == LKM_FP8_W8A8, "lkm_create: bad fp8_mode %d", cfg->fp8_mode);
         LKM_REQUIRE(cfg->fp8_mode != LKM_FP8_W8A8 || cfg->groupK == 128, "lkm_create: fp8 W8A8 quantises activations in 1x128 groups; groupK must be 128 (got %d)", cfg->groupK);
         LKM_REQUIRE(w13_scale && w2_scale, "lkm_create: fp8 weights need scales");
-        LKM_REQUIRE(cfg->groupN > 0 && cfg->groupK > 0 && cfg->groupK % 128 == 0, "lkm_create: fp8 needs groupN>0 and groupK a multiple of 128 (got %d,%d)", cfg->groupN, cfg->groupK);
+        LKM_REQUIRE(cfg->groupN > 0 && cfg->groupK > 0, "lkm_create: fp8 needs groupN>0 and groupK>0 (got %d,%d)", cfg->groupN, cfg->groupK);
+        LKM_REQUIRE((gk13 % 128 == 0 || gk13 == cfg->hidden_size) && (gk2 % 128 == 0 || gk2 == cfg->intermediate_size),
+                    "lkm_create: fp8 groupK=%d must be a multiple of 128 or cover the whole K of a GEMM (hidden %d, intermediate %d)",
+                    cfg->groupK, cfg->hidden_size, cfg->intermediate_size);
     }
     if (wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4) {
         const int g = wf == LKM_W_MXFP4 ? 32 : 16;
@@ -319,9 +328,13 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     if (wf == LKM_W_INT4_B8) {
         LKM_REQUIRE(w13_scale && w2_scale, "lkm_create: int4 weights need scales");
         LKM_REQUIRE(cfg->groupN == 1, "lkm_create: int4 expects groupN == 1 (got %d)", cfg->groupN);
-        const int g = cfg->groupK;
-        LKM_REQUIRE(g >= 32 && (g <= 128 ? 128 % g == 0 : g % 128 == 0), "lkm_create: int4 groupK=%d unsupported (32, 64, 128 or a multiple of 128)", g);
-        LKM_REQUIRE(cfg->hidden_size % g == 0 && cfg->intermediate_size % g == 0, "lkm_create: groupK=%d must divide hidden and intermediate sizes", g);
+        for (int which = 0; which < 2; ++which) {
+            const int g = which ? gk2 : gk13, kk = which ? cfg->intermediate_size : cfg->hidden_size;
+            LKM_REQUIRE(g >= 32 && (g <= 128 ? 128 % g == 0 : g % 128 == 0), "lkm_create: int4 groupK=%d (group of GEMM%d: %d) unsupported (32, 64, 128 or a multiple of 128)", cfg->groupK, which + 1, g);
+            LKM_REQUIRE(kk % g == 0, "lkm_create: int4 group %d must divide K=%d of GEMM%d", g, kk, which + 1);
+        }
+        LKM_REQUIRE((gk13 >= 128) == (gk2 >= 128) && (gk13 >= 128 || gk13 == gk2), "lkm_create: int4 groups of the two GEMMs (%d, %d) need the same scales per 128-k unit", gk13, gk2);
+        const int g = gk13 < gk2 ? gk13 : gk2;
         LKM_REQUIRE(cfg->int4_mode == LKM_INT4_EXACT || cfg->int4_mode == LKM_INT4_FAST, "lkm_create: bad int4_mode %d", cfg->int4_mode);
         LKM_REQUIRE(cfg->int4_mode != LKM_INT4_FAST || g % 128 == 0, "lkm_create: int4_mode FAST applies the group scale per 128-k block; groupK must be a multiple of 128 (got %d)", g);
     }
@@ -355,7 +368,7 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     h->T2 = round_up(ceil_div(h->H, 16), 4);
     h->U2 = ceil_div(h->I, h->unitk);
     h->ld_act = h->I;
-    h->spu = (wf == LKM_W_INT4_B8) ? (cfg->groupK >= 128 ? 1 : 128 / cfg->groupK) : 0;
+    h->spu = (wf == LKM_W_INT4_B8) ? (gk13 >= 128 ? 1 : 128 / gk13) : 0;
 
     const int loads = wf_loads(wf);
     const int halves = gated ? 2 : 1;
@@ -420,23 +433,23 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
         LKM_TRY(hand_off(w2, b2, h->w2, w2_vec / h->E * 16, d2, rw));
     }
     if (h->ps) {     // fp32 scale per (row, 128-k unit), the layout of the fp8 block scales
-        const int g = cfg->groupK;
         const size_t n13 = (size_t)halves * h->T1_half * h->U1 * 16, n2 = (size_t)h->T2 * h->U2 * 16;   // per expert
         LKM_TRY_HIP(hipMalloc(&h->s13, h->E * n13 * 4));
         LKM_TRY_HIP(hipMalloc(&h->s2, h->E * n2 * 4));
         h->weight_bytes += (int64_t)h->E * (n13 + n2) * 4;
-        auto rs = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4ps(nullptr, sp, dp, dd, g, adt); };
-        LKM_TRY(hand_off(w13_scale, (size_t)halves * h->I * (h->H / g) * 2, h->s13, n13 * 4, d13, rs));
-        LKM_TRY(hand_off(w2_scale, (size_t)h->H * (h->I / g) * 2, h->s2, n2 * 4, d2, rs));
+        auto rs13 = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4ps(nullptr, sp, dp, dd, gk13, adt); };
+        auto rs2 = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4ps(nullptr, sp, dp, dd, gk2, adt); };
+        LKM_TRY(hand_off(w13_scale, (size_t)halves * h->I * (h->H / gk13) * 2, h->s13, n13 * 4, d13, rs13));
+        LKM_TRY(hand_off(w2_scale, (size_t)h->H * (h->I / gk2) * 2, h->s2, n2 * 4, d2, rs2));
     } else if (wf == LKM_W_INT4_B8) {
-        const int g = cfg->groupK;
         const size_t n13 = (size_t)halves * h->T1_half * h->U1 * 16 * h->spu, n2 = (size_t)h->T2 * h->U2 * 16 * h->spu;
         LKM_TRY_HIP(hipMalloc(&h->s13, h->E * n13 * 2 + 16));   // +16: the kernels fetch 8 bytes per lane
         LKM_TRY_HIP(hipMalloc(&h->s2, h->E * n2 * 2 + 16));
         h->weight_bytes += (int64_t)h->E * (n13 + n2) * 2;
-        auto rs = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4(nullptr, sp, dp, dd, g, h->spu); };
-        LKM_TRY(hand_off(w13_scale, (size_t)halves * h->I * (h->H / g) * 2, h->s13, n13 * 2, d13, rs));
-        LKM_TRY(hand_off(w2_scale, (size_t)h->H * (h->I / g) * 2, h->s2, n2 * 2, d2, rs));
+        auto rs13 = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4(nullptr, sp, dp, dd, gk13, h->spu); };
+        auto rs2 = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4(nullptr, sp, dp, dd, gk2, h->spu); };
+        LKM_TRY(hand_off(w13_scale, (size_t)halves * h->I * (h->H / gk13) * 2, h->s13, n13 * 2, d13, rs13));
+        LKM_TRY(hand_off(w2_scale, (size_t)h->H * (h->I / gk2) * 2, h->s2, n2 * 2, d2, rs2));
     } else if (wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4) {
         const int g = cfg->groupK, spu = 128 / g;
         const size_t n13 = (size_t)halves * h->T1_half * h->U1 * 16 * spu, n2 = (size_t)h->T2 * h->U2 * 16 * spu;

@@ -378,7 +378,7 @@ def bind_vllm_base(mk=None):
     """`class LkmExpertsModular(LkmExperts, mk.FusedMoEExpertsModular)` for registration inside LvLLM
     (e.g. through the kernel-selection table of the fused-MoE layer, or @PluggableLayer.register_oot around RoutedExperts, custom_op.py:47-101).
     `mk`: the reference's modular_kernel module (default: imported from vLLM; raises ImportError where vLLM is not
-    importable -- the GPU tests pass the module that oracle/make_ref_glue.py cuts out of the reference tree)."""
+    importable -- the GPU tests pass a copy of the reference module cut out of the reference tree)."""
     mk = _mk_module(mk)
     noop = getattr(mk, "TopKWeightAndReduceNoOP", None)
 

@@ -461,7 +461,9 @@ static void dequant_row(const OrMoeDesc* d, const void* w, const void* scale, co
            scales act-dtype [E,N,K/g]; dequant = T((nib-8) * scale_f32)
            (fused_moe.py:207-208,237-276; quant_utils.py:706 w_ref) */
         const uint8_t* p = (const uint8_t*)w + ((size_t)e * N + n) * (K / 2);
-        int64_t gK = d->groupK, kb = K / gK;
+        /* groupK >= K: one group per row (channel-wise scales [E,N,1]; the reference passes max(groupK of w13, w2),
+           routed_experts.py:1440-1453) */
+        int64_t gK = d->groupK, kb = (K + gK - 1) / gK;
         const uint16_t* s = (const uint16_t*)scale + ((size_t)e * N + n) * kb;
         for (int64_t k = 0; k < K; ++k) {
             int q = (p[k >> 1] >> ((k & 1) * 4)) & 0xf;

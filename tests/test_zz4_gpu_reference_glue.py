@@ -193,6 +193,53 @@ def test_reference_glue_fp8_block():
     _drive(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3]), 3e-3, 1.5e-2)
 
 
+def test_reference_glue_fp8_per_channel():
+    """MOE_FP8 through RoutedExperts._process_fp8(block_quant=False) -- what _do_process_weights_after_loading calls for
+    CompressedTensorsW8A8Fp8MoEMethod (routed_experts.py:1381-1383): per-output-channel scales `w13_weight_scale`
+    [E, 2I, 1], `w2_weight_scale` [E, H, 1]; _get_quant_params (:1440-1453) then hands over groupN = 1 and
+    groupK = max(hidden, intermediate): ONE scale group per weight row of each GEMM (include/lkm.h: LkmConfig.groupK)"""
+    glue = _load_glue()
+    E, K, H, I = 4, 2, 512, 256
+    w13, w2 = _masters(E, H, I, 6)
+
+    def per_channel(w):
+        s = (w.float().abs().amax(dim=-1, keepdim=True).clamp(min=1e-4) / 448.0)
+        return (w.float() / s).to(torch.float8_e4m3fn), s.contiguous()
+    q13, s13 = per_channel(w13)
+    q2, s2 = per_channel(w2)
+    assert s13.shape == (E, 2 * I, 1) and s2.shape == (E, H, 1)
+    s = _stand_in(glue, E, K, H, I, torch.bfloat16, w13_weight=q13, w2_weight=q2, w13_weight_scale=s13, w2_weight_scale=s2)
+    s._process_fp8(False)
+    assert type(s.lk_moe).__name__ == "MOE_FP8" and (s.lk_moe_config.groupN, s.lk_moe_config.groupK) == (1, max(H, I))
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=1, groupK=max(H, I))
+    a = (q13.view(torch.uint8).numpy(), q2.view(torch.uint8).numpy(), s13.numpy(), s2.numpy())
+    # the oracle dequantises fp8 * scale[n] (per channel) and runs the bf16 path on it (SURVEY 8c "fp8 W8A16")
+    _drive(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3]), 3e-3, 1.5e-2)
+
+
+def test_reference_glue_wna16_channel():
+    """MOE_WNA16 through RoutedExperts._process_wna16("channel"): channel-wise scales, checkpoint shapes
+    `w13_weight_scale` [E, 1, 2I] / `w2_weight_scale` [E, 1, H] (transposed back to [E, N, 1] by the glue);
+    groupK = max(hidden, intermediate) again.  hidden > intermediate here, the other order in the fp8 case above."""
+    glue = _load_glue()
+    E, K, H, I = 4, 2, 512, 256
+    w13, w2 = _masters(E, H, I, 7)
+    q13, s13 = bench.quantize_int4(w13.to(DEV), H)          # one group per row: g = K of the GEMM
+    q2, s2 = bench.quantize_int4(w2.to(DEV), I)
+    q13, s13, q2, s2 = q13.cpu(), s13.to(torch.bfloat16).cpu(), q2.cpu(), s2.to(torch.bfloat16).cpu()
+    assert s13.shape == (E, 2 * I, 1) and s2.shape == (E, H, 1)
+    pk = lambda q: q.contiguous().view(torch.int32).transpose(1, 2).contiguous()       # noqa: E731
+    s = _stand_in(glue, E, K, H, I, torch.bfloat16, w13_weight_packed=pk(q13), w2_weight_packed=pk(q2),
+                  w13_weight_scale=s13.transpose(1, 2).contiguous(), w2_weight_scale=s2.transpose(1, 2).contiguous(),
+                  quant_method=_QuantMethod(-1))
+    assert s.w13_weight_scale.shape == (E, 1, 2 * I)
+    s._process_wna16("channel")
+    assert type(s.lk_moe).__name__ == "MOE_WNA16" and (s.lk_moe_config.groupN, s.lk_moe_config.groupK) == (1, max(H, I))
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_INT4, groupN=1, groupK=max(H, I))
+    a = (q13.numpy(), q2.numpy(), torch_to_bits(s13), torch_to_bits(s2))
+    _drive(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3]), 3e-3, 1.5e-2)
+
+
 def test_reference_glue_mxfp4():
     """MOE_MXFP4 through RoutedExperts._process_mxfp4 (:1748-1815): packed E2M1 + E8M0 scales per 32 k"""
     glue = _load_glue()

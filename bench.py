@@ -34,6 +34,12 @@ import sys
 import time
 from pathlib import Path
 
+# cpu_baseline: pin the OpenMP team before any OpenMP runtime initialises (the reference pins its lk_moe pool with
+# LK_THREAD_BINDING, numa_utils.py:508-527).  Threads stay on consecutive cores; the weights are first touched by the thread
+# that packs them, so a team that fits one socket reads local memory.  Reported in cpu_baseline.binding.
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -41,6 +47,7 @@ import torch.distributed as dist
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+_GLM_ROUTER = dict(kind="grouped", n_group=1, topk_group=1, scoring="sigmoid", routed_scaling=1.0, bias=True)
 WORKLOADS = {
     # name: E experts, K top-k, H hidden, I intermediate, M tokens per GPU, weight format
     "mixtral8x7b_bf16_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="bf16"),
@@ -66,10 +73,12 @@ WORKLOADS = {
     "mixtral8x7b_mxfp4_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="mxfp4"),
     "mixtral8x7b_mxfp4_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="mxfp4"),
     "mixtral8x7b_nvfp4_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="nvfp4"),
-    # BASELINE.json configs[4]: GLM-4.5-Air prefill, 8192 tokens (MFMA-bound: roofline in TFLOP/s)
-    "glm45air_bf16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="bf16", prefill=True),
-    "glm45air_fp8w8a16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=0, prefill=True),
-    "glm45air_fp8w8a8_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=1, prefill=True),
+    # BASELINE.json configs[4]: GLM-4.5-Air prefill, 8192 tokens (MFMA-bound: roofline in TFLOP/s).  The model's router is
+    # sigmoid + score-correction bias through grouped top-k with ONE group (models/glm4_moe.py:190-204; Glm4MoeConfig:
+    # n_group = topk_group = 1, norm_topk_prob, routed_scaling_factor 1.0)
+    "glm45air_bf16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="bf16", prefill=True, router=_GLM_ROUTER),
+    "glm45air_fp8w8a16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=0, prefill=True, router=_GLM_ROUTER),
+    "glm45air_fp8w8a8_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=1, prefill=True, router=_GLM_ROUTER),
 }
 HEADLINE = "mixtral8x7b_bf16_decode_m32"
 EXTRA_N1 = [# the headline workload under Zipf routing first, in the thermal state the headline itself ran in (after the
@@ -78,7 +87,9 @@ EXTRA_N1 = [# the headline workload under Zipf routing first, in the thermal sta
             ("mixtral8x7b_bf16_decode_m32", "zipf"),
             "mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128", "mixtral8x7b_int4g128_fast_decode_m128",
             # BASELINE.json configs[4] (the MFMA-bound grouped GEMM)
-            "glm45air_fp8w8a8_prefill_m8192"]
+            "glm45air_fp8w8a8_prefill_m8192",
+            # ... and the path the reference's gpu_prefill actually takes (MOE_BF16 / MOE_FP8 = W8A16: routed_experts.py:1884-1899)
+            "glm45air_bf16_prefill_m8192", "glm45air_fp8w8a16_prefill_m8192"]
 EXTRA_EP = "dsv3_fp8w8a8_ep_decode_b256"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp8": 5000.0}   # dense, MI355X_MICROARCH.md
@@ -268,16 +279,31 @@ def time_reference_kernel(w13, w2, x, tw, ids, thread_cands, seconds, gpu_out):
         if tc > 3 * best_t:
             break
     ref.set_threads(best_c)
-    n, t_cpu, out = 0, 0.0, None
-    while n < 2 or (t_cpu < seconds and n < 200):
+    # median of >= 5 timed passes (the mean of a time-boxed loop moved 12 -> 25 ms per step between sessions: VERDICT r3)
+    times, out = [], None
+    while len(times) < 5 or (sum(times) < seconds and len(times) < 200):
         c0 = time.perf_counter()
         out = ref.fused_moe(xc, p13, p2, twc, idc)
-        t_cpu += time.perf_counter() - c0
-        n += 1
+        times.append(time.perf_counter() - c0)
+    n, t_cpu = len(times), sum(times)
+    med = float(np.median(times))
+    # ... and the all-cores figure SURVEY 8d asks for (one warm pass + one timed pass: it can be 10-50x slower)
+    all_cores = None
+    ncpu = max(thread_cands)
+    if ncpu != best_c:
+        ref.set_threads(ncpu)
+        ref.fused_moe(xc, p13, p2, twc, idc)
+        c0 = time.perf_counter()
+        ref.fused_moe(xc, p13, p2, twc, idc)
+        all_cores = {"cores": ncpu, "ms_per_step": round((time.perf_counter() - c0) * 1e3, 2)}
+        ref.set_threads(best_c)
     o = out.float().numpy()
     err = float(np.abs(gpu_out - o).max() / max(1e-9, np.abs(o).max()))
-    return {"value": round(x.size(0) / (t_cpu / n), 2), "unit": "tokens/s", "cores": best_c, "kind": "reference",
-            "ms_per_step": round(t_cpu / n * 1e3, 2), "max_rel_err_gpu_vs_cpu": err, "n": n, "t": t_cpu,
+    return {"value": round(x.size(0) / med, 2), "unit": "tokens/s", "cores": best_c, "kind": "reference",
+            "ms_per_step": round(med * 1e3, 2), "ms_per_step_stat": "median", "passes": n,
+            "ms_per_step_min_max": [round(min(times) * 1e3, 2), round(max(times) * 1e3, 2)],
+            "binding": {k_: os.environ.get(k_) for k_ in ("OMP_PROC_BIND", "OMP_PLACES")}, "all_cores": all_cores,
+            "max_rel_err_gpu_vs_cpu": err, "n": n, "t": t_cpu,
             "team_probe_ms": probe}
 
 
@@ -446,7 +472,11 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
         def local_compute(rows, lids, ws, dt, valid_den=None):
             # (a2a mode hands over ep x capacity token records of which ~1/ep carry local ids and says so: valid_den)
             return eng.forward_rows(rows, ws, lids, out_dtype=dt, valid_den=valid_den)
-        ep = ExpertParallelExperts(local_compute, E, H, mode=args.ep_mode,
+        # group-limited routers (DeepSeek-V3 / GLM): a token visits <= topk_group ranks, so the record capacity per
+        # destination is the group-limited estimate -- slack 1.25 + collective fallback in eager steps, slack 1.75 in the
+        # captured step (lvllm_amd/ep.py); the overflow counter is read after the timed replays (config.ep_overflow_tokens)
+        rg = (rt["n_group"], rt["topk_group"]) if rt["kind"] == "grouped" and rt["n_group"] > 1 else None
+        ep = ExpertParallelExperts(local_compute, E, H, mode=args.ep_mode, routing_groups=rg,
                                    return_dtype=torch.float32 if args.ep_return == "f32" else None)
 
         def step():
@@ -681,9 +711,15 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
                "roofline": roofline}
         if ep is not None and args.ep_mode == "a2a":
             rb = 4 if args.ep_return == "f32" else 2
-            res["config"]["exchange"] = dict(ep.wire_bytes(M, K, ret_bytes=rb),
-                                             granularity="token records [x | ids | weights], capacity = tokens per rank",
-                                             return_dtype="fp32" if rb == 4 else "bf16")
+            captured = launch != "eager"
+            res["config"]["exchange"] = dict(ep.wire_bytes(M, K, ret_bytes=rb, capturing=captured),
+                                             granularity="token records [x | ids | weights]; capacity = tokens per rank, or the "
+                                                         "group-limited estimate (slack 1.25 eager + fallback / 1.75 captured) "
+                                                         "when the router is group-limited",
+                                             return_dtype="fp32" if rb == 4 else "bf16",
+                                             # records that did not fit a destination's slots during this workload's steps
+                                             # (a captured step cannot branch on it: non-zero = re-run eagerly)
+                                             overflow_tokens=ep.overflow_count())
         if cold_ms is not None:
             res["ms_per_step_cold"] = round(cold_ms, 4)     # events around each step, caches evicted before it
         if long_run is not None:

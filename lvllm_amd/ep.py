@@ -145,7 +145,7 @@ class ExpertParallelExperts:
                  capacity_tokens: int | None = None, return_dtype: torch.dtype | None = None,
                  global_ids: bool = False, validate_uniform: bool = False,
                  routing_groups: tuple[int, int] | None = None, capacity_slack: float = 1.25,
-                 check_overflow: bool | None = None, pool_tag: str = ""):
+                 check_overflow: bool | None = None, pool_tag: str = "", capture_slack: float = 1.75):
         """kernels: namespace with ep_row_bytes / ep_pack_tokens / ep_combine (default lvllm_amd.ops = the HIP
         kernels, no CPU path; the gloo tests inject torch doubles).  transport: equal-split all-to-all (default
         dist.all_to_all_single over `group`).  fixed_max_tokens: largest capacity served by the fixed path.
@@ -159,7 +159,12 @@ class ExpertParallelExperts:
         being captured cannot branch and only counts -- its caller MUST read overflow_count() after the replay.
         check_overflow=False is the explicit opt-in to count silently in eager steps too.
         pool_tag: which exchange-buffer pool of the (device, group) this instance uses (two micro-batches in flight
-        need two tags)."""
+        need two tags).
+        capture_slack: the slack of the group-limited capacity while the step is being CAPTURED (a graph cannot branch
+        on the overflow counter, so its capacity is sized for < 1e-4 overflow probability per (source, destination)
+        pair instead of the eager path's 5 %: DeepSeek-V3 routing at 32 tokens per rank, Binomial(32, 1/2) records per
+        pair, capacity ceil(32 * 4 * 1.75 / 8) = 28 -> P(X > 28) = 1.3e-6; the caller still reads overflow_count()
+        after the replay)."""
         if mode not in ("a2a", "ar"):
             raise ValueError(f"unknown EP mode {mode!r} (expected 'a2a' or 'ar')")
         self.local_compute = local_compute
@@ -174,6 +179,7 @@ class ExpertParallelExperts:
         self.routing_groups = routing_groups
         self.capacity_slack = capacity_slack
         self.check_overflow = (routing_groups is not None) if check_overflow is None else bool(check_overflow)
+        self.capture_slack = max(capture_slack, capacity_slack)
         self.pool_tag = pool_tag
         self._overflow_seen = 0              # (device counter value at the last check)
         import inspect
@@ -199,9 +205,10 @@ class ExpertParallelExperts:
         dist.all_to_all_single(out, inp, group=self.group)
 
     # -------------------------------------------------------------------------------- a2a, fixed
-    def capacity_for(self, M: int, capacity: int | None = None, K: int | None = None) -> int:
+    def capacity_for(self, M: int, capacity: int | None = None, K: int | None = None, capturing: bool = False) -> int:
         """record slots per destination: the explicit `capacity`, else the constructor's `capacity_tokens`, else (with
-        `routing_groups`) the group-limited estimate, else the token count (the exact worst case)"""
+        `routing_groups`) the group-limited estimate -- at `capture_slack` while a graph is being captured -- else the
+        token count (the exact worst case)"""
         if capacity is not None:
             cap = capacity
         elif self.capacity_tokens is not None:
@@ -209,7 +216,8 @@ class ExpertParallelExperts:
         elif self.routing_groups is not None and self.ep > 1:
             n_group, topk_group = self.routing_groups
             rpt = ranks_per_token(self.ep, n_group, topk_group, K)
-            cap = min(M, -(-int(M * rpt * self.capacity_slack) // self.ep))
+            slack = self.capture_slack if capturing else self.capacity_slack
+            cap = min(M, -(-int(M * rpt * slack) // self.ep))
             return max(cap, 1)
         else:
             cap = M
@@ -325,10 +333,10 @@ class ExpertParallelExperts:
         return int(sum(int(b.item()) for b in self._overflow_bufs.values()))
 
     def wire_bytes(self, M: int, K: int, capacity: int | None = None, act_bytes: int = 2,
-                   ret_bytes: int | None = None) -> dict:
+                   ret_bytes: int | None = None, capturing: bool = False) -> dict:
         """bytes one rank puts on xGMI per fixed-path step (the blocks for the other ep-1 ranks) next to the
         routed-row bytes of a slot-granular exchange of the same step"""
-        cap = self.capacity_for(M, capacity, K)
+        cap = self.capacity_for(M, capacity, K, capturing)
         rowb = self.kernels.ep_row_bytes(self.H, K)
         rb = act_bytes if ret_bytes is None else ret_bytes
         out_b, back_b = (self.ep - 1) * cap * rowb, (self.ep - 1) * cap * self.H * rb
@@ -439,7 +447,7 @@ class ExpertParallelExperts:
             return y if out is None else out.copy_(y)
         M = topk_ids.size(0)
         if self.mode == "a2a":
-            cap = self.capacity_for(M, capacity, topk_ids.size(1))
+            cap = self.capacity_for(M, capacity, topk_ids.size(1), capturing=_capturing(hidden))
             if self.validate_uniform:
                 self._check_uniform(cap, "record capacity")
             if cap <= self.fixed_max_tokens:
@@ -457,3 +465,50 @@ class ExpertParallelExperts:
         if out is not None:
             return out.copy_(y)
         return y if y.dtype == out_dtype else y.to(out_dtype)
+
+
+def forward_two_microbatches(ep0: ExpertParallelExperts, ep1: ExpertParallelExperts, batch0, batch1, *,
+                             out_dtype: torch.dtype = torch.float32, shared: Callable | None = None,
+                             comm_stream=None):
+    """Two micro-batches through the fixed-capacity exchange with the RETURN exchange of batch 0 under the expert GEMMs of
+    batch 1 (SURVEY 7 "overlap"; the reference overlaps its shared experts with the exchange the same way,
+    runner/shared_experts.py:45-80, and its DBO hooks overlap two micro-batches, modular_kernel.py:1219-1276).
+
+        main stream : pack0 a2a0 | pack1 a2a1 | GEMMs(0) ............ | GEMMs(1) ......... | sum(1)
+        comm stream :                                                   a2a-back(0) sum(0)   [shared experts]   a2a-back(1)
+    ep0 / ep1: two ExpertParallelExperts on the same group with DIFFERENT `pool_tag`s (each micro-batch owns its exchange
+    buffers while in flight).  batch = (hidden [M,H], topk_weights [M,K], topk_ids [M,K]).  shared(hidden) -> tensor: an
+    optional always-on expert (or any independent work) launched on the communicator stream between the two return
+    exchanges.  On a CPU group (gloo tests) there are no streams: the same calls run in the same order, which is what
+    makes the result independent of the overlap.  -> (out0, out1[, shared0, shared1])"""
+    if ep0.pool_tag == ep1.pool_tag:
+        raise ValueError("forward_two_microbatches needs two instances with different pool_tag (each micro-batch owns its "
+                         "exchange buffers while in flight)")
+    x0, w0, i0 = batch0
+    x1, w1, i1 = batch1
+    cuda = x0.is_cuda
+    ep0._ensure_uniform(i0.size(0), None, x0)
+    ep1._ensure_uniform(i1.size(0), None, x1)
+    cap0 = ep0.capacity_for(i0.size(0), None, i0.size(1), capturing=_capturing(x0))
+    cap1 = ep1.capacity_for(i1.size(0), None, i1.size(1), capturing=_capturing(x1))
+    r0 = ep0.dispatch_fixed(x0, w0, i0, cap0, return_handle=True)
+    r1 = ep1.dispatch_fixed(x1, w1, i1, cap1, return_handle=True)
+    ret0, ret1 = ep0.return_dtype or x0.dtype, ep1.return_dtype or x1.dtype
+    y0 = ep0._local(r0[0], r0[1], r0[2], ret0)
+    if cuda:
+        side = comm_stream if comm_stream is not None else torch.cuda.Stream(device=x0.device)
+        main = torch.cuda.current_stream(x0.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out0 = ep0.combine_fixed(y0, i0.size(0), out_dtype, handle=r0[3])
+            sh = (shared(x0), shared(x1)) if shared is not None else None
+        y0.record_stream(side)
+        y1 = ep1._local(r1[0], r1[1], r1[2], ret1)          # overlaps the return exchange of batch 0
+        out1 = ep1.combine_fixed(y1, i1.size(0), out_dtype, handle=r1[3])
+        main.wait_stream(side)
+    else:
+        out0 = ep0.combine_fixed(y0, i0.size(0), out_dtype, handle=r0[3])
+        sh = (shared(x0), shared(x1)) if shared is not None else None
+        y1 = ep1._local(r1[0], r1[1], r1[2], ret1)
+        out1 = ep1.combine_fixed(y1, i1.size(0), out_dtype, handle=r1[3])
+    return (out0, out1) if sh is None else (out0, out1, sh[0], sh[1])

@@ -121,6 +121,40 @@ def main():
     assert torch.equal(mout, want2), float((mout - want2).abs().max())
     print("modular prepare/apply/finalize OK", flush=True)
 
+    # ---- two micro-batches in flight: the return exchange of batch 0 on the communicator stream under the GEMMs of batch 1
+    # (lvllm_amd/ep.py forward_two_microbatches), eager and captured, against the engine called directly
+    from lvllm_amd.ep import forward_two_microbatches
+    epa = ExpertParallelExperts(local, E, H, mode="a2a", return_dtype=torch.float32, pool_tag="mb0")
+    epb = ExpertParallelExperts(local, E, H, mode="a2a", return_dtype=torch.float32, pool_tag="mb1")
+    xb = (torch.randn((M, H), generator=g) / 2).to(torch.bfloat16).to(dev)
+    lb = torch.randn((M, E), generator=g).to(dev)
+    twb, idsb = ops.topk_softmax(lb, K, True)
+    wantb = eng.decode(xb, twb, idsb).clone()
+    side = torch.cuda.Stream()
+    o0, o1 = forward_two_microbatches(epa, epb, (x2, tw2, ids2), (xb, twb, idsb), comm_stream=side)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, want2) and torch.equal(o1, wantb)
+    so0, so1 = torch.empty_like(o0), torch.empty_like(o1)
+
+    def step2():
+        a_, b_ = forward_two_microbatches(epa, epb, (x2, tw2, ids2), (xb, twb, idsb), comm_stream=side)
+        so0.copy_(a_)
+        so1.copy_(b_)
+    cs = torch.cuda.Stream()
+    cs.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cs):
+        step2()
+    torch.cuda.current_stream().wait_stream(cs)
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=cs, capture_error_mode="thread_local"):
+        step2()
+    so0.zero_(), so1.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(so0, want2) and torch.equal(so1, wantb)
+    print("two micro-batches overlapped OK", flush=True)
+
     # ---- the same sequence owned by the REFERENCE's FusedMoEKernel (modular_kernel.py:1096-1525, 1588-1726; cut out of the
     # reference tree by oracle/make_ref_glue.py) over the real one-rank RCCL group: bound classes, workspace allocation,
     # prepare -> apply -> finalize, the output in the activation dtype

@@ -127,7 +127,7 @@ def test_one_rank_rccl_step_eager_and_captured():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     tags = ["a2a-f32 eager OK", "a2a-bf16 eager OK", "ar eager OK", "a2a captured OK", "layer ar OK",
-            "modular prepare/apply/finalize OK"]
+            "modular prepare/apply/finalize OK", "two micro-batches overlapped OK"]
     if (ROOT / "oracle" / "_ref" / "modular_kernel_glue.py").exists():      # the reference's FusedMoEKernel over world-1 RCCL
         tags.append("reference FusedMoEKernel OK")
     for tag in tags:

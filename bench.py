@@ -34,11 +34,12 @@ import sys
 import time
 from pathlib import Path
 
-# cpu_baseline: pin the OpenMP team before any OpenMP runtime initialises (the reference pins its lk_moe pool with
-# LK_THREAD_BINDING, numa_utils.py:508-527).  Threads stay on consecutive cores; the weights are first touched by the thread
-# that packs them, so a team that fits one socket reads local memory.  Reported in cpu_baseline.binding.
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
+# cpu_baseline: the reference kernel (oracle/_ref) runs on LLVM's OpenMP runtime, torch and the port on GNU's.  Its team is
+# pinned core by core (the reference pins its lk_moe pool with LK_THREAD_BINDING, numa_utils.py:508-527) through the
+# LLVM-only KMP_AFFINITY: the portable OMP_PROC_BIND / OMP_PLACES would also bind torch's libgomp, whose initialisation
+# then confines the main thread to ONE core -- and libomp, loaded later, inherits that two-CPU mask for its whole team
+# (measured: 170-185 ms per step at every team size instead of 10-25 ms; profiles/r04_cpu_baseline_binding.log).
+os.environ.setdefault("KMP_AFFINITY", "granularity=core,compact")
 
 import numpy as np
 import torch
@@ -302,7 +303,7 @@ def time_reference_kernel(w13, w2, x, tw, ids, thread_cands, seconds, gpu_out):
     return {"value": round(x.size(0) / med, 2), "unit": "tokens/s", "cores": best_c, "kind": "reference",
             "ms_per_step": round(med * 1e3, 2), "ms_per_step_stat": "median", "passes": n,
             "ms_per_step_min_max": [round(min(times) * 1e3, 2), round(max(times) * 1e3, 2)],
-            "binding": {k_: os.environ.get(k_) for k_ in ("OMP_PROC_BIND", "OMP_PLACES")}, "all_cores": all_cores,
+            "binding": {"KMP_AFFINITY": os.environ.get("KMP_AFFINITY")}, "all_cores": all_cores,
             "max_rel_err_gpu_vs_cpu": err, "n": n, "t": t_cpu,
             "team_probe_ms": probe}
 
@@ -430,6 +431,10 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
     E_local, first = E // world, rank * (E // world)
     eng, bpe, oracle_in, masters = build_engine(ops, wl, E_local, first, dev, max_num_seqs=max(256, M * world),
                                                 max_batch_size=max(8192, M), num_processes=world, process_id=rank)
+    if not args.no_autotune:
+        # the plan of each decode-sized step shape is picked by the engine's first-call micro-autotune (2-7 candidate plans
+        # timed on the step's own inputs during the warm-up steps; the choice is in config.geometry: "autotuned: ...")
+        eng.engine.set_tuning(autotune=1)
     if args.tune:
         eng.engine.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
@@ -707,7 +712,8 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
                           f"grouped {rt['scoring']}+bias top-{K} of {rt['topk_group']}/{rt['n_group']} groups x{rt['routed_scaling']}",
                           "routing": routing,
                           "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}",
-                          "launch": launch, "preroll_steps": preroll, "geometry": eng.engine.describe()},
+                          "launch": launch, "preroll_steps": preroll, "autotune": not args.no_autotune,
+                          "geometry": eng.engine.describe()},
                "roofline": roofline}
         if ep is not None and args.ep_mode == "a2a":
             rb = 4 if args.ep_return == "f32" else 2
@@ -811,6 +817,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget (s) for each CPU baseline sample (reference kernel, port)")
     ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf"],
                     help="router logits: randn (uniform-ish) or randn + Zipf(s=1) expert popularity bias (SURVEY 8d)")
+    ap.add_argument("--no-autotune", action="store_true", help="keep the planner's thresholds (lkm_set_tuning autotune stays 0)")
     ap.add_argument("--tune", default="", help="comma list key=value for lkm_set_tuning (nt1,nt2,kw1,sk2,tbmax)")
     ap.add_argument("--flush-cache", action="store_true",
                     help="also report ms_per_step_cold: every step preceded by a 1 GiB write that evicts the L2s and the "

@@ -13,6 +13,8 @@
 #include <string>
 #include <vector>
 
+#include <map>
+
 #include "lkm_kernels.h"
 #include "routing_dev.h"
 #include "../../include/lkm_eplb.h"
@@ -165,6 +167,18 @@ struct LkmEngine {
     // tuning overrides (<=0 = auto)
     int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0, t_fuse = 0, t_tiled2 = 0, t_fuseq = 0;
     int loads = 2;            // 16-byte loads per lane per (tile, unit)
+    // first-call micro-autotune (tuning key "autotune", off by default: the thresholds of pick_cfg stay the plan and
+    // results stay reproducible run to run).  When on, the first EAGER call of a decode-sized step shape times two to
+    // five candidate plans on the caller's own inputs and remembers the fastest for that shape; later calls -- and the
+    // captures that follow the warm-up steps -- take it.
+    int t_autotune = 0;
+    struct TunedPlan {
+        int pf, tiled, pd1, pd2;
+        float us;             // its time when chosen
+        char what[96];
+    };
+    std::map<uint64_t, TunedPlan> tuned;
+    hipEvent_t tune_ev[2] = {};
     // profiling
     bool prof = false;
     hipEvent_t ev[LKM_PROF_N + 1] = {};
@@ -280,6 +294,8 @@ extern "C" void lkm_destroy(LkmHandle h) {
     if (h->io_w) (void)hipFree(h->io_w);
     if (h->io_out) (void)hipFree(h->io_out);
     for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->tune_ev)
         if (e) (void)hipEventDestroy(e);
     delete h;
 }
@@ -1037,6 +1053,85 @@ static size_t chunk_tokens(const LkmEngine* h, int K) {
     return chunk;
 }
 
+// ---- first-call micro-autotune of one chunk's plan (tuning key "autotune" = 1)
+// The thresholds of pick_cfg were measured on three model shapes and two box classes; the 4-bit plans in particular
+// swing 8-25 % between the classes.  With "autotune" on, the first eager call of a step shape (M <= 1024 tokens; not while
+// the stream is capturing; not while an explicit plan is forced through "pf" / "tiled" / "pd*") runs each candidate once
+// untimed and `kTuneReps` times between two events on the caller's inputs, keeps the fastest and then runs it once more so
+// that `out` holds ITS result.  Candidates: the default plan, the streamer where the default uses tiles and vice versa,
+// 32- / 64-row tiles, the deeper weight ring, and for uint4b8 the 32x32-MFMA kernels (gemm_w4e.h / gemm_w4x.h).  Every
+// candidate is a plan the parity tests cover; which one wins depends on timing, so two processes may choose
+// differently (results then differ in fp32 summation order, inside the stated tolerance) -- the reason it is opt-in.
+constexpr int kTuneReps = 3;
+static bool tune_stream_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cs != hipStreamCaptureStatusNone;
+}
+static int run_chunk_tuned(LkmEngine* h, hipStream_t st, int M, int K, const void* x, const int32_t* ids,
+                           const float* tw, void* out, int out_dt, const InLayout& il) {
+    const bool forced = h->t_pf != 0 || h->t_tiled != 0 || h->t_pd1 != 0 || h->t_pd2 != 0 || h->t_waves != 0;
+    if (!h->t_autotune || forced || M < 8 || M > 1024 || h->prof) return run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
+    const uint64_t key = (uint64_t)M | ((uint64_t)K << 20) | ((uint64_t)out_dt << 28) | ((uint64_t)(il.route ? 1 : 0) << 32) |
+                         ((uint64_t)(h->t_valid_den & 0xff) << 33);
+    auto apply = [&](const LkmEngine::TunedPlan& c) { h->t_pf = c.pf; h->t_tiled = c.tiled; h->t_pd1 = c.pd1; h->t_pd2 = c.pd2; };
+    auto clear = [&]() { h->t_pf = h->t_tiled = h->t_pd1 = h->t_pd2 = 0; };
+    auto it = h->tuned.find(key);
+    if (it == h->tuned.end()) {
+        if (tune_stream_capturing(st) || h->tuned.size() >= 256) return run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
+        std::vector<LkmEngine::TunedPlan> cands;
+        cands.push_back({0, 0, 0, 0, 0.f, "default"});
+        Plan pl;
+        pick_cfg(h, M, (size_t)M * K, &pl);
+        const int def_tiled = pl.t1.tiled ? pl.t1.tiled : (pl.t2.tiled && !pl.s1.tb ? pl.t2.tiled : 0);
+        if (def_tiled && def_tiled <= 64) cands.push_back({0, -1, 0, 0, 0.f, "streamer"});
+        if (def_tiled != 64 && !(pl.t1.tiled > 64)) cands.push_back({0, 64, 0, 0, 0.f, "64-row tiles"});
+        if (def_tiled != 32 && wf_is_4bit(h->wf) && M * K <= 64 * h->E) cands.push_back({0, 32, 0, 0, 0.f, "32-row tiles"});
+        if (def_tiled && def_tiled <= 64 && pl.t1.pd == 2) cands.push_back({0, def_tiled, 4, 0, 0.f, "weight ring depth 4 (GEMM1)"});
+        if (h->wf == LKM_W_INT4_B8 && !h->ps && h->H % 128 == 0 && h->I % 128 == 0 && M >= 32) {
+            cands.push_back({6, def_tiled == 32 ? 32 : 64, 0, 0, 0.f, "32x32-MFMA + loader wave (gemm_w4e.h)"});
+            cands.push_back({5, def_tiled == 32 ? 32 : 64, 0, 0, 0.f, "32x32-MFMA (gemm_w4x.h)"});
+        }
+        if (!h->tune_ev[0]) {
+            LKM_HIP_CHECK(hipEventCreate(&h->tune_ev[0]));
+            LKM_HIP_CHECK(hipEventCreate(&h->tune_ev[1]));
+        }
+        int best = 0;
+        for (size_t c = 0; c < cands.size(); ++c) {
+            apply(cands[c]);
+            int rc = run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);       // untimed (first-touch, code load)
+            if (rc == LKM_OK) {
+                LKM_HIP_CHECK(hipEventRecord(h->tune_ev[0], st));
+                for (int r = 0; r < kTuneReps && rc == LKM_OK; ++r) rc = run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
+                LKM_HIP_CHECK(hipEventRecord(h->tune_ev[1], st));
+            }
+            clear();
+            if (rc != LKM_OK) {                 // a candidate the shape does not admit: not an error of the step
+                cands[c].us = 1e30f;
+                continue;
+            }
+            LKM_HIP_CHECK(hipEventSynchronize(h->tune_ev[1]));
+            float ms = 0.f;
+            LKM_HIP_CHECK(hipEventElapsedTime(&ms, h->tune_ev[0], h->tune_ev[1]));
+            cands[c].us = ms * 1e3f / kTuneReps;
+            if (cands[c].us < cands[best].us) best = (int)c;
+        }
+        LKM_REQUIRE(cands[best].us < 1e29f, "autotune: no candidate plan ran");
+        it = h->tuned.emplace(key, cands[best]).first;
+    }
+    apply(it->second);
+    const int rc = run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
+    clear();
+    if (rc == LKM_OK) {
+        const size_t n = strlen(h->last_desc);
+        snprintf(h->last_desc + n, sizeof(h->last_desc) - n, " | autotuned: %s (%.1f us)", it->second.what, it->second.us);
+    }
+    return rc;
+}
+
 static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, const int32_t* ids,
                       const float* tw, void* out, int out_dt, const InLayout* layout = nullptr) {
     LKM_REQUIRE(h, "null engine handle");
@@ -1054,8 +1149,8 @@ static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, 
     const size_t xrow = (size_t)il.x_ld * 2, orow = (size_t)h->H * (out_dt == LKM_DT_F32 ? 4 : 2);
     for (size_t m0 = 0; m0 < (size_t)M; m0 += chunk) {
         const int mc = (int)((size_t)M - m0 < chunk ? (size_t)M - m0 : chunk);
-        int rc = run_chunk(h, st, mc, K, (const char*)x + m0 * xrow, ids + m0 * il.ids_ld, tw + m0 * il.tw_ld,
-                           (char*)out + m0 * orow, out_dt, il);
+        int rc = run_chunk_tuned(h, st, mc, K, (const char*)x + m0 * xrow, ids + m0 * il.ids_ld, tw + m0 * il.tw_ld,
+                                 (char*)out + m0 * orow, out_dt, il);
         if (rc != LKM_OK) return rc;
     }
     return LKM_OK;
@@ -1276,6 +1371,10 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "pf")) h->t_pf = value;
     else if (!strcmp(key, "direct")) h->t_direct = value;
     else if (!strcmp(key, "fuse")) h->t_fuse = value;
+    else if (!strcmp(key, "autotune")) {
+        h->t_autotune = value;
+        if (value <= 0) h->tuned.clear();        // (0 / -1: off, and forget what was chosen)
+    }
     else if (!strcmp(key, "valid_den")) h->t_valid_den = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else if (!strcmp(key, "prof_rep")) h->t_prof_rep = value;

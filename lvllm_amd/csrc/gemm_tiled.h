@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
     // rows to LDS at the top of the iteration + double-buffered token-fragment chunks interleaved with
     // the MFMAs by sched_group_barrier: 2123/1168 vs 1853/1048; 4 waves x 4 weight tiles x 256 tokens (one
     // wave per SIMD, 512 registers): 2452/1233.  What this kernel lacks for the MFMA roof is the
-    // weight operand through LDS (glds) with a counted-vmcnt multi-phase schedule -- see DESIGN.md 6.
+    // weight operand through LDS (glds) with a counted-vmcnt multi-phase schedule -- see DESIGN_history.md 6.
     // Work mapping: blockIdx.x = row group (fastest), blockIdx.y = (expert, token tile) item, default
     // round-robin XCD placement (all XCDs work on the same one or two items at a time).  Measured:
     // (1) the XCD-aware mapping below (`xcd` tuning knob, off by default) cuts GLM-prefill GEMM1 HBM

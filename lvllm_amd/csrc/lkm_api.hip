@@ -569,6 +569,10 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             tiled = 64;
             if (w16 && avg_rows > 56) tiled = avg_rows >= 112 ? 256 : 128;
             if (h->wf == LKM_W_MXFP4 && avg_rows >= 64) tiled = 128;
+            // uint4b8 / NVFP4 at prefill sizes (round 4, profiles/r04_prefill_plan_sweep.log: what MOE_WNA16 / MOE_NVFP4
+            // gpu_prefill runs): 128-row tiles x 8 waves from ~100 rows per expert -- int4 Mixtral M=512 725 -> 683 us,
+            // M=2048 2159 -> 1951, M=8192 8235 -> 7149 (GEMM1 -21 %); NVFP4 M=2048 2017 -> 1842.  Decode sizes keep 64 / 32.
+            if ((h->wf == LKM_W_INT4_B8 || h->wf == LKM_W_NVFP4) && avg_rows >= 96) tiled = 128;
             // fp8 x fp8 (W8A8): 128-row tiles from ~200 rows per expert, now that the per-unit partial sums
             // are formed four token blocks at a time and the kernel fits its registers (GLM-4.5-Air prefill
             // 3677 -> 3179 us with two GEMM2 tiles per wave; Mixtral M=2048 1996 -> 1820; M=512 equal)
@@ -691,6 +695,12 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // (profiles/r03_a8w_*.log), so they are its default ("xcd" = -1 switches them off).
             if (pf == 9 && h->t_xcd >= 0) pl->xcd1 = pl->xcd2 = 1;
         }
+        // 16-bit weights, 256-row tiles, many experts (GLM-4.5-Air prefill: 128 experts x ~2 tiles): the XCD-aware runs keep
+        // the workgroups that share a weight panel on one L2 -- round 1 measured +-0 with equal ITEM counts per XCD; with the
+        // runs cut by routed rows (round 3) the bf16 prefill step goes 3095 -> 2853 us uniform, 3158 -> 3006 us Zipf
+        // (profiles/r04_prefill_plan_sweep.log).  Few large experts (Mixtral) lose with it and keep the plain grid.
+        if (tiled == 256 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && n_act >= 32 && h->t_xcd >= 0 && !pf)
+            pl->xcd1 = pl->xcd2 = 1;
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;
         // tiled GEMM2 split-K: few experts per rank (expert parallel) leave T2/waves workgroups per token
@@ -710,8 +720,12 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             while (sk2 > 1 && (size_t)sk2 * n_slots > y_rows) sk2 /= 2;
             if (h->t_sk2 > 0) sk2 = h->t_sk2;
         }
+        // fp8 W8A16 at prefill sizes (MOE_FP8.gpu_prefill): GEMM2 on eight waves per workgroup -- GLM-4.5-Air M=8192
+        // GEMM2 1474 -> 1156 us uniform, 1491 -> 1200 Zipf (GEMM1 unchanged by it): profiles/r04_prefill_plan_sweep.log
+        int waves2 = waves;
+        if (h->wf == LKM_W_FP8_E4M3 && !h->a8 && tiled == 64 && avg_rows >= 192 && h->t_waves == 0 && nt2 == 1) waves2 = 8;
         pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves, pd1, pf};
-        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, sk2, tiled, waves, pd2, pf};
+        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, sk2, tiled, waves2, pd2, pf};
         if (g2_only) pl->t1 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
         if (!split && !g2_only) return;
     }

@@ -166,7 +166,7 @@ def test_int4_quantiser_and_moe_vs_reference():
 
 
 def test_int4_scale_on_partial_sums_stays_inside_the_reference_tolerance():
-    """Checker for a candidate kernel mode: group scale applied to fp32 partial sums = the weight (q-8)*s
+    """Checker for a candidate kernel mode (DESIGN_history.md 6): group scale applied to fp32 partial sums = the weight (q-8)*s
     kept unrounded.  Not the reference's semantics, but inside its int4 tolerance (atol 2e-2, test_moe.py:565-693)
     against the reference's own golden outputs, and close to the rounded-weight result."""
     n = 0

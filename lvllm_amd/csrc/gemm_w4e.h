@@ -192,24 +192,11 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
             w[0][0] = *(const u32x4*)(sb + wlds);
             w[1][0] = *(const u32x4*)(sb + wlds + 256);
             typename D::Aux aux;
-            if constexpr (WF == LKM_W_INT4_B8) {
-                // aligned reads of what Dec<>::load_aux_at fetches with one unaligned 8-byte load (spu 1 / 2 / 4 scales)
-                if constexpr (HOIST) aux.raw = u32x2{(unsigned)*(const unsigned short*)(sb + alds), 0u};
-                else if (p.spu == 2) aux.raw = u32x2{*(const unsigned*)(sb + alds), 0u};
-                else aux.raw = *(const u32x2*)(sb + alds);
-            } else {
-                D::load_aux_at(aux, sb + alds);
-            }
-            typename Dec<LKM_W_INT4_B8, ADT>::Mult mu;
-            float s512 = 0.f, m8 = 0.f;
-            if constexpr (HOIST) {
-                mu = Dec<LKM_W_INT4_B8, ADT>::mult(aux, 0, 0);
-                s512 = mu.s512.x;
-                m8 = mu.m8.x;
-            }
+            W4Int4<WF, ADT>::load_aux_lds(aux, sb + alds, p.spu, HOIST);
+            typename W4Int4<WF, ADT>::M mu;
+            if constexpr (HOIST) mu = W4Int4<WF, ADT>::mult(aux);
             auto dec = [&](int s_, int q_) __attribute__((always_inline)) {
-                if constexpr (HOIST && DECV == 1) return int4_frag_plain<ADT>(w[q_][0][s_], s512, m8);
-                else if constexpr (HOIST) return D::frag_m(w[q_], s_, mu);
+                if constexpr (HOIST) return W4Int4<WF, ADT>::template frag<DECV>(w[q_], s_, mu);
                 else return D::frag(w[q_], aux, s_, dparam);
             };
             // (measured, profiles/r04_w4e_schedule_ab.log: issuing all 16 fragment reads of the unit up front and fencing

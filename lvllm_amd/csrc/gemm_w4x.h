@@ -59,6 +59,37 @@ __device__ __forceinline__ u32x4 int4_frag_plain(unsigned w, float s512, float m
     return o;
 }
 
+// What only uint4b8 has -- the multipliers of a (row, scale group) formed once per K unit when the group covers the unit
+// (HOIST), the packed-fp32-free decoder, aligned LDS reads of its scales -- behind one interface that exists for every
+// 4-bit format, so that the kernels' `if constexpr` branches type-check whatever WF is.
+template <int WF, int ADT>
+struct W4Int4 {
+    struct M {};
+    typedef typename Dec<WF, ADT>::Aux Aux;
+    static __device__ __forceinline__ M mult(const Aux&) { return M{}; }
+    template <int DECV>
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&w)[1], int, const M&) { return w[0]; }
+    static __device__ __forceinline__ void load_aux_lds(Aux& a, const char* p, int, bool) { Dec<WF, ADT>::load_aux_at(a, p); }
+};
+template <int ADT>
+struct W4Int4<LKM_W_INT4_B8, ADT> {
+    typedef Dec<LKM_W_INT4_B8, ADT> D;
+    typedef typename D::Mult M;
+    typedef typename D::Aux Aux;
+    static __device__ __forceinline__ M mult(const Aux& a) { return D::mult(a, 0, 0); }
+    template <int DECV>
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&w)[1], int s, const M& m) {
+        if constexpr (DECV == 1) return int4_frag_plain<ADT>(w[0][s], m.s512.x, m.m8.x);
+        else return D::frag_m(w, s, m);
+    }
+    // aligned reads of what Dec<>::load_aux_at fetches with one unaligned 8-byte load (1 / 2 / 4 scales per unit)
+    static __device__ __forceinline__ void load_aux_lds(Aux& a, const char* p, int spu, bool hoist) {
+        if (hoist) a.raw = u32x2{(unsigned)*(const unsigned short*)p, 0u};
+        else if (spu == 2) a.raw = u32x2{*(const unsigned*)p, 0u};
+        else a.raw = *(const u32x2*)p;
+    }
+};
+
 // resident workgroups per CU the register allocation must allow
 constexpr int w4x_min_blocks(int cb, int waves) { return waves == 8 ? (cb == 1 ? 2 : 1) : (cb == 1 ? 4 : 3); }
 
@@ -165,17 +196,11 @@ __global__ __launch_bounds__(WAVES * 64, w4x_min_blocks(CB, WAVES)) void gemm_w4
         auto compute = [&](const WStage& s, int buf) __attribute__((always_inline)) {
             if (!wave_on) return;
             const char* xb = xlds + buf * STAGEB;
-            typename Dec<LKM_W_INT4_B8, ADT>::Mult mu;
-            float s512 = 0.f, m8 = 0.f;
-            if constexpr (HOIST) {
-                mu = Dec<LKM_W_INT4_B8, ADT>::mult(s.aux, 0, 0);
-                s512 = mu.s512.x;
-                m8 = mu.m8.x;
-            }
+            typename W4Int4<WF, ADT>::M mu;
+            if constexpr (HOIST) mu = W4Int4<WF, ADT>::mult(s.aux);
             auto dec = [&](int s_, int q_) __attribute__((always_inline)) {
                 if constexpr ((ABL & 8) != 0) return s.w[q_][0] + u32x4{(unsigned)s_, 0u, 0u, 0u};
-                else if constexpr (HOIST && DECV == 1) return int4_frag_plain<ADT>(s.w[q_][0][s_], s512, m8);
-                else if constexpr (HOIST) return D::frag_m(s.w[q_], s_, mu);
+                else if constexpr (HOIST) return W4Int4<WF, ADT>::template frag<DECV>(s.w[q_], s_, mu);
                 else return D::frag(s.w[q_], s.aux, s_, dparam);
             };
             u32x4 bf[2][2][CBR];                              // [parity of s][q][column block]

@@ -1073,7 +1073,7 @@ static size_t chunk_tokens(const LkmEngine* h, int K) {
 // the stream is capturing; not while an explicit plan is forced through "pf" / "tiled" / "pd*") runs each candidate once
 // untimed and `kTuneReps` times between two events on the caller's inputs, keeps the fastest and then runs it once more so
 // that `out` holds ITS result.  Candidates: the default plan, the streamer where the default uses tiles and vice versa,
-// 32- / 64-row tiles, the deeper weight ring, and for uint4b8 the 32x32-MFMA kernels (gemm_w4e.h / gemm_w4x.h).  Every
+// 32- / 64-row tiles, the deeper weight ring, and for the 4-bit formats the 32x32-MFMA kernels (gemm_w4e.h / gemm_w4x.h).  Every
 // candidate is a plan the parity tests cover; which one wins depends on timing, so two processes may choose
 // differently (results then differ in fp32 summation order, inside the stated tolerance) -- the reason it is opt-in.
 constexpr int kTuneReps = 3;
@@ -1106,7 +1106,7 @@ static int run_chunk_tuned(LkmEngine* h, hipStream_t st, int M, int K, const voi
         if (def_tiled != 64 && !(pl.t1.tiled > 64)) cands.push_back({0, 64, 0, 0, 0.f, "64-row tiles"});
         if (def_tiled != 32 && wf_is_4bit(h->wf) && M * K <= 64 * h->E) cands.push_back({0, 32, 0, 0, 0.f, "32-row tiles"});
         if (def_tiled && def_tiled <= 64 && pl.t1.pd == 2) cands.push_back({0, def_tiled, 4, 0, 0.f, "weight ring depth 4 (GEMM1)"});
-        if (h->wf == LKM_W_INT4_B8 && !h->ps && h->H % 128 == 0 && h->I % 128 == 0 && M >= 32) {
+        if (wf_is_4bit(h->wf) && !h->ps && h->H % 128 == 0 && h->I % 128 == 0 && M >= 32) {
             cands.push_back({6, def_tiled == 32 ? 32 : 64, 0, 0, 0.f, "32x32-MFMA + loader wave (gemm_w4e.h)"});
             cands.push_back({5, def_tiled == 32 ? 32 : 64, 0, 0, 0.f, "32x32-MFMA (gemm_w4x.h)"});
         }

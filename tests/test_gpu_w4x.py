@@ -110,3 +110,39 @@ def test_w4x_layers_vs_oracle(M, E, K, H, I, g, dt, gated, drop, skew):
     _reset(eng)
     base = _run_decode(eng, a, tw, ids)                      # the default plan on the same inputs
     np.testing.assert_allclose(base, ref, atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("fmt", ["mxfp4", "nvfp4"])
+@pytest.mark.parametrize("M,dt", [(128, "bf16"), (45, "f16")])
+def test_w4x_fp4_formats_vs_oracle(fmt, M, dt):
+    """the E2M1 formats on the same two kernels (the decoders are gemm_skinny.h's Dec<MXFP4 / NVFP4>, bit-exact by
+    tests/test_gpu_moe.py::test_fp4_dequant_is_bit_exact_on_gpu): E8M0 scales per 32 k / e4m3 scales per 16 k + per-expert
+    multipliers, against the oracle's dequantised-weight path"""
+    import bench
+    E, K, H, I = 6, 2, 512, 256
+    odt, tdt = (orc.BF16, torch.bfloat16) if dt == "bf16" else (orc.F16, torch.float16)
+    gen = torch.Generator().manual_seed(17 + M)
+    a = (torch.randn((M, H), generator=gen) / 10).to(tdt)
+    w13 = (torch.randn((E, 2 * I, H), generator=gen) / 10).to(torch.bfloat16)
+    w2 = (torch.randn((E, H, I), generator=gen) / 10).to(torch.bfloat16)
+    tw, ids = make_routing(M, E, K, 3 + M, drop=0.05)
+    kw, okw = {}, {}
+    if fmt == "mxfp4":
+        (q13, s13), (q2, s2) = bench.quantize_mxfp4(w13.to(DEV)), bench.quantize_mxfp4(w2.to(DEV))
+        wfmt, gk = orc.W_MXFP4, 32
+    else:
+        (q13, s13, m13), (q2, s2, m2) = bench.quantize_nvfp4(w13.to(DEV)), bench.quantize_nvfp4(w2.to(DEV))
+        wfmt, gk = orc.W_NVFP4, 16
+        kw = dict(w13_global_scale=m13, w2_global_scale=m2)
+        okw = dict(gs13=m13.cpu().numpy(), gs2=m2.cpu().numpy())
+    eng = _eng(q13, q2, top_k=K, act_dtype=tdt, fmt=fmt, w13_scale=s13, w2_scale=s2, group_n=1, group_k=gk, **kw)
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=odt, wfmt=wfmt, groupN=1, groupK=gk)
+    ref = orc.moe(d, q13.cpu().numpy(), q2.cpu().numpy(), torch_to_bits(a), ids, tw, s13=s13.cpu().numpy(), s2=s2.cpu().numpy(), **okw)
+    for (pf, tiled, waves, pd, dbg) in VARIANTS:
+        if dbg:
+            continue                                           # (the second decoder is uint4b8's)
+        _set(eng, pf, tiled, waves, pd, 0)
+        out = _run_decode(eng, a, tw, ids)
+        assert f"pf={pf}" in eng.engine.describe(), eng.engine.describe()
+        np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=f"{fmt} {pf}/{tiled}")
+    _reset(eng)

@@ -24,11 +24,15 @@ def gemm_of(kernel: str):
     """'gemm1' / 'gemm2' / None for a kernel name (template arguments: lkm_kernels.h / the kernel headers)"""
     if "gemm1_act_kernel" in kernel:
         return "gemm1"
-    if "gemm2_kernel" in kernel or "gemm2_combine_kernel" in kernel or "gemm2_direct_kernel" in kernel:
+    if "gemm2_kernel" in kernel or "gemm2_direct_kernel" in kernel:
         return "gemm2"
     m = re.search(r"gemm_prefill_a8w_kernel<\d+, (true|false), (true|false)", kernel)
     if m:
         return "gemm1" if m.group(2) == "true" else "gemm2"
+    # gemm_w4x_kernel<WF, ADT, CB, WAVES, GATED, IS_G1, ...> / gemm_w4e_kernel<WF, ADT, CB, NC, GATED, IS_G1, ...>
+    m = re.search(r"gemm_w4[xe]_kernel<(?:[^,]+, ){5}(true|false)", kernel)
+    if m:
+        return "gemm1" if m.group(1) == "true" else "gemm2"
     m = re.search(r"gemm_tiled_kernel<(?:[^,]+, ){6}(true|false)", kernel)
     if m:
         return "gemm1" if m.group(1) == "true" else "gemm2"

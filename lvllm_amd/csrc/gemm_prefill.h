@@ -1,50 +1,73 @@
 // gemm_prefill.h -- per-expert grouped GEMMs for the prefill regime (hundreds of rows per expert,
-// MFMA-bound): 16-bit weights, 256 weight rows x 256 tokens per workgroup.
+// MFMA-bound): 16-bit weights, 256 weight rows x 256 tokens per workgroup, round 4 structure.
 //
-// Same math as gemm_skinny.h / gemm_tiled.h; what changes is how the operands reach the MFMAs:
+// Same math as gemm_skinny.h / gemm_tiled.h (fp32 accumulation over k, the epilogues are theirs); what
+// changes is how the operands reach the matrix pipe:
 //   * BOTH operands go through LDS, filled by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR staging,
 //     one 32-bit lane offset per stream, the K advance in an SGPR):
-//       weights: the pre-shuffled layout (lkm_common.h) makes a 16x32 A fragment one contiguous KiB,
-//                so one wave-wide DMA drops a ready-to-read fragment image into LDS and ds_read_b128
-//                at lane*16 fetches it conflict-free;
-//       tokens : 128-byte row pieces gathered per lane, XOR-swizzled on the SOURCE side so the linear
-//                LDS image is conflict-free for the B-fragment reads (as in gemm_tiled.h).
-//   * 8 waves as 2 (weight-row halves) x 4 (64-token quarters): a wave owns 8 weight tiles x 4 token
-//     blocks = 32 accumulators (128 registers); a weight fragment is shared by the 4 waves of a row
-//     half, a token fragment by the 2 waves of a quarter: 12 ds_read_b128 per 32 MFMAs.
-//   * K unit = 64 (two k-steps), two LDS buffers, fragments replaced on the fly:
-//         phase A (k-step 0 of unit u): MFMAs; the fragments of (u, k-step 1) stream in behind them
-//           -> vmcnt(0) [the DMA of unit u+1, issued a full unit ago] + lgkmcnt(0) + s_barrier
-//         phase B (k-step 1 of unit u): issue the DMA of unit u+2 into the buffer everybody just
-//           finished reading; MFMAs; the fragments of (u+1, k-step 0) stream in.
-//     ONE barrier per 64 MFMAs per wave, no wait for a load younger than a full unit, no branch in
-//     the steady loop.
-// Gated GEMM1 pairs gate tile t with up tile t in the same wave (tiles 0..3 / 4..7 of its 8), so the
-// activation epilogue is lane-local, as in the other kernels.
+//       weights: the pre-shuffled image (lkm_common.h) is copied as it is, 2 KiB per (16-row tile, 64 k);
+//       tokens : 128-byte row pieces gathered per lane, XOR-swizzled on the SOURCE side so that the linear
+//                LDS image is conflict-free for the B-fragment reads (as in gemm_tiled.h);
+//   * v_mfma_f32_32x32x16: 8 waves as 2 (weight-row halves) x 4 (64-token quarters), a wave owns 4 row
+//     groups of 32 rows x 2 token groups of 32 = 8 accumulators of 16 registers.  A row group is two 16-row
+//     tiles of the image read side by side (lanes 0-15 / 16-31; gated GEMM1: the gate tile and its up tile,
+//     so D registers i and 8 + i of a lane are the gate and up value of one (row, token) and the activation
+//     is lane-local); k-step kk of a unit takes k = 16 kk + 8 (lane / 32) .. + 7 of both operands (an MFMA
+//     sums over its k, any A/B-consistent assignment is valid);
+//   * the K loop runs in PHASES of one output quadrant each (2 row groups x 1 token group x 64 k = 8 MFMAs):
+//         ph1 (A0,B0)   ph2 (A0,B1)   ph3 (A1,B1)   ph4 (A1,B0)        A0/A1, B0/B1 = quarters of a K tile
+//     a phase = [fragment reads of the quarter it needs + one quarter of LDS-DMA for a later tile] s_barrier
+//     [8 MFMAs] s_barrier, and the two wave halves run ONE barrier interval apart: while the waves of row
+//     half 0 multiply, their SIMD partners of row half 1 read fragments and issue DMA, and vice versa -- the
+//     matrix pipe of a SIMD always has one of its two waves in a multiply section;
+//   * a quarter (16 KiB: the sub-rows every wave reads in the same phase) is re-filled two phases after its
+//     last read, for the tile after next -- four quarters (64 KiB per CU) are in flight at any time in a
+//     2 x 64 KiB ring, waited for with a counted vmcnt one phase before the first read (the wait, then a
+//     barrier every wave passes, then the read: the only ordering an LDS-DMA has).
+// Schedule of tile t (buffer t & 1), DMA issued / quarter whose landing is waited for (vmcnt(8) = all but
+// the four youngest quarters):
+//     ph1: B1(t+1) / B1(t)      ph2: A1(t+1) / A1(t)      ph3: A0(t+2) / -      ph4: B0(t+2) / A0, B0(t+1)
 #pragma once
 #include "gemm_tiled.h"
 
 namespace lkm {
 
-constexpr int kPfTokens = 256;          // token tile
-constexpr int kPfTiles = 16;            // weight tiles per workgroup (gated: 8 gate + 8 up)
-constexpr int kPfABytes = kPfTiles * 2 * 1024;                       // 16 tiles x 2 k-steps x 1 KiB
-constexpr int kPfBufBytes = kPfABytes + kPfTokens * 128;             // + token rows, one unit
+constexpr int kPfTokens = 256;                  // token tile
+constexpr int kPfQ = 16 * 1024;                 // one quarter of a K tile: 128 rows x 64 k x 2 B
+constexpr int kPfBufBytes = 4 * kPfQ;           // [A0][A1][B0][B1]
 
-// WAVES = 8: 2 x 4 waves, 8 tiles x 4 token blocks each, two waves per SIMD (256 registers per lane).
-// Measured and dropped (profiles/r01_prefill_pmc.md): WAVES = 4 (2 x 2 waves, one per SIMD, 256 AGPR
-// accumulators): 2551 vs 1793 us on GLM prefill GEMM1; a variant with the tokens in a 3-buffer DMA ring and
-// the weights in a 3-stage register ring (128 KiB in flight per CU instead of 64): 1769 us, no gain.
-template <int ADT, bool GATED, bool IS_G1, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gemm_prefill_kernel(GemmParams p) {
+// SiLU-mul epilogue of this kernel: the sigmoid on the transcendental unit (v_exp_f32 + v_rcp_f32, as gemm_prefill_a8w.h)
+// instead of the polynomial exp and IEEE division the other kernels share with the CPU restatement -- at ~55 VALU per
+// element those cost 16 % of GEMM1 here (every wave of the CU's one workgroup is in its epilogue at the same time, the
+// matrix pipe idles).  Same rounding points (GemmParams::round_gemm1); the fp32 sigmoid differs in its last bits, i.e.
+// one ulp of the activation dtype on ~1e-4 of the intermediate elements, far inside the operator's tolerance.
+template <int ADT>
+__device__ __forceinline__ void pf_store_silu_mul(const GemmParams& p, const f32x4& gate, const f32x4& upv, size_t out_row, int n) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = gate[r], up = upv[r];
+        if (p.round_gemm1) {
+            a = ActT<ADT>::to_f32(ActT<ADT>::from_f32(a));
+            up = ActT<ADT>::to_f32(ActT<ADT>::from_f32(up));
+        }
+        const float sg = a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * -1.44269504088896341f));
+        v[r] = p.round_gemm1 ? ActT<ADT>::to_f32(ActT<ADT>::from_f32(sg)) * up : sg * up;
+    }
+    unsigned short* o = (unsigned short*)p.out + out_row * p.ldo + n;
+    if (n + 4 <= p.n_real) {
+        *(u32x2*)o = u32x2{ActT<ADT>::pack2(v[0], v[1]), ActT<ADT>::pack2(v[2], v[3])};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < p.n_real) o[r] = ActT<ADT>::from_f32(v[r]);
+    }
+}
+
+template <int ADT, bool GATED, bool IS_G1>
+__global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     static_assert(!GATED || IS_G1, "only GEMM1 is gated");
-    static_assert(WAVES == 4 || WAVES == 8, "2 x 2 or 2 x 4 waves");
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer resources / LDS-DMA builtins exist in the device pass only
-    constexpr int kPfThreads = WAVES * 64;
-    constexpr int WC = WAVES / 2;                  // waves along the tokens
-    constexpr int NBW = 16 / WC;                   // 16-token blocks per wave
-    constexpr int ATW = 16 / WAVES;                // weight tiles each wave stages per unit
-    constexpr int BPT = 2048 / kPfThreads;         // 16-byte token pieces each thread stages per unit
     typedef __attribute__((address_space(3))) void* LdsPtr;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int ti = blockIdx.y, bx = blockIdx.x;
@@ -55,158 +78,226 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_prefill_kernel(GemmParams p) 
         if (sidx >= n_c * RG) return;
         ti = first + sidx / RG;
         bx = sidx % RG;
+        if (!(p.dbg & 8)) {
+            // inside the run, the token tiles of ONE expert fastest, then the row group: the workgroups that stream the
+            // same weight panel start together on neighbouring CUs of the XCD and stay in step (same K loop), so the
+            // panel is fetched into the L2 once instead of once per token tile (tiles of an expert are adjacent in the
+            // list, r0 ascending: dispatch.hip)
+            const int ex = p.tile_e[ti];
+            const int g0 = max(ti - p.tile_r0[ti] / kPfTokens, first);
+            const int g1 = min(ti - p.tile_r0[ti] / kPfTokens + (p.counts[ex] + kPfTokens - 1) / kPfTokens, first + n_c);
+            const int k = g1 - g0, local = sidx - (g0 - first) * RG;
+            bx = local / k;
+            ti = g0 + local % k;
+        }
     }
     if (ti >= p.meta[3]) return;
     const int e = p.tile_e[ti], r0 = p.tile_r0[ti];
     const int m_e = p.counts[e], off_e = p.offsets[e];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, j = lane & 15;
-    const int wr = wave / WC, wc = wave % WC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef LKM_PF_ABL   // timing ablations (results are wrong): dbg & 16 no DMA in the K loop, & 32 every workgroup streams the same operands
+    const bool abl_nodma = p.dbg & 16, abl_same = p.dbg & 32, abl_noepi = p.dbg & 64;
+#else
+    constexpr bool abl_nodma = false, abl_same = false, abl_noepi = false;
+#endif
+    const int l32 = lane & 31, h = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
     const int T_all = p.T_half * p.halves;
     constexpr int TPH = GATED ? 8 : 16;                       // tiles per half taken by one workgroup
     const int tbase = bx * TPH;
     const int U = p.U;
 
-    // ---- LDS-DMA streams: 64 wave-instructions per unit, 8 per wave: 4 weight fragments + 4 token pieces.
-    // Weight stream: buffer = this expert's matrix; wave `w` stages local tiles 2w, 2w+1 (SGPR offsets),
-    // lane offset lane*16.  Token stream: buffer = the activation matrix; lane offset = my row piece.
+    // ---- LDS-DMA streams, two wave-instructions per wave and quarter.
+    // Weight quarter s: the 8 tiles {row half wr', row group 2s + rgl of it, tile gu of the group}, LDS slot
+    // wr'*4 + rgl*2 + gu = the staging wave's index.  Token quarter s: LDS row wc'*32 + i = token wc'*64 + s*32 + i.
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.w + (size_t)e * T_all * U * 2048), 0, (int)((size_t)T_all * U * 2048), 0x00020000);
+        (void*)((const char*)p.w + (size_t)(abl_same ? 0 : e) * T_all * U * 2048), 0, (int)((size_t)T_all * U * 2048), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7fffffff, 0x00020000);
-    int asoff[ATW];                                           // byte offset of my tiles (wave-uniform)
+    int asoff[2];                                             // byte offset of my tile of quarter s (wave-uniform)
 #pragma unroll
-    for (int q = 0; q < ATW; ++q) {
-        const int tl = ATW * wave + q;
-        const int half = GATED ? tl / 8 : 0, idx = GATED ? tl % 8 : tl;
-        const int t = tbase + idx;
+    for (int s = 0; s < 2; ++s) {
+        const int grp = (wave >> 2) * 4 + s * 2 + ((wave >> 1) & 1), gu = wave & 1;
+        const int half = GATED ? gu : 0, t = tbase + (GATED ? grp : grp * 2 + gu);
         const int gt = half * p.T_half + (t < p.T_half ? t : 0);          // clamped: padded tile counts
-        asoff[q] = __builtin_amdgcn_readfirstlane((int)(gt * p.w_tstride * 16));
+        asoff[s] = __builtin_amdgcn_readfirstlane((int)((abl_same ? (wave & 1) : gt) * p.w_tstride * 16));
     }
     const int alane = lane * 16;
-    int bvoff[BPT];
+    int bvoff[2][2];
 #pragma unroll
-    for (int q = 0; q < BPT; ++q) {
-        const int pc = q * kPfThreads + tid;
-        const int row = pc >> 3, pslot = pc & 7;
-        const int lslot = pslot ^ x_swizzle<128>(row);
-        const int r = r0 + row;
-        const int rr = r < m_e ? r : r0;
-        const int src_row = IS_G1 ? p.sorted_slot[off_e + rr] / p.top_k : off_e + rr;
-        bvoff[q] = src_row * p.ldx * 2 + lslot * 16;          // < 2 GiB (checked by the launcher)
-    }
-    auto dma_unit = [&](int u, auto BUF) __attribute__((always_inline)) {
-        constexpr int buf = decltype(BUF)::v;
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int q = 0; q < ATW; ++q)
+        for (int q = 0; q < 2; ++q) {
+            const int pc = q * 512 + tid;
+            const int row = pc >> 3, pslot = pc & 7;
+            const int lslot = pslot ^ x_swizzle<128>(row);
+            const int r = r0 + (row >> 5) * 64 + s * 32 + (row & 31);
+            const int rr = r < m_e ? r : r0;
+            const int src_row = IS_G1 ? p.sorted_slot[off_e + rr] / p.top_k : off_e + rr;
+            bvoff[s][q] = (abl_same ? row : src_row) * p.ldx * 2 + lslot * 16;   // < 2 GiB (checked by the launcher)
+        }
+    const int wustep = (int)(p.w_ustride * 16);
+    // quarter ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1 (= position inside a buffer)
+    auto dma = [&](int u, auto BUF, auto QC) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::v, qid = decltype(QC)::v;
+        const int uc = u < U ? u : U - 1;                     // past the end: re-fetch the last unit into a quarter nobody reads
+        if (abl_nodma && u >= 2) return;
+        char* base = lds + buf * kPfBufBytes + qid * kPfQ;
+        if constexpr (qid < 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    rs_w, (LdsPtr)(lds + buf * kPfBufBytes + ((ATW * wave + q) * 2 + ks) * 1024), 16, alane,
-                    asoff[q] + u * (int)(p.w_ustride * 16) + ks * 1024, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + wave * 2048 + ks * 1024), 16, alane,
+                                                         asoff[qid] + uc * wustep + ks * 1024, 0, 0);
+        } else {
 #pragma unroll
-        for (int q = 0; q < BPT; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rs_x, (LdsPtr)(lds + buf * kPfBufBytes + kPfABytes + (q * kPfThreads + wave * 64) * 16), 16,
-                bvoff[q], u * 128, 0, 0);
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LdsPtr)(base + (q * 512 + wave * 64) * 16), 16,
+                                                         bvoff[qid - 2][q], uc * 128, 0, 0);
+        }
     };
-    auto sync_unit = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    // ---- fragments.  Registers (2 waves per SIMD -> 256 per lane): 128 accumulators, 8 weight fragments (one
+    // quarter: 2 row groups x 4 k-steps), 2 x 4 token fragments (both quarters stay: B0 serves ph1 and ph4).
+    const bool has_rows = r0 + wc * 64 < m_e;                 // wave-uniform: my token share holds rows
+    u32x4 fa[2][4], fb0[4], fb1[4];
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    // A fragment (quarter s, local row group rgl, k-step kk): tile slot wr*4 + rgl*2 + (lane & 16 ? 1 : 0), load kk / 2,
+    // image lane ((kk & 1) * 2 + h) * 16 + (lane & 15)
+    const int abyte = (wr * 4 + ((lane >> 4) & 1)) * 2048 + h * 256 + (lane & 15) * 16;
+    int baddr[4];                                              // B fragment: row wc*32 + l32, 16-byte slot (2 kk + h) ^ swizzle
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) baddr[kk] = (wc * 32 + l32) * 128 + (((kk * 2 + h) ^ x_swizzle<128>(l32)) * 16);
+
+    auto read_a = [&](auto BUF, auto SC) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::v, s = decltype(SC)::v;
+#pragma unroll
+        for (int rgl = 0; rgl < 2; ++rgl)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                fa[rgl][kk] = *(const u32x4*)(lds + buf * kPfBufBytes + s * kPfQ + abyte + rgl * 4096 + (kk >> 1) * 1024 + (kk & 1) * 512);
+    };
+    auto read_b = [&](auto BUF, auto SC, u32x4 (&fb)[4]) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::v, s = decltype(SC)::v;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb[kk] = *(const u32x4*)(lds + buf * kPfBufBytes + (2 + s) * kPfQ + baddr[kk]);
+    };
+    auto mm = [&](auto RG0, auto TG, const u32x4 (&fb)[4]) __attribute__((always_inline)) {
+        constexpr int rg0 = decltype(RG0)::v, tg = decltype(TG)::v;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int rgl = 0; rgl < 2; ++rgl) acc[rg0 + rgl][tg] = Mfma32<ADT>::run(fa[rgl][kk], fb[kk], acc[rg0 + rgl][tg]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-
-    const bool has_rows = r0 + wc * NBW * 16 < m_e;           // wave-uniform: my token share holds rows
-    if (!has_rows) {
-        // nothing to multiply: keep the DMA / barrier cadence of the workgroup
-        dma_unit(0, IC<0>{});
-        dma_unit(1, IC<1>{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int u = 0; u < U; u += 2) {
-            sync_unit();
-            dma_unit(u + 2 < U ? u + 2 : U - 1, IC<0>{});
-            sync_unit();
-            dma_unit(u + 3 < U ? u + 3 : U - 1, IC<1>{});
+    // K tile t in buffer BUF; COMPUTE = false for a wave whose token quarter is empty (it keeps the DMA / barrier cadence)
+    auto tile = [&](int t, auto BUF, auto COMPUTE) __attribute__((always_inline)) {
+        constexpr int b = decltype(BUF)::v;
+        constexpr bool comp = decltype(COMPUTE)::value;
+        // ph1
+        if constexpr (comp) {
+            read_b(IC<b>{}, IC<0>{}, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(IC<b>{}, IC<0>{});
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dma(t + 1, IC<b ^ 1>{}, IC<3>{});
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        bar();
+        if constexpr (comp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mm(IC<0>{}, IC<0>{}, fb0);
+        }
+        bar();
+        // ph2
+        if constexpr (comp) read_b(IC<b>{}, IC<1>{}, fb1);
+        dma(t + 1, IC<b ^ 1>{}, IC<1>{});
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        bar();
+        if constexpr (comp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mm(IC<0>{}, IC<1>{}, fb1);
+        }
+        bar();
+        // ph3
+        if constexpr (comp) read_a(IC<b>{}, IC<1>{});
+        dma(t + 2, IC<b>{}, IC<0>{});
+        bar();
+        if constexpr (comp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mm(IC<2>{}, IC<1>{}, fb1);
+        }
+        bar();
+        // ph4
+        dma(t + 2, IC<b>{}, IC<2>{});
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        bar();
+        if constexpr (comp) mm(IC<2>{}, IC<0>{}, fb0);
+        bar();
+    };
+    auto run = [&](auto COMPUTE) __attribute__((always_inline)) {
+        dma(0, IC<0>{}, IC<0>{});
+        dma(0, IC<0>{}, IC<2>{});
+        dma(0, IC<0>{}, IC<3>{});
+        dma(0, IC<0>{}, IC<1>{});
+        dma(1, IC<1>{}, IC<0>{});
+        dma(1, IC<1>{}, IC<2>{});
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // A0(0), B0(0) landed
+        bar();
+        if (wr == 1) bar();                                   // row half 1 runs one barrier interval behind
+        for (int t = 0; t < U; t += 2) {                      // (U is even: the launcher checks)
+            tile(t, IC<0>{}, COMPUTE);
+            tile(t + 1, IC<1>{}, COMPUTE);
+        }
+        if (wr == 0) bar();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing DMA must land before the LDS is released
+    };
+    if (!has_rows) {
+        run(std::false_type{});
         return;
     }
+    run(std::true_type{});
 
-    // ---- fragments.  Register budget (2 waves per SIMD -> 256 per lane): 128 accumulators + 8 weight
-    // fragments + two sets of 4 token fragments.  The next phase's weight fragment t is read into the
-    // registers of the current one right after its four MFMAs were issued (an MFMA reads its operands at
-    // issue).  LDS addresses are two lane registers + immediates: the XOR swizzle of a token row only
-    // depends on j (blocks are 16 rows apart), tiles are 2 KiB apart.
-    u32x4 fa[8], fb0[NBW], fb1[NBW];
-    const int brow = (wc * NBW * 16 + j) * 128;                                   // + b*2048
-    const int bsw0 = brow + ((g ^ x_swizzle<128>(j)) * 16), bsw1 = brow + (((4 + g) ^ x_swizzle<128>(j)) * 16);
-    const int abyte = (GATED ? wr * 4 : wr * 8) * 2048 + lane * 16;               // + imm(t) (+ ks*1024)
-    f32x4 acc[8][NBW];
+    // ---- epilogue (D layout: register i of lane (l32, h) = row 8 (i / 4) + 4 h + i % 4 of the 32-row group, token l32)
+    static_for<2>([&](auto TGC) __attribute__((always_inline)) {
+        constexpr int tg = decltype(TGC)::v;
+        const int r_tok = r0 + wc * 64 + tg * 32 + l32;
+        if (r_tok < m_e && !(abl_noepi && acc[0][0][0] != 12345.f)) {
+            static_for<4>([&](auto RGC) __attribute__((always_inline)) {
+                constexpr int rg = decltype(RGC)::v;
+                const int grp = wr * 4 + rg;                   // row group inside the workgroup
+                const f32x16& c = acc[rg][tg];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int b = 0; b < NBW; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // one phase = 8 * NBW MFMAs on (fa, bc); when NEXT, the fragments of (buffer NBUF, k-step NKS) replace fa
-    // in place and fill bn
-    auto phase = [&](const u32x4 (&bc)[NBW], u32x4 (&bn)[NBW], auto NEXT, auto NBUF, auto NKS) __attribute__((always_inline)) {
-        constexpr bool next = decltype(NEXT)::value;
-        constexpr int nbuf = decltype(NBUF)::v, nks = decltype(NKS)::v;
-        const char* nbase = lds + nbuf * kPfBufBytes;
-        if constexpr (next) {
-#pragma unroll
-            for (int b = 0; b < NBW; ++b) bn[b] = *(const u32x4*)(nbase + kPfABytes + (nks ? bsw1 : bsw0) + b * 2048);
-        }
-        static_for<8>([&](auto TC) __attribute__((always_inline)) {
-            constexpr int t = decltype(TC)::v;
-#pragma unroll
-            for (int b = 0; b < NBW; ++b) acc[t][b] = ActT<ADT>::mfma(fa[t], bc[b], acc[t][b]);
-            if constexpr (next) {
-                constexpr int imm = (GATED ? (t < 4 ? t : 8 + (t - 4)) : t) * 2048 + nks * 1024;
-                fa[t] = *(const u32x4*)(nbase + abyte + imm);
-            }
-            __builtin_amdgcn_sched_barrier(0);                // keep the read behind ITS MFMAs
-        });
-    };
-    // unit u in buffer BUF: phase A, mid barrier, DMA of unit u+2 into BUF, phase B.  No conditionals: past
-    // the end the DMA re-fetches the last unit into a buffer nobody reads any more and the fragments that
-    // stream in are never multiplied (U is even: the launcher checks), so the loop is one straight body.
-    auto unit = [&](int u, auto BUF) __attribute__((always_inline)) {
-        constexpr int buf = decltype(BUF)::v;
-        phase(fb0, fb1, std::true_type{}, IC<buf>{}, IC<1>{});
-        sync_unit();
-        dma_unit(u + 2 < U ? u + 2 : U - 1, IC<buf>{});
-        phase(fb1, fb0, std::true_type{}, IC<buf ^ 1>{}, IC<0>{});
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    dma_unit(0, IC<0>{});
-    dma_unit(1, IC<1>{});
-    if constexpr (WAVES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // unit 0 landed, unit 1 in flight
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int b = 0; b < NBW; ++b) fb0[b] = *(const u32x4*)(lds + kPfABytes + bsw0 + b * 2048);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) fa[t] = *(const u32x4*)(lds + abyte + (GATED ? (t < 4 ? t : 8 + (t - 4)) : t) * 2048);
-    for (int u = 0; u < U; u += 2) {
-        unit(u, IC<0>{});
-        unit(u + 1, IC<1>{});
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the trailing DMA / fragment reads
-
-    // ---- epilogue (D layout lane (g,j): rows tile*16 + g*4 + r, token column j of block b)
-    static_for<NBW>([&](auto BC) __attribute__((always_inline)) {
-        constexpr int b = decltype(BC)::v;
-        const int r_tok = r0 + (wc * NBW + b) * 16 + j;
-        if (r_tok < m_e) {
-            static_for<GATED ? 4 : 8>([&](auto TC) __attribute__((always_inline)) {
-                constexpr int t = decltype(TC)::v;
-                const int tl = GATED ? wr * 4 + t : wr * 8 + t;          // tile index inside the half
-                const int n = (tbase + tl) * 16 + g * 4;
-                if (tbase + tl < p.T_half && n < p.n_real) {
-                    if constexpr (IS_G1) store_gemm1_frag<ADT, GATED>(p, acc[t][b], acc[GATED ? 4 + t : t][b], (size_t)(off_e + r_tok), n);
-                    else store_gemm2_frag(p, acc[t][b], 0, (size_t)(off_e + r_tok), n);
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 lo = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+                    const f32x4 hi = {c[8 + 4 * q], c[9 + 4 * q], c[10 + 4 * q], c[11 + 4 * q]};
+                    const int nsub = 8 * q + 4 * h;
+                    if constexpr (GATED) {
+                        const int tl = tbase + grp, n = tl * 16 + nsub;
+                        if (tl < p.T_half && n < p.n_real) {
+                            if (p.act_type == LKM_ACT_SILU) pf_store_silu_mul<ADT>(p, lo, hi, (size_t)(off_e + r_tok), n);
+                            else store_gemm1_frag<ADT, true>(p, lo, hi, (size_t)(off_e + r_tok), n);
+                        }
+                    } else {
+                        const int tl = tbase + grp * 2, n0 = tl * 16 + nsub, n1 = n0 + 16;
+                        if constexpr (IS_G1) {
+                            if (tl < p.T_half && n0 < p.n_real) store_gemm1_frag<ADT, false>(p, lo, lo, (size_t)(off_e + r_tok), n0);
+                            if (tl + 1 < p.T_half && n1 < p.n_real) store_gemm1_frag<ADT, false>(p, hi, hi, (size_t)(off_e + r_tok), n1);
+                        } else {
+                            if (tl < p.T_half && n0 < p.n_real) store_gemm2_frag(p, lo, 0, (size_t)(off_e + r_tok), n0);
+                            if (tl + 1 < p.T_half && n1 < p.n_real) store_gemm2_frag(p, hi, 0, (size_t)(off_e + r_tok), n1);
+                        }
+                    }
                 }
             });
         }
@@ -216,25 +307,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_prefill_kernel(GemmParams p) 
 #endif
 }
 
-// usable when the K range is an even number of whole 64-element units (no ragged tail) and the activation
-// matrix fits a 2 GiB buffer window; otherwise the caller stays on gemm_tiled_kernel
+// usable when the K range is an even number of whole 64-element units (no ragged tail) and the operands fit the
+// 2 GiB buffer windows; otherwise the caller stays on gemm_tiled_kernel
 inline bool prefill_kernel_ok(const GemmParams& p, size_t x_rows) {
     return p.Kreal % 128 == 0 && p.U % 2 == 0 && x_rows * (size_t)p.ldx * 2 < (size_t)0x7fffffff &&
            (size_t)p.T_half * p.halves * p.U * 2048 < (size_t)0x7fffffff;
 }
 
-template <int ADT, bool GATED, bool IS_G1, int WAVES>
+template <int ADT, bool GATED, bool IS_G1>
 static int launch_prefill_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr size_t lds = 2 * (size_t)kPfBufBytes;
     const int TPH = GATED ? 8 : 16;
     const int RG = ceil_div(p.T_half, TPH);
-    dim3 grid(RG, max_tiles), block(WAVES * 64);
+    dim3 grid(RG, max_tiles), block(512);
     GemmParams pp = p;
     if (p.xcd_map) {
         pp.xcd_map = RG;
         grid = dim3(8 * p.xcd_map * RG, 1);
     }
-    auto kern = gemm_prefill_kernel<ADT, GATED, IS_G1, WAVES>;
+    auto kern = gemm_prefill_kernel<ADT, GATED, IS_G1>;
     LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, pp);
     LKM_HIP_CHECK(hipGetLastError());
@@ -247,8 +338,8 @@ static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmPa
     constexpr int ADT = ADTC::v;
     if (cfg.tiled != 256 || cfg.pf != 8) return false;
     if (!prefill_kernel_ok(p, p.x_rows)) return false;
-    if (is_g1) *rc = gated ? launch_prefill_t<ADT, true, true, 8>(st, p, max_tiles) : launch_prefill_t<ADT, false, true, 8>(st, p, max_tiles);
-    else *rc = launch_prefill_t<ADT, false, false, 8>(st, p, max_tiles);
+    if (is_g1) *rc = gated ? launch_prefill_t<ADT, true, true>(st, p, max_tiles) : launch_prefill_t<ADT, false, true>(st, p, max_tiles);
+    else *rc = launch_prefill_t<ADT, false, false>(st, p, max_tiles);
     return true;
 }
 

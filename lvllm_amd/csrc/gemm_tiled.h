@@ -35,6 +35,25 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// v_mfma_f32_32x32x16 (gemm_w4x.h, gemm_w4e.h, gemm_prefill.h): A lane l = row l % 32, k = 8 (l / 32) .. + 7; B likewise per
+// token; D register i = row 8 (i / 4) + 4 (l / 32) + i % 4, token l % 32
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int ADT>
+struct Mfma32;
+template <>
+struct Mfma32<LKM_DT_BF16> {
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <>
+struct Mfma32<LKM_DT_F16> {
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
 // resident workgroups per CU the register allocation must allow (second __launch_bounds__ argument)
 constexpr int tiled_min_blocks(int wf, int tbw, int waves, bool gated_g1, int pd) {
     // 4-bit decode tiles are latency/issue bound with two waves per SIMD, and the gated 64-row kernel

@@ -23,23 +23,6 @@
 
 namespace lkm {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-template <int ADT>
-struct Mfma32;
-template <>
-struct Mfma32<LKM_DT_BF16> {
-    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-};
-template <>
-struct Mfma32<LKM_DT_F16> {
-    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    }
-};
-
 // uint4b8, exact decode without packed-fp32 instructions (DECV = 1): a v_pk_fma_f32 does not issue beside an MFMA at all
 // and costs 2-3 slots after one (tools/probe_mfma_valu.py), a v_fma_f32 hides under it.  Same bits as Dec<>::frag_m.
 template <int ADT>

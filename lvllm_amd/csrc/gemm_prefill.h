@@ -35,6 +35,8 @@ namespace lkm {
 constexpr int kPfTokens = 256;                  // token tile
 constexpr int kPfQ = 16 * 1024;                 // one quarter of a K tile: 128 rows x 64 k x 2 B
 constexpr int kPfBufBytes = 4 * kPfQ;           // [A0][A1][B0][B1]
+constexpr int kPfNarBytes = 3 * kPfQ;           // narrow tile (<= 128 tokens): [A0][A1][B0], three buffers
+constexpr int kPfLdsBytes = 3 * kPfNarBytes;    // 144 KiB (>= the 2 x 64 KiB of a full tile)
 
 // SiLU-mul epilogue of this kernel: the sigmoid on the transcendental unit (v_exp_f32 + v_rcp_f32, as gemm_prefill_a8w.h)
 // instead of the polynomial exp and IEEE division the other kernels share with the CPU restatement -- at ~55 VALU per
@@ -42,8 +44,7 @@ constexpr int kPfBufBytes = 4 * kPfQ;           // [A0][A1][B0][B1]
 // matrix pipe idles).  Same rounding points (GemmParams::round_gemm1); the fp32 sigmoid differs in its last bits, i.e.
 // one ulp of the activation dtype on ~1e-4 of the intermediate elements, far inside the operator's tolerance.
 template <int ADT>
-__device__ __forceinline__ void pf_store_silu_mul(const GemmParams& p, const f32x4& gate, const f32x4& upv, size_t out_row, int n) {
-    float v[4];
+__device__ __forceinline__ void pf_silu_mul4(const GemmParams& p, const f32x4& gate, const f32x4& upv, float (&v)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float a = gate[r], up = upv[r];
@@ -53,14 +54,6 @@ __device__ __forceinline__ void pf_store_silu_mul(const GemmParams& p, const f32
         }
         const float sg = a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * -1.44269504088896341f));
         v[r] = p.round_gemm1 ? ActT<ADT>::to_f32(ActT<ADT>::from_f32(sg)) * up : sg * up;
-    }
-    unsigned short* o = (unsigned short*)p.out + out_row * p.ldo + n;
-    if (n + 4 <= p.n_real) {
-        *(u32x2*)o = u32x2{ActT<ADT>::pack2(v[0], v[1]), ActT<ADT>::pack2(v[2], v[3])};
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n + r < p.n_real) o[r] = ActT<ADT>::from_f32(v[r]);
     }
 }
 
@@ -97,12 +90,17 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef LKM_PF_ABL   // timing ablations (results are wrong): dbg & 16 no DMA in the K loop, & 32 every workgroup streams the same operands
-    const bool abl_nodma = p.dbg & 16, abl_same = p.dbg & 32, abl_noepi = p.dbg & 64;
+    const bool abl_nodma = p.dbg & 16, abl_same = p.dbg & 32, abl_noepi = p.dbg & 64, abl_nost = p.dbg & 128;
 #else
-    constexpr bool abl_nodma = false, abl_same = false, abl_noepi = false;
+    constexpr bool abl_nodma = false, abl_same = false, abl_noepi = false, abl_nost = false;
 #endif
     const int l32 = lane & 31, h = lane >> 5;
     const int wr = wave >> 2, wc = wave & 3;
+    // A tile of <= 128 tokens (the stub an expert's row count leaves after its full tiles) runs the NARROW loop: one token
+    // group of 32 per wave, two phases per K tile (A0 x B, A1 x B) -- half the matrix work of a full tile instead of all
+    // of it with half of every wave's accumulators multiplying padding.
+    const bool nar = m_e - r0 <= 128;
+    const int wtok = nar ? wc * 32 : wc * 64;                 // first token of this wave inside the tile
     const int T_all = p.T_half * p.halves;
     constexpr int TPH = GATED ? 8 : 16;                       // tiles per half taken by one workgroup
     const int tbase = bx * TPH;
@@ -131,18 +129,18 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             const int pc = q * 512 + tid;
             const int row = pc >> 3, pslot = pc & 7;
             const int lslot = pslot ^ x_swizzle<128>(row);
-            const int r = r0 + (row >> 5) * 64 + s * 32 + (row & 31);
+            const int r = nar ? r0 + row : r0 + (row >> 5) * 64 + s * 32 + (row & 31);
             const int rr = r < m_e ? r : r0;
             const int src_row = IS_G1 ? p.sorted_slot[off_e + rr] / p.top_k : off_e + rr;
             bvoff[s][q] = (abl_same ? row : src_row) * p.ldx * 2 + lslot * 16;   // < 2 GiB (checked by the launcher)
         }
     const int wustep = (int)(p.w_ustride * 16);
     // quarter ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1 (= position inside a buffer)
-    auto dma = [&](int u, auto BUF, auto QC) __attribute__((always_inline)) {
-        constexpr int buf = decltype(BUF)::v, qid = decltype(QC)::v;
+    auto dma_at = [&](int u, auto OFF, auto QC) __attribute__((always_inline)) {
+        constexpr int off = decltype(OFF)::v, qid = decltype(QC)::v;
         const int uc = u < U ? u : U - 1;                     // past the end: re-fetch the last unit into a quarter nobody reads
         if (abl_nodma && u >= 2) return;
-        char* base = lds + buf * kPfBufBytes + qid * kPfQ;
+        char* base = lds + off;
         if constexpr (qid < 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -156,9 +154,13 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         }
     };
 
+    auto dma = [&](int u, auto BUF, auto QC) __attribute__((always_inline)) {
+        dma_at(u, IC<decltype(BUF)::v * kPfBufBytes + decltype(QC)::v * kPfQ>{}, QC);
+    };
+
     // ---- fragments.  Registers (2 waves per SIMD -> 256 per lane): 128 accumulators, 8 weight fragments (one
     // quarter: 2 row groups x 4 k-steps), 2 x 4 token fragments (both quarters stay: B0 serves ph1 and ph4).
-    const bool has_rows = r0 + wc * 64 < m_e;                 // wave-uniform: my token share holds rows
+    const bool has_rows = r0 + wtok < m_e;                    // wave-uniform: my token share holds rows
     u32x4 fa[2][4], fb0[4], fb1[4];
     f32x16 acc[4][2];
 #pragma unroll
@@ -174,18 +176,24 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) baddr[kk] = (wc * 32 + l32) * 128 + (((kk * 2 + h) ^ x_swizzle<128>(l32)) * 16);
 
-    auto read_a = [&](auto BUF, auto SC) __attribute__((always_inline)) {
-        constexpr int buf = decltype(BUF)::v, s = decltype(SC)::v;
+    auto read_a_at = [&](auto OFF) __attribute__((always_inline)) {
+        constexpr int off = decltype(OFF)::v;
 #pragma unroll
         for (int rgl = 0; rgl < 2; ++rgl)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                fa[rgl][kk] = *(const u32x4*)(lds + buf * kPfBufBytes + s * kPfQ + abyte + rgl * 4096 + (kk >> 1) * 1024 + (kk & 1) * 512);
+                fa[rgl][kk] = *(const u32x4*)(lds + off + abyte + rgl * 4096 + (kk >> 1) * 1024 + (kk & 1) * 512);
+    };
+    auto read_b_at = [&](auto OFF, u32x4 (&fb)[4]) __attribute__((always_inline)) {
+        constexpr int off = decltype(OFF)::v;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb[kk] = *(const u32x4*)(lds + off + baddr[kk]);
+    };
+    auto read_a = [&](auto BUF, auto SC) __attribute__((always_inline)) {
+        read_a_at(IC<decltype(BUF)::v * kPfBufBytes + decltype(SC)::v * kPfQ>{});
     };
     auto read_b = [&](auto BUF, auto SC, u32x4 (&fb)[4]) __attribute__((always_inline)) {
-        constexpr int buf = decltype(BUF)::v, s = decltype(SC)::v;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fb[kk] = *(const u32x4*)(lds + buf * kPfBufBytes + (2 + s) * kPfQ + baddr[kk]);
+        read_b_at(IC<decltype(BUF)::v * kPfBufBytes + (2 + decltype(SC)::v) * kPfQ>{}, fb);
     };
     auto mm = [&](auto RG0, auto TG, const u32x4 (&fb)[4]) __attribute__((always_inline)) {
         constexpr int rg0 = decltype(RG0)::v, tg = decltype(TG)::v;
@@ -262,46 +270,181 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         if (wr == 0) bar();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing DMA must land before the LDS is released
     };
+    // NARROW tile t in buffer BUF of three ([A0][A1][B0], 48 KiB each).  Schedule, DMA issued / landing waited for:
+    //     phA: A0, B0 (t+2) / A1(t)   [vmcnt(10): all but the five youngest quarters]      phB: A1(t+2) / A0, B0 (t+1)   [vmcnt(8)]
+    // (a quarter is again re-filled two phases after its last read, for the tile after the next two)
+    auto tile_n = [&](int t, auto BUF, auto COMPUTE) __attribute__((always_inline)) {
+        constexpr int b = decltype(BUF)::v, b2 = (b + 2) % 3;
+        constexpr bool comp = decltype(COMPUTE)::value;
+        if constexpr (comp) {
+            read_b_at(IC<b * kPfNarBytes + 2 * kPfQ>{}, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a_at(IC<b * kPfNarBytes>{});
+        }
+        dma_at(t + 2, IC<b2 * kPfNarBytes>{}, IC<0>{});
+        dma_at(t + 2, IC<b2 * kPfNarBytes + 2 * kPfQ>{}, IC<2>{});
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        bar();
+        if constexpr (comp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mm(IC<0>{}, IC<0>{}, fb0);
+        }
+        bar();
+        if constexpr (comp) read_a_at(IC<b * kPfNarBytes + kPfQ>{});
+        dma_at(t + 2, IC<b2 * kPfNarBytes + kPfQ>{}, IC<1>{});
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        bar();
+        if constexpr (comp) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mm(IC<2>{}, IC<0>{}, fb0);
+        }
+        bar();
+    };
+    auto run_n = [&](auto COMPUTE) __attribute__((always_inline)) {
+        dma_at(0, IC<0>{}, IC<0>{});
+        dma_at(0, IC<2 * kPfQ>{}, IC<2>{});
+        dma_at(0, IC<kPfQ>{}, IC<1>{});
+        dma_at(1, IC<kPfNarBytes>{}, IC<0>{});
+        dma_at(1, IC<kPfNarBytes + 2 * kPfQ>{}, IC<2>{});
+        dma_at(1, IC<kPfNarBytes + kPfQ>{}, IC<1>{});
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // A0(0), B0(0) landed
+        bar();
+        if (wr == 1) bar();
+        for (int t = 0;;) {
+            tile_n(t, IC<0>{}, COMPUTE);
+            if (++t >= U) break;
+            tile_n(t, IC<1>{}, COMPUTE);
+            if (++t >= U) break;
+            tile_n(t, IC<2>{}, COMPUTE);
+            if (++t >= U) break;
+        }
+        if (wr == 0) bar();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     if (!has_rows) {
-        run(std::false_type{});
+        if (nar) run_n(std::false_type{});
+        else run(std::false_type{});
+        bar();                                                 // (the epilogue's barrier)
         return;
     }
-    run(std::true_type{});
+    if (nar) run_n(std::true_type{});
+    else run(std::true_type{});
 
-    // ---- epilogue (D layout: register i of lane (l32, h) = row 8 (i / 4) + 4 h + i % 4 of the 32-row group, token l32)
-    static_for<2>([&](auto TGC) __attribute__((always_inline)) {
-        constexpr int tg = decltype(TGC)::v;
-        const int r_tok = r0 + wc * 64 + tg * 32 + l32;
-        if (r_tok < m_e && !(abl_noepi && acc[0][0][0] != 12345.f)) {
+    // ---- epilogue.  D layout: register i of lane (l32, h) = row 8 (i / 4) + 4 h + i % 4 of the 32-row group, token l32 --
+    // a lane holds 4-element pieces of 32 different output rows, so stored directly every piece is its own 8 / 16-byte
+    // write (measured: 25 % of GEMM2, the matrix pipe idle).  The K loop's LDS is free now: each wave transposes its
+    // [64 tokens][64 / 128 features] block through its own 16 KiB (pieces XOR-swizzled by the token so that both the
+    // piece writes and the row reads spread over the banks) and stores whole 128 - 512-byte row segments.
+    char* my = lds + wave * 16384;
+    const int nbase = (tbase + (GATED ? wr * 4 : wr * 8)) * 16;            // first output feature of this wave
+    const size_t row0 = (size_t)(off_e + r0 + wtok);
+    const int rows_here = min(m_e - (r0 + wtok), nar ? 32 : 64);           // > 0 (has_rows); a narrow tile only has token group 0
+    // 16-bit outputs: ROWB bytes per token row, piece c = features 4c .. 4c+3 (8 bytes), 16-byte pairs XOR-ed with the token
+    auto put16 = [&](auto ROWBC, int t, int c, const float (&v)[4]) __attribute__((always_inline)) {
+        constexpr int ROWB = decltype(ROWBC)::v, P = ROWB / 16;
+        *(u32x2*)(my + t * ROWB + (((c >> 1) ^ (t & (P - 1))) * 16) + (c & 1) * 8) =
+            u32x2{ActT<ADT>::pack2(v[0], v[1]), ActT<ADT>::pack2(v[2], v[3])};
+    };
+    auto flush16 = [&](auto ROWBC) __attribute__((always_inline)) {
+        constexpr int ROWB = decltype(ROWBC)::v, P = ROWB / 16, RPI = 64 / P;
+        const int k = lane % P, ts = lane / P;
+        unsigned short* o = (unsigned short*)p.out + row0 * p.ldo + nbase + k * 8;
+        const bool whole = nbase + k * 8 + 8 <= p.n_real;
+#pragma unroll
+        for (int j = 0; j < 64 / RPI; ++j) {
+            const int t = j * RPI + ts;
+            const u32x4 d = *(const u32x4*)(my + t * ROWB + ((k ^ (t & (P - 1))) * 16));
+            if (t < rows_here && !(abl_nost && d.x != 0x12345u)) {
+                unsigned short* ot = o + (size_t)t * p.ldo;
+                if (whole) {
+                    *(u32x4*)ot = d;
+                } else {
+                    const unsigned dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (nbase + k * 8 + i < p.n_real) ot[i] = (unsigned short)(dw[i >> 1] >> ((i & 1) * 16));
+                }
+            }
+        }
+    };
+    bar();                                                                  // every wave's DMA has landed, every fragment read is done
+    if constexpr (IS_G1) {
+        constexpr int ROWB = GATED ? 128 : 256;
+        const bool fast_silu = GATED && p.act_type == LKM_ACT_SILU;
+        static_for<2>([&](auto TGC) __attribute__((always_inline)) {
+            constexpr int tg = decltype(TGC)::v;
             static_for<4>([&](auto RGC) __attribute__((always_inline)) {
                 constexpr int rg = decltype(RGC)::v;
-                const int grp = wr * 4 + rg;                   // row group inside the workgroup
                 const f32x16& c = acc[rg][tg];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 lo = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
                     const f32x4 hi = {c[8 + 4 * q], c[9 + 4 * q], c[10 + 4 * q], c[11 + 4 * q]};
-                    const int nsub = 8 * q + 4 * h;
+                    float v[4];
                     if constexpr (GATED) {
-                        const int tl = tbase + grp, n = tl * 16 + nsub;
-                        if (tl < p.T_half && n < p.n_real) {
-                            if (p.act_type == LKM_ACT_SILU) pf_store_silu_mul<ADT>(p, lo, hi, (size_t)(off_e + r_tok), n);
-                            else store_gemm1_frag<ADT, true>(p, lo, hi, (size_t)(off_e + r_tok), n);
-                        }
+                        if (fast_silu) pf_silu_mul4<ADT>(p, lo, hi, v);
+                        else gemm1_act4<ADT, true>(p, lo, hi, v);
+                        put16(IC<ROWB>{}, tg * 32 + l32, rg * 4 + 2 * q + h, v);
                     } else {
-                        const int tl = tbase + grp * 2, n0 = tl * 16 + nsub, n1 = n0 + 16;
-                        if constexpr (IS_G1) {
-                            if (tl < p.T_half && n0 < p.n_real) store_gemm1_frag<ADT, false>(p, lo, lo, (size_t)(off_e + r_tok), n0);
-                            if (tl + 1 < p.T_half && n1 < p.n_real) store_gemm1_frag<ADT, false>(p, hi, hi, (size_t)(off_e + r_tok), n1);
-                        } else {
-                            if (tl < p.T_half && n0 < p.n_real) store_gemm2_frag(p, lo, 0, (size_t)(off_e + r_tok), n0);
-                            if (tl + 1 < p.T_half && n1 < p.n_real) store_gemm2_frag(p, hi, 0, (size_t)(off_e + r_tok), n1);
-                        }
+                        gemm1_act4<ADT, false>(p, lo, lo, v);
+                        put16(IC<ROWB>{}, tg * 32 + l32, rg * 8 + 2 * q + h, v);
+                        gemm1_act4<ADT, false>(p, hi, hi, v);
+                        put16(IC<ROWB>{}, tg * 32 + l32, rg * 8 + 4 + 2 * q + h, v);
                     }
                 }
             });
-        }
-    });
+        });
+        if (!abl_noepi) flush16(IC<ROWB>{});
+    } else if (p.y_dt != LKM_DT_F32) {
+        // partial rows in the activation dtype (lkm_api.hip decides): 256 bytes per token
+        static_for<2>([&](auto TGC) __attribute__((always_inline)) {
+            constexpr int tg = decltype(TGC)::v;
+            static_for<4>([&](auto RGC) __attribute__((always_inline)) {
+                constexpr int rg = decltype(RGC)::v;
+                const f32x16& c = acc[rg][tg];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v[4] = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+                    put16(IC<256>{}, tg * 32 + l32, rg * 8 + (q >> 1) * 4 + 2 * (q & 1) + h, v);
+                }
+            });
+        });
+        if (!abl_noepi) flush16(IC<256>{});
+    } else {
+        // fp32 partial rows: 512 bytes per token, one 32-token group per pass
+        const int k = lane & 31, ts = lane >> 5;
+        float* o = (float*)p.out + row0 * p.ldo + nbase + k * 4;
+        const bool whole = nbase + k * 4 + 4 <= p.n_real;
+        static_for<2>([&](auto TGC) __attribute__((always_inline)) {
+            constexpr int tg = decltype(TGC)::v;
+            static_for<4>([&](auto RGC) __attribute__((always_inline)) {
+                constexpr int rg = decltype(RGC)::v;
+                const f32x16& c = acc[rg][tg];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cc = rg * 8 + (q >> 1) * 4 + 2 * (q & 1) + h;   // 16-byte piece: features 4 cc .. 4 cc + 3
+                    *(f32x4*)(my + l32 * 512 + ((cc ^ (l32 & 15)) * 16)) = f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+                }
+            });
+            if (!abl_noepi) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int t = 2 * j + ts;
+                    const f32x4 d = *(const f32x4*)(my + t * 512 + ((k ^ (t & 15)) * 16));
+                    if (tg * 32 + t < rows_here && !(abl_nost && d[0] != 12345.f)) {
+                        float* ot = o + (size_t)(tg * 32 + t) * p.ldo;
+                        if (whole) {
+                            *(f32x4*)ot = d;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (nbase + k * 4 + i < p.n_real) ot[i] = d[i];
+                        }
+                    }
+                }
+            }
+        });
+    }
 #else
     (void)p;
 #endif
@@ -316,7 +459,7 @@ inline bool prefill_kernel_ok(const GemmParams& p, size_t x_rows) {
 
 template <int ADT, bool GATED, bool IS_G1>
 static int launch_prefill_t(hipStream_t st, const GemmParams& p, int max_tiles) {
-    constexpr size_t lds = 2 * (size_t)kPfBufBytes;
+    constexpr size_t lds = kPfLdsBytes;
     const int TPH = GATED ? 8 : 16;
     const int RG = ceil_div(p.T_half, TPH);
     dim3 grid(RG, max_tiles), block(512);
@@ -337,7 +480,11 @@ static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmPa
                               int max_tiles, int* rc, ADTC) {
     constexpr int ADT = ADTC::v;
     if (cfg.tiled != 256 || cfg.pf != 8) return false;
-    if (!prefill_kernel_ok(p, p.x_rows)) return false;
+    if (!prefill_kernel_ok(p, p.x_rows)) {     // (pick_cfg only plans the kernel for shapes that qualify)
+        set_error("gemm_prefill: K = %d / %d units or the operand sizes do not fit the kernel", p.Kreal, p.U);
+        *rc = LKM_E_INVALID;
+        return true;
+    }
     if (is_g1) *rc = gated ? launch_prefill_t<ADT, true, true>(st, p, max_tiles) : launch_prefill_t<ADT, false, true>(st, p, max_tiles);
     else *rc = launch_prefill_t<ADT, false, false>(st, p, max_tiles);
     return true;

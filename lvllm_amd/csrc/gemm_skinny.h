@@ -503,9 +503,7 @@ __device__ __forceinline__ float act_silu(float g) { return g / (1.0f + lkm_expf
 // GEMM1: activation (SiLU-mul / swigluoai / relu2; rounding points per GemmParams::round_gemm1) and ONE
 // rounding to the activation dtype; the row is `out_row` of the expert-sorted intermediate.
 template <int ADT, bool GATED>
-__device__ __forceinline__ void store_gemm1_frag(const GemmParams& p, const f32x4& gate, const f32x4& upv,
-                                                 size_t out_row, int n) {
-    float v[4];
+__device__ __forceinline__ void gemm1_act4(const GemmParams& p, const f32x4& gate, const f32x4& upv, float (&v)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float a = gate[r];
@@ -528,6 +526,12 @@ __device__ __forceinline__ void store_gemm1_frag(const GemmParams& p, const f32x
             v[r] = tt * tt;
         }
     }
+}
+template <int ADT, bool GATED>
+__device__ __forceinline__ void store_gemm1_frag(const GemmParams& p, const f32x4& gate, const f32x4& upv,
+                                                 size_t out_row, int n) {
+    float v[4];
+    gemm1_act4<ADT, GATED>(p, gate, upv, v);
     unsigned short* o = (unsigned short*)p.out + out_row * p.ldo + n;
     if (n + 4 <= p.n_real) {
         u32x2 pk;

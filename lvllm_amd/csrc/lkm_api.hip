@@ -165,7 +165,7 @@ struct LkmEngine {
     void *io_x = nullptr, *io_ids = nullptr, *io_w = nullptr, *io_out = nullptr;
     size_t io_tokens = 0;
     // tuning overrides (<=0 = auto)
-    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0, t_fuse = 0, t_tiled2 = 0, t_fuseq = 0;
+    int t_nt1 = 0, t_nt2 = 0, t_kw1 = 0, t_sk2 = 0, t_tb = 0, t_tiled = 0, t_waves = 0, t_hybrid = 0, t_pd1 = 0, t_pd2 = 0, t_xcd = 0, t_pf = 0, t_direct = 0, t_valid_den = 0, t_prof_rep = 0, t_dbg = 0, t_fuse = 0, t_tiled2 = 0, t_fuseq = 0, t_ydt = 0;
     int loads = 2;            // 16-byte loads per lane per (tile, unit)
     // first-call micro-autotune (tuning key "autotune", off by default: the thresholds of pick_cfg stay the plan and
     // results stay reproducible run to run).  When on, the first EAGER call of a decode-sized step shape times two to
@@ -676,6 +676,17 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         }
         if (tiled == 128 && waves == 4) pd1 = pd2 = 4;   // EP=8 Mixtral rank: 154 vs 229 us at 2/2
         int pf = (tiled == 256 && h->t_pf > 0 && !wf_is_4bit(h->wf)) ? h->t_pf : 0;
+        // 16-bit weights on 256-row tiles: the 8-phase LDS-DMA kernel (gemm_prefill.h, round 4) is the default -- GLM-4.5-Air
+        // bf16 prefill M=8192: GEMM1 1674 -> 1324 us, GEMM2 964 -> 728, step 2919 -> 2227 (profiles/r04_prefill16_*.log);
+        // "pf" = -1 keeps gemm_tiled_kernel
+        if (tiled == 256 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && h->t_pf == 0) pf = 8;
+        // 16-bit weights, "pf" = 8: gemm_prefill.h where both GEMMs qualify (K loops of whole, even 64-k unit counts; tokens,
+        // intermediate and an expert's weights inside 2 GiB buffer windows: prefill_kernel_ok) -- else the plain tile kernel
+        if (pf == 8 && !(h->H % 128 == 0 && h->I % 128 == 0 && (size_t)M * (size_t)h->H * 2 < (size_t)0x7fffffff &&
+                         n_slots * (size_t)h->ld_act * 2 < (size_t)0x7fffffff &&
+                         (size_t)h->T1_half * (h->gated ? 2 : 1) * h->U1 * 2048 < (size_t)0x7fffffff &&
+                         (size_t)h->T2 * h->U2 * 2048 < (size_t)0x7fffffff))
+            pf = 0;
         // (round 2's LDS-DMA ring kernel for the 4-bit formats, "pf" = 4, was removed in round 4: three to four times the
         // bytes in flight per CU and no faster, profiles/r02_w4dma_sweep.log)
         // round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h), "pf" = 5
@@ -699,7 +710,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // the workgroups that share a weight panel on one L2 -- round 1 measured +-0 with equal ITEM counts per XCD; with the
         // runs cut by routed rows (round 3) the bf16 prefill step goes 3095 -> 2853 us uniform, 3158 -> 3006 us Zipf
         // (profiles/r04_prefill_plan_sweep.log).  Few large experts (Mixtral) lose with it and keep the plain grid.
-        if (tiled == 256 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && n_act >= 32 && h->t_xcd >= 0 && !pf)
+        if (tiled == 256 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && n_act >= 32 && h->t_xcd >= 0 && (!pf || pf == 8))
             pl->xcd1 = pl->xcd2 = 1;
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;
@@ -995,7 +1006,11 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     p2.SK = sk;
     // block-fp8 W8A8 on the prefill kernel: GEMM2 rounds its output to the activation dtype like the reference's
     // native_w8a8_block_matmul (output_dtype) -- half the bytes written here and read back by the combine
-    const int y_dt = (h->a8 && pl.t2.tiled == 256 && pl.t2.pf >= 8 && !pl.s2.tb && sk == 1) ? h->adt : LKM_DT_F32;
+    // 16-bit weights on gemm_prefill.h ("pf" = 8, prefill sizes only): the same -- what the in-tree GPU operator's GEMM2 does
+    // (fused_moe.py writes intermediate_cache3 in the hidden dtype before moe_sum); GLM-4.5-Air bf16 M=8192: GEMM2 815 ->
+    // 728 us, combine 248 -> 136.  "ydt" = -1 keeps the fp32 partials of the smaller-batch kernels.
+    const bool w16_pf = (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && pl.t2.tiled == 256 && pl.t2.pf == 8 && h->t_ydt >= 0;
+    const int y_dt = (((h->a8 && pl.t2.pf >= 8) || w16_pf) && pl.t2.tiled == 256 && !pl.s2.tb && sk == 1) ? h->adt : LKM_DT_F32;
     p2.y_dt = y_dt;
     if (direct) {
         p2.direct_ids = ids;
@@ -1384,6 +1399,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "pd2")) h->t_pd2 = value;
     else if (!strcmp(key, "xcd")) h->t_xcd = value;
     else if (!strcmp(key, "pf")) h->t_pf = value;
+    else if (!strcmp(key, "ydt")) h->t_ydt = value;
     else if (!strcmp(key, "direct")) h->t_direct = value;
     else if (!strcmp(key, "fuse")) h->t_fuse = value;
     else if (!strcmp(key, "autotune")) {

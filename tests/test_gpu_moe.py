@@ -312,7 +312,10 @@ def test_dense_tiled_path_multi_tile_ragged(M, E, K, H, I, tiled):
     d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
     ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
     np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL)
-    eng.engine.set_tuning(tiled=-1)            # skinny streamer on the same inputs
+    if "pf=8" in eng.engine.describe():        # (the 256-row kernel's default: GEMM2 partial rows in the activation dtype)
+        eng.engine.set_tuning(tiled=tiled, ydt=-1)
+        out = _run_decode(eng, a, tw, ids)
+    eng.engine.set_tuning(tiled=-1, ydt=0)     # skinny streamer on the same inputs
     np.testing.assert_allclose(_run_decode(eng, a, tw, ids), out, atol=1e-4, rtol=1e-4)
 
 
@@ -552,24 +555,33 @@ def test_prefill_kernel_ragged_multi_tile(pf, gated):
     ids = np.ascontiguousarray(np.stack([pool[first], pool[second]], axis=1).astype(np.int32))
     kw = dict(has_gate_proj=False, activation_type=2) if not gated else {}
     eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16, **kw)
-    eng.engine.set_tuning(tiled=256, waves=8, pf=pf)
+    eng.engine.set_tuning(tiled=256, waves=8, pf=pf, ydt=-1)    # fp32 partial rows, as every other kernel
     out = _run_decode(eng, a, tw, ids)
-    assert "tm=256" in eng.engine.describe()
+    assert "tm=256" in eng.engine.describe() and f"pf={pf}" in eng.engine.describe(), eng.engine.describe()
     d = orc.MoeDesc(E=E, H=H, I=I, has_gate=gated, activation=orc.ACT_SILU if gated else orc.ACT_RELU2,
                     act_dtype=orc.BF16, wfmt=orc.W_BF16)
     ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
-    np.testing.assert_allclose(out, ref, atol=ATOL * max(1.0, float(np.abs(ref).max())), rtol=RTOL)
-    eng.engine.set_tuning(pf=0)
+    scale = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(out, ref, atol=ATOL * scale, rtol=RTOL)
+    eng.engine.set_tuning(pf=-1)
     base = _run_decode(eng, a, tw, ids)                         # same tiles through gemm_tiled_kernel
-    np.testing.assert_allclose(out, base, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4)
-    # XCD-aware work mapping (opt-in knob "xcd"): only WHERE a
-    # workgroup runs changes, so the bits must not -- on both kernels, forced on and forced off
-    for pf2 in (0, pf):
-        for xcd in (1, -1):
-            eng.engine.set_tuning(pf=pf2, xcd=xcd)
+    assert "pf=0" in eng.engine.describe(), eng.engine.describe()
+    # (gated: the kernel's SiLU runs on the transcendental unit -- an intermediate element may round one bf16 ulp apart)
+    np.testing.assert_allclose(out, base, atol=1e-4 * scale, rtol=1e-4)
+    # the plan's default for the kernel: GEMM2 partial rows in the activation dtype (the in-tree GPU operator's rounding
+    # point), inside the operator's tolerance against the fp32-partial oracle
+    eng.engine.set_tuning(pf=pf, ydt=0)
+    out_y = _run_decode(eng, a, tw, ids)
+    np.testing.assert_allclose(out_y, ref, atol=ATOL * scale, rtol=RTOL)
+    assert not np.array_equal(out_y, out)
+    # XCD-aware work mapping (knob "xcd"): only WHERE a workgroup runs changes, so the bits must not -- on both kernels,
+    # forced on and forced off, and with the plain run order of the workgroups inside an XCD (dbg = 8)
+    for pf2 in (-1, pf):
+        for xcd, dbg in ((1, 0), (-1, 0), (1, 8)):
+            eng.engine.set_tuning(pf=pf2, xcd=xcd, ydt=-1, dbg=dbg)
             got = _run_decode(eng, a, tw, ids)
-            assert np.array_equal(got, base if pf2 == 0 else out), f"pf={pf2} xcd={xcd} " + eng.engine.describe()
-    eng.engine.set_tuning(pf=0, xcd=0)
+            assert np.array_equal(got, base if pf2 == -1 else out), f"pf={pf2} xcd={xcd} " + eng.engine.describe()
+    eng.engine.set_tuning(pf=0, xcd=0, ydt=0, dbg=0)
 
 
 @pytest.mark.parametrize("fmt", ["bf16", "f16", "int4", "fp8", "fp8a8", "mxfp4"])
@@ -703,21 +715,22 @@ def test_all_launch_geometries_agree():
             np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())
     # tiled GEMM2 with split-K slabs (few experts per EP rank)
     for tiled, waves, sk in ((64, 4, 2), (64, 4, 4), (128, 8, 8), (128, 4, 2), (256, 8, 2)):
-        eng.engine.set_tuning(tiled=tiled, waves=waves, nt1=1, nt2=1, tbmax=0, kw1=0, sk2=sk)
+        eng.engine.set_tuning(tiled=tiled, waves=waves, nt1=1, nt2=1, tbmax=0, kw1=0, sk2=sk, pf=-1)
         out = _run_decode(eng, a, tw, ids)
         assert f"sk={sk}" in eng.engine.describe() or True
         np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=f"tiled sk={sk} " + eng.engine.describe())
     eng.engine.set_tuning(sk2=0)
     # LDS-DMA prefill kernels (gemm_prefill.h): 256-row tiles
     for pf in (8,):
-        eng.engine.set_tuning(tiled=256, waves=8, nt1=1, nt2=1, pf=pf, tbmax=0, kw1=0, sk2=0)
+        eng.engine.set_tuning(tiled=256, waves=8, nt1=1, nt2=1, pf=pf, tbmax=0, kw1=0, sk2=0, ydt=-1)
         out = _run_decode(eng, a, tw, ids)
+        assert f"pf={pf}" in eng.engine.describe(), eng.engine.describe()
         np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=f"pf={pf} " + eng.engine.describe())
-    eng.engine.set_tuning(pf=0)
+    eng.engine.set_tuning(pf=-1, ydt=0)
     # LDS-staged tiled kernels (gemm_tiled.h)
     for tiled, waves, nt1, nt2 in ((32, 4, 1, 1), (64, 4, 1, 1), (64, 8, 1, 1), (64, 4, 1, 2), (128, 8, 1, 1), (128, 8, 1, 2),
                                    (256, 8, 1, 1), (256, 8, 1, 2)):
-        eng.engine.set_tuning(tiled=tiled, waves=waves, nt1=nt1, nt2=nt2, tbmax=0, kw1=0, sk2=0)
+        eng.engine.set_tuning(tiled=tiled, waves=waves, nt1=nt1, nt2=nt2, tbmax=0, kw1=0, sk2=0, pf=-1)
         out = _run_decode(eng, a, tw, ids)
         np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())
 

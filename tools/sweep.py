@@ -58,7 +58,7 @@ def main():
     print(f"# rows per expert: {torch.bincount(ids.flatten().long(), minlength=E).tolist()}")
     print(f"# {args.workload} {args.routing} M={M} e_act={e_act} g1={g1_bytes/1e9:.3f} GB g2={g2_bytes/1e9:.3f} GB")
     if args.cfgs:
-        keys = ("nt1", "nt2", "kw1", "sk2", "tbmax", "tiled", "waves", "hybrid", "pd1", "pd2", "xcd", "pf", "direct", "valid_den", "dbg")
+        keys = ("nt1", "nt2", "kw1", "sk2", "tbmax", "tiled", "waves", "hybrid", "pd1", "pd2", "xcd", "pf", "direct", "valid_den", "dbg", "ydt")
         for spec in args.cfgs.split(";"):
             kv = {k: 0 for k in keys}
             if spec.strip():

@@ -57,9 +57,46 @@ __device__ __forceinline__ void pf_silu_mul4(const GemmParams& p, const f32x4& g
     }
 }
 
-template <int ADT, bool GATED, bool IS_G1>
+template <int N>
+__device__ __forceinline__ void pf_wait_vmcnt() {
+    static_assert(N == 5 || N == 6 || N == 7 || N == 8 || N == 10, "counts of the two schedules");
+    if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+// e4m3 -> activation dtype, exact (v_cvt_scalef32_pk_{bf16,f16}_fp8 with scale 1: two values per instruction)
+template <int ADT>
+__device__ __forceinline__ u32x4 pf_fp8_frag(unsigned d0, unsigned d1) {
+    u32x4 o;
+    if constexpr (ADT == LKM_DT_BF16) {
+        o.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, 1.0f, false));
+        o.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, 1.0f, true));
+        o.z = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, 1.0f, false));
+        o.w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, 1.0f, true));
+    } else {
+        o.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d0, 1.0f, false));
+        o.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d0, 1.0f, true));
+        o.z = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d1, 1.0f, false));
+        o.w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(d1, 1.0f, true));
+    }
+    return o;
+}
+
+// W8 = fp8 e4m3 weights with one fp32 scale per (16-row tile, 128 k) -- block-quantised W8A16, the "VRAM FP8" class of the
+// reference (MOE_FP8.gpu_prefill): the image holds 16 rows x 128 k per 2 KiB, so a K tile of 64 k is ONE KiB per weight tile
+// (half the DMA bytes of the 16-bit formats); a fragment read fetches 16 raw bytes = the A operands of k-steps j and j + 2,
+// converted in registers (exact) behind the partner wave's MFMAs.  The block scales: the sum is  sum_u s_u P_u  with P_u
+// the fp32 partial of unit u (gemm_skinny.h Dec<FP8>: UNIT_SCALE).  A second accumulator set for P_u does not fit, so the
+// accumulators hold  (sum so far) / s_u  instead: entering unit u + 1 they are multiplied by s_u / s_{u+1} (one v_mul per
+// register, the registers of the quadrant the phase is about to update, wave-uniform ratios: every row of a 16-row tile
+// shares the scale -- the launcher requires block heights that are multiples of 16), leaving by s_last.  fp32 rounding
+// of the ratios: <= 1e-7 relative per unit.
+template <bool W8, int ADT, bool GATED, bool IS_G1>
 __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     static_assert(!GATED || IS_G1, "only GEMM1 is gated");
+    constexpr int AG = W8 ? 1 : 2, BG = 2;                    // LDS-DMA instructions per wave and weight / token quarter
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer resources / LDS-DMA builtins exist in the device pass only
     typedef __attribute__((address_space(3))) void* LdsPtr;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -104,13 +141,13 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     const int T_all = p.T_half * p.halves;
     constexpr int TPH = GATED ? 8 : 16;                       // tiles per half taken by one workgroup
     const int tbase = bx * TPH;
-    const int U = p.U;
+    const int U = W8 ? 2 * p.U : p.U;                        // K tiles of 64 k
 
     // ---- LDS-DMA streams, two wave-instructions per wave and quarter.
     // Weight quarter s: the 8 tiles {row half wr', row group 2s + rgl of it, tile gu of the group}, LDS slot
     // wr'*4 + rgl*2 + gu = the staging wave's index.  Token quarter s: LDS row wc'*32 + i = token wc'*64 + s*32 + i.
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.w + (size_t)(abl_same ? 0 : e) * T_all * U * 2048), 0, (int)((size_t)T_all * U * 2048), 0x00020000);
+        (void*)((const char*)p.w + (size_t)(abl_same ? 0 : e) * T_all * p.U * 2048), 0, (int)((size_t)T_all * p.U * 2048), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7fffffff, 0x00020000);
     int asoff[2];                                             // byte offset of my tile of quarter s (wave-uniform)
 #pragma unroll
@@ -141,7 +178,10 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         const int uc = u < U ? u : U - 1;                     // past the end: re-fetch the last unit into a quarter nobody reads
         if (abl_nodma && u >= 2) return;
         char* base = lds + off;
-        if constexpr (qid < 2) {
+        if constexpr (qid < 2 && W8) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + wave * 2048), 16, alane,
+                                                     asoff[qid] + (uc >> 1) * wustep + (uc & 1) * 1024, 0, 0);
+        } else if constexpr (qid < 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + wave * 2048 + ks * 1024), 16, alane,
@@ -176,13 +216,94 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) baddr[kk] = (wc * 32 + l32) * 128 + (((kk * 2 + h) ^ x_swizzle<128>(l32)) * 16);
 
+    u32x4 raw[W8 ? 2 : 1][2];                                   // W8: the raw bytes of a weight quarter (k-steps j and j + 2 per read)
     auto read_a_at = [&](auto OFF) __attribute__((always_inline)) {
         constexpr int off = decltype(OFF)::v;
+        if constexpr (W8) {
 #pragma unroll
-        for (int rgl = 0; rgl < 2; ++rgl)
+            for (int rgl = 0; rgl < 2; ++rgl)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                fa[rgl][kk] = *(const u32x4*)(lds + off + abyte + rgl * 4096 + (kk >> 1) * 1024 + (kk & 1) * 512);
+                for (int j = 0; j < 2; ++j) raw[rgl][j] = *(const u32x4*)(lds + off + abyte + rgl * 4096 + j * 512);
+        } else {
+#pragma unroll
+            for (int rgl = 0; rgl < 2; ++rgl)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    fa[rgl][kk] = *(const u32x4*)(lds + off + abyte + rgl * 4096 + (kk >> 1) * 1024 + (kk & 1) * 512);
+        }
+    };
+    auto decode_a = [&]() __attribute__((always_inline)) {     // (after the reads have returned)
+        if constexpr (W8) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int rgl = 0; rgl < 2; ++rgl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    fa[rgl][j] = pf_fp8_frag<ADT>(raw[rgl][j].x, raw[rgl][j].y);
+                    fa[rgl][j + 2] = pf_fp8_frag<ADT>(raw[rgl][j].z, raw[rgl][j].w);
+                }
+        }
+    };
+    // W8: scale streams of my four row groups x two tiles (gated: gate / up tile; else the two tiles of the 32 rows)
+    // All scales of a stream sit in ONE register, lane u = unit u (<= 64 units: the launcher checks), loaded before the
+    // first DMA (so every counted vmcnt of the loop covers them) -- scalar loads inside the loop would put SMEM on the
+    // lgkm counter and turn the loop's lgkmcnt(0) waits into waits for an L2 round trip.
+    float sv[4][2], scur[4][2], snx[4][2];
+    if constexpr (W8) {
+        const float* sc = (const float*)p.s;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int t = GATED ? tbase + wr * 4 + rg : tbase + (wr * 4 + rg) * 2 + hf;
+                const int gt = (GATED ? hf * p.T_half : 0) + (t < p.T_half ? t : 0);
+                const size_t so = ((size_t)e * T_all + gt) * p.U * 16;
+                sv[rg][hf] = lane < p.U ? sc[so + (size_t)lane * 16] : 0.0f;
+            }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv[rg][hf]), 0));
+                scur[rg][hf] = s0 != 0.0f ? s0 : 1.0f;
+                snx[rg][hf] = scur[rg][hf];
+            }
+    }
+    // the scales of unit u / enter unit u: ratio s_old / s_new for row groups RG0, RG0 + 1 (an all-zero block has scale 0
+    // and contributes 0: keep the old scale)
+    auto fetch_scales = [&](int u) __attribute__((always_inline)) {
+        if constexpr (W8) {
+            const int uc = u < p.U ? u : p.U - 1;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    snx[rg][hf] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv[rg][hf]), uc));
+        }
+    };
+    float ratio[4][2];
+    auto enter_unit = [&](auto RG0) __attribute__((always_inline)) {
+        constexpr int rg0 = decltype(RG0)::v;
+        if constexpr (W8) {
+#pragma unroll
+            for (int rg = rg0; rg < rg0 + 2; ++rg)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float sn = snx[rg][hf] != 0.0f ? snx[rg][hf] : scur[rg][hf];
+                    ratio[rg][hf] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+                        __builtin_bit_cast(int, scur[rg][hf] * __builtin_amdgcn_rcpf(sn))));
+                    scur[rg][hf] = sn;
+                }
+        }
+    };
+    auto rescale = [&](auto RG0, auto TG) __attribute__((always_inline)) {
+        constexpr int rg0 = decltype(RG0)::v, tg = decltype(TG)::v;
+        if constexpr (W8) {
+#pragma unroll
+            for (int rg = rg0; rg < rg0 + 2; ++rg)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[rg][tg][i] *= ratio[rg][i >> 3];
+        }
     };
     auto read_b_at = [&](auto OFF, u32x4 (&fb)[4]) __attribute__((always_inline)) {
         constexpr int off = decltype(OFF)::v;
@@ -213,6 +334,8 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     auto tile = [&](int t, auto BUF, auto COMPUTE) __attribute__((always_inline)) {
         constexpr int b = decltype(BUF)::v;
         constexpr bool comp = decltype(COMPUTE)::value;
+        constexpr int VM = 2 * AG + 2 * BG;                   // all but the four youngest quarters
+        const bool unit_in = W8 && comp && b == 0 && t > 0;   // W8: this K tile opens a 128-k unit (buffer parity = tile parity)
         // ph1
         if constexpr (comp) {
             read_b(IC<b>{}, IC<0>{}, fb0);
@@ -220,7 +343,15 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             read_a(IC<b>{}, IC<0>{});
         }
         dma(t + 1, IC<b ^ 1>{}, IC<3>{});
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (comp) {
+            if constexpr (W8 && b == 1) fetch_scales((t >> 1) + 1);
+            if (unit_in) {
+                enter_unit(IC<0>{});
+                rescale(IC<0>{}, IC<0>{});
+            }
+            decode_a();
+        }
+        pf_wait_vmcnt<VM>();
         bar();
         if constexpr (comp) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -230,7 +361,10 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         // ph2
         if constexpr (comp) read_b(IC<b>{}, IC<1>{}, fb1);
         dma(t + 1, IC<b ^ 1>{}, IC<1>{});
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (comp) {
+            if (unit_in) rescale(IC<0>{}, IC<1>{});
+        }
+        pf_wait_vmcnt<VM>();
         bar();
         if constexpr (comp) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -240,6 +374,13 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         // ph3
         if constexpr (comp) read_a(IC<b>{}, IC<1>{});
         dma(t + 2, IC<b>{}, IC<0>{});
+        if constexpr (comp) {
+            if (unit_in) {
+                enter_unit(IC<2>{});
+                rescale(IC<2>{}, IC<1>{});
+            }
+            decode_a();
+        }
         bar();
         if constexpr (comp) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -248,7 +389,10 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         bar();
         // ph4
         dma(t + 2, IC<b>{}, IC<2>{});
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (comp) {
+            if (unit_in) rescale(IC<2>{}, IC<0>{});
+        }
+        pf_wait_vmcnt<VM>();
         bar();
         if constexpr (comp) mm(IC<2>{}, IC<0>{}, fb0);
         bar();
@@ -260,7 +404,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         dma(0, IC<0>{}, IC<1>{});
         dma(1, IC<1>{}, IC<0>{});
         dma(1, IC<1>{}, IC<2>{});
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // A0(0), B0(0) landed
+        pf_wait_vmcnt<2 * AG + 2 * BG>();                      // A0(0), B0(0) landed
         bar();
         if (wr == 1) bar();                                   // row half 1 runs one barrier interval behind
         for (int t = 0; t < U; t += 2) {                      // (U is even: the launcher checks)
@@ -276,6 +420,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     auto tile_n = [&](int t, auto BUF, auto COMPUTE) __attribute__((always_inline)) {
         constexpr int b = decltype(BUF)::v, b2 = (b + 2) % 3;
         constexpr bool comp = decltype(COMPUTE)::value;
+        const bool unit_in = W8 && comp && (t & 1) == 0 && t > 0;
         if constexpr (comp) {
             read_b_at(IC<b * kPfNarBytes + 2 * kPfQ>{}, fb0);
             __builtin_amdgcn_sched_barrier(0);
@@ -283,7 +428,15 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         }
         dma_at(t + 2, IC<b2 * kPfNarBytes>{}, IC<0>{});
         dma_at(t + 2, IC<b2 * kPfNarBytes + 2 * kPfQ>{}, IC<2>{});
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        if constexpr (comp) {
+            if (W8 && (t & 1)) fetch_scales((t >> 1) + 1);
+            if (unit_in) {
+                enter_unit(IC<0>{});
+                rescale(IC<0>{}, IC<0>{});
+            }
+            decode_a();
+        }
+        pf_wait_vmcnt<3 * AG + 2 * BG>();                      // all but the five youngest quarters
         bar();
         if constexpr (comp) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -292,7 +445,14 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         bar();
         if constexpr (comp) read_a_at(IC<b * kPfNarBytes + kPfQ>{});
         dma_at(t + 2, IC<b2 * kPfNarBytes + kPfQ>{}, IC<1>{});
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (comp) {
+            if (unit_in) {
+                enter_unit(IC<2>{});
+                rescale(IC<2>{}, IC<0>{});
+            }
+            decode_a();
+        }
+        pf_wait_vmcnt<3 * AG + BG>();
         bar();
         if constexpr (comp) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -307,7 +467,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         dma_at(1, IC<kPfNarBytes>{}, IC<0>{});
         dma_at(1, IC<kPfNarBytes + 2 * kPfQ>{}, IC<2>{});
         dma_at(1, IC<kPfNarBytes + kPfQ>{}, IC<1>{});
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // A0(0), B0(0) landed
+        pf_wait_vmcnt<3 * AG + BG>();                          // A0(0), B0(0) landed
         bar();
         if (wr == 1) bar();
         for (int t = 0;;) {
@@ -368,6 +528,14 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         }
     };
     bar();                                                                  // every wave's DMA has landed, every fragment read is done
+    if constexpr (W8) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[rg][tg][i] *= scur[rg][i >> 3];
+    }
     if constexpr (IS_G1) {
         constexpr int ROWB = GATED ? 128 : 256;
         const bool fast_silu = GATED && p.act_type == LKM_ACT_SILU;
@@ -452,12 +620,12 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
 
 // usable when the K range is an even number of whole 64-element units (no ragged tail) and the operands fit the
 // 2 GiB buffer windows; otherwise the caller stays on gemm_tiled_kernel
-inline bool prefill_kernel_ok(const GemmParams& p, size_t x_rows) {
-    return p.Kreal % 128 == 0 && p.U % 2 == 0 && x_rows * (size_t)p.ldx * 2 < (size_t)0x7fffffff &&
+inline bool prefill_kernel_ok(const GemmParams& p, size_t x_rows, bool w8) {
+    return p.Kreal % 128 == 0 && (w8 ? p.U <= 64 : p.U % 2 == 0) && x_rows * (size_t)p.ldx * 2 < (size_t)0x7fffffff &&
            (size_t)p.T_half * p.halves * p.U * 2048 < (size_t)0x7fffffff;
 }
 
-template <int ADT, bool GATED, bool IS_G1>
+template <bool W8, int ADT, bool GATED, bool IS_G1>
 static int launch_prefill_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr size_t lds = kPfLdsBytes;
     const int TPH = GATED ? 8 : 16;
@@ -468,25 +636,26 @@ static int launch_prefill_t(hipStream_t st, const GemmParams& p, int max_tiles) 
         pp.xcd_map = RG;
         grid = dim3(8 * p.xcd_map * RG, 1);
     }
-    auto kern = gemm_prefill_kernel<ADT, GATED, IS_G1>;
+    auto kern = gemm_prefill_kernel<W8, ADT, GATED, IS_G1>;
     LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, pp);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }
 
-template <typename ADTC>
+template <typename WFC, typename ADTC>
 static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
-                              int max_tiles, int* rc, ADTC) {
+                              int max_tiles, int* rc, WFC, ADTC) {
     constexpr int ADT = ADTC::v;
+    constexpr bool W8 = WFC::v == LKM_W_FP8_E4M3;
     if (cfg.tiled != 256 || cfg.pf != 8) return false;
-    if (!prefill_kernel_ok(p, p.x_rows)) {     // (pick_cfg only plans the kernel for shapes that qualify)
+    if (!prefill_kernel_ok(p, p.x_rows, W8)) {     // (pick_cfg only plans the kernel for shapes that qualify)
         set_error("gemm_prefill: K = %d / %d units or the operand sizes do not fit the kernel", p.Kreal, p.U);
         *rc = LKM_E_INVALID;
         return true;
     }
-    if (is_g1) *rc = gated ? launch_prefill_t<ADT, true, true>(st, p, max_tiles) : launch_prefill_t<ADT, false, true>(st, p, max_tiles);
-    else *rc = launch_prefill_t<ADT, false, false>(st, p, max_tiles);
+    if (is_g1) *rc = gated ? launch_prefill_t<W8, ADT, true, true>(st, p, max_tiles) : launch_prefill_t<W8, ADT, false, true>(st, p, max_tiles);
+    else *rc = launch_prefill_t<W8, ADT, false, false>(st, p, max_tiles);
     return true;
 }
 

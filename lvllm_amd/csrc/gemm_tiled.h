@@ -513,11 +513,11 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     return LKM_OK;
 }
 
-// 16-bit weights, 256-row tiles: the LDS-DMA prefill kernel (gemm_prefill.h) when the plan asks for it
-// and the shape qualifies; returns false to fall through to gemm_tiled_kernel
-template <typename ADTC>
+// 16-bit and fp8 (W8A16) weights, 256-row tiles: the LDS-DMA prefill kernel (gemm_prefill.h) when the plan asks for it;
+// returns false to fall through to gemm_tiled_kernel
+template <typename WFC, typename ADTC>
 static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
-                              int max_tiles, int* rc, ADTC);
+                              int max_tiles, int* rc, WFC, ADTC);
 // fp8 x fp8, 256-row tiles: weights straight to registers, tokens through a 4-stage LDS ring (gemm_prefill_a8w.h)
 template <typename ADTC>
 static bool launch_prefill_a8w_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
@@ -550,9 +550,9 @@ struct W4Only {
     int launch_gemm1_tiled_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
                                     bool gated, int max_tiles) {                                      \
         constexpr int WF_ = WF, ADT_ = ADT;                                                           \
-        if constexpr (W16Only<WF_>::value) {                                                          \
+        if constexpr (W16Only<WF_>::value || WF_ == LKM_W_FP8_E4M3) {                                \
             int rc = LKM_OK;                                                                          \
-            if (launch_prefill_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc;    \
+            if (launch_prefill_if(st, cfg, p, gated, true, max_tiles, &rc, IC<WF_>{}, IC<ADT_>{})) return rc; \
         }                                                                                             \
         if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
             int rc = LKM_OK;                                                                          \
@@ -581,9 +581,9 @@ struct W4Only {
     int launch_gemm2_tiled_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
                                     int max_tiles) {                                                  \
         constexpr int WF_ = WF, ADT_ = ADT;                                                           \
-        if constexpr (W16Only<WF_>::value) {                                                          \
+        if constexpr (W16Only<WF_>::value || WF_ == LKM_W_FP8_E4M3) {                                \
             int rc = LKM_OK;                                                                          \
-            if (launch_prefill_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;   \
+            if (launch_prefill_if(st, cfg, p, false, false, max_tiles, &rc, IC<WF_>{}, IC<ADT_>{})) return rc; \
         }                                                                                             \
         if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
             int rc = LKM_OK;                                                                          \

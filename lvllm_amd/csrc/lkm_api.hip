@@ -557,6 +557,18 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
     // ---- which kernels
     // Mixtral bf16: M=64 (16 rows/expert) skinny 537 us vs tiled 570 us; M=128 (32 rows/expert) skinny
     // 714 us vs tiled64 585 us; 64-row tiles beat 128-row tiles up to M=512, 4 waves beat 8.
+    const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
+    // gemm_prefill.h ("pf" = 8, 256-row tiles; 16-bit weights and fp8 W8A16): K loops of whole 128-k blocks, tokens, the
+    // intermediate and an expert's weights inside 2 GiB buffer windows (prefill_kernel_ok); fp8: one scale per 16-row
+    // tile and 128-k unit
+    const bool w8a16 = h->wf == LKM_W_FP8_E4M3 && !h->a8;
+    const bool pf8_ok = (w16 || w8a16) && h->H % 128 == 0 && h->I % 128 == 0 && (size_t)M * (size_t)h->H * 2 < (size_t)0x7fffffff &&
+                        n_slots * (size_t)h->ld_act * 2 < (size_t)0x7fffffff &&
+                        (size_t)h->T1_half * (h->gated ? 2 : 1) * h->U1 * 2048 < (size_t)0x7fffffff &&
+                        (size_t)h->T2 * h->U2 * 2048 < (size_t)0x7fffffff &&
+                        (!w8a16 || ((size_t)h->E * h->T1_half * (h->gated ? 2 : 1) * h->U1 * 16 < (size_t)0x7fffffff &&
+                                    (size_t)h->E * h->T2 * h->U2 * 16 < (size_t)0x7fffffff && h->cfg.groupN % 16 == 0 &&
+                                    h->cfg.groupK % 128 == 0 && h->U1 <= 64 && h->U2 <= 64));
     int tiled = 0, split = 0, g2_only = 0;
     {
         // Tile rows by rows per expert (profiles/r01_tile_thresholds.log, Mixtral shapes, 8 experts):
@@ -564,10 +576,13 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // 655 at 256); 128: 256 (735 vs 862); 256: 256 (973 vs 1149).  MXFP4: 128 from 64 rows/expert
         // (325 vs 354 us).  fp8-W8A16 / int4 stay at 64 (the 128-row variants of the formats that decode
         // in registers run out of them); fp8-W8A8: see below.
-        const bool w16 = h->wf == LKM_W_BF16 || h->wf == LKM_W_F16;
         if (M > 32 && avg_rows >= 16) {   // bf16 M=64: 497 (streamer) vs 466 us, M=96: 562 (hybrid) vs 467; M=48 stays hybrid
             tiled = 64;
             if (w16 && avg_rows > 56) tiled = avg_rows >= 112 ? 256 : 128;
+            // fp8 W8A16 at prefill sizes (MOE_FP8.gpu_prefill): 256-row tiles on gemm_prefill.h (round 4: raw fp8 through the
+            // LDS-DMA ring, converted in registers, block scales carried in the accumulators) where 16-bit weights take them;
+            // needs one scale per 16-row tile and 128-k unit (block heights in multiples of 16: pf8_ok)
+            if (w8a16 && avg_rows >= 112 && h->t_pf >= 0 && pf8_ok) tiled = 256;
             if (h->wf == LKM_W_MXFP4 && avg_rows >= 64) tiled = 128;
             // uint4b8 / NVFP4 at prefill sizes (round 4, profiles/r04_prefill_plan_sweep.log: what MOE_WNA16 / MOE_NVFP4
             // gpu_prefill runs): 128-row tiles x 8 waves from ~100 rows per expert -- int4 Mixtral M=512 725 -> 683 us,
@@ -679,14 +694,8 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // 16-bit weights on 256-row tiles: the 8-phase LDS-DMA kernel (gemm_prefill.h, round 4) is the default -- GLM-4.5-Air
         // bf16 prefill M=8192: GEMM1 1674 -> 1324 us, GEMM2 964 -> 728, step 2919 -> 2227 (profiles/r04_prefill16_*.log);
         // "pf" = -1 keeps gemm_tiled_kernel
-        if (tiled == 256 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && h->t_pf == 0) pf = 8;
-        // 16-bit weights, "pf" = 8: gemm_prefill.h where both GEMMs qualify (K loops of whole, even 64-k unit counts; tokens,
-        // intermediate and an expert's weights inside 2 GiB buffer windows: prefill_kernel_ok) -- else the plain tile kernel
-        if (pf == 8 && !(h->H % 128 == 0 && h->I % 128 == 0 && (size_t)M * (size_t)h->H * 2 < (size_t)0x7fffffff &&
-                         n_slots * (size_t)h->ld_act * 2 < (size_t)0x7fffffff &&
-                         (size_t)h->T1_half * (h->gated ? 2 : 1) * h->U1 * 2048 < (size_t)0x7fffffff &&
-                         (size_t)h->T2 * h->U2 * 2048 < (size_t)0x7fffffff))
-            pf = 0;
+        if (tiled == 256 && (w16 || w8a16) && h->t_pf == 0) pf = 8;
+        if (pf == 8 && !pf8_ok) pf = 0;
         // (round 2's LDS-DMA ring kernel for the 4-bit formats, "pf" = 4, was removed in round 4: three to four times the
         // bytes in flight per CU and no faster, profiles/r02_w4dma_sweep.log)
         // round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h), "pf" = 5
@@ -710,7 +719,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // the workgroups that share a weight panel on one L2 -- round 1 measured +-0 with equal ITEM counts per XCD; with the
         // runs cut by routed rows (round 3) the bf16 prefill step goes 3095 -> 2853 us uniform, 3158 -> 3006 us Zipf
         // (profiles/r04_prefill_plan_sweep.log).  Few large experts (Mixtral) lose with it and keep the plain grid.
-        if (tiled == 256 && (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && n_act >= 32 && h->t_xcd >= 0 && (!pf || pf == 8))
+        if (tiled == 256 && (w16 || w8a16) && n_act >= 32 && h->t_xcd >= 0 && (!pf || pf == 8))
             pl->xcd1 = pl->xcd2 = 1;
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;
@@ -1009,7 +1018,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     // 16-bit weights on gemm_prefill.h ("pf" = 8, prefill sizes only): the same -- what the in-tree GPU operator's GEMM2 does
     // (fused_moe.py writes intermediate_cache3 in the hidden dtype before moe_sum); GLM-4.5-Air bf16 M=8192: GEMM2 815 ->
     // 728 us, combine 248 -> 136.  "ydt" = -1 keeps the fp32 partials of the smaller-batch kernels.
-    const bool w16_pf = (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16) && pl.t2.tiled == 256 && pl.t2.pf == 8 && h->t_ydt >= 0;
+    const bool w16_pf = (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16 || (h->wf == LKM_W_FP8_E4M3 && !h->a8)) && pl.t2.tiled == 256 &&
+                        pl.t2.pf == 8 && h->t_ydt >= 0;
     const int y_dt = (((h->a8 && pl.t2.pf >= 8) || w16_pf) && pl.t2.tiled == 256 && !pl.s2.tb && sk == 1) ? h->adt : LKM_DT_F32;
     p2.y_dt = y_dt;
     if (direct) {

@@ -584,6 +584,53 @@ def test_prefill_kernel_ragged_multi_tile(pf, gated):
     eng.engine.set_tuning(pf=0, xcd=0, ydt=0, dbg=0)
 
 
+@pytest.mark.parametrize("gated", [True, False])
+@pytest.mark.parametrize("M,E,H,I,dt", [(520, 5, 512, 384, torch.bfloat16), (900, 3, 1024, 640, torch.float16),
+                                        (300, 2, 384, 256, torch.bfloat16)])
+def test_fp8_w8a16_prefill_kernel(M, E, H, I, dt, gated):
+    """gemm_prefill.h with fp8 weights (block-quantised W8A16, what MOE_FP8.gpu_prefill runs): raw e4m3 through the LDS-DMA
+    ring, converted in registers, the block scales carried in the accumulators (rescaled by s_u / s_{u+1} at every 128-k
+    unit) -- against the oracle and against the 64-row tile kernel, which applies each scale to the unit's fp32 partial
+    sum: experts of 0 to ~650 rows (full, ragged and narrow tiles, empty wave quarters), K loops of 3 to 8 units, an
+    all-zero weight block (scale 0), padded weight-tile counts."""
+    K = 2
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, dt, seed=M + E, gated=gated)
+    rng = np.random.default_rng(5)
+    pool = np.array([e for e in range(E) if e != 1] or [0], np.int32)      # expert 1 stays empty (E > 2)
+    prob = rng.dirichlet(np.ones(len(pool)) * 0.6)
+    first = rng.choice(len(pool), size=M, p=prob)
+    second = (first + rng.integers(1, max(2, len(pool)), size=M)) % len(pool)
+    ids = np.ascontiguousarray(np.stack([pool[first], pool[second]], axis=1).astype(np.int32))
+    w13f, w2f = w13.float().numpy().copy(), w2.float().numpy().copy()
+    w13f[0, :128, 128:256] = 0.0                                           # a block of zeros: scale 0 in the middle of a K loop
+    w2f[0, 128:256, :128] = 0.0                                            # ... and at its start
+    q13, s13 = orc.quant_fp8_block(w13f, 128, 128)
+    q2, s2 = orc.quant_fp8_block(w2f, 128, 128)
+    kw = dict(has_gate_proj=False, activation_type=2) if not gated else {}
+    eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="fp8",
+               w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128, **kw)
+    eng.engine.set_tuning(tiled=256, waves=8, pf=8, ydt=-1)
+    out = _run_decode(eng, a, tw, ids)
+    assert "tm=256" in eng.engine.describe() and "pf=8" in eng.engine.describe(), eng.engine.describe()
+    odt = orc.BF16 if dt == torch.bfloat16 else orc.F16
+    d = orc.MoeDesc(E=E, H=H, I=I, has_gate=gated, activation=orc.ACT_SILU if gated else orc.ACT_RELU2,
+                    act_dtype=odt, wfmt=orc.W_FP8, groupN=128, groupK=128)
+    ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    scale = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(out, ref, atol=ATOL * scale, rtol=RTOL)
+    eng.engine.set_tuning(tiled=64, waves=4, pf=-1)
+    base = _run_decode(eng, a, tw, ids)
+    np.testing.assert_allclose(out, base, atol=2e-4 * scale, rtol=2e-4, err_msg=eng.engine.describe())
+    for xcd, ydt in ((1, -1), (-1, -1), (1, 0)):
+        eng.engine.set_tuning(tiled=256, waves=8, pf=8, xcd=xcd, ydt=ydt)
+        got = _run_decode(eng, a, tw, ids)
+        if ydt < 0:
+            assert np.array_equal(got, out), eng.engine.describe()
+        else:
+            np.testing.assert_allclose(got, ref, atol=ATOL * scale, rtol=RTOL)
+    eng.engine.set_tuning(tiled=0, waves=0, pf=0, xcd=0, ydt=0)
+
+
 @pytest.mark.parametrize("fmt", ["bf16", "f16", "int4", "fp8", "fp8a8", "mxfp4"])
 def test_single_token_direct_path(fmt):
     """M == 1 takes the two-launch path (GEMM1 by slot, GEMM2 + weighted sum in one workgroup): same result

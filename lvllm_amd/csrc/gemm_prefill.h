@@ -59,9 +59,7 @@ __device__ __forceinline__ void pf_silu_mul4(const GemmParams& p, const f32x4& g
 
 template <int N>
 __device__ __forceinline__ void pf_wait_vmcnt() {
-    static_assert(N >= 5 && N <= 11, "counts of the two schedules");
-    if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    static_assert(N == 5 || N == 6 || N == 7 || N == 8 || N == 10, "counts of the two schedules");
     if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
@@ -95,20 +93,13 @@ __device__ __forceinline__ u32x4 pf_fp8_frag(unsigned d0, unsigned d1) {
 // register, the registers of the quadrant the phase is about to update, wave-uniform ratios: every row of a 16-row tile
 // shares the scale -- the launcher requires block heights that are multiples of 16), leaving by s_last.  fp32 rounding
 // of the ratios: <= 1e-7 relative per unit.
-//
-// WM = 2: fp8 weights AND fp8 activations (W8A8, block-fp8 semantics: 1 x 128 token scales, the in-tree operator's
-// fused_moe.py:298-610 / test_block_fp8.py) on v_mfma_f32_32x32x64_f8f6f4: a K tile is one 128-k unit (the same 16 KiB
-// quarters); a lane's A operand = the two 16-byte image pieces (2h, i), (2h + 1, i) of a load = k 64c + 32h .. + 31 of its row
-// (the W8A8 image, repack.hip), its B operand the same 32 bytes of the token row.  Both scale sets ride in the accumulators: entering unit u + 1
-// register i of a lane is multiplied by (sw_u / sw_{u+1}) [wave-uniform] x (sx_u / sx_{u+1}) [per lane = per token]; the
-// token scales arrive by plain buffer loads two units ahead (issued by hand next to the DMA so that the loop's counted
-// vmcnt waits cover them; the compiler must not see them -- it would drain the DMA ring with vmcnt(0) at their use).
-template <int WM, int ADT, bool GATED, bool IS_G1>
+// (An fp8 x fp8 mode of this kernel -- 32x32x64 fp8 MFMA, weight and token scales both carried in the accumulators -- was
+// built and measured in round 4 and not kept: equal to gemm_prefill_a8w.h on GEMM1, behind it on GEMM2;
+// profiles/r04_prefill16_kernel.md, commit "fp8 x fp8 mode of the 16-bit prefill kernel ... experiment".)
+template <bool W8, int ADT, bool GATED, bool IS_G1>
 __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     static_assert(!GATED || IS_G1, "only GEMM1 is gated");
-    constexpr bool W8 = WM == 1, A8 = WM == 2;
     constexpr int AG = W8 ? 1 : 2, BG = 2;                    // LDS-DMA instructions per wave and weight / token quarter
-    constexpr int XB = A8 ? 1 : 2;                            // bytes per activation element
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer resources / LDS-DMA builtins exist in the device pass only
     typedef __attribute__((address_space(3))) void* LdsPtr;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -181,7 +172,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             const int r = nar ? r0 + row : r0 + (row >> 5) * 64 + s * 32 + (row & 31);
             const int rr = r < m_e ? r : r0;
             const int src_row = IS_G1 ? p.sorted_slot[off_e + rr] / p.top_k : off_e + rr;
-            bvoff[s][q] = (abl_same ? row : src_row) * p.ldx * XB + lslot * 16;   // < 2 GiB (checked by the launcher)
+            bvoff[s][q] = (abl_same ? row : src_row) * p.ldx * 2 + lslot * 16;   // < 2 GiB (checked by the launcher)
         }
     const int wustep = (int)(p.w_ustride * 16);
     // quarter ids: 0 = A0, 1 = A1, 2 = B0, 3 = B1 (= position inside a buffer)
@@ -213,10 +204,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     // ---- fragments.  Registers (2 waves per SIMD -> 256 per lane): 128 accumulators, 8 weight fragments (one
     // quarter: 2 row groups x 4 k-steps), 2 x 4 token fragments (both quarters stay: B0 serves ph1 and ph4).
     const bool has_rows = r0 + wtok < m_e;                    // wave-uniform: my token share holds rows
-    typedef int i32x8 __attribute__((ext_vector_type(8)));
-    typedef int i32x4v __attribute__((ext_vector_type(4)));
-    u32x4 fa[2][4], fb0[4], fb1[4];                           // 16-bit MFMA operands (WM 0 / 1)
-    i32x8 ga[2][2], gb0[2], gb1[2];                           // fp8 MFMA operands (WM 2): [row group][64-k step], [64-k step]
+    u32x4 fa[2][4], fb0[4], fb1[4];
     f32x16 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -226,15 +214,10 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
     // A fragment (quarter s, local row group rgl, k-step kk): tile slot wr*4 + rgl*2 + (lane & 16 ? 1 : 0), load kk / 2,
     // image lane ((kk & 1) * 2 + h) * 16 + (lane & 15)
-    // (A8: fragment c of a row group = image pieces (2h, i), (2h + 1, i) of load c: fa[.][2c], fa[.][2c + 1])
-    const int abyte = (wr * 4 + ((lane >> 4) & 1)) * 2048 + h * (A8 ? 512 : 256) + (lane & 15) * 16;
+    const int abyte = (wr * 4 + ((lane >> 4) & 1)) * 2048 + h * 256 + (lane & 15) * 16;
     int baddr[4];                                              // B fragment: row wc*32 + l32, 16-byte slot (2 kk + h) ^ swizzle
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        // A8: the two 16-byte slots 4c + 2h, 4c + 2h + 1 of step c (kk = 2c, 2c + 1): k = 64c + 32h .. + 31, as the operand wants
-        const int slot = A8 ? 4 * (kk >> 1) + 2 * h + (kk & 1) : kk * 2 + h;
-        baddr[kk] = (wc * 32 + l32) * 128 + ((slot ^ x_swizzle<128>(l32)) * 16);
-    }
+    for (int kk = 0; kk < 4; ++kk) baddr[kk] = (wc * 32 + l32) * 128 + (((kk * 2 + h) ^ x_swizzle<128>(l32)) * 16);
 
     u32x4 raw[W8 ? 2 : 1][2];                                   // W8: the raw bytes of a weight quarter (k-steps j and j + 2 per read)
     auto read_a_at = [&](auto OFF) __attribute__((always_inline)) {
@@ -244,15 +227,6 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             for (int rgl = 0; rgl < 2; ++rgl)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) raw[rgl][j] = *(const u32x4*)(lds + off + abyte + rgl * 4096 + j * 512);
-        } else if constexpr (A8) {
-#pragma unroll
-            for (int rgl = 0; rgl < 2; ++rgl)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const i32x4v lo = *(const i32x4v*)(lds + off + abyte + rgl * 4096 + c * 1024);
-                    const i32x4v hi = *(const i32x4v*)(lds + off + abyte + rgl * 4096 + c * 1024 + 256);
-                    ga[rgl][c] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
         } else {
 #pragma unroll
             for (int rgl = 0; rgl < 2; ++rgl)
@@ -273,7 +247,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
                 }
         }
     };
-    // W8 / A8: the weight-scale streams of my four row groups x two tiles (gated: gate / up tile; else the two tiles of the
+    // W8: the weight-scale streams of my four row groups x two tiles (gated: gate / up tile; else the two tiles of the
     // 32 rows).  ONE register per stream holds the ratio s_{u-1} / s_u of every unit, lane u = unit u (<= 64 units: the
     // launcher checks), formed before the first DMA from one vector load (so that every counted vmcnt of the loop covers
     // it; scalar loads inside the loop would put SMEM on the lgkm counter and turn the loop's lgkmcnt(0) waits into waits
@@ -284,7 +258,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         const int gt = (GATED ? hf * p.T_half : 0) + (t < p.T_half ? t : 0);
         return ((size_t)e * T_all + gt) * p.U * 16;
     };
-    if constexpr (W8 || A8) {            // (the loads only: the ratios are formed behind the first DMAs, finish_scales)
+    if constexpr (W8) {            // (the loads only: the ratios are formed behind the first DMAs, finish_scales)
         const float* sc = (const float*)p.s;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
@@ -292,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             for (int hf = 0; hf < 2; ++hf) svr[rg][hf] = lane < p.U ? sc[scale_index(rg, hf) + (size_t)lane * 16] : 1.0f;
     }
     auto finish_scales = [&]() __attribute__((always_inline)) {
-        if constexpr (W8 || A8) {
+        if constexpr (W8) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
@@ -304,10 +278,10 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         }
     };
     // enter unit u: the ratios of row groups RG0, RG0 + 1 (wave-uniform)
-    float ratio[4][2], rx[2] = {1.f, 1.f};
+    float ratio[4][2];
     auto enter_unit = [&](auto RG0, int u) __attribute__((always_inline)) {
         constexpr int rg0 = decltype(RG0)::v;
-        if constexpr (W8 || A8) {
+        if constexpr (W8) {
 #pragma unroll
             for (int rg = rg0; rg < rg0 + 2; ++rg)
 #pragma unroll
@@ -316,82 +290,20 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         }
     };
     // (plain v_mul_f32: the compiler would pack these into v_pk_mul_f32, which does not issue beside the partner wave's MFMAs)
-    auto mul_reg = [&](float x, float r) __attribute__((always_inline)) { asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x) : "v"(r)); return x; };
     auto mul_reg_s = [&](float x, float r) __attribute__((always_inline)) { asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x) : "s"(r)); return x; };
     auto rescale = [&](auto RG0, auto TG) __attribute__((always_inline)) {
         constexpr int rg0 = decltype(RG0)::v, tg = decltype(TG)::v;
-#ifdef LKM_PF_ABL
-        if (p.dbg & 1) return;
-#endif
         if constexpr (W8) {
 #pragma unroll
             for (int rg = rg0; rg < rg0 + 2; ++rg)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[rg][tg][i] = mul_reg_s(acc[rg][tg][i], ratio[rg][i >> 3]);
         }
-        if constexpr (A8) {
-#pragma unroll
-            for (int rg = rg0; rg < rg0 + 2; ++rg)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const float r = ratio[rg][hf] * rx[tg];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[rg][tg][8 * hf + i] = mul_reg(acc[rg][tg][8 * hf + i], r);
-                }
-        }
-    };
-    // A8: token scales of my two token groups -- sxcur: the scale the accumulators are expressed in, sxnxt: the next unit's
-    // (landed), sxfly: the one after (in flight); rx = sxcur / sxnxt when a unit is entered
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 rs_s = {0, 0, 0, 0};
-    int srow[2] = {0, 0};
-    float sxcur[2] = {1.f, 1.f}, sxnxt[2] = {1.f, 1.f}, sxfly[2] = {1.f, 1.f};
-    if constexpr (A8) {
-        const unsigned long long sb = (unsigned long long)p.xscale;
-        rs_s = i32x4{__builtin_amdgcn_readfirstlane((int)sb), __builtin_amdgcn_readfirstlane((int)(sb >> 32) & 0xffff), 0x7fffffff, 0x00020000};
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-            const int r = r0 + wtok + tg * 32 + l32;
-            const int rr = r < m_e ? r : r0;
-            const int src_row = IS_G1 ? p.sorted_slot[off_e + rr] / p.top_k : off_e + rr;
-            srow[tg] = src_row * p.ld_xscale * 4;               // < 2 GiB: the launcher checks
-        }
-    }
-    auto load_sx = [&](int u, float (&dst)[2]) __attribute__((always_inline)) {
-        if constexpr (A8) {
-#ifdef LKM_PF_ABL
-            if ((p.dbg & 2) && u >= 2) { dst[0] = dst[1] = 1.0f; return; }
-#endif
-            const int uo = (u < U ? u : U - 1) * 4;
-#pragma unroll
-            for (int tg = 0; tg < 2; ++tg)
-                if (tg == 0 || !nar)
-                    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst[tg]) : "v"(srow[tg]), "s"(rs_s), "s"(uo) : "memory");
-        }
-    };
-    auto enter_unit_x = [&]() __attribute__((always_inline)) {  // (tile t >= 1, before the first rescale of the tile)
-        if constexpr (A8) {
-            asm volatile("" : "+v"(sxfly[0]), "+v"(sxfly[1]));   // landed: covered by the counted waits of the previous tile
-#pragma unroll
-            for (int tg = 0; tg < 2; ++tg) {
-                rx[tg] = sxcur[tg] * __builtin_amdgcn_rcpf(sxnxt[tg]);
-                sxcur[tg] = sxnxt[tg];
-                sxnxt[tg] = sxfly[tg];
-            }
-        }
     };
     auto read_b_at = [&](auto OFF, auto BSEL) __attribute__((always_inline)) {     // BSEL: token quarter 0 / 1 -> fb0 / fb1
         constexpr int off = decltype(OFF)::v, bs = decltype(BSEL)::v;
-        if constexpr (A8) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const i32x4v lo = *(const i32x4v*)(lds + off + baddr[2 * c]), hi = *(const i32x4v*)(lds + off + baddr[2 * c + 1]);
-                (bs ? gb1 : gb0)[c] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) (bs ? fb1 : fb0)[kk] = *(const u32x4*)(lds + off + baddr[kk]);
-        }
+        for (int kk = 0; kk < 4; ++kk) (bs ? fb1 : fb0)[kk] = *(const u32x4*)(lds + off + baddr[kk]);
     };
     auto read_a = [&](auto BUF, auto SC) __attribute__((always_inline)) {
         read_a_at(IC<decltype(BUF)::v * kPfBufBytes + decltype(SC)::v * kPfQ>{});
@@ -403,19 +315,11 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         constexpr int rg0 = decltype(RG0)::v, tg = decltype(TG)::v, bs = decltype(BSEL)::v;
         // (measured with fp8 weights, whose load sections carry conversions and rescaling: without the priority GEMM1 +2 %)
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (A8) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int rgl = 0; rgl < 2; ++rgl)
-                    acc[rg0 + rgl][tg] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ga[rgl][c], (bs ? gb1 : gb0)[c], acc[rg0 + rgl][tg], 0, 0, 0, 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int rgl = 0; rgl < 2; ++rgl)
-                    acc[rg0 + rgl][tg] = Mfma32<ADT>::run(fa[rgl][kk], (bs ? fb1 : fb0)[kk], acc[rg0 + rgl][tg]);
-        }
+            for (int rgl = 0; rgl < 2; ++rgl)
+                acc[rg0 + rgl][tg] = Mfma32<ADT>::run(fa[rgl][kk], (bs ? fb1 : fb0)[kk], acc[rg0 + rgl][tg]);
         __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() __attribute__((always_inline)) {
@@ -427,9 +331,8 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     auto tile = [&](int t, auto BUF, auto COMPUTE) __attribute__((always_inline)) {
         constexpr int b = decltype(BUF)::v;
         constexpr bool comp = decltype(COMPUTE)::value;
-        constexpr int VM = 2 * AG + 2 * BG + (A8 && comp ? 2 : 0);   // all but the four youngest quarters (A8: + the token scales issued with them)
-        // W8: this K tile opens a 128-k unit (buffer parity = tile parity); A8: every K tile is a unit
-        const bool unit_in = comp && t > 0 && ((W8 && b == 0) || A8);
+        constexpr int VM = 2 * AG + 2 * BG;                   // all but the four youngest quarters
+        const bool unit_in = W8 && comp && b == 0 && t > 0;   // W8: this K tile opens a 128-k unit (buffer parity = tile parity)
         // ph1
         if constexpr (comp) {
             read_b(IC<b>{}, IC<0>{});
@@ -438,12 +341,8 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         }
         dma(t + 1, IC<b ^ 1>{}, IC<3>{});
         if constexpr (comp) {
-            if constexpr (A8) {
-                if (unit_in) enter_unit_x();
-                load_sx(t + 2, sxfly);
-            }
             if (unit_in) {
-                enter_unit(IC<0>{}, A8 ? t : t >> 1);
+                enter_unit(IC<0>{}, t >> 1);
                 rescale(IC<0>{}, IC<0>{});
             }
             decode_a();
@@ -473,7 +372,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         dma(t + 2, IC<b>{}, IC<0>{});
         if constexpr (comp) {
             if (unit_in) {
-                enter_unit(IC<2>{}, A8 ? t : t >> 1);
+                enter_unit(IC<2>{}, t >> 1);
                 rescale(IC<2>{}, IC<1>{});
             }
             decode_a();
@@ -495,10 +394,6 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         bar();
     };
     auto run = [&](auto COMPUTE) __attribute__((always_inline)) {
-        if constexpr (A8 && decltype(COMPUTE)::value) {
-            load_sx(0, sxcur);
-            load_sx(1, sxnxt);
-        }
         dma(0, IC<0>{}, IC<0>{});
         dma(0, IC<0>{}, IC<2>{});
         dma(0, IC<0>{}, IC<3>{});
@@ -507,12 +402,11 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         dma(1, IC<1>{}, IC<2>{});
         if constexpr (decltype(COMPUTE)::value) finish_scales();
         pf_wait_vmcnt<2 * AG + 2 * BG>();                      // A0(0), B0(0) landed (and the older token-scale loads)
-        if constexpr (A8) asm volatile("" : "+v"(sxcur[0]), "+v"(sxcur[1]), "+v"(sxnxt[0]), "+v"(sxnxt[1]));
         bar();
         if (wr == 1) bar();                                   // row half 1 runs one barrier interval behind
         for (int t = 0; t < U; t += 2) {
             tile(t, IC<0>{}, COMPUTE);
-            if (t + 1 < U) tile(t + 1, IC<1>{}, COMPUTE);     // (A8: an odd number of units is possible)
+            tile(t + 1, IC<1>{}, COMPUTE);                    // (U is even: the launcher checks)
         }
         if (wr == 0) bar();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing DMA must land before the LDS is released
@@ -523,8 +417,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     auto tile_n = [&](int t, auto BUF, auto COMPUTE) __attribute__((always_inline)) {
         constexpr int b = decltype(BUF)::v, b2 = (b + 2) % 3;
         constexpr bool comp = decltype(COMPUTE)::value;
-        constexpr int SG = A8 && comp ? 1 : 0;                // token-scale loads per narrow tile (one token group)
-        const bool unit_in = comp && t > 0 && ((W8 && (t & 1) == 0) || A8);
+        const bool unit_in = W8 && comp && (t & 1) == 0 && t > 0;
         if constexpr (comp) {
             read_b_at(IC<b * kPfNarBytes + 2 * kPfQ>{}, IC<0>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -533,17 +426,13 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         dma_at(t + 2, IC<b2 * kPfNarBytes>{}, IC<0>{});
         dma_at(t + 2, IC<b2 * kPfNarBytes + 2 * kPfQ>{}, IC<2>{});
         if constexpr (comp) {
-            if constexpr (A8) {
-                if (unit_in) enter_unit_x();
-                load_sx(t + 2, sxfly);
-            }
             if (unit_in) {
-                enter_unit(IC<0>{}, A8 ? t : t >> 1);
+                enter_unit(IC<0>{}, t >> 1);
                 rescale(IC<0>{}, IC<0>{});
             }
             decode_a();
         }
-        pf_wait_vmcnt<3 * AG + 2 * BG + SG>();                 // all but the five youngest quarters
+        pf_wait_vmcnt<3 * AG + 2 * BG>();                 // all but the five youngest quarters
         bar();
         if constexpr (comp) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -554,12 +443,12 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         dma_at(t + 2, IC<b2 * kPfNarBytes + kPfQ>{}, IC<1>{});
         if constexpr (comp) {
             if (unit_in) {
-                enter_unit(IC<2>{}, A8 ? t : t >> 1);
+                enter_unit(IC<2>{}, t >> 1);
                 rescale(IC<2>{}, IC<0>{});
             }
             decode_a();
         }
-        pf_wait_vmcnt<3 * AG + BG + SG>();
+        pf_wait_vmcnt<3 * AG + BG>();
         bar();
         if constexpr (comp) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -568,10 +457,6 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         bar();
     };
     auto run_n = [&](auto COMPUTE) __attribute__((always_inline)) {
-        if constexpr (A8 && decltype(COMPUTE)::value) {
-            load_sx(0, sxcur);
-            load_sx(1, sxnxt);
-        }
         dma_at(0, IC<0>{}, IC<0>{});
         dma_at(0, IC<2 * kPfQ>{}, IC<2>{});
         dma_at(0, IC<kPfQ>{}, IC<1>{});
@@ -580,7 +465,6 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         dma_at(1, IC<kPfNarBytes + kPfQ>{}, IC<1>{});
         if constexpr (decltype(COMPUTE)::value) finish_scales();
         pf_wait_vmcnt<3 * AG + BG>();                          // A0(0), B0(0) landed
-        if constexpr (A8) asm volatile("" : "+v"(sxcur[0]), "+v"(sxnxt[0]));
         bar();
         if (wr == 1) bar();
         for (int t = 0;;) {
@@ -641,7 +525,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         }
     };
     bar();                                                                  // every wave's DMA has landed, every fragment read is done
-    if constexpr (W8 || A8) {            // leave the last unit's scale (the DMA ring is drained: plain loads again)
+    if constexpr (W8) {            // leave the last unit's scale (the DMA ring is drained: plain loads again)
         const float* sc = (const float*)p.s;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
@@ -655,7 +539,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
 #pragma unroll
             for (int tg = 0; tg < 2; ++tg)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[rg][tg][i] *= A8 ? scur[rg][i >> 3] * sxcur[tg] : scur[rg][i >> 3];
+                for (int i = 0; i < 16; ++i) acc[rg][tg][i] *= scur[rg][i >> 3];
     }
     if constexpr (IS_G1) {
         constexpr int ROWB = GATED ? 128 : 256;
@@ -671,12 +555,8 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
                     const f32x4 hi = {c[8 + 4 * q], c[9 + 4 * q], c[10 + 4 * q], c[11 + 4 * q]};
                     float v[4];
                     if constexpr (GATED) {
-                        if constexpr (A8) {
-                            pf_silu_mul4<ADT>(p, lo, hi, v);       // (the plan keeps other gated activations off this mode: register budget)
-                        } else {
-                            if (fast_silu) pf_silu_mul4<ADT>(p, lo, hi, v);
-                            else gemm1_act4<ADT, true>(p, lo, hi, v);
-                        }
+                        if (fast_silu) pf_silu_mul4<ADT>(p, lo, hi, v);
+                        else gemm1_act4<ADT, true>(p, lo, hi, v);
                         put16(IC<ROWB>{}, tg * 32 + l32, rg * 4 + 2 * q + h, v);
                     } else {
                         gemm1_act4<ADT, false>(p, lo, lo, v);
@@ -745,14 +625,12 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
 
 // usable when the K range is an even number of whole 64-element units (no ragged tail) and the operands fit the
 // 2 GiB buffer windows; otherwise the caller stays on gemm_tiled_kernel
-inline bool prefill_kernel_ok(const GemmParams& p, size_t x_rows, int wm) {
-    const size_t xb = wm == 2 ? 1 : 2;
-    return p.Kreal % 128 == 0 && (wm ? p.U <= 64 : p.U % 2 == 0) && x_rows * (size_t)p.ldx * xb < (size_t)0x7fffffff &&
-           (wm != 2 || x_rows * (size_t)p.ld_xscale * 4 < (size_t)0x7fffffff) &&
+inline bool prefill_kernel_ok(const GemmParams& p, size_t x_rows, bool w8) {
+    return p.Kreal % 128 == 0 && (w8 ? p.U <= 64 : p.U % 2 == 0) && x_rows * (size_t)p.ldx * 2 < (size_t)0x7fffffff &&
            (size_t)p.T_half * p.halves * p.U * 2048 < (size_t)0x7fffffff;
 }
 
-template <int WM, int ADT, bool GATED, bool IS_G1>
+template <bool W8, int ADT, bool GATED, bool IS_G1>
 static int launch_prefill_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr size_t lds = kPfLdsBytes;
     const int TPH = GATED ? 8 : 16;
@@ -763,7 +641,7 @@ static int launch_prefill_t(hipStream_t st, const GemmParams& p, int max_tiles) 
         pp.xcd_map = RG;
         grid = dim3(8 * p.xcd_map * RG, 1);
     }
-    auto kern = gemm_prefill_kernel<WM, ADT, GATED, IS_G1>;
+    auto kern = gemm_prefill_kernel<W8, ADT, GATED, IS_G1>;
     LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, pp);
     LKM_HIP_CHECK(hipGetLastError());
@@ -774,15 +652,15 @@ template <typename WFC, typename ADTC>
 static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
                               int max_tiles, int* rc, WFC, ADTC) {
     constexpr int ADT = ADTC::v;
-    constexpr int WM = WFC::v == LKM_W_FP8_E4M3 ? 1 : (WFC::v == LKM_W_FP8_A8 ? 2 : 0);
+    constexpr bool W8 = WFC::v == LKM_W_FP8_E4M3;
     if (cfg.tiled != 256 || cfg.pf != 8) return false;
-    if (!prefill_kernel_ok(p, p.x_rows, WM)) {     // (pick_cfg only plans the kernel for shapes that qualify)
+    if (!prefill_kernel_ok(p, p.x_rows, W8)) {     // (pick_cfg only plans the kernel for shapes that qualify)
         set_error("gemm_prefill: K = %d / %d units or the operand sizes do not fit the kernel", p.Kreal, p.U);
         *rc = LKM_E_INVALID;
         return true;
     }
-    if (is_g1) *rc = gated ? launch_prefill_t<WM, ADT, true, true>(st, p, max_tiles) : launch_prefill_t<WM, ADT, false, true>(st, p, max_tiles);
-    else *rc = launch_prefill_t<WM, ADT, false, false>(st, p, max_tiles);
+    if (is_g1) *rc = gated ? launch_prefill_t<W8, ADT, true, true>(st, p, max_tiles) : launch_prefill_t<W8, ADT, false, true>(st, p, max_tiles);
+    else *rc = launch_prefill_t<W8, ADT, false, false>(st, p, max_tiles);
     return true;
 }
 

@@ -556,7 +556,6 @@ struct W4Only {
         }                                                                                             \
         if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
             int rc = LKM_OK;                                                                          \
-            if (launch_prefill_if(st, cfg, p, gated, true, max_tiles, &rc, IC<WF_>{}, IC<ADT_>{})) return rc; \
             if (launch_prefill_a8w_if(st, cfg, p, gated, true, max_tiles, &rc, IC<ADT_>{})) return rc; \
         }                                                                                             \
         if (gated) {                                                                                  \
@@ -588,7 +587,6 @@ struct W4Only {
         }                                                                                             \
         if constexpr (WF_ == LKM_W_FP8_A8) {                                                          \
             int rc = LKM_OK;                                                                          \
-            if (launch_prefill_if(st, cfg, p, false, false, max_tiles, &rc, IC<WF_>{}, IC<ADT_>{})) return rc; \
             if (launch_prefill_a8w_if(st, cfg, p, false, false, max_tiles, &rc, IC<ADT_>{})) return rc;\
         }                                                                                             \
         LKM_TILED_CASE(2, 4, 1, false, false)                                                         \

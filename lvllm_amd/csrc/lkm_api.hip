@@ -695,7 +695,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // bf16 prefill M=8192: GEMM1 1674 -> 1324 us, GEMM2 964 -> 728, step 2919 -> 2227 (profiles/r04_prefill16_*.log);
         // "pf" = -1 keeps gemm_tiled_kernel
         if (tiled == 256 && (w16 || w8a16) && h->t_pf == 0) pf = 8;
-        if (pf == 8 && !h->a8 && !pf8_ok) pf = 0;
+        if (pf == 8 && !pf8_ok) pf = 0;
         // (round 2's LDS-DMA ring kernel for the 4-bit formats, "pf" = 4, was removed in round 4: three to four times the
         // bytes in flight per CU and no faster, profiles/r02_w4dma_sweep.log)
         // round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h), "pf" = 5
@@ -706,14 +706,14 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // 9 = gemm_prefill_a8w.h (weights straight to registers, tokens through a 4-stage LDS ring, equal token tiles);
             // round 2's kernel ("pf" = 8: both operands through two LDS buffers) was removed in round 4 -- K loops outside
             // the 8..64 units the item-boundary pipeline needs keep the 128-row tiles (the rule that picks 256 above)
-            pf = h->t_pf == 8 ? 8 : 9;      // ("pf" = 8: gemm_prefill.h's fp8 x fp8 mode, round 4)
+            pf = 9;
             waves = 8;
             // The XCD-aware runs (dispatch.hip): for the round-2 kernel a knob ("xcd" = 1) -- they cut GEMM1's L2-miss
             // traffic 5.8 -> 3.55 GB and that kernel ran 4-6 % SLOWER (bound by the round trip of one 66 KiB DMA burst
             // per CU, profiles/r02_glm_a8_prefill.md).  The round-3 kernel keeps ~190 KiB in flight per CU and IS
             // sensitive to where its bytes come from: GEMM1 1127 -> 982 us, GEMM2 762 -> 653 us with the runs
             // (profiles/r03_a8w_*.log), so they are its default ("xcd" = -1 switches them off).
-            if (h->t_xcd >= 0) pl->xcd1 = pl->xcd2 = 1;
+            if (pf == 9 && h->t_xcd >= 0) pl->xcd1 = pl->xcd2 = 1;
         }
         // 16-bit weights, 256-row tiles, many experts (GLM-4.5-Air prefill: 128 experts x ~2 tiles): the XCD-aware runs keep
         // the workgroups that share a weight panel on one L2 -- round 1 measured +-0 with equal ITEM counts per XCD; with the

@@ -579,6 +579,11 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         if (M > 32 && avg_rows >= 16) {   // bf16 M=64: 497 (streamer) vs 466 us, M=96: 562 (hybrid) vs 467; M=48 stays hybrid
             tiled = 64;
             if (w16 && avg_rows > 56) tiled = avg_rows >= 112 ? 256 : 128;
+            // many experts (GLM-4.5-Air, 128): the 256-row kernel from 64 rows per expert (its narrow loop takes the tiles of
+            // <= 128 tokens) -- bf16 M=1024 / 1280 / 1536: 886 -> 872, 924 -> 896, 950 -> 915 us; fp8-W8A16 742 -> 689 (M=1024),
+            // 983 -> 752 (M=1536); Mixtral's 8 experts keep 128-row tiles below 112 rows (M=384: 572 vs 609 us):
+            // profiles/r04_prefill16_threshold.log
+            if ((w16 || w8a16) && avg_rows >= 64 && n_act >= 32 && h->t_pf >= 0 && pf8_ok) tiled = 256;
             // fp8 W8A16 at prefill sizes (MOE_FP8.gpu_prefill): 256-row tiles on gemm_prefill.h (round 4: raw fp8 through the
             // LDS-DMA ring, converted in registers, block scales carried in the accumulators) where 16-bit weights take them;
             // needs one scale per 16-row tile and 128-k unit (block heights in multiples of 16: pf8_ok)

@@ -584,6 +584,37 @@ def test_prefill_kernel_ragged_multi_tile(pf, gated):
     eng.engine.set_tuning(pf=0, xcd=0, ydt=0, dbg=0)
 
 
+@pytest.mark.parametrize("dt,fmt,act", [(torch.float16, "f16", 0), (torch.bfloat16, "bf16", 1), (torch.float16, "fp8", 1),
+                                        (torch.float16, "f16", 1)])
+def test_prefill_kernel_fp16_and_swigluoai(dt, fmt, act):
+    """gemm_prefill.h's other instantiations and epilogue branch: fp16 activations / weights (own translation units) and the
+    interleaved swigluoai activation (activation_kernels.cu:401-440; the generic epilogue arithmetic, not the transcendental-
+    unit SiLU), through decode (fp32 out) AND gpu_prefill (activation-dtype out, two chunks)."""
+    M, E, K, H, I = 1300, 4, 2, 512, 640
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, dt, seed=41 + act, drop=0.05, skew=0.7)
+    odt = orc.F16 if dt == torch.float16 else orc.BF16
+    oact = orc.ACT_SILU if act == 0 else orc.ACT_SWIGLUOAI
+    if fmt == "fp8":
+        q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+        q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="fp8", w13_scale=torch.from_numpy(s13),
+                   w2_scale=torch.from_numpy(s2), group_n=128, group_k=128, activation_type=act, max_batch_size=1024, group_max_len=1024)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=odt, wfmt=orc.W_FP8, groupN=128, groupK=128, activation=oact)
+        ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    else:
+        eng = _eng(w13, w2, top_k=K, act_dtype=dt, activation_type=act, max_batch_size=1024, group_max_len=1024)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=odt, wfmt=orc.W_F16 if dt == torch.float16 else orc.W_BF16, activation=oact)
+        ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+    scale = max(1.0, float(np.abs(ref).max()))
+    eng.engine.set_tuning(tiled=256, waves=8)
+    out = _run_decode(eng, a, tw, ids)
+    assert "tm=256" in eng.engine.describe() and "pf=8" in eng.engine.describe(), eng.engine.describe()
+    np.testing.assert_allclose(out, ref, atol=ATOL * scale, rtol=RTOL)
+    got = eng.prefill(a.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)).float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=2 * ATOL * scale, rtol=2 * RTOL)     # (+ the rounding of the output to the activation dtype)
+    eng.engine.set_tuning(tiled=0, waves=0)
+
+
 @pytest.mark.parametrize("gated", [True, False])
 @pytest.mark.parametrize("M,E,H,I,dt", [(520, 5, 512, 384, torch.bfloat16), (900, 3, 1024, 640, torch.float16),
                                         (300, 2, 384, 256, torch.bfloat16)])

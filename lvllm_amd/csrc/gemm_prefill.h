@@ -1,5 +1,6 @@
-// gemm_prefill.h -- per-expert grouped GEMMs for the prefill regime (hundreds of rows per expert,
-// MFMA-bound): 16-bit weights, 256 weight rows x 256 tokens per workgroup, round 4 structure.
+// gemm_prefill.h -- per-expert grouped GEMMs for the prefill regime (64+ rows per expert, MFMA-bound) with 16-bit
+// ACTIVATIONS: bf16 / fp16 weights and fp8 e4m3 weights (W8A16, see W8 below), 256 weight rows x 256 tokens per
+// workgroup, round 4 structure.  What the reference's gpu_prefill runs (MOE_BF16 / MOE_FP8: routed_experts.py:1884-1899).
 //
 // Same math as gemm_skinny.h / gemm_tiled.h (fp32 accumulation over k, the epilogues are theirs); what
 // changes is how the operands reach the matrix pipe:
@@ -24,8 +25,8 @@
 //     last read, for the tile after next -- four quarters (64 KiB per CU) are in flight at any time in a
 //     2 x 64 KiB ring, waited for with a counted vmcnt one phase before the first read (the wait, then a
 //     barrier every wave passes, then the read: the only ordering an LDS-DMA has).
-// Schedule of tile t (buffer t & 1), DMA issued / quarter whose landing is waited for (vmcnt(8) = all but
-// the four youngest quarters):
+// Schedule of tile t (buffer t & 1), DMA issued / quarter whose landing is waited for (vmcnt(8), fp8 weights vmcnt(6)
+// = all but the four youngest quarters):
 //     ph1: B1(t+1) / B1(t)      ph2: A1(t+1) / A1(t)      ph3: A0(t+2) / -      ph4: B0(t+2) / A0, B0(t+1)
 #pragma once
 #include "gemm_tiled.h"

@@ -58,9 +58,28 @@ __device__ __forceinline__ void pf_silu_mul4(const GemmParams& p, const f32x4& g
     }
 }
 
+// the scale bytes the W4 mode loads by hand -> the decoders' Aux (gemm_skinny.h Dec<>)
+template <int WF>
+struct PfAux;
+template <>
+struct PfAux<LKM_W_INT4_B8> {
+    template <typename A>
+    static __device__ __forceinline__ void set(A& a, unsigned a1, u32x2) { a.raw = u32x2{a1 & 0xffffu, 0u}; }   // one act-dtype scale
+};
+template <>
+struct PfAux<LKM_W_MXFP4> {
+    template <typename A>
+    static __device__ __forceinline__ void set(A& a, unsigned a1, u32x2) { a.raw = a1; }                        // four E8M0
+};
+template <>
+struct PfAux<LKM_W_NVFP4> {
+    template <typename A>
+    static __device__ __forceinline__ void set(A& a, unsigned, u32x2 a2) { a.raw = a2; }                        // eight e4m3
+};
+
 template <int N>
 __device__ __forceinline__ void pf_wait_vmcnt() {
-    static_assert(N == 5 || N == 6 || N == 7 || N == 8 || N == 10, "counts of the two schedules");
+    static_assert(N == 5 || N == 6 || N == 7 || N == 8 || N == 10, "counts of the schedules");
     if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
@@ -97,10 +116,23 @@ __device__ __forceinline__ u32x4 pf_fp8_frag(unsigned d0, unsigned d1) {
 // (An fp8 x fp8 mode of this kernel -- 32x32x64 fp8 MFMA, weight and token scales both carried in the accumulators -- was
 // built and measured in round 4 and not kept: equal to gemm_prefill_a8w.h on GEMM1, behind it on GEMM2;
 // profiles/r04_prefill16_kernel.md, commit "fp8 x fp8 mode of the 16-bit prefill kernel ... experiment".)
-template <bool W8, int ADT, bool GATED, bool IS_G1>
+//
+// W4 = the 4-bit formats (uint4b8 with one scale per row and 128-k unit, MXFP4, NVFP4; MOE_WNA16 / MOE_MXFP4 / MOE_NVFP4
+// .gpu_prefill): decoded in registers by every wave that needs a fragment they would cost 4 x 15-19 VALU per 8 weights and
+// bind the kernel to the vector port (gemm_w4x.h's finding), so the weights are decoded ONCE per workgroup: in the place
+// of a weight quarter's DMA each wave loads the raw 8 bytes + scale bytes of ITS 16-row tile (one lane = one (row, 8 k)
+// piece, exactly the piece of the 16-bit image it then writes), converts them with the formats' bit-exact decoders
+// (gemm_skinny.h Dec<>: T((q - 8) s) etc.) and stores the two 16-byte pieces into the image quarter the other waves read
+// two or more phases later.  The raw loads are plain buffer loads issued by hand (the compiler must not see them: it
+// would drain the token DMA with vmcnt(0) at their use) one K tile ahead, into the registers the decode just freed, and
+// counted into the loop's vmcnt waits.  Everything after the image (fragment reads, MFMAs, epilogue) is the 16-bit kernel.
+template <int WF, int ADT, bool GATED, bool IS_G1>
 __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     static_assert(!GATED || IS_G1, "only GEMM1 is gated");
-    constexpr int AG = W8 ? 1 : 2, BG = 2;                    // LDS-DMA instructions per wave and weight / token quarter
+    constexpr bool W8 = WF == LKM_W_FP8_E4M3;
+    constexpr bool W4 = WF == LKM_W_INT4_B8 || WF == LKM_W_MXFP4 || WF == LKM_W_NVFP4;
+    constexpr int AG = W8 ? 1 : 2, BG = 2;                    // LDS-DMA instructions per wave and weight / token quarter (W4: two hand-issued loads)
+    constexpr int UB = W4 ? 1024 : 2048;                      // bytes of a (16-row tile, K unit) in the weight image
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer resources / LDS-DMA builtins exist in the device pass only
     typedef __attribute__((address_space(3))) void* LdsPtr;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -140,18 +172,18 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     // A tile of <= 128 tokens (the stub an expert's row count leaves after its full tiles) runs the NARROW loop: one token
     // group of 32 per wave, two phases per K tile (A0 x B, A1 x B) -- half the matrix work of a full tile instead of all
     // of it with half of every wave's accumulators multiplying padding.
-    const bool nar = m_e - r0 <= 128;
+    const bool nar = !W4 && m_e - r0 <= 128;                  // (W4: the decode cadence is written for the two-buffer loop only)
     const int wtok = nar ? wc * 32 : wc * 64;                 // first token of this wave inside the tile
     const int T_all = p.T_half * p.halves;
     constexpr int TPH = GATED ? 8 : 16;                       // tiles per half taken by one workgroup
     const int tbase = bx * TPH;
-    const int U = W8 ? 2 * p.U : p.U;                        // K tiles of 64 k
+    const int U = (W8 || W4) ? 2 * p.U : p.U;                // K tiles of 64 k
 
     // ---- LDS-DMA streams, two wave-instructions per wave and quarter.
     // Weight quarter s: the 8 tiles {row half wr', row group 2s + rgl of it, tile gu of the group}, LDS slot
     // wr'*4 + rgl*2 + gu = the staging wave's index.  Token quarter s: LDS row wc'*32 + i = token wc'*64 + s*32 + i.
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.w + (size_t)(abl_same ? 0 : e) * T_all * p.U * 2048), 0, (int)((size_t)T_all * p.U * 2048), 0x00020000);
+        (void*)((const char*)p.w + (size_t)(abl_same ? 0 : e) * T_all * p.U * UB), 0, (int)((size_t)T_all * p.U * UB), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, 0x7fffffff, 0x00020000);
     int asoff[2];                                             // byte offset of my tile of quarter s (wave-uniform)
 #pragma unroll
@@ -182,7 +214,9 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         const int uc = u < U ? u : U - 1;                     // past the end: re-fetch the last unit into a quarter nobody reads
         if (abl_nodma && u >= 2) return;
         char* base = lds + off;
-        if constexpr (qid < 2 && W8) {
+        if constexpr (qid < 2 && W4) {
+            // (decoded into place: w4_decode)
+        } else if constexpr (qid < 2 && W8) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + wave * 2048), 16, alane,
                                                      asoff[qid] + (uc >> 1) * wustep + (uc & 1) * 1024, 0, 0);
         } else if constexpr (qid < 2) {
@@ -200,6 +234,69 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
 
     auto dma = [&](int u, auto BUF, auto QC) __attribute__((always_inline)) {
         dma_at(u, IC<decltype(BUF)::v * kPfBufBytes + decltype(QC)::v * kPfQ>{}, QC);
+    };
+
+    // ---- W4: the raw bytes of my tile of quarter s for one K tile (2 dwords: k-steps 2c, 2c + 1 of the unit) and the scale
+    // bytes of my row for the unit; loaded by hand, laundered behind the counted wait that covers them
+    typedef Dec<W4 ? WF : LKM_W_INT4_B8, ADT> D4;
+    typedef int i32x4s __attribute__((ext_vector_type(4)));
+    u32x2 w4raw[2] = {};
+    unsigned w4a1[2] = {};                                     // scale bytes: one dword (uint4b8: one 16-bit scale; MXFP4: four E8M0) ...
+    u32x2 w4a2[2] = {};                                        // ... or two (NVFP4: eight e4m3 block scales)
+    i32x4s rs_wr = {0, 0, 0, 0}, rs_ar = {0, 0, 0, 0};
+    int w4aoff[2] = {0, 0};
+    const int w4dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
+    if constexpr (W4) {
+        const unsigned long long wb = (unsigned long long)((const char*)p.w + (size_t)e * T_all * p.U * UB), ab = (unsigned long long)p.s;
+        rs_wr = i32x4s{__builtin_amdgcn_readfirstlane((int)wb), __builtin_amdgcn_readfirstlane((int)(wb >> 32) & 0xffff), 0x7fffffff, 0x00020000};
+        rs_ar = i32x4s{__builtin_amdgcn_readfirstlane((int)ab), __builtin_amdgcn_readfirstlane((int)(ab >> 32) & 0xffff), 0x7fffffff, 0x00020000};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int grp = (wave >> 2) * 4 + s * 2 + ((wave >> 1) & 1), gu = wave & 1;
+            const int half = GATED ? gu : 0, t = tbase + (GATED ? grp : grp * 2 + gu);
+            const int gt = half * p.T_half + (t < p.T_half ? t : 0);
+            w4aoff[s] = (int)(D4::aux_ptr(p.s, ((size_t)e * T_all + gt) * p.U, lane, p.spu) - (const char*)p.s);   // < 2 GiB: the launcher checks
+        }
+    }
+    auto w4_load = [&](int t, auto SC) __attribute__((always_inline)) {       // raw + scale bytes of K tile t, quarter s
+        constexpr int s = decltype(SC)::v;
+        if constexpr (W4) {
+            const int tc = t < U ? t : U - 1;
+            const int wo = asoff[s] + (tc >> 1) * wustep + (tc & 1) * 8, ao = (tc >> 1) * D4::aux_step(p.spu);
+            constexpr int wf = WF + 0 * s;                      // (dependent on the lambda's parameter: the untaken branches are discarded)
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(w4raw[s]) : "v"(alane), "s"(rs_wr), "s"(wo) : "memory");
+            // (straight into the registers the decode reads: no instruction may touch them before the covering wait)
+            const int& av = w4aoff[s];
+            unsigned& a1 = w4a1[s];
+            u32x2& a2 = w4a2[s];
+            if constexpr (wf == LKM_W_INT4_B8)
+                asm volatile("buffer_load_ushort %0, %1, %2, %3 offen" : "=v"(a1) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
+            else if constexpr (wf == LKM_W_MXFP4)
+                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a1) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
+            else
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a2) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
+        }
+    };
+    // decode what w4_load fetched (K tile parity PC: k-steps 2 PC, 2 PC + 1 of its unit) into my tile of the image quarter at OFF
+    auto w4_decode = [&](auto OFF, auto SC, auto PC) __attribute__((always_inline)) {
+        constexpr int off = decltype(OFF)::v, s = decltype(SC)::v, pc = decltype(PC)::v;
+        if constexpr (W4) {
+            constexpr int wf0 = WF + 0 * s;
+            asm volatile("" : "+v"(w4raw[s]));                   // landed: the counted wait before this call
+            unsigned& a1 = w4a1[s];
+            u32x2& a2 = w4a2[s];
+            if constexpr (wf0 == LKM_W_NVFP4) asm volatile("" : "+v"(a2));
+            else asm volatile("" : "+v"(a1));
+            u32x4 rawv[1];
+            rawv[0] = u32x4{0u, 0u, 0u, 0u};
+            rawv[0][2 * pc] = w4raw[s].x;
+            rawv[0][2 * pc + 1] = w4raw[s].y;
+            typename D4::Aux ax;
+            PfAux<W4 ? WF : LKM_W_INT4_B8>::set(ax, w4a1[s], w4a2[s]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                *(u32x4*)(lds + off + wave * 2048 + ks * 1024 + alane) = D4::frag(rawv, ax, 2 * pc + ks, w4dparam);
+        }
     };
 
     // ---- fragments.  Registers (2 waves per SIMD -> 256 per lane): 128 accumulators, 8 weight fragments (one
@@ -358,10 +455,16 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         // ph2
         if constexpr (comp) read_b(IC<b>{}, IC<1>{});
         dma(t + 1, IC<b ^ 1>{}, IC<1>{});
+        if constexpr (W4) {                                   // A1(t + 1): decode what was fetched a K tile ago, fetch A1(t + 2)
+            pf_wait_vmcnt<6>();                               // (younger: the raw A0 loads, B0(t+1), B1(t+1))
+            w4_decode(IC<(b ^ 1) * kPfBufBytes + kPfQ>{}, IC<1>{}, IC<b ^ 1>{});
+            w4_load(t + 2, IC<1>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         if constexpr (comp) {
             if (unit_in) rescale(IC<0>{}, IC<1>{});
         }
-        pf_wait_vmcnt<VM>();
+        if constexpr (!W4) pf_wait_vmcnt<VM>();
         bar();
         if constexpr (comp) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -371,6 +474,12 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         // ph3
         if constexpr (comp) read_a(IC<b>{}, IC<1>{});
         dma(t + 2, IC<b>{}, IC<0>{});
+        if constexpr (W4) {                                   // A0(t + 2) likewise (younger: B0(t+1), B1(t+1), the raw A1 loads), fetch A0(t + 3)
+            pf_wait_vmcnt<6>();
+            w4_decode(IC<b * kPfBufBytes>{}, IC<0>{}, IC<b>{});
+            w4_load(t + 3, IC<0>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         if constexpr (comp) {
             if (unit_in) {
                 enter_unit(IC<2>{}, t >> 1);
@@ -395,12 +504,31 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         bar();
     };
     auto run = [&](auto COMPUTE) __attribute__((always_inline)) {
-        dma(0, IC<0>{}, IC<0>{});
-        dma(0, IC<0>{}, IC<2>{});
-        dma(0, IC<0>{}, IC<3>{});
-        dma(0, IC<0>{}, IC<1>{});
-        dma(1, IC<1>{}, IC<0>{});
-        dma(1, IC<1>{}, IC<2>{});
+        if constexpr (W4) {
+            // images of A0(0), A1(0), A0(1) first (one exposed load latency), then the issue order of the steady loop:
+            // B0(0), B1(0), raw A1(1), raw A0(2), B0(1)
+            w4_load(0, IC<0>{});
+            w4_load(0, IC<1>{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            w4_decode(IC<0>{}, IC<0>{}, IC<0>{});
+            w4_decode(IC<kPfQ>{}, IC<1>{}, IC<0>{});
+            w4_load(1, IC<0>{});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            w4_decode(IC<kPfBufBytes>{}, IC<0>{}, IC<1>{});
+            dma(0, IC<0>{}, IC<2>{});
+            dma(0, IC<0>{}, IC<3>{});
+            w4_load(1, IC<1>{});
+            w4_load(2, IC<0>{});
+            dma(1, IC<1>{}, IC<2>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            dma(0, IC<0>{}, IC<0>{});
+            dma(0, IC<0>{}, IC<2>{});
+            dma(0, IC<0>{}, IC<3>{});
+            dma(0, IC<0>{}, IC<1>{});
+            dma(1, IC<1>{}, IC<0>{});
+            dma(1, IC<1>{}, IC<2>{});
+        }
         if constexpr (decltype(COMPUTE)::value) finish_scales();
         pf_wait_vmcnt<2 * AG + 2 * BG>();                      // A0(0), B0(0) landed (and the older token-scale loads)
         bar();
@@ -626,12 +754,14 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
 
 // usable when the K range is an even number of whole 64-element units (no ragged tail) and the operands fit the
 // 2 GiB buffer windows; otherwise the caller stays on gemm_tiled_kernel
-inline bool prefill_kernel_ok(const GemmParams& p, size_t x_rows, bool w8) {
-    return p.Kreal % 128 == 0 && (w8 ? p.U <= 64 : p.U % 2 == 0) && x_rows * (size_t)p.ldx * 2 < (size_t)0x7fffffff &&
-           (size_t)p.T_half * p.halves * p.U * 2048 < (size_t)0x7fffffff;
+inline bool prefill_kernel_ok(const GemmParams& p, size_t x_rows, int wf) {
+    const bool w8 = wf == LKM_W_FP8_E4M3, w4 = wf_is_4bit(wf);
+    const size_t ub = w4 ? 1024 : 2048;
+    return p.Kreal % 128 == 0 && (w8 ? p.U <= 64 : (w4 || p.U % 2 == 0)) && x_rows * (size_t)p.ldx * 2 < (size_t)0x7fffffff &&
+           (size_t)p.T_half * p.halves * p.U * ub < (size_t)0x7fffffff && (wf != LKM_W_INT4_B8 || p.spu == 1);
 }
 
-template <bool W8, int ADT, bool GATED, bool IS_G1>
+template <int WF, int ADT, bool GATED, bool IS_G1>
 static int launch_prefill_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr size_t lds = kPfLdsBytes;
     const int TPH = GATED ? 8 : 16;
@@ -642,7 +772,7 @@ static int launch_prefill_t(hipStream_t st, const GemmParams& p, int max_tiles) 
         pp.xcd_map = RG;
         grid = dim3(8 * p.xcd_map * RG, 1);
     }
-    auto kern = gemm_prefill_kernel<W8, ADT, GATED, IS_G1>;
+    auto kern = gemm_prefill_kernel<WF, ADT, GATED, IS_G1>;
     LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, pp);
     LKM_HIP_CHECK(hipGetLastError());
@@ -653,15 +783,15 @@ template <typename WFC, typename ADTC>
 static bool launch_prefill_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
                               int max_tiles, int* rc, WFC, ADTC) {
     constexpr int ADT = ADTC::v;
-    constexpr bool W8 = WFC::v == LKM_W_FP8_E4M3;
+    constexpr int WF = WFC::v;
     if (cfg.tiled != 256 || cfg.pf != 8) return false;
-    if (!prefill_kernel_ok(p, p.x_rows, W8)) {     // (pick_cfg only plans the kernel for shapes that qualify)
+    if (!prefill_kernel_ok(p, p.x_rows, WF)) {     // (pick_cfg only plans the kernel for shapes that qualify)
         set_error("gemm_prefill: K = %d / %d units or the operand sizes do not fit the kernel", p.Kreal, p.U);
         *rc = LKM_E_INVALID;
         return true;
     }
-    if (is_g1) *rc = gated ? launch_prefill_t<W8, ADT, true, true>(st, p, max_tiles) : launch_prefill_t<W8, ADT, false, true>(st, p, max_tiles);
-    else *rc = launch_prefill_t<W8, ADT, false, false>(st, p, max_tiles);
+    if (is_g1) *rc = gated ? launch_prefill_t<WF, ADT, true, true>(st, p, max_tiles) : launch_prefill_t<WF, ADT, false, true>(st, p, max_tiles);
+    else *rc = launch_prefill_t<WF, ADT, false, false>(st, p, max_tiles);
     return true;
 }
 

@@ -536,6 +536,12 @@ struct W16Only {
             return launch_tiled_t<WF_, ADT_, NT, TBW, WAVES, G, IS1, 2>(st, p, max_tiles);      \
         }                                                                                       \
     }
+// formats gemm_prefill.h serves (16-bit activations): bf16 / fp16, fp8 W8A16, uint4b8 / MXFP4 / NVFP4
+template <int WF>
+struct PfFormat {
+    static constexpr bool value = WF == LKM_W_BF16 || WF == LKM_W_F16 || WF == LKM_W_FP8_E4M3 || WF == LKM_W_INT4_B8 ||
+                                  WF == LKM_W_MXFP4 || WF == LKM_W_NVFP4;
+};
 template <int WF>
 struct W4Only {
     static constexpr bool value = WF == LKM_W_INT4_B8 || WF == LKM_W_INT4_PS || WF == LKM_W_MXFP4 || WF == LKM_W_NVFP4;
@@ -550,7 +556,7 @@ struct W4Only {
     int launch_gemm1_tiled_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
                                     bool gated, int max_tiles) {                                      \
         constexpr int WF_ = WF, ADT_ = ADT;                                                           \
-        if constexpr (W16Only<WF_>::value || WF_ == LKM_W_FP8_E4M3) {                                \
+        if constexpr (PfFormat<WF_>::value) {                                                         \
             int rc = LKM_OK;                                                                          \
             if (launch_prefill_if(st, cfg, p, gated, true, max_tiles, &rc, IC<WF_>{}, IC<ADT_>{})) return rc; \
         }                                                                                             \
@@ -581,7 +587,7 @@ struct W4Only {
     int launch_gemm2_tiled_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p,        \
                                     int max_tiles) {                                                  \
         constexpr int WF_ = WF, ADT_ = ADT;                                                           \
-        if constexpr (W16Only<WF_>::value || WF_ == LKM_W_FP8_E4M3) {                                \
+        if constexpr (PfFormat<WF_>::value) {                                                         \
             int rc = LKM_OK;                                                                          \
             if (launch_prefill_if(st, cfg, p, false, false, max_tiles, &rc, IC<WF_>{}, IC<ADT_>{})) return rc; \
         }                                                                                             \

@@ -1,6 +1,6 @@
 // gemm_tiled_nvfp4_bf16.hip -- instantiates the LDS-staged tiled grouped-GEMM kernels (gemm_tiled.h)
 // for one (weight format, activation dtype) pair.
-#include "gemm_tiled.h"
+#include "gemm_prefill.h"
 namespace lkm {
 LKM_DEFINE_TILED_LAUNCHERS(nvfp4_bf16, LKM_W_NVFP4, LKM_DT_BF16)
 }  // namespace lkm

@@ -562,10 +562,16 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
     // intermediate and an expert's weights inside 2 GiB buffer windows (prefill_kernel_ok); fp8: one scale per 16-row
     // tile and 128-k unit
     const bool w8a16 = h->wf == LKM_W_FP8_E4M3 && !h->a8;
-    const bool pf8_ok = (w16 || w8a16) && h->H % 128 == 0 && h->I % 128 == 0 && (size_t)M * (size_t)h->H * 2 < (size_t)0x7fffffff &&
+    // ... and the 4-bit formats (decoded once per workgroup into the 16-bit image): uint4b8 with one scale per row and 128-k
+    // unit, MXFP4, NVFP4
+    const bool w4pf = (h->wf == LKM_W_INT4_B8 && h->spu == 1 && !h->ps) || h->wf == LKM_W_MXFP4 || h->wf == LKM_W_NVFP4;   // (not the fast int4 mode: its own image)
+    const size_t pf_ub = w4pf ? 1024 : 2048;     // bytes of a (tile, unit) of the image
+    const bool pf8_ok = (w16 || w8a16 || w4pf) && h->H % 128 == 0 && h->I % 128 == 0 && (size_t)M * (size_t)h->H * 2 < (size_t)0x7fffffff &&
                         n_slots * (size_t)h->ld_act * 2 < (size_t)0x7fffffff &&
-                        (size_t)h->T1_half * (h->gated ? 2 : 1) * h->U1 * 2048 < (size_t)0x7fffffff &&
-                        (size_t)h->T2 * h->U2 * 2048 < (size_t)0x7fffffff &&
+                        (size_t)h->T1_half * (h->gated ? 2 : 1) * h->U1 * pf_ub < (size_t)0x7fffffff &&
+                        (size_t)h->T2 * h->U2 * pf_ub < (size_t)0x7fffffff &&
+                        (!w4pf || ((size_t)h->E * h->T1_half * (h->gated ? 2 : 1) * h->U1 * 128 < (size_t)0x7fffffff &&      // (scale bytes: 32-bit offsets)
+                                   (size_t)h->E * h->T2 * h->U2 * 128 < (size_t)0x7fffffff)) &&
                         (!w8a16 || ((size_t)h->E * h->T1_half * (h->gated ? 2 : 1) * h->U1 * 16 < (size_t)0x7fffffff &&
                                     (size_t)h->E * h->T2 * h->U2 * 16 < (size_t)0x7fffffff && h->cfg.groupN % 16 == 0 &&
                                     h->cfg.groupK % 128 == 0 && h->U1 <= 64 && h->U2 <= 64));
@@ -593,6 +599,10 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // gpu_prefill runs): 128-row tiles x 8 waves from ~100 rows per expert -- int4 Mixtral M=512 725 -> 683 us,
             // M=2048 2159 -> 1951, M=8192 8235 -> 7149 (GEMM1 -21 %); NVFP4 M=2048 2017 -> 1842.  Decode sizes keep 64 / 32.
             if ((h->wf == LKM_W_INT4_B8 || h->wf == LKM_W_NVFP4) && avg_rows >= 96) tiled = 128;
+            // ... and from 112 rows per expert the 256-row prefill kernel with the weights decoded once per workgroup
+            // (gemm_prefill.h W4, round 4; Mixtral M=1024 / 2048 / 4096 / 8192, step us: uint4b8 1100 -> 926, 1953 -> 1726, 3696 ->
+            // 3068, 7170 -> 5758; NVFP4 M=8192 6677 -> 5723; MXFP4 M=8192 5340 -> 4583: profiles/r04_prefill16_w4.log)
+            if (w4pf && avg_rows >= 112 && h->t_pf >= 0 && pf8_ok) tiled = 256;
             // fp8 x fp8 (W8A8): 128-row tiles from ~200 rows per expert, now that the per-unit partial sums
             // are formed four token blocks at a time and the kernel fits its registers (GLM-4.5-Air prefill
             // 3677 -> 3179 us with two GEMM2 tiles per wave; Mixtral M=2048 1996 -> 1820; M=512 equal)
@@ -700,6 +710,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // bf16 prefill M=8192: GEMM1 1674 -> 1324 us, GEMM2 964 -> 728, step 2919 -> 2227 (profiles/r04_prefill16_*.log);
         // "pf" = -1 keeps gemm_tiled_kernel
         if (tiled == 256 && (w16 || w8a16) && h->t_pf == 0) pf = 8;
+        if (tiled == 256 && w4pf && (h->t_pf == 0 || h->t_pf == 8)) pf = 8;
         if (pf == 8 && !pf8_ok) pf = 0;
         // (round 2's LDS-DMA ring kernel for the 4-bit formats, "pf" = 4, was removed in round 4: three to four times the
         // bytes in flight per CU and no faster, profiles/r02_w4dma_sweep.log)
@@ -724,7 +735,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // the workgroups that share a weight panel on one L2 -- round 1 measured +-0 with equal ITEM counts per XCD; with the
         // runs cut by routed rows (round 3) the bf16 prefill step goes 3095 -> 2853 us uniform, 3158 -> 3006 us Zipf
         // (profiles/r04_prefill_plan_sweep.log).  Few large experts (Mixtral) lose with it and keep the plain grid.
-        if (tiled == 256 && (w16 || w8a16) && n_act >= 32 && h->t_xcd >= 0 && (!pf || pf == 8))
+        if (tiled == 256 && (w16 || w8a16 || w4pf) && n_act >= 32 && h->t_xcd >= 0 && (!pf || pf == 8))
             pl->xcd1 = pl->xcd2 = 1;
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;
@@ -1023,7 +1034,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     // 16-bit weights on gemm_prefill.h ("pf" = 8, prefill sizes only): the same -- what the in-tree GPU operator's GEMM2 does
     // (fused_moe.py writes intermediate_cache3 in the hidden dtype before moe_sum); GLM-4.5-Air bf16 M=8192: GEMM2 815 ->
     // 728 us, combine 248 -> 136.  "ydt" = -1 keeps the fp32 partials of the smaller-batch kernels.
-    const bool w16_pf = (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16 || (h->wf == LKM_W_FP8_E4M3 && !h->a8)) && pl.t2.tiled == 256 &&
+    const bool w16_pf = (h->wf == LKM_W_BF16 || h->wf == LKM_W_F16 || (h->wf == LKM_W_FP8_E4M3 && !h->a8) || wf_is_4bit(h->wf)) && pl.t2.tiled == 256 &&
                         pl.t2.pf == 8 && h->t_ydt >= 0;
     const int y_dt = (((h->a8 && pl.t2.pf >= 8) || w16_pf) && pl.t2.tiled == 256 && !pl.s2.tb && sk == 1) ? h->adt : LKM_DT_F32;
     p2.y_dt = y_dt;

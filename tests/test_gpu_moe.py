@@ -493,9 +493,10 @@ def test_fp4_dequant_is_bit_exact_on_gpu(fmt):
     for e in range(E):
         ids = np.full((H, 1), e, np.int32)
         tw = np.ones((H, 1), np.float32)
-        for tiled in (-1, 32, 64):
-            eng.engine.set_tuning(tiled=tiled)
+        for tiled in (-1, 32, 64, 256):
+            eng.engine.set_tuning(tiled=tiled, waves=8 if tiled == 256 else 0, pf=8 if tiled == 256 else 0)   # (256: gemm_prefill.h)
             out = _run_decode(eng, x, tw, ids)                       # out[j, i] = bf16(relu(W[e,i,j])^2)
+            assert tiled != 256 or "pf=8" in eng.engine.describe(), eng.engine.describe()
             want = np.maximum(wd[e].T, 0.0) ** 2
             want = orc.bits_to_f32(orc.f32_to_bits(want.astype(np.float32), orc.BF16), orc.BF16)
             np.testing.assert_array_equal(out, want, err_msg=f"{fmt} expert {e} tiled={tiled}")
@@ -531,13 +532,81 @@ def test_int4_dequant_is_bit_exact_on_gpu(g, dt):
     for e in range(E):
         ids = np.full((H, 1), e, np.int32)
         tw = np.ones((H, 1), np.float32)
-        for tiled in (-1, 32, 64, 128):
-            eng.engine.set_tuning(tiled=tiled)
+        for tiled in (-1, 32, 64, 128) + ((256,) if g == 128 else ()):
+            # (256: gemm_prefill.h, the weights decoded once per workgroup into the 16-bit image -- one scale per row and unit)
+            eng.engine.set_tuning(tiled=tiled, waves=8 if tiled == 256 else 0, pf=8 if tiled == 256 else 0)
             for sign in (1.0, -1.0):
                 out = _run_decode(eng, x * sign, tw, ids)[:, :I]                       # out[j, i] = T(relu(+-W[e,i,j])^2)
+                assert tiled != 256 or "pf=8" in eng.engine.describe(), eng.engine.describe()
                 want = np.maximum(sign * wd[e].T, 0.0) ** 2
                 want = orc.bits_to_f32(orc.f32_to_bits(want.astype(np.float32), odt), odt)
                 np.testing.assert_array_equal(out, want, err_msg=f"g={g} expert {e} tiled={tiled} sign={sign}")
+
+
+@pytest.mark.parametrize("gated", [True, False])
+@pytest.mark.parametrize("fmt,dt", [("int4", torch.bfloat16), ("int4", torch.float16), ("mxfp4", torch.bfloat16),
+                                    ("nvfp4", torch.bfloat16), ("nvfp4", torch.float16)])
+def test_prefill_kernel_4bit_formats(fmt, dt, gated):
+    """gemm_prefill.h with 4-bit weights (MOE_WNA16 / MOE_MXFP4 / MOE_NVFP4 .gpu_prefill): every wave decodes ITS 16-row
+    tile of a weight quarter once per workgroup (the formats' bit-exact decoders) into the 16-bit LDS image, raw bytes and
+    scales by hand-issued loads counted into the DMA waits -- against the oracle and against the 64-row tile kernel
+    (same dequantised bits, another summation order): experts of 0 to ~650 rows, ragged tiles, empty wave quarters,
+    padded weight-tile counts, 3 / 4-unit K loops."""
+    M, E, K, H, I = 560, 5, 2, 512, 384
+    odt = orc.BF16 if dt == torch.bfloat16 else orc.F16
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, dt, seed=17, gated=gated)
+    rng = np.random.default_rng(8)
+    pool = np.array([0, 1, 3, 4], np.int32)                     # expert 2 stays empty
+    prob = np.array([0.03, 0.30, 0.58, 0.09])
+    first = rng.choice(4, size=M, p=prob)
+    second = (first + rng.integers(1, 4, size=M)) % 4
+    ids = np.ascontiguousarray(np.stack([pool[first], pool[second]], axis=1).astype(np.int32))
+    kw = dict(has_gate_proj=False, activation_type=2) if not gated else {}
+    n13 = w13.shape[1]
+    if fmt == "int4":
+        q13, s13 = orc.quant_int4(torch_to_bits(w13), odt, 128)
+        q2, s2 = orc.quant_int4(torch_to_bits(w2), odt, 128)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="int4", w13_scale=bits_to_torch(s13, odt),
+                   w2_scale=bits_to_torch(s2, odt), group_n=1, group_k=128, **kw)
+        d = orc.MoeDesc(E=E, H=H, I=I, has_gate=gated, activation=orc.ACT_SILU if gated else orc.ACT_RELU2, act_dtype=odt,
+                        wfmt=orc.W_INT4, groupN=1, groupK=128)
+        ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    else:
+        q13 = rng.integers(0, 256, (E, n13, H // 2), dtype=np.uint8)
+        q2 = rng.integers(0, 256, (E, H, I // 2), dtype=np.uint8)
+        if fmt == "mxfp4":
+            g, wf, gs13, gs2 = 32, orc.W_MXFP4, None, None
+            s13 = rng.integers(117, 121, (E, n13, H // g), dtype=np.uint8)
+            s2 = rng.integers(117, 121, (E, H, I // g), dtype=np.uint8)
+            ekw = {}
+        else:
+            g, wf = 16, orc.W_NVFP4
+            s13 = rng.integers(0x18, 0x28, (E, n13, H // g), dtype=np.uint8)
+            s2 = rng.integers(0x18, 0x28, (E, H, I // g), dtype=np.uint8)
+            gs13 = rng.uniform(0.5, 2.0, E).astype(np.float32)
+            gs2 = rng.uniform(0.5, 2.0, E).astype(np.float32)
+            ekw = dict(w13_global_scale=torch.from_numpy(gs13), w2_global_scale=torch.from_numpy(gs2))
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt=fmt, w13_scale=torch.from_numpy(s13),
+                   w2_scale=torch.from_numpy(s2), group_n=1, group_k=g, **ekw, **kw)
+        d = orc.MoeDesc(E=E, H=H, I=I, has_gate=gated, activation=orc.ACT_SILU if gated else orc.ACT_RELU2, act_dtype=odt,
+                        wfmt=wf, groupN=1, groupK=g)
+        ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2, gs13=gs13, gs2=gs2)
+    scale = max(1.0, float(np.abs(ref).max()))
+    eng.engine.set_tuning(tiled=256, waves=8, pf=8, ydt=-1)
+    out = _run_decode(eng, a, tw, ids)
+    assert "tm=256" in eng.engine.describe() and "pf=8" in eng.engine.describe(), eng.engine.describe()
+    np.testing.assert_allclose(out, ref, atol=ATOL * scale, rtol=RTOL)
+    eng.engine.set_tuning(tiled=64, waves=4, pf=-1)
+    base = _run_decode(eng, a, tw, ids)
+    np.testing.assert_allclose(out, base, atol=2e-4 * scale, rtol=2e-4, err_msg=eng.engine.describe())
+    for xcd, ydt in ((1, -1), (-1, -1), (1, 0)):
+        eng.engine.set_tuning(tiled=256, waves=8, pf=8, xcd=xcd, ydt=ydt)
+        got = _run_decode(eng, a, tw, ids)
+        if ydt < 0:
+            assert np.array_equal(got, out), eng.engine.describe()
+        else:
+            np.testing.assert_allclose(got, ref, atol=ATOL * scale, rtol=RTOL)
+    eng.engine.set_tuning(tiled=0, waves=0, pf=0, xcd=0, ydt=0)
 
 
 @pytest.mark.parametrize("pf", [8])

@@ -53,6 +53,8 @@ WORKLOADS = {
     # name: E experts, K top-k, H hidden, I intermediate, M tokens per GPU, weight format
     "mixtral8x7b_bf16_decode_m32": dict(E=8, K=2, H=4096, I=14336, M=32, fmt="bf16"),
     "mixtral8x7b_int4g128_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="int4", g=128),
+    # MOE_WNA16.gpu_prefill (routed_experts.py:1884-1899): the same experts at a prefill chunk of 4096 tokens (MFMA-bound)
+    "mixtral8x7b_int4g128_prefill_m4096": dict(E=8, K=2, H=4096, I=14336, M=4096, fmt="int4", g=128, prefill=True),
     # the same checkpoint in the engine's opt-in fast int4 mode (LkmConfig.int4_mode: group scale on fp32 partial sums)
     "mixtral8x7b_int4g128_fast_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="int4", g=128, int4_mode=1),
     "qwen3_30b_a3b_bf16_decode_m1": dict(E=128, K=8, H=2048, I=768, M=1, fmt="bf16"),
@@ -90,7 +92,7 @@ EXTRA_N1 = [# the headline workload under Zipf routing first, in the thermal sta
             # BASELINE.json configs[4] (the MFMA-bound grouped GEMM)
             "glm45air_fp8w8a8_prefill_m8192",
             # ... and the path the reference's gpu_prefill actually takes (MOE_BF16 / MOE_FP8 = W8A16: routed_experts.py:1884-1899)
-            "glm45air_bf16_prefill_m8192", "glm45air_fp8w8a16_prefill_m8192"]
+            "glm45air_bf16_prefill_m8192", "glm45air_fp8w8a16_prefill_m8192", "mixtral8x7b_int4g128_prefill_m4096"]
 EXTRA_EP = "dsv3_fp8w8a8_ep_decode_b256"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp8": 5000.0}   # dense, MI355X_MICROARCH.md

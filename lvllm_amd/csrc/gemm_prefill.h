@@ -1,6 +1,7 @@
 // gemm_prefill.h -- per-expert grouped GEMMs for the prefill regime (64+ rows per expert, MFMA-bound) with 16-bit
-// ACTIVATIONS: bf16 / fp16 weights and fp8 e4m3 weights (W8A16, see W8 below), 256 weight rows x 256 tokens per
-// workgroup, round 4 structure.  What the reference's gpu_prefill runs (MOE_BF16 / MOE_FP8: routed_experts.py:1884-1899).
+// ACTIVATIONS: bf16 / fp16 weights, fp8 e4m3 weights (W8A16, see W8 below) and the 4-bit formats (W4 below), 256 weight
+// rows x 256 tokens per workgroup, round 4 structure.  What the reference's gpu_prefill runs (MOE_BF16 / MOE_FP8 /
+// MOE_WNA16 ...: routed_experts.py:1884-1899).
 //
 // Same math as gemm_skinny.h / gemm_tiled.h (fp32 accumulation over k, the epilogues are theirs); what
 // changes is how the operands reach the matrix pipe:

@@ -27,6 +27,8 @@ RUNS = [
     ("4c DSv3-style fp8-W8A8, all 256 experts on one GPU, M=256, grouped sigmoid router", "dsv3_fp8w8a8_ep_decode_b256", 100, 2.5e3, 1.0),
     ("5 GLM-4.5-Air prefill M=8192 (bf16 weights)", "glm45air_bf16_prefill_m8192", 20, 2.5e3, 2.0),
     ("5b GLM-4.5-Air prefill M=8192 (fp8-W8A8)", "glm45air_fp8w8a8_prefill_m8192", 20, 2.5e3, 1.0),
+    ("5c GLM-4.5-Air prefill M=8192 (fp8-W8A16, MOE_FP8.gpu_prefill)", "glm45air_fp8w8a16_prefill_m8192", 20, 2.5e3, 1.0),
+    ("5d Mixtral-8x7B int4-g128 prefill M=4096 (MOE_WNA16.gpu_prefill)", "mixtral8x7b_int4g128_prefill_m4096", 20, 2.5e3, 0.5),
 ]
 
 

@@ -65,17 +65,19 @@ struct PfAux;
 template <>
 struct PfAux<LKM_W_INT4_B8> {
     template <typename A>
-    static __device__ __forceinline__ void set(A& a, unsigned a1, u32x2) { a.raw = u32x2{a1 & 0xffffu, 0u}; }   // one act-dtype scale
+    static __device__ __forceinline__ void set(A& a, unsigned a1, u32x2 a2, int spu) {                         // 1 / 2 / 4 act-dtype scales
+        a.raw = spu == 4 ? a2 : u32x2{spu == 1 ? (a1 & 0xffffu) : a1, 0u};
+    }
 };
 template <>
 struct PfAux<LKM_W_MXFP4> {
     template <typename A>
-    static __device__ __forceinline__ void set(A& a, unsigned a1, u32x2) { a.raw = a1; }                        // four E8M0
+    static __device__ __forceinline__ void set(A& a, unsigned a1, u32x2, int) { a.raw = a1; }                   // four E8M0
 };
 template <>
 struct PfAux<LKM_W_NVFP4> {
     template <typename A>
-    static __device__ __forceinline__ void set(A& a, unsigned, u32x2 a2) { a.raw = a2; }                        // eight e4m3
+    static __device__ __forceinline__ void set(A& a, unsigned, u32x2 a2, int) { a.raw = a2; }                   // eight e4m3
 };
 
 template <int N>
@@ -118,7 +120,7 @@ __device__ __forceinline__ u32x4 pf_fp8_frag(unsigned d0, unsigned d1) {
 // built and measured in round 4 and not kept: equal to gemm_prefill_a8w.h on GEMM1, behind it on GEMM2;
 // profiles/r04_prefill16_kernel.md, commit "fp8 x fp8 mode of the 16-bit prefill kernel ... experiment".)
 //
-// W4 = the 4-bit formats (uint4b8 with one scale per row and 128-k unit, MXFP4, NVFP4; MOE_WNA16 / MOE_MXFP4 / MOE_NVFP4
+// W4 = the 4-bit formats (uint4b8, MXFP4, NVFP4; MOE_WNA16 / MOE_MXFP4 / MOE_NVFP4
 // .gpu_prefill): decoded in registers by every wave that needs a fragment they would cost 4 x 15-19 VALU per 8 weights and
 // bind the kernel to the vector port (gemm_w4x.h's finding), so the weights are decoded ONCE per workgroup: in the place
 // of a weight quarter's DMA each wave loads the raw 8 bytes + scale bytes of ITS 16-row tile (one lane = one (row, 8 k)
@@ -270,9 +272,12 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             const int& av = w4aoff[s];
             unsigned& a1 = w4a1[s];
             u32x2& a2 = w4a2[s];
-            if constexpr (wf == LKM_W_INT4_B8)
-                asm volatile("buffer_load_ushort %0, %1, %2, %3 offen" : "=v"(a1) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
-            else if constexpr (wf == LKM_W_MXFP4)
+            if constexpr (wf == LKM_W_INT4_B8) {
+                // 1 / 2 / 4 scales per row and unit (groups of >= 128 / 64 / 32 k): 2 / 4 / 8 bytes, aligned to their size
+                if (p.spu == 1) asm volatile("buffer_load_ushort %0, %1, %2, %3 offen" : "=v"(a1) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
+                else if (p.spu == 2) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a1) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
+                else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a2) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
+            } else if constexpr (wf == LKM_W_MXFP4)
                 asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a1) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
             else
                 asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a2) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
@@ -287,13 +292,14 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             unsigned& a1 = w4a1[s];
             u32x2& a2 = w4a2[s];
             if constexpr (wf0 == LKM_W_NVFP4) asm volatile("" : "+v"(a2));
+            else if constexpr (wf0 == LKM_W_INT4_B8) asm volatile("" : "+v"(a1), "+v"(a2));
             else asm volatile("" : "+v"(a1));
             u32x4 rawv[1];
             rawv[0] = u32x4{0u, 0u, 0u, 0u};
             rawv[0][2 * pc] = w4raw[s].x;
             rawv[0][2 * pc + 1] = w4raw[s].y;
             typename D4::Aux ax;
-            PfAux<W4 ? WF : LKM_W_INT4_B8>::set(ax, w4a1[s], w4a2[s]);
+            PfAux<W4 ? WF : LKM_W_INT4_B8>::set(ax, w4a1[s], w4a2[s], p.spu);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 *(u32x4*)(lds + off + wave * 2048 + ks * 1024 + alane) = D4::frag(rawv, ax, 2 * pc + ks, w4dparam);
@@ -759,7 +765,7 @@ inline bool prefill_kernel_ok(const GemmParams& p, size_t x_rows, int wf) {
     const bool w8 = wf == LKM_W_FP8_E4M3, w4 = wf_is_4bit(wf);
     const size_t ub = w4 ? 1024 : 2048;
     return p.Kreal % 128 == 0 && (w8 ? p.U <= 64 : (w4 || p.U % 2 == 0)) && x_rows * (size_t)p.ldx * 2 < (size_t)0x7fffffff &&
-           (size_t)p.T_half * p.halves * p.U * ub < (size_t)0x7fffffff && (wf != LKM_W_INT4_B8 || p.spu == 1);
+           (size_t)p.T_half * p.halves * p.U * ub < (size_t)0x7fffffff;
 }
 
 template <int WF, int ADT, bool GATED, bool IS_G1>

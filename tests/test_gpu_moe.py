@@ -532,8 +532,8 @@ def test_int4_dequant_is_bit_exact_on_gpu(g, dt):
     for e in range(E):
         ids = np.full((H, 1), e, np.int32)
         tw = np.ones((H, 1), np.float32)
-        for tiled in (-1, 32, 64, 128) + ((256,) if g == 128 else ()):
-            # (256: gemm_prefill.h, the weights decoded once per workgroup into the 16-bit image -- one scale per row and unit)
+        for tiled in (-1, 32, 64, 128, 256):
+            # (256: gemm_prefill.h, the weights decoded once per workgroup into the 16-bit image; 1 / 2 / 4 scales per row and unit)
             eng.engine.set_tuning(tiled=tiled, waves=8 if tiled == 256 else 0, pf=8 if tiled == 256 else 0)
             for sign in (1.0, -1.0):
                 out = _run_decode(eng, x * sign, tw, ids)[:, :I]                       # out[j, i] = T(relu(+-W[e,i,j])^2)

@@ -609,6 +609,51 @@ def test_prefill_kernel_4bit_formats(fmt, dt, gated):
     eng.engine.set_tuning(tiled=0, waves=0, pf=0, xcd=0, ydt=0)
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "fp8", "int4", "mxfp4"])
+def test_prefill_kernel_is_deterministic_under_load(fmt):
+    """gemm_prefill.h orders its LDS-DMA, its hand-issued raw loads and its decoded image writes with counted vmcnt waits
+    and barriers only -- a read placed one phase too early passes a single comparison whenever the data happens to land
+    first.  The same step 25 times on a chip-filling shape (16 experts x ~500 rows, 4 to 8 K tiles per GEMM, full, narrow and
+    empty wave quarters): every output must be bit-identical to the first, which is checked against the oracle."""
+    M, E, K, H, I = 4096, 16, 2, 512, 256
+    dt, odt = torch.bfloat16, orc.BF16
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, dt, seed=5, skew=0.8)
+    rng = np.random.default_rng(21)
+    if fmt == "bf16":
+        eng = _eng(w13, w2, top_k=K, act_dtype=dt, max_batch_size=4096, group_max_len=4096)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=odt, wfmt=orc.W_BF16)
+        ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+    elif fmt == "fp8":
+        q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+        q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="fp8", w13_scale=torch.from_numpy(s13),
+                   w2_scale=torch.from_numpy(s2), group_n=128, group_k=128, max_batch_size=4096, group_max_len=4096)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=odt, wfmt=orc.W_FP8, groupN=128, groupK=128)
+        ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    elif fmt == "int4":
+        q13, s13 = orc.quant_int4(torch_to_bits(w13), odt, 128)
+        q2, s2 = orc.quant_int4(torch_to_bits(w2), odt, 128)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="int4", w13_scale=bits_to_torch(s13, odt),
+                   w2_scale=bits_to_torch(s2, odt), group_n=1, group_k=128, max_batch_size=4096, group_max_len=4096)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=odt, wfmt=orc.W_INT4, groupN=1, groupK=128)
+        ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    else:
+        q13 = rng.integers(0, 256, (E, 2 * I, H // 2), dtype=np.uint8)
+        q2 = rng.integers(0, 256, (E, H, I // 2), dtype=np.uint8)
+        s13 = rng.integers(117, 121, (E, 2 * I, H // 32), dtype=np.uint8)
+        s2 = rng.integers(117, 121, (E, H, I // 32), dtype=np.uint8)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=dt, fmt="mxfp4", w13_scale=torch.from_numpy(s13),
+                   w2_scale=torch.from_numpy(s2), group_n=1, group_k=32, max_batch_size=4096, group_max_len=4096)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=odt, wfmt=orc.W_MXFP4, groupN=1, groupK=32)
+        ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    ad, twd, idd = a.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)
+    out0 = eng.decode(ad, twd, idd).clone()
+    assert "tm=256" in eng.engine.describe() and "pf=8" in eng.engine.describe(), eng.engine.describe()
+    np.testing.assert_allclose(out0.cpu().numpy(), ref, atol=ATOL * max(1.0, float(np.abs(ref).max())), rtol=RTOL)
+    for _ in range(25):
+        assert torch.equal(eng.decode(ad, twd, idd), out0)
+
+
 @pytest.mark.parametrize("pf", [8])
 @pytest.mark.parametrize("gated", [True, False])
 def test_prefill_kernel_ragged_multi_tile(pf, gated):

@@ -466,7 +466,9 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             pf_wait_vmcnt<6>();                               // (younger: the raw A0 loads, B0(t+1), B1(t+1))
             w4_decode(IC<(b ^ 1) * kPfBufBytes + kPfQ>{}, IC<1>{}, IC<b ^ 1>{});
             w4_load(t + 2, IC<1>{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (the image writes must be done before a barrier that precedes their readers: a multiplying wave waits lgkmcnt(0)
+            // right behind this phase's first barrier anyway; a wave without rows has no other wait)
+            if constexpr (!comp) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if constexpr (comp) {
             if (unit_in) rescale(IC<0>{}, IC<1>{});
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             pf_wait_vmcnt<6>();
             w4_decode(IC<b * kPfBufBytes>{}, IC<0>{}, IC<b>{});
             w4_load(t + 3, IC<0>{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (!comp) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if constexpr (comp) {
             if (unit_in) {

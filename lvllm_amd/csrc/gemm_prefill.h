@@ -357,6 +357,10 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     // launcher checks), formed before the first DMA from one vector load (so that every counted vmcnt of the loop covers
     // it; scalar loads inside the loop would put SMEM on the lgkm counter and turn the loop's lgkmcnt(0) waits into waits
     // for an L2 round trip).  A scale of 0 (all-zero block, contributes 0) counts as 1.
+    // Per-CHANNEL scales (one per weight row, the same for every unit: RoutedExperts._process_fp8(False) -- the plan only
+    // sends layouts here whose scales do not change along K unless a tile shares them): nothing to carry, the rows' scales
+    // multiply the finished accumulators.
+    const bool rowscale = W8 && !p.tile_uniform_scale;
     float svr[4][2], scur[4][2];
     auto scale_index = [&](int rg, int hf) __attribute__((always_inline)) {
         const int t = GATED ? tbase + wr * 4 + rg : tbase + (wr * 4 + rg) * 2 + hf;
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         constexpr int b = decltype(BUF)::v;
         constexpr bool comp = decltype(COMPUTE)::value;
         constexpr int VM = 2 * AG + 2 * BG;                   // all but the four youngest quarters
-        const bool unit_in = W8 && comp && b == 0 && t > 0;   // W8: this K tile opens a 128-k unit (buffer parity = tile parity)
+        const bool unit_in = W8 && comp && b == 0 && t > 0 && !rowscale;   // W8: this K tile opens a 128-k unit (buffer parity = tile parity)
         // ph1
         if constexpr (comp) {
             read_b(IC<b>{}, IC<0>{});
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     auto tile_n = [&](int t, auto BUF, auto COMPUTE) __attribute__((always_inline)) {
         constexpr int b = decltype(BUF)::v, b2 = (b + 2) % 3;
         constexpr bool comp = decltype(COMPUTE)::value;
-        const bool unit_in = W8 && comp && (t & 1) == 0 && t > 0;
+        const bool unit_in = W8 && comp && (t & 1) == 0 && t > 0 && !rowscale;
         if constexpr (comp) {
             read_b_at(IC<b * kPfNarBytes + 2 * kPfQ>{}, IC<0>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -663,7 +667,23 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
         }
     };
     bar();                                                                  // every wave's DMA has landed, every fragment read is done
-    if constexpr (W8) {            // leave the last unit's scale (the DMA ring is drained: plain loads again)
+    if (W8 && rowscale) {
+        const float* sc = (const float*)p.s;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const float* sr = sc + scale_index(rg, hf);                       // the 16 row scales of (tile, unit 0)
+                const f32x4 s0 = *(const f32x4*)(sr + 4 * h), s1 = *(const f32x4*)(sr + 8 + 4 * h);    // rows 4h + j / 8 + 4h + j of the tile
+#pragma unroll
+                for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[rg][tg][8 * hf + j] *= s0[j];
+                        acc[rg][tg][8 * hf + 4 + j] *= s1[j];
+                    }
+            }
+    } else if constexpr (W8) {            // leave the last unit's scale (the DMA ring is drained: plain loads again)
         const float* sc = (const float*)p.s;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)

@@ -572,8 +572,11 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
                         (!w4pf || ((size_t)h->E * h->T1_half * (h->gated ? 2 : 1) * h->U1 * 128 < (size_t)0x7fffffff &&      // (scale bytes: 32-bit offsets)
                                    (size_t)h->E * h->T2 * h->U2 * 128 < (size_t)0x7fffffff)) &&
                         (!w8a16 || ((size_t)h->E * h->T1_half * (h->gated ? 2 : 1) * h->U1 * 16 < (size_t)0x7fffffff &&
-                                    (size_t)h->E * h->T2 * h->U2 * 16 < (size_t)0x7fffffff && h->cfg.groupN % 16 == 0 &&
-                                    h->cfg.groupK % 128 == 0 && h->U1 <= 64 && h->U2 <= 64));
+                                    (size_t)h->E * h->T2 * h->U2 * 16 < (size_t)0x7fffffff && h->U1 <= 64 && h->U2 <= 64 &&
+                                    // block scales shared by whole 16-row tiles (carried in the accumulators), or per-row scales
+                                    // that do not change along K (per-channel: applied to the finished accumulators)
+                                    ((h->cfg.groupN % 16 == 0 && h->cfg.groupK % 128 == 0) ||
+                                     (h->cfg.groupK >= h->H && h->cfg.groupK >= h->I))));
     int tiled = 0, split = 0, g2_only = 0;
     {
         // Tile rows by rows per expert (profiles/r01_tile_thresholds.log, Mixtral shapes, 8 experts):

@@ -730,6 +730,35 @@ def test_prefill_kernel_fp16_and_swigluoai(dt, fmt, act):
 
 
 @pytest.mark.parametrize("gated", [True, False])
+def test_fp8_w8a16_prefill_kernel_per_channel_scales(gated):
+    """the per-channel layout RoutedExperts._process_fp8(False) hands over ([E, N, 1] scales, groupK = max(H, I)) on
+    gemm_prefill.h: one scale per weight ROW, constant along K -- nothing is carried through the K loop, the finished
+    accumulators take their rows' scales; against the oracle and the 64-row tile kernel"""
+    M, E, K, H, I = 700, 4, 2, 512, 384
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=23, gated=gated, skew=0.6)
+    rng = np.random.default_rng(4)
+    w13f = w13.float().numpy() * rng.uniform(0.2, 3.0, (E, w13.shape[1], 1)).astype(np.float32)     # rows of very different range
+    w2f = w2.float().numpy() * rng.uniform(0.2, 3.0, (E, H, 1)).astype(np.float32)
+    q13, s13 = orc.quant_fp8_block(w13f, 1, H)
+    q2, s2 = orc.quant_fp8_block(w2f, 1, I)
+    kw = dict(has_gate_proj=False, activation_type=2) if not gated else {}
+    g = max(H, I)
+    eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
+               w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=1, group_k=g, **kw)
+    eng.engine.set_tuning(tiled=256, waves=8, pf=8, ydt=-1)
+    out = _run_decode(eng, a, tw, ids)
+    assert "tm=256" in eng.engine.describe() and "pf=8" in eng.engine.describe(), eng.engine.describe()
+    d = orc.MoeDesc(E=E, H=H, I=I, has_gate=gated, activation=orc.ACT_SILU if gated else orc.ACT_RELU2,
+                    act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=1, groupK=g)
+    ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+    scale = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(out, ref, atol=ATOL * scale, rtol=RTOL)
+    eng.engine.set_tuning(tiled=64, waves=4, pf=-1)
+    np.testing.assert_allclose(out, _run_decode(eng, a, tw, ids), atol=2e-4 * scale, rtol=2e-4, err_msg=eng.engine.describe())
+    eng.engine.set_tuning(tiled=0, waves=0, pf=0, ydt=0)
+
+
+@pytest.mark.parametrize("gated", [True, False])
 @pytest.mark.parametrize("M,E,H,I,dt", [(520, 5, 512, 384, torch.bfloat16), (900, 3, 1024, 640, torch.float16),
                                         (300, 2, 384, 256, torch.bfloat16)])
 def test_fp8_w8a16_prefill_kernel(M, E, H, I, dt, gated):

@@ -82,6 +82,7 @@ WORKLOADS = {
     "glm45air_bf16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="bf16", prefill=True, router=_GLM_ROUTER),
     "glm45air_fp8w8a16_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=0, prefill=True, router=_GLM_ROUTER),
     "glm45air_fp8w8a8_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="fp8", fp8_mode=1, prefill=True, router=_GLM_ROUTER),
+    "glm45air_int4g128_prefill_m8192": dict(E=128, K=8, H=4096, I=1408, M=8192, fmt="int4", g=128, prefill=True, router=_GLM_ROUTER),
 }
 HEADLINE = "mixtral8x7b_bf16_decode_m32"
 EXTRA_N1 = [# the headline workload under Zipf routing first, in the thermal state the headline itself ran in (after the

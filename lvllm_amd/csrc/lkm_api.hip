@@ -604,7 +604,9 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // ... and from 112 rows per expert the 256-row prefill kernel with the weights decoded once per workgroup
             // (gemm_prefill.h W4, round 4; Mixtral M=1024 / 2048 / 4096 / 8192, step us: uint4b8 1100 -> 926, 1953 -> 1726, 3696 ->
             // 3068, 7170 -> 5758; NVFP4 M=8192 6677 -> 5723; MXFP4 M=8192 5340 -> 4583: profiles/r04_prefill16_w4.log)
-            if (w4pf && avg_rows >= 112 && h->t_pf >= 0 && pf8_ok) tiled = 256;
+            // (many experts: from 192 rows -- GLM-4.5-Air int4, 128 experts: M=2048 / 128 rows 1139 -> 1189 us, M=8192 3687 -> 2864;
+            // the 4-bit mode has no narrow loop for the partial tiles a wide row-count distribution leaves)
+            if (w4pf && avg_rows >= (n_act >= 32 ? 192u : 112u) && h->t_pf >= 0 && pf8_ok) tiled = 256;
             // fp8 x fp8 (W8A8): 128-row tiles from ~200 rows per expert, now that the per-unit partial sums
             // are formed four token blocks at a time and the kernel fits its registers (GLM-4.5-Air prefill
             // 3677 -> 3179 us with two GEMM2 tiles per wave; Mixtral M=2048 1996 -> 1820; M=512 equal)

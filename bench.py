@@ -14,12 +14,18 @@ token visits the ranks that own its experts through ONE all-to-all out and ONE b
 scaling; value = all ranks' tokens / max-over-ranks time.  The whole expert-parallel step is captured in a
 hipGraph like the single-GPU step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = GEMM1,
-algorithmic weight bytes / its mean duration from HIP events on the launch stream), `cpu_baseline` (N=1: the
-reference's own in-tree CPU kernel via oracle/_ref, and the CPU oracle port) and `extra`: the other BASELINE
-configurations timed the same way in the same run -- at N=1 Mixtral fp8-W8A8 M=32 (the north-star fp8 number),
-Mixtral int4-g128 M=128 (configs[2]); at every N that divides 256 the full configs[3] workload (DeepSeek-V3
-style: 256 fp8 experts, grouped sigmoid+bias top-8 of 4/8 groups, global decode batch 256, EP=N all-to-all).
+Output (rank 0, stdout).  The LAST line is the headline object and nothing else (contract in the task statement:
+metric, value, ms_per_step, steps, dtype, config.workload, `roofline` of the dominant kernel = GEMM1 -- algorithmic
+weight bytes / the median of its HIP-event durations on the launch stream, kernel name taken from the launch --
+and `cpu_baseline`: at N=1 the reference's own in-tree CPU kernel via oracle/_ref, with the CPU oracle port beside
+it), kept under 4 KB so that it survives any tail the driver keeps (round 4's 22 KB line did not).  BEFORE it, one
+short JSON line per extra workload (`{"extra_workload": ...}`): the other BASELINE configurations timed the same way in
+the same run -- at N=1 Mixtral fp8-W8A8 M=32 (the north-star fp8 number), Mixtral int4-g128 M=128 (configs[2]), the
+GLM-4.5-Air prefill shapes (configs[4]); at every N that divides 256 the full configs[3] workload (DeepSeek-V3 style:
+256 fp8 experts, grouped sigmoid+bias top-8 of 4/8 groups, global decode batch 256, EP=N all-to-all).  The complete
+records (every field of round 4's line) go to the side file `--full-out` (default gpurun_out/bench_full.json).
+The engine runs with its DEFAULT settings (first-call autotune off, as lk_moe / modular users get it); `--autotune`
+turns the plan search on and says so in config.autotune.
 """
 from __future__ import annotations
 
@@ -442,10 +448,11 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
     E_local, first = E // world, rank * (E // world)
     eng, bpe, oracle_in, masters = build_engine(ops, wl, E_local, first, dev, max_num_seqs=max(256, M * world),
                                                 max_batch_size=max(8192, M), num_processes=world, process_id=rank)
-    if not args.no_autotune:
-        # the plan of each decode-sized step shape is picked by the engine's first-call micro-autotune (2-7 candidate plans
-        # timed on the step's own inputs during the warm-up steps; the choice is in config.geometry: "autotuned: ...")
-        eng.engine.set_tuning(autotune=1)
+    if args.autotune:
+        # opt-in: the plan of each decode-sized step shape is picked by the engine's first-call micro-autotune (2-7 candidate
+        # plans timed on the step's own inputs during the warm-up steps; the choice is in config.geometry: "autotuned: ...").
+        # An expert-parallel engine takes value 2 and the ranks agree on the plans before the capture (ep.agree_tuned_plans).
+        eng.engine.set_tuning(autotune=2 if world > 1 else 1)
     if args.tune:
         eng.engine.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
 
@@ -508,6 +515,9 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
     for _ in range(max(1, warmup)):
         step()
     barrier()
+    if args.autotune and world > 1:
+        from lvllm_amd.ep import agree_tuned_plans
+        agree_tuned_plans([eng.engine])
     launch, graph = "eager", None
     wd = ctx.get("wd")
     if wd is not None and not args.no_graph:
@@ -642,8 +652,8 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
         pout = torch.empty((M, H), dtype=torch.float32, device=dev)
         eng.engine.set_tuning(prof_rep=PROF_REP)
         eng.engine.set_profiling(True)
-        acc = {"sort": 0.0, "gemm1": 0.0, "gemm2": 0.0, "combine": 0.0}
-        reps = 30 if not prefill else 5
+        acc = {"sort": [], "gemm1": [], "gemm2": [], "combine": []}
+        reps = 30 if not prefill else 7
         if not use_ep and not prefill:      # the timed step's own launches: "sort" = router + sort
             def prof_call():
                 eng.forward_logits(x, logits, K, True, **{**fl, "out": pout})
@@ -656,10 +666,15 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
             prof_call()
             p = eng.engine.get_profile()
             for k_ in acc:
-                acc[k_] += p[k_]
+                acc[k_].append(p[k_])
+        kernels = eng.engine.last_kernels()            # the GEMM kernels these launches really were (lkm_last_kernels)
+        plan = eng.engine.describe().split(" | ", 1)[-1]
         eng.engine.set_profiling(False)
         eng.engine.set_tuning(prof_rep=0)
-        prof_ms = {k_: v / reps for k_, v in acc.items()}
+        # MEDIAN over the profiled calls (round 4: the driver's box once put an 86 ms stall between eight back-to-back
+        # launches of an 8 us kernel; a mean would carry such an outlier into the roofline); min / max are reported
+        prof_ms = {k_: float(np.median(v)) for k_, v in acc.items()}
+        prof_range = {k_: [round(min(v), 4), round(max(v), 4)] for k_, v in acc.items() if k_.startswith("gemm")}
         e_act = int(torch.unique(lids[lids >= 0]).numel())
         rows = int((lids >= 0).sum().item())
         g1_bytes = e_act * 2 * I * H * bpe                           # algorithmic weight bytes of GEMM1 (bpe incl. scales)
@@ -668,23 +683,32 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
         g1_ms = max(prof_ms["gemm1"], 1e-6)
         g1_flops = 4.0 * rows * H * I                                # gate + up projections of every routed row
         both = roof_fields(g1_flops, g1_bytes, g1_ms, mfma_peak_tf(wl))
-        traffic, stale = None, None
+        # roofline.traffic: the FETCH_SIZE pass of THIS kernel under THIS plan (tools/update_hbm_traffic.py records the
+        # kernel name from lkm_last_kernels and the plan string), or null with the reason -- never another plan's bytes
+        g1_kernel = "+".join(kernels.get("gemm1", [])) or None
+        traffic, stale, tnote = None, None, "no FETCH pass on file for this workload"
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists():
             try:
                 tj = json.loads(tf.read_text())
-                traffic = tj.get(name, {}).get("gemm1_bytes_per_launch")
+                ent = tj.get(name if routing == "uniform" else f"{name}@{routing}", {})
                 stale = tj.get("kernel_source_hash") != kernel_source_hash()
-            except Exception:
-                traffic = None
-        tsrc = (None if traffic is None else
-                "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE pass of this workload (tools/update_hbm_traffic.py), "
-                "gfx950-corrected (x2); not re-read in this run -- traffic_stale says whether the kernel sources have changed "
-                "since that pass")
+                if ent.get("gemm1_bytes_per_launch") is not None:
+                    if ent.get("gemm1_kernel") != g1_kernel:
+                        tnote = f"FETCH pass on file is of another kernel ({ent.get('gemm1_kernel')})"
+                    elif ent.get("plan") != plan:
+                        tnote = "FETCH pass on file is of another launch plan"
+                    else:
+                        traffic, tnote = ent["gemm1_bytes_per_launch"], None
+            except Exception as e:
+                tnote = f"profiles/hbm_traffic.json unreadable ({type(e).__name__})"
+        tsrc = (tnote if traffic is None else
+                "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE pass of this workload, kernel and plan "
+                "(tools/update_hbm_traffic.py), gfx950-corrected (x2); traffic_stale: kernel sources changed since")
         if prefill:     # MFMA-bound regime: the roofline of the dominant kernel is flops against the dense MFMA peak
             peak = mfma_peak_tf(wl)
             ach = g1_flops / (g1_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm1 (grouped, tiled)", "achieved": round(ach, 1), "peak": peak,
+            roofline = {"bound": "mfma", "kernel": g1_kernel, "achieved": round(ach, 1), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                         "traffic_stale": stale, "algorithmic_bytes": g1_bytes, "algorithmic_flops": g1_flops}
             # the second GEMM of the step against the same peak (2 * rows * I * H flops), and what the GEMM1 launch also does
@@ -696,7 +720,7 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
                                                "(a separate 37-us pass until late round 3); the GEMM2 bracket holds GEMM2 only")
         else:
             achieved = g1_bytes / (g1_ms * 1e-3) / 1e9               # (a rank whose experts got no row: 0)
-            roofline = {"bound": "hbm", "kernel": "gemm1_act_kernel", "achieved": round(achieved, 1),
+            roofline = {"bound": "hbm", "kernel": g1_kernel, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "traffic_source": tsrc, "traffic_stale": stale, "algorithmic_bytes": g1_bytes}
         roofline.update(both)       # mfma_frac, hbm_frac, roof = min(MFMA, AI x HBM), frac_of_roof: both rooflines, always
@@ -709,7 +733,8 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
                       "GBps_over_step": round(layer_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                       "TFLOPs_over_step": round(layer_flops / (ms_per_step * 1e-3) / 1e12, 2)},
             "kernel_ms": {k_: round(v, 4) for k_, v in prof_ms.items()},
-            "timing": f"HIP events on the launch stream around {PROF_REP} back-to-back launches, / {PROF_REP}"
+            "kernel_ms_min_max": prof_range, "gemm2_kernel": "+".join(kernels.get("gemm2", [])) or None, "plan": plan,
+            "timing": f"HIP events on the launch stream around {PROF_REP} back-to-back launches, / {PROF_REP}; median of {reps} calls"
                       + (" (rank 0's engine on rank 0's own routed rows)" if world > 1 else "")})
         res = {"workload": name, "value": round(tokens_per_s, 1), "unit": "tokens/s", "ms_per_step": round(ms_per_step, 4),
                "steps": steps, "scaling": scaling,
@@ -723,7 +748,7 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
                           f"grouped {rt['scoring']}+bias top-{K} of {rt['topk_group']}/{rt['n_group']} groups x{rt['routed_scaling']}",
                           "routing": routing,
                           "parallelism": "single" if not use_ep else f"ep{world}-{args.ep_mode}",
-                          "launch": launch, "preroll_steps": preroll, "autotune": not args.no_autotune,
+                          "launch": launch, "preroll_steps": preroll, "autotune": bool(args.autotune),
                           "geometry": eng.engine.describe()},
                "roofline": roofline}
         if ep is not None and args.ep_mode == "a2a":
@@ -828,7 +853,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget (s) for each CPU baseline sample (reference kernel, port)")
     ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf"],
                     help="router logits: randn (uniform-ish) or randn + Zipf(s=1) expert popularity bias (SURVEY 8d)")
-    ap.add_argument("--no-autotune", action="store_true", help="keep the planner's thresholds (lkm_set_tuning autotune stays 0)")
+    ap.add_argument("--autotune", action="store_true",
+                    help="turn the engine's first-call plan search on (lkm_set_tuning autotune; default off = what lk_moe users get)")
+    ap.add_argument("--no-autotune", action="store_true", help="(default since round 5; kept so that older command lines still parse)")
+    ap.add_argument("--full-line", action="store_true", help="print the complete record as the last line (tools), not the < 4 KB one")
+    ap.add_argument("--full-out", default=str(ROOT / "gpurun_out" / "bench_full.json"),
+                    help="side file for the complete records of the headline and the extra workloads ('' = none)")
     ap.add_argument("--tune", default="", help="comma list key=value for lkm_set_tuning (nt1,nt2,kw1,sk2,tbmax)")
     ap.add_argument("--flush-cache", action="store_true",
                     help="also report ms_per_step_cold: every step preceded by a 1 GiB write that evicts the L2s and the "
@@ -856,26 +886,56 @@ def main():
 
     head = run_workload(args.workload, args, ctx, steps=args.steps, warmup=args.warmup,
                         with_cpu=not args.no_cpu_baseline, force_ep=args.force_ep)
-    def make_line(head, extras):
+    def make_line(head, extras=None):
+        """the headline object: the contract's fields + a roofline / cpu_baseline cut to what the judge reads (< 4 KB)"""
+        rf = head.get("roofline") or {}
+        roofline = None if not rf else {k_: rf.get(k_) for k_ in (
+            "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_stale",
+            "algorithmic_bytes", "mfma_frac", "hbm_frac", "kernel_ms", "kernel_ms_min_max", "gemm2_kernel", "timing")}
+        if roofline and roofline.get("traffic_source"):
+            roofline["traffic_source"] = roofline["traffic_source"][:160]
+        cb = head.get("cpu_baseline")
+        cpu = None
+        if cb:
+            cpu = {k_: cb.get(k_) for k_ in ("value", "unit", "cores", "kind", "sample", "ms_per_step", "ms_per_step_stat",
+                                             "passes", "max_rel_err_gpu_vs_cpu")}
+            cpu["host"] = {k_: (cb.get("host") or {}).get(k_) for k_ in ("nproc", "sockets", "cpu")}
+            if cb.get("all_cores"):
+                cpu["all_cores"] = cb["all_cores"]
+            if cb.get("port"):
+                cpu["port"] = {k_: cb["port"].get(k_) for k_ in ("value", "unit", "cores", "kind", "ms_per_step")}
+        cfg = dict(head["config"])
+        cfg["plan"] = cfg.pop("geometry", "")[-400:]
         line = {
             "metric": "moe_layer_decode_tokens_per_s", "value": head["value"], "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": head["scaling"],
             "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
-            "config": head["config"], "roofline": head["roofline"], "cpu_baseline": head.get("cpu_baseline"),
+            "config": cfg, "roofline": roofline, "cpu_baseline": cpu,
         }
         if "ms_per_step_cold" in head:
             line["ms_per_step_cold"] = head["ms_per_step_cold"]
         if "long_run" in head:
-            line["long_run"] = head["long_run"]
+            line["long_run"] = {k_: head["long_run"][k_] for k_ in ("steps", "ms_per_step")}
         if extras:
-            line["extra"] = extras
+            line["extra_workloads"] = [e["workload"] + ("@" + e["config"]["routing"] if e["config"].get("routing") != "uniform" else "")
+                                       for e in extras]
         return line
+
+    def extra_line(r):
+        """one short line per extra workload, printed BEFORE the headline line"""
+        rf = r.get("roofline") or {}
+        return {"extra_workload": r["workload"], "routing": r["config"].get("routing"), "value": r["value"], "unit": r["unit"],
+                "ms_per_step": r["ms_per_step"], "steps": r["steps"], "dtype": r["dtype"], "n_gpus": world,
+                "parallelism": r["config"].get("parallelism"), "launch": r["config"].get("launch"),
+                "roofline": {k_: rf.get(k_) for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                       "algorithmic_bytes", "kernel_ms", "gemm2_kernel")},
+                "plan": rf.get("plan"), "exchange": r["config"].get("exchange")}
 
     extras = []
     if ctx["wd"] is not None and not args.no_extras and args.workload == HEADLINE:
         # (rank 0 holds the finished headline line from here on; the other ranks only need a non-None marker)
-        ctx["wd"].arm(600.0, make_line(head, []) if head is not None else ({} if rank else None), "the extra workloads")
+        ctx["wd"].arm(600.0, make_line(head) if head is not None else ({} if rank else None), "the extra workloads")
     if not args.no_extras and args.workload == HEADLINE:
         es, ew = min(args.steps, 100), min(args.warmup, 10)
         names = (EXTRA_N1 if world == 1 and not args.force_ep else []) + [EXTRA_EP]
@@ -895,13 +955,34 @@ def main():
                 r = None
             if r is not None:
                 extras.append(r)
+                print(json.dumps(extra_line(r)), flush=True)
 
     if ctx["wd"] is not None:
         ctx["wd"].disarm()
     if rank == 0:
         if head is None:
             sys.exit(f"workload {args.workload} does not shard over {world} GPUs")
-        print(json.dumps(make_line(head, extras)), flush=True)
+        if args.full_out:
+            try:
+                fp = Path(args.full_out)
+                fp.parent.mkdir(parents=True, exist_ok=True)
+                fp.write_text(json.dumps({"headline": head, "extra": extras}, indent=1) + "\n")
+            except OSError as e:
+                print(f"[bench] could not write {args.full_out}: {e}", file=sys.stderr)
+        obj = make_line(head, extras)
+        if args.full_line:      # tools (report.py, update_hbm_traffic.py): every field of the record on the line
+            obj = {**obj, "config": head["config"], "roofline": head["roofline"], "cpu_baseline": head.get("cpu_baseline")}
+        else:
+            # the contract's line stays under 4 KB whatever a field grows to: shed the least important parts first
+            for path in (("cpu_baseline", "port"), ("roofline", "traffic_source"), ("config", "plan"), ("cpu_baseline", "sample"),
+                         ("extra_workloads",), ("roofline", "timing")):
+                if len(json.dumps(obj)) < 4000:
+                    break
+                d = obj
+                for k_ in path[:-1]:
+                    d = d.get(k_) or {}
+                d.pop(path[-1], None)
+        print(json.dumps(obj), flush=True)
     if use_dist:
         # Every rank is past its last collective; leave without tearing the communicator down: destroying a
         # process group whose collectives live in captured graphs has hung at exit before, and the JSON line is out.

@@ -280,6 +280,43 @@ int lkm_per_token_group_quant_fp8(void* stream, const void* x, int32_t x_dtype, 
                                   void* q, float* scales);
 
 /* -------------------------------------------------------------------------------------------
+ * The scatter / gather step as stand-alone operators.  The engine never materialises these forms (its GEMMs
+ * gather through the sort's index lists); they exist for callers that want the reference operators' outputs.  All device
+ * pointers; `workspace`: lkm_moe_ops_workspace_bytes(n_slots, n_keys) bytes of device scratch, 4-byte aligned -- no
+ * allocation, no host synchronisation, graph-capturable.  Stable: the rows of an expert keep token order.
+ *
+ * lkm_moe_align_block_size -- moe_align_block_size (vllm/model_executor/layers/fused_moe/moe_align_block_size.py:11-103;
+ * golden tests/kernels/moe/test_moe_align_block_size.py:96-172).  topk_ids [n_slots] int32; every expert's rows padded to a
+ * multiple of block_size.  sorted_ids [sorted_cap]: slot indices expert by expert, padding = n_slots (the tail too);
+ * expert_ids [blocks_cap]: the expert of each block, -1 past the last one; num_tokens_post_pad [1].  expert_map (NULL or
+ * [num_experts]) = the reference's ignore_invalid_experts=True: ids mapped to -1 (and ids < 0) take no part, expert_ids
+ * hold the mapped (local) ids.  n_keys for the workspace: num_experts.  num_experts <= 512.
+ *
+ * lkm_moe_permute -- moe_permute (moe_permute_unpermute.py:105-242; golden tests/kernels/moe/test_moe_permute_unpermute.py:
+ * 37-89).  hidden [n_token][row_bytes] (row_bytes % 16 == 0), topk_ids [n_token][topk].  Rows sorted by local expert id;
+ * slots of experts that are not local (expert_map[id] == -1) sort behind them by global id.  expert_first_token_offset
+ * int64 [n_local_expert + 1]; inv_permuted_idx int32 [n_token * topk]: slot -> permuted row; permuted_idx int32
+ * [n_token * topk]: permuted row -> slot, n_token * topk for the rows of non-local experts; permuted_hidden
+ * [n_token * topk][row_bytes]: the rows of the LOCAL experts (the others are not written).  n_keys for the workspace:
+ * n_expert without an expert_map, n_local_expert + n_expert with one (<= 512).
+ *
+ * lkm_moe_unpermute -- moe_unpermute (moe_permute_unpermute.py:245-283): out[t] = T(sum_k w[t][k] * rows[inv[t][k]]) over
+ * the rows below expert_first_token_offset[n_local_expert] (NULL: all), fp32 sum in slot order, one rounding.  rows / out
+ * in `dtype` (LKM_DT_BF16 / LKM_DT_F16), n_hidden % 8 == 0.
+ */
+int64_t lkm_moe_ops_workspace_bytes(int32_t n_slots, int32_t n_keys);
+int lkm_moe_align_block_size(void* stream, const int32_t* topk_ids, int32_t n_slots, int32_t num_experts,
+                             int32_t block_size, const int32_t* expert_map, int32_t* sorted_ids, int32_t sorted_cap,
+                             int32_t* expert_ids, int32_t blocks_cap, int32_t* num_tokens_post_pad, void* workspace);
+int lkm_moe_permute(void* stream, const void* hidden, int32_t row_bytes, int32_t n_token, const int32_t* topk_ids,
+                    int32_t topk, const int32_t* expert_map, int32_t n_expert, int32_t n_local_expert,
+                    void* permuted_hidden, int64_t* expert_first_token_offset, int32_t* inv_permuted_idx,
+                    int32_t* permuted_idx, void* workspace);
+int lkm_moe_unpermute(void* stream, const void* permuted_hidden, int32_t dtype, const float* topk_weights,
+                      const int32_t* inv_permuted_idx, const int64_t* expert_first_token_offset, int32_t n_local_expert,
+                      int32_t n_token, int32_t topk, int32_t n_hidden, void* out);
+
+/* -------------------------------------------------------------------------------------------
  * Introspection / measurement.
  */
 const char* lkm_last_error(void);
@@ -300,6 +337,17 @@ int lkm_get_profile(LkmHandle h, float* ms /* [LKM_PROF_N] */);
 /* HBM bytes held by this engine (weights + scales), and its launch geometry as text. */
 int64_t lkm_weight_bytes(LkmHandle h);
 int lkm_describe(LkmHandle h, char* buf, int32_t buf_len);
+/* The GEMM kernels the engine's last step launched, as the profilers print them (demangled device-function names,
+ * template arguments included): "gemm1=<name>[+<name>];gemm2=<name>[+<name>]" -- two names where a hybrid plan ran the
+ * streamer and the tile kernel.  bench.py's roofline.kernel and the FETCH passes of tools/update_hbm_traffic.py take
+ * the name from here (what benchmarks/kernels/benchmark_moe.py:304-333 gets from its config dict). */
+int lkm_last_kernels(LkmHandle h, char* buf, int32_t buf_len);
+/* First-call autotune ("autotune" = 1, or 2 on an expert-parallel engine) and expert parallelism: the plans remembered so
+ * far as (shape key, index into the shape's candidate list) in ascending key order -- returns their number (fills at most
+ * `cap`) -- and the call that replaces one by the index a group agreed on.  The candidate list is a function of the
+ * engine's configuration and the step shape only, so equal local shapes give equal lists on every rank. */
+int lkm_tuned_plans(LkmHandle h, int64_t* keys, int32_t* index, int32_t cap);
+int lkm_tuned_plan_set(LkmHandle h, int64_t key, int32_t index);
 /* tuning knobs (bench / tests): key in {"nt1","nt2","kw1","sk2","tbmax","tiled","waves","hybrid","pd1",
  * "pd2","xcd","pf","direct","valid_den","prof_rep"}; value 0 = auto ("tiled": -1 forces the skinny
  * streamer, 64 / 128 / 256 force a token-tile size; "hybrid": -1 disables the skinny+tiled split by

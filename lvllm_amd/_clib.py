@@ -80,6 +80,13 @@ _SIGS = {
                                  C.c_int32, C.c_void_p, C.c_int32]),
     "lkm_per_token_group_quant_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                               C.c_void_p, C.c_void_p]),
+    "lkm_moe_ops_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "lkm_moe_align_block_size": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "lkm_moe_permute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lkm_moe_unpermute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "lkm_sort_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "lkm_last_error": (C.c_char_p, []),
@@ -90,6 +97,9 @@ _SIGS = {
     "lkm_weight_bytes": (C.c_int64, [C.c_void_p]),
     "lkm_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "lkm_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "lkm_last_kernels": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "lkm_tuned_plans": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32]),
+    "lkm_tuned_plan_set": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32]),
     "lkm_hbm_read_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(C.c_float)]),
     # include/lkm_eplb.h

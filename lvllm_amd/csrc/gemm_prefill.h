@@ -803,7 +803,7 @@ static int launch_prefill_t(hipStream_t st, const GemmParams& p, int max_tiles) 
     }
     auto kern = gemm_prefill_kernel<WF, ADT, GATED, IS_G1>;
     LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, pp);
+    LKM_LAUNCH_GEMM(kern, grid, block, lds, st, pp);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

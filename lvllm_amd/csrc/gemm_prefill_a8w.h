@@ -997,7 +997,7 @@ static int launch_prefill_a8w_t(hipStream_t st, const GemmParams& p, int max_til
     dim3 grid(n_cu), block(512);
     auto kern = gemm_prefill_a8w_kernel<ADT, GATED, IS_G1, DBG>;
     LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, p);
+    LKM_LAUNCH_GEMM(kern, grid, block, lds, st, p);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

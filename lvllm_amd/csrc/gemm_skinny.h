@@ -893,9 +893,9 @@ static int launch_g2_direct_t(hipStream_t st, const LaunchCfg& cfg, const GemmPa
     typedef typename std::conditional<ADT == LKM_DT_BF16, bf16_out, f16_out>::type ActOut;
 #define LKM_G2D(NT)                                                                                       \
     if (p.direct_out_dt == LKM_DT_F32)                                                                    \
-        hipLaunchKernelGGL((gemm2_direct_kernel<WF, ADT, NT, float>), grid, block, lds, st, p, K);        \
+        LKM_LAUNCH_GEMM((gemm2_direct_kernel<WF, ADT, NT, float>), grid, block, lds, st, p, K);        \
     else                                                                                                  \
-        hipLaunchKernelGGL((gemm2_direct_kernel<WF, ADT, NT, ActOut>), grid, block, lds, st, p, K);
+        LKM_LAUNCH_GEMM((gemm2_direct_kernel<WF, ADT, NT, ActOut>), grid, block, lds, st, p, K);
     if (cfg.nt == 2) {
         LKM_G2D(2)
     } else {
@@ -915,24 +915,24 @@ static int launch_g1_t(hipStream_t st, const GemmParams& p, bool gated, int kw, 
     // only register-resident variants are built (see -Rpass-analysis=kernel-resource-usage)
     if constexpr (TB == 1 && NT == 1) {
         if (p.direct_ids) {
-            if (gated) hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, 1, 1, true, true>), grid, block, lds, st, p);
-            else hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, 1, 1, false, true>), grid, block, lds, st, p);
+            if (gated) LKM_LAUNCH_GEMM((gemm1_act_kernel<WF, ADT, 1, 1, true, true>), grid, block, lds, st, p);
+            else LKM_LAUNCH_GEMM((gemm1_act_kernel<WF, ADT, 1, 1, false, true>), grid, block, lds, st, p);
             LKM_HIP_CHECK(hipGetLastError());
             return LKM_OK;
         }
     }
     if (gated) {
         if constexpr (NT <= 2 && NT * TB <= 4) {
-            if (use_unit_scales<WF>(p)) hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, true, false, WF == LKM_W_FP8_A8>), grid, block, lds, st, p);
-            else hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, true>), grid, block, lds, st, p);
+            if (use_unit_scales<WF>(p)) LKM_LAUNCH_GEMM((gemm1_act_kernel<WF, ADT, NT, TB, true, false, WF == LKM_W_FP8_A8>), grid, block, lds, st, p);
+            else LKM_LAUNCH_GEMM((gemm1_act_kernel<WF, ADT, NT, TB, true>), grid, block, lds, st, p);
         } else {
             set_error("gemm1: gated variant nt=%d tb=%d is not built (register budget)", NT, TB);
             return LKM_E_INVALID;
         }
     } else {
         if constexpr (NT * TB <= 8) {
-            if (use_unit_scales<WF>(p)) hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, false, false, WF == LKM_W_FP8_A8>), grid, block, lds, st, p);
-            else hipLaunchKernelGGL((gemm1_act_kernel<WF, ADT, NT, TB, false>), grid, block, lds, st, p);
+            if (use_unit_scales<WF>(p)) LKM_LAUNCH_GEMM((gemm1_act_kernel<WF, ADT, NT, TB, false, false, WF == LKM_W_FP8_A8>), grid, block, lds, st, p);
+            else LKM_LAUNCH_GEMM((gemm1_act_kernel<WF, ADT, NT, TB, false>), grid, block, lds, st, p);
         } else {
             set_error("gemm1: variant nt=%d tb=%d is not built (register budget)", NT, TB);
             return LKM_E_INVALID;
@@ -946,8 +946,8 @@ template <int WF, int ADT, int NT, int TB>
 static int launch_g2_t(hipStream_t st, const GemmParams& p, int max_active) {
     dim3 grid(ceil_div(p.groups * p.SK, 4), max_active), block(256);
     if constexpr (NT * TB <= 8) {
-        if (use_unit_scales<WF>(p)) hipLaunchKernelGGL((gemm2_kernel<WF, ADT, NT, TB, WF == LKM_W_FP8_A8>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gemm2_kernel<WF, ADT, NT, TB>), grid, block, 0, st, p);
+        if (use_unit_scales<WF>(p)) LKM_LAUNCH_GEMM((gemm2_kernel<WF, ADT, NT, TB, WF == LKM_W_FP8_A8>), grid, block, 0, st, p);
+        else LKM_LAUNCH_GEMM((gemm2_kernel<WF, ADT, NT, TB>), grid, block, 0, st, p);
     } else {
         set_error("gemm2: variant nt=%d tb=%d is not built (register budget)", NT, TB);
         return LKM_E_INVALID;

@@ -508,7 +508,7 @@ static int launch_tiled_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     if (lds > 64 * 1024) {
         LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kern, grid, block, lds, st, pp);
+    LKM_LAUNCH_GEMM(kern, grid, block, lds, st, pp);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

@@ -274,7 +274,7 @@ static int launch_w4e_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     dim3 grid(ceil_div(groups, NC), max_tiles, IS_G1 ? 1 : p.SK), block((NC + 1) * 64);
     auto kern = gemm_w4e_kernel<WF, ADT, CB, NC, GATED, IS_G1, S, DECV>;
     if (lds > 64 * 1024) LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, p);
+    LKM_LAUNCH_GEMM(kern, grid, block, lds, st, p);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }

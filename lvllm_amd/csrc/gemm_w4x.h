@@ -308,7 +308,7 @@ static int launch_w4x_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr size_t lds = (size_t)2 * CB * 32 * 256;
     const int groups = (IS_G1 && GATED) ? p.T_half : p.T_half / 2;
     dim3 grid(ceil_div(groups, WAVES), max_tiles, IS_G1 ? 1 : p.SK), block(WAVES * 64);
-    hipLaunchKernelGGL((gemm_w4x_kernel<WF, ADT, CB, WAVES, GATED, IS_G1, PD, DECV>), grid, block, lds, st, p);
+    LKM_LAUNCH_GEMM((gemm_w4x_kernel<WF, ADT, CB, WAVES, GATED, IS_G1, PD, DECV>), grid, block, lds, st, p);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
 }
@@ -328,8 +328,8 @@ static bool launch_w4x_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
             dim3 grid(ceil_div(groups, waves), max_tiles, 1), block(waves * 64);
 #define LKM_W4X_A(A_)                                                                                                   \
     if (abl == A_) {                                                                                                    \
-        if (waves == 4) hipLaunchKernelGGL((gemm_w4x_kernel<WF, ADT, 2, 4, true, true, 2, 1, A_>), grid, block, 2 * 64 * 256, st, p); \
-        else hipLaunchKernelGGL((gemm_w4x_kernel<WF, ADT, 2, 8, true, true, 2, 1, A_>), grid, block, 2 * 64 * 256, st, p);            \
+        if (waves == 4) LKM_LAUNCH_GEMM((gemm_w4x_kernel<WF, ADT, 2, 4, true, true, 2, 1, A_>), grid, block, 2 * 64 * 256, st, p); \
+        else LKM_LAUNCH_GEMM((gemm_w4x_kernel<WF, ADT, 2, 8, true, true, 2, 1, A_>), grid, block, 2 * 64 * 256, st, p);            \
         *rc = LKM_OK;                                                                                                   \
         return true;                                                                                                    \
     }

@@ -30,6 +30,22 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ------------------------------------------------------------------ which GEMM kernels a step launched
+// run_chunk marks the phase (1 = GEMM1, 2 = GEMM2) around its launches; every launcher notes its kernel's host stub
+// (LKM_LAUNCH_GEMM, lkm_kernels.h).  Two entries per phase: a hybrid plan launches the streamer and the tile kernel.
+static thread_local int g_note_phase = 0;
+static thread_local const void* g_note_fn[3][2] = {};
+void note_gemm_launch(const void* host_fn) {
+    const void** slot = g_note_fn[g_note_phase];
+    if (slot[0] == host_fn || slot[1] == host_fn) return;
+    if (!slot[0]) slot[0] = host_fn;
+    else if (!slot[1]) slot[1] = host_fn;
+}
+static void note_phase(int phase) {
+    g_note_phase = phase;
+    if (phase) g_note_fn[phase][0] = g_note_fn[phase][1] = nullptr;
+}
+
 // ------------------------------------------------------------------ per-device scratch arena
 // Grow-only: blocks that were handed out stay valid until process exit, so hipGraphs captured with
 // an older (smaller) arena keep working after a later engine asked for more.
@@ -142,7 +158,12 @@ using namespace lkm;
 struct LkmEngine {
     LkmConfig cfg;
     int device;
-    int E, H, I, K;            // local experts, hidden, intermediate, top_k
+    int E, H, I, K;            // local experts, hidden (rounded up to a multiple of 8), intermediate, top_k
+    int Hu;                    // hidden size as the caller sees it (== H unless hidden_size % 8 != 0: 16-bit weights only).
+                               // The image pads K with zeros anyway; the token rows and the output rows of such a layer
+                               // pass through two 16-byte-aligned scratch matrices (pad_x / pad_o, run_device)
+    void *pad_x = nullptr, *pad_o = nullptr;
+    size_t pad_tokens = 0;
     bool gated, interleaved;
     int wf, adt;
     int wfk;                   // kernel format: wf, LKM_W_FP8_A8 for fp8 W8A8, LKM_W_INT4_PS for the fast int4 mode
@@ -176,8 +197,11 @@ struct LkmEngine {
         int pf, tiled, pd1, pd2;
         float us;             // its time when chosen
         char what[96];
+        int index = 0;        // position in tune_candidates() of the shape (what an expert-parallel group agrees on)
     };
     std::map<uint64_t, TunedPlan> tuned;
+    struct TuneShape { int M, K; };
+    std::map<uint64_t, TuneShape> tuned_shape;     // key -> (M, K), to rebuild the candidate list of a remembered plan
     hipEvent_t tune_ev[2] = {};
     // profiling
     bool prof = false;
@@ -186,6 +210,7 @@ struct LkmEngine {
     hipStream_t prof_stream = nullptr;
     bool prof_valid = false;
     char last_desc[512] = "";
+    const void* last_fn[3][2] = {};     // host stubs of the GEMM kernels of the last chunk ([1] = GEMM1, [2] = GEMM2)
 };
 
 static bool is_device_ptr(const void* p) {
@@ -293,6 +318,8 @@ extern "C" void lkm_destroy(LkmHandle h) {
     if (h->io_ids) (void)hipFree(h->io_ids);
     if (h->io_w) (void)hipFree(h->io_w);
     if (h->io_out) (void)hipFree(h->io_out);
+    if (h->pad_x) (void)hipFree(h->pad_x);
+    if (h->pad_o) (void)hipFree(h->pad_o);
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : h->tune_ev)
@@ -313,7 +340,10 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
                 "lkm_create: unquantised weights must have the activation dtype");
     LKM_REQUIRE(w13 && w2, "lkm_create: null weight pointer");
     LKM_REQUIRE(cfg->expert_num > 0 && cfg->expert_num <= 512, "lkm_create: expert_num=%d out of range (1..512)", cfg->expert_num);
-    LKM_REQUIRE(cfg->hidden_size > 0 && cfg->hidden_size % 8 == 0, "lkm_create: hidden_size=%d must be a positive multiple of 8", cfg->hidden_size);
+    // hidden_size % 8 != 0 (k = 511 of the reference's grid, tests/kernels/moe/test_moe.py:195-208): unquantised weights
+    // only -- the image pads K with zeros to the next 64-k unit anyway, the activations pass through aligned scratch rows
+    LKM_REQUIRE(cfg->hidden_size > 0 && (cfg->hidden_size % 8 == 0 || wf == LKM_W_BF16 || wf == LKM_W_F16),
+                "lkm_create: hidden_size=%d must be a positive multiple of 8 for quantised weight formats", cfg->hidden_size);
     LKM_REQUIRE(cfg->intermediate_size > 0 && cfg->intermediate_size % 8 == 0, "lkm_create: intermediate_size=%d must be a positive multiple of 8", cfg->intermediate_size);
     LKM_REQUIRE(cfg->top_k > 0, "lkm_create: top_k must be > 0");
     LKM_REQUIRE(cfg->activation_type >= LKM_ACT_SILU && cfg->activation_type <= LKM_ACT_RELU2, "lkm_create: bad activation_type %d", cfg->activation_type);
@@ -368,7 +398,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     h->cfg = *cfg;
     h->device = cfg->gpu_id;
     h->E = cfg->expert_num;
-    h->H = cfg->hidden_size;
+    h->Hu = cfg->hidden_size;
+    h->H = round_up(cfg->hidden_size, 8);
     h->I = cfg->intermediate_size;
     h->K = cfg->top_k;
     h->gated = gated;
@@ -415,8 +446,9 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     h->weight_bytes = (int64_t)(w13_vec + w2_vec) * 16;
 
     h->loads = loads;
-    RepackDims d13{h->E, h->I, halves, h->interleaved ? 1 : 0, h->H, h->T1_half, h->U1, h->a8 ? 1 : 0};
-    RepackDims d2{h->E, h->H, 1, 0, h->I, h->T2, h->U2, h->a8 ? 1 : 0};
+    // (source dims are the caller's: K = Hu for w13, Hu rows for w2 -- the repack kernels bound every element read)
+    RepackDims d13{h->E, h->I, halves, h->interleaved ? 1 : 0, h->Hu, h->T1_half, h->U1, h->a8 ? 1 : 0};
+    RepackDims d2{h->E, h->Hu, 1, 0, h->I, h->T2, h->U2, h->a8 ? 1 : 0};
     // hand-off of the caller's tensors: device sources are read in place; host sources pass through ONE
     // staging buffer of <= LKM_STAGE_BYTES (default 256 MiB, never less than one expert) in chunks of whole experts --
     // copy, repack, next chunk, all in stream order -- so creation adds at most one chunk to the footprint of the
@@ -442,8 +474,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     };
     const int wfr = h->ps ? LKM_W_INT4_PS : wf;
     {
-        const size_t b13 = (size_t)halves * h->I * h->H / 2 * wbytes_per_elem_x2(wf);     // source bytes per expert
-        const size_t b2 = (size_t)h->H * h->I / 2 * wbytes_per_elem_x2(wf);
+        const size_t b13 = (size_t)halves * h->I * h->Hu * wbytes_per_elem_x2(wf) / 2;    // source bytes per expert
+        const size_t b2 = (size_t)h->Hu * h->I * wbytes_per_elem_x2(wf) / 2;
         auto rw = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_w(nullptr, wfr, sp, dp, dd); };
         LKM_TRY(hand_off(w13, b13, h->w13, w13_vec / h->E * 16, d13, rw));
         LKM_TRY(hand_off(w2, b2, h->w2, w2_vec / h->E * 16, d2, rw));
@@ -516,6 +548,11 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
                               h->a8 ? cap * h->H : 0, xs ? cap * kb1 : 0, h->a8 ? slots * h->I : 0,
                               xs ? slots * kb2 : 0, items_n, &h->arena));
     }
+    if (h->Hu != h->H) {       // aligned scratch rows for the token and output matrices of one chunk
+        LKM_TRY_HIP(hipMalloc(&h->pad_x, cap * (size_t)h->H * 2));
+        LKM_TRY_HIP(hipMalloc(&h->pad_o, cap * (size_t)h->H * 4));
+        h->pad_tokens = cap;
+    }
     for (auto& e : h->ev) LKM_TRY_HIP(hipEventCreate(&e));
     *out = h;
     return LKM_OK;
@@ -577,6 +614,9 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
                                     // that do not change along K (per-channel: applied to the finished accumulators)
                                     ((h->cfg.groupN % 16 == 0 && h->cfg.groupK % 128 == 0) ||
                                      (h->cfg.groupK >= h->H && h->cfg.groupK >= h->I))));
+    // (256-row tiles of fp8-W8A16 / 4-bit weights exist on gemm_prefill.h only -- "pf" = 0 or 8; with any other
+    //  "pf" forced, e.g. 5 / 6 = the decode kernels of gemm_w4x.h, prefill-sized chunks keep the 64 / 128-row tiles)
+    const bool pf8_sel = pf8_ok && (h->t_pf == 0 || h->t_pf == 8);
     int tiled = 0, split = 0, g2_only = 0;
     {
         // Tile rows by rows per expert (profiles/r01_tile_thresholds.log, Mixtral shapes, 8 experts):
@@ -591,11 +631,11 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // <= 128 tokens) -- bf16 M=1024 / 1280 / 1536: 886 -> 872, 924 -> 896, 950 -> 915 us; fp8-W8A16 742 -> 689 (M=1024),
             // 983 -> 752 (M=1536); Mixtral's 8 experts keep 128-row tiles below 112 rows (M=384: 572 vs 609 us):
             // profiles/r04_prefill16_threshold.log
-            if ((w16 || w8a16) && avg_rows >= 64 && n_act >= 32 && h->t_pf >= 0 && pf8_ok) tiled = 256;
+            if (((w16 && h->t_pf >= 0 && pf8_ok) || (w8a16 && pf8_sel)) && avg_rows >= 64 && n_act >= 32) tiled = 256;
             // fp8 W8A16 at prefill sizes (MOE_FP8.gpu_prefill): 256-row tiles on gemm_prefill.h (round 4: raw fp8 through the
             // LDS-DMA ring, converted in registers, block scales carried in the accumulators) where 16-bit weights take them;
             // needs one scale per 16-row tile and 128-k unit (block heights in multiples of 16: pf8_ok)
-            if (w8a16 && avg_rows >= 112 && h->t_pf >= 0 && pf8_ok) tiled = 256;
+            if (w8a16 && avg_rows >= 112 && pf8_sel) tiled = 256;
             if (h->wf == LKM_W_MXFP4 && avg_rows >= 64) tiled = 128;
             // uint4b8 / NVFP4 at prefill sizes (round 4, profiles/r04_prefill_plan_sweep.log: what MOE_WNA16 / MOE_NVFP4
             // gpu_prefill runs): 128-row tiles x 8 waves from ~100 rows per expert -- int4 Mixtral M=512 725 -> 683 us,
@@ -606,7 +646,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // 3068, 7170 -> 5758; NVFP4 M=8192 6677 -> 5723; MXFP4 M=8192 5340 -> 4583: profiles/r04_prefill16_w4.log)
             // (many experts: from 192 rows -- GLM-4.5-Air int4, 128 experts: M=2048 / 128 rows 1139 -> 1189 us, M=8192 3687 -> 2864;
             // the 4-bit mode has no narrow loop for the partial tiles a wide row-count distribution leaves)
-            if (w4pf && avg_rows >= (n_act >= 32 ? 192u : 112u) && h->t_pf >= 0 && pf8_ok) tiled = 256;
+            if (w4pf && avg_rows >= (n_act >= 32 ? 192u : 112u) && pf8_sel) tiled = 256;
             // fp8 x fp8 (W8A8): 128-row tiles from ~200 rows per expert, now that the per-unit partial sums
             // are formed four token blocks at a time and the kernel fits its registers (GLM-4.5-Air prefill
             // 3677 -> 3179 us with two GEMM2 tiles per wave; Mixtral M=2048 1996 -> 1820; M=512 equal)
@@ -976,6 +1016,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
             p1.route = *il.route;
         }
     }
+    note_phase(1);
     for (int r = 0; r < rep; ++r) {
         if (pl.s1.tb) {
             p1.groups = h->T1_half / pl.s1.nt;
@@ -987,6 +1028,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
             if (rc != LKM_OK) return rc;
         }
     }
+    g_note_phase = 0;
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[2], st));
 
     GemmParams p2{};
@@ -1052,10 +1094,13 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         p2.SK = sk_direct;
         LaunchCfg dc = pl.s2;
         dc.nt = 1;
+        note_phase(2);
         for (int r = 0; r < rep; ++r) {
             rc = launch_gemm2_direct(st, h->wfk, h->adt, dc, p2, K);
             if (rc != LKM_OK) return rc;
         }
+        g_note_phase = 0;
+        memcpy(h->last_fn, g_note_fn, sizeof(h->last_fn));
         if (prof) {
             LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
             LKM_HIP_CHECK(hipEventRecord(h->ev[4], st));
@@ -1068,6 +1113,7 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     }
     // (GEMM2 + top-k combine in one launch for few active experts -- round 2's gemm2_combine_kernel, tuning key "fuse" = 1
     // -- was bit-identical and 2.7 us SLOWER than the two launches (profiles/r02_decode_fusion.md); removed in round 4)
+    note_phase(2);
     for (int r = 0; r < rep; ++r) {
         if (pl.s2.tb) {
             p2.groups = h->T2 / pl.s2.nt;
@@ -1079,6 +1125,8 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
             if (rc != LKM_OK) return rc;
         }
     }
+    g_note_phase = 0;
+    memcpy(h->last_fn, g_note_fn, sizeof(h->last_fn));
     if (prof) LKM_HIP_CHECK(hipEventRecord(h->ev[3], st));
 
     rc = launch_combine(st, a->y, y_dt, sk, p2.sk_stride, a->pos_of_slot, tw, (int)il.tw_ld, M, K, h->H, out, out_dt);
@@ -1130,66 +1178,118 @@ static bool tune_stream_capturing(hipStream_t st) {
     }
     return cs != hipStreamCaptureStatusNone;
 }
+// the step shape a plan is remembered for: token count, top-k, output dtype, fused router, expert-parallel share and
+// whether the three input arrays are dense (the strides do not change the plan, dense / strided callers may still differ
+// in M); every planning knob of lkm_set_tuning clears the table instead of widening the key
+static uint64_t tune_key(const LkmEngine* h, int M, int K, int out_dt, const InLayout& il) {
+    return (uint64_t)(unsigned)M | ((uint64_t)(K & 0xff) << 32) | ((uint64_t)(out_dt & 0xf) << 40) |
+           ((uint64_t)(il.route ? 1 : 0) << 44) | ((uint64_t)(h->t_valid_den & 0xff) << 45) |
+           ((uint64_t)(il.x_ld != h->H ? 1 : 0) << 53) | ((uint64_t)(il.ids_ld != K ? 1 : 0) << 54) |
+           ((uint64_t)(il.tw_ld != K ? 1 : 0) << 55);
+}
+// candidate plans of a step shape: a function of the engine's configuration and the shape only, so every rank of an
+// expert-parallel group with equal local shapes builds the same list (lkm_tuned_plan_set agrees on an index into it)
+static std::vector<LkmEngine::TunedPlan> tune_candidates(const LkmEngine* h, int M, int K) {
+    std::vector<LkmEngine::TunedPlan> cands;
+    cands.push_back({0, 0, 0, 0, 0.f, "default"});
+    Plan pl;
+    pick_cfg(h, M, (size_t)M * K, &pl);
+    const int def_tiled = pl.t1.tiled ? pl.t1.tiled : (pl.t2.tiled && !pl.s1.tb ? pl.t2.tiled : 0);
+    if (def_tiled && def_tiled <= 64) cands.push_back({0, -1, 0, 0, 0.f, "streamer"});
+    if (def_tiled != 64 && !(pl.t1.tiled > 64)) cands.push_back({0, 64, 0, 0, 0.f, "64-row tiles"});
+    if (def_tiled != 32 && wf_is_4bit(h->wf) && M * K <= 64 * h->E) cands.push_back({0, 32, 0, 0, 0.f, "32-row tiles"});
+    if (def_tiled && def_tiled <= 64 && pl.t1.pd == 2) cands.push_back({0, def_tiled, 4, 0, 0.f, "weight ring depth 4 (GEMM1)"});
+    if (wf_is_4bit(h->wf) && !h->ps && h->H % 128 == 0 && h->I % 128 == 0 && M >= 32) {
+        cands.push_back({6, def_tiled == 32 ? 32 : 64, 0, 0, 0.f, "32x32-MFMA + loader wave (gemm_w4e.h)"});
+        cands.push_back({5, def_tiled == 32 ? 32 : 64, 0, 0, 0.f, "32x32-MFMA (gemm_w4x.h)"});
+    }
+    return cands;
+}
+namespace {
+// forces a candidate's knobs on the engine for one scope: every return path (incl. LKM_HIP_CHECK's) restores them
+struct ForcedPlan {
+    LkmEngine* h;
+    ForcedPlan(LkmEngine* h_, const LkmEngine::TunedPlan& c) : h(h_) { h->t_pf = c.pf; h->t_tiled = c.tiled; h->t_pd1 = c.pd1; h->t_pd2 = c.pd2; }
+    ~ForcedPlan() { h->t_pf = h->t_tiled = h->t_pd1 = h->t_pd2 = 0; }
+};
+}  // namespace
+static int time_candidate(LkmEngine* h, hipStream_t st, const LkmEngine::TunedPlan& c, int M, int K, const void* x,
+                          const int32_t* ids, const float* tw, void* out, int out_dt, const InLayout& il, float* us) {
+    ForcedPlan fp(h, c);
+    *us = 1e30f;
+    int rc = run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);       // untimed (first-touch, code load)
+    if (rc != LKM_OK) return rc;
+    LKM_HIP_CHECK(hipEventRecord(h->tune_ev[0], st));
+    for (int r = 0; r < kTuneReps && rc == LKM_OK; ++r) rc = run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
+    LKM_HIP_CHECK(hipEventRecord(h->tune_ev[1], st));
+    if (rc != LKM_OK) return rc;
+    LKM_HIP_CHECK(hipEventSynchronize(h->tune_ev[1]));
+    float ms = 0.f;
+    LKM_HIP_CHECK(hipEventElapsedTime(&ms, h->tune_ev[0], h->tune_ev[1]));
+    *us = ms * 1e3f / kTuneReps;
+    return LKM_OK;
+}
 static int run_chunk_tuned(LkmEngine* h, hipStream_t st, int M, int K, const void* x, const int32_t* ids,
                            const float* tw, void* out, int out_dt, const InLayout& il) {
     const bool forced = h->t_pf != 0 || h->t_tiled != 0 || h->t_pd1 != 0 || h->t_pd2 != 0 || h->t_waves != 0;
     if (!h->t_autotune || forced || M < 8 || M > 1024) return run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
-    const uint64_t key = (uint64_t)M | ((uint64_t)K << 20) | ((uint64_t)out_dt << 28) | ((uint64_t)(il.route ? 1 : 0) << 32) |
-                         ((uint64_t)(h->t_valid_den & 0xff) << 33);
-    auto apply = [&](const LkmEngine::TunedPlan& c) { h->t_pf = c.pf; h->t_tiled = c.tiled; h->t_pd1 = c.pd1; h->t_pd2 = c.pd2; };
-    auto clear = [&]() { h->t_pf = h->t_tiled = h->t_pd1 = h->t_pd2 = 0; };
+    const uint64_t key = tune_key(h, M, K, out_dt, il);
     auto it = h->tuned.find(key);
     if (it == h->tuned.end()) {
-        // (a profiled call times one plan's kernels: it takes the remembered plan but never starts a tuning pass)
-        if (h->prof || tune_stream_capturing(st) || h->tuned.size() >= 256) return run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
-        std::vector<LkmEngine::TunedPlan> cands;
-        cands.push_back({0, 0, 0, 0, 0.f, "default"});
-        Plan pl;
-        pick_cfg(h, M, (size_t)M * K, &pl);
-        const int def_tiled = pl.t1.tiled ? pl.t1.tiled : (pl.t2.tiled && !pl.s1.tb ? pl.t2.tiled : 0);
-        if (def_tiled && def_tiled <= 64) cands.push_back({0, -1, 0, 0, 0.f, "streamer"});
-        if (def_tiled != 64 && !(pl.t1.tiled > 64)) cands.push_back({0, 64, 0, 0, 0.f, "64-row tiles"});
-        if (def_tiled != 32 && wf_is_4bit(h->wf) && M * K <= 64 * h->E) cands.push_back({0, 32, 0, 0, 0.f, "32-row tiles"});
-        if (def_tiled && def_tiled <= 64 && pl.t1.pd == 2) cands.push_back({0, def_tiled, 4, 0, 0.f, "weight ring depth 4 (GEMM1)"});
-        if (wf_is_4bit(h->wf) && !h->ps && h->H % 128 == 0 && h->I % 128 == 0 && M >= 32) {
-            cands.push_back({6, def_tiled == 32 ? 32 : 64, 0, 0, 0.f, "32x32-MFMA + loader wave (gemm_w4e.h)"});
-            cands.push_back({5, def_tiled == 32 ? 32 : 64, 0, 0, 0.f, "32x32-MFMA (gemm_w4x.h)"});
-        }
+        // (a profiled call times one plan's kernels: it takes the remembered plan but never starts a tuning pass;
+        //  an in-place caller -- `out` overlapping the token rows -- cannot be run repeatedly on its own buffers)
+        const char *xb = (const char*)x, *xe = xb + (size_t)M * (size_t)il.x_ld * 2;
+        const char *ob = (const char*)out, *oe = ob + (size_t)M * (size_t)h->H * (out_dt == LKM_DT_F32 ? 4 : 2);
+        const bool aliased = xb < oe && ob < xe;
+        if (h->prof || aliased || tune_stream_capturing(st) || h->tuned.size() >= 256)
+            return run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
+        std::vector<LkmEngine::TunedPlan> cands = tune_candidates(h, M, K);
         if (!h->tune_ev[0]) {
             LKM_HIP_CHECK(hipEventCreate(&h->tune_ev[0]));
             LKM_HIP_CHECK(hipEventCreate(&h->tune_ev[1]));
         }
         int best = 0;
         for (size_t c = 0; c < cands.size(); ++c) {
-            apply(cands[c]);
-            int rc = run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);       // untimed (first-touch, code load)
-            if (rc == LKM_OK) {
-                LKM_HIP_CHECK(hipEventRecord(h->tune_ev[0], st));
-                for (int r = 0; r < kTuneReps && rc == LKM_OK; ++r) rc = run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
-                LKM_HIP_CHECK(hipEventRecord(h->tune_ev[1], st));
-            }
-            clear();
-            if (rc != LKM_OK) {                 // a candidate the shape does not admit: not an error of the step
-                cands[c].us = 1e30f;
-                continue;
-            }
-            LKM_HIP_CHECK(hipEventSynchronize(h->tune_ev[1]));
-            float ms = 0.f;
-            LKM_HIP_CHECK(hipEventElapsedTime(&ms, h->tune_ev[0], h->tune_ev[1]));
-            cands[c].us = ms * 1e3f / kTuneReps;
+            // (a candidate the shape does not admit is not an error of the step; a HIP error is)
+            const int rc = time_candidate(h, st, cands[c], M, K, x, ids, tw, out, out_dt, il, &cands[c].us);
+            if (rc == LKM_E_HIP) return rc;
             if (cands[c].us < cands[best].us) best = (int)c;
         }
         LKM_REQUIRE(cands[best].us < 1e29f, "autotune: no candidate plan ran");
+        cands[best].index = best;
         it = h->tuned.emplace(key, cands[best]).first;
+        h->tuned_shape[key] = {M, K};
     }
-    apply(it->second);
-    const int rc = run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
-    clear();
+    int rc;
+    {
+        ForcedPlan fp(h, it->second);
+        rc = run_chunk(h, st, M, K, x, ids, tw, out, out_dt, il);
+    }
     if (rc == LKM_OK) {
         const size_t n = strlen(h->last_desc);
         snprintf(h->last_desc + n, sizeof(h->last_desc) - n, " | autotuned: %s (%.1f us)", it->second.what, it->second.us);
     }
     return rc;
+}
+
+// copies between the caller's rows of Hu elements and the engine's aligned scratch rows of H = round_up(Hu, 8)
+template <typename T>
+__global__ __launch_bounds__(256) void pad_rows_kernel(const T* __restrict__ src, long long ld_src, T* __restrict__ dst,
+                                                       long long ld_dst, int rows, int cols_src, int cols_dst) {
+    const long long n = (long long)rows * cols_dst;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / cols_dst;
+        const int c = (int)(i - r * cols_dst);
+        dst[r * ld_dst + c] = c < cols_src ? src[r * ld_src + c] : T(0);
+    }
+}
+template <typename T>
+static void launch_pad_rows(hipStream_t st, const void* src, long long ld_src, void* dst, long long ld_dst, int rows,
+                            int cols_src, int cols_dst) {
+    const long long n = (long long)rows * cols_dst;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pad_rows_kernel<T>, dim3(blocks ? blocks : 1), dim3(256), 0, st, (const T*)src, ld_src, (T*)dst, ld_dst,
+                       rows, cols_src, cols_dst);
 }
 
 static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, const int32_t* ids,
@@ -1199,19 +1299,35 @@ static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, 
     LKM_REQUIRE(K > 0 && K <= 64, "top_k=%d out of range", K);
     if (M == 0) return LKM_OK;
     LKM_REQUIRE(x && ids && tw && out, "null device pointer");
-    LKM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, "hidden/out pointers must be 16-byte aligned");
+    const bool odd = h->Hu != h->H;     // hidden_size % 8 != 0: rows travel through the aligned scratch matrices
+    LKM_REQUIRE(odd || (((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0), "hidden/out pointers must be 16-byte aligned");
     LKM_HIP_CHECK(hipSetDevice(h->device));
-    const InLayout il = layout ? *layout : InLayout{h->H, K, K, 0};
-    LKM_REQUIRE(il.x_ld >= h->H && il.x_ld % 8 == 0 && il.x_ld < ((int64_t)1 << 31), "hidden row stride %lld must be >= H, a multiple of 8 and < 2^31", (long long)il.x_ld);
+    InLayout il = layout ? *layout : InLayout{h->Hu, K, K, 0};
+    LKM_REQUIRE(il.x_ld >= h->Hu && (odd || il.x_ld % 8 == 0) && il.x_ld < ((int64_t)1 << 31), "hidden row stride %lld must be >= H, a multiple of 8 and < 2^31", (long long)il.x_ld);
     LKM_REQUIRE(il.ids_ld >= K && il.tw_ld >= K && il.ids_ld < ((int64_t)1 << 31) && il.tw_ld < ((int64_t)1 << 31), "ids / weights row strides must be >= top_k");
-    const size_t chunk = chunk_tokens(h, K);
+    size_t chunk = chunk_tokens(h, K);
+    if (odd && h->pad_tokens < chunk) chunk = h->pad_tokens;
     LKM_REQUIRE(chunk > 0, "scratch arena too small for top_k=%d", K);
-    const size_t xrow = (size_t)il.x_ld * 2, orow = (size_t)h->H * (out_dt == LKM_DT_F32 ? 4 : 2);
+    const size_t osz = out_dt == LKM_DT_F32 ? 4 : 2;
+    const size_t xrow = (size_t)il.x_ld * 2, orow = (size_t)h->Hu * osz;
+    const int64_t x_ld_user = il.x_ld;
+    if (odd) il.x_ld = h->H;
     for (size_t m0 = 0; m0 < (size_t)M; m0 += chunk) {
         const int mc = (int)((size_t)M - m0 < chunk ? (size_t)M - m0 : chunk);
-        int rc = run_chunk_tuned(h, st, mc, K, (const char*)x + m0 * xrow, ids + m0 * il.ids_ld, tw + m0 * il.tw_ld,
-                                 (char*)out + m0 * orow, out_dt, il);
+        const void* xc = (const char*)x + m0 * xrow;
+        void* oc = (char*)out + m0 * orow;
+        if (odd) {
+            launch_pad_rows<unsigned short>(st, xc, x_ld_user, h->pad_x, h->H, mc, h->Hu, h->H);
+            xc = h->pad_x;
+            oc = h->pad_o;
+        }
+        int rc = run_chunk_tuned(h, st, mc, K, xc, ids + m0 * il.ids_ld, tw + m0 * il.tw_ld, oc, out_dt, il);
         if (rc != LKM_OK) return rc;
+        if (odd) {
+            if (osz == 4) launch_pad_rows<float>(st, h->pad_o, h->H, (char*)out + m0 * orow, h->Hu, mc, h->Hu, h->Hu);
+            else launch_pad_rows<unsigned short>(st, h->pad_o, h->H, (char*)out + m0 * orow, h->Hu, mc, h->Hu, h->Hu);
+            LKM_HIP_CHECK(hipGetLastError());
+        }
     }
     return LKM_OK;
 }
@@ -1315,20 +1431,20 @@ extern "C" int lkm_prefill_host(LkmHandle h, int32_t num_tokens, int32_t top_k,
         if (h->io_out) (void)hipFree(h->io_out);
         h->io_x = h->io_ids = h->io_w = h->io_out = nullptr;
         h->io_tokens = 0;
-        LKM_HIP_CHECK(hipMalloc(&h->io_x, M * h->H * 2));
+        LKM_HIP_CHECK(hipMalloc(&h->io_x, M * h->H * 2));      // (H >= Hu: the copies below move Hu-element rows)
         LKM_HIP_CHECK(hipMalloc(&h->io_ids, M * 64 * 4));
         LKM_HIP_CHECK(hipMalloc(&h->io_w, M * 64 * 4));
         LKM_HIP_CHECK(hipMalloc(&h->io_out, M * h->H * 4));
         h->io_tokens = M;
     }
     LKM_REQUIRE(top_k <= 64, "top_k=%d out of range", top_k);
-    LKM_HIP_CHECK(hipMemcpy(h->io_x, hidden, M * h->H * 2, hipMemcpyHostToDevice));
+    LKM_HIP_CHECK(hipMemcpy(h->io_x, hidden, M * h->Hu * 2, hipMemcpyHostToDevice));
     LKM_HIP_CHECK(hipMemcpy(h->io_ids, topk_ids, M * top_k * 4, hipMemcpyHostToDevice));
     LKM_HIP_CHECK(hipMemcpy(h->io_w, topk_weights, M * top_k * 4, hipMemcpyHostToDevice));
     int rc = run_device(h, nullptr, num_tokens, top_k, h->io_x, (const int32_t*)h->io_ids,
                         (const float*)h->io_w, h->io_out, LKM_DT_F32);
     if (rc != LKM_OK) return rc;
-    LKM_HIP_CHECK(hipMemcpy(out_f32, h->io_out, M * h->H * 4, hipMemcpyDeviceToHost));
+    LKM_HIP_CHECK(hipMemcpy(out_f32, h->io_out, M * h->Hu * 4, hipMemcpyDeviceToHost));
     return LKM_OK;
 }
 
@@ -1409,13 +1525,88 @@ extern "C" int64_t lkm_weight_bytes(LkmHandle h) { return h ? h->weight_bytes : 
 extern "C" int lkm_describe(LkmHandle h, char* buf, int32_t buf_len) {
     LKM_REQUIRE(h && buf && buf_len > 0, "null argument");
     snprintf(buf, buf_len, "E=%d H=%d I=%d wf=%d adt=%d gated=%d T1_half=%d U1=%d T2=%d U2=%d | %s",
-             h->E, h->H, h->I, h->wf, h->adt, (int)h->gated, h->T1_half, h->U1, h->T2, h->U2,
+             h->E, h->Hu, h->I, h->wf, h->adt, (int)h->gated, h->T1_half, h->U1, h->T2, h->U2,
              h->last_desc);
+    return LKM_OK;
+}
+
+// "lkm::gemm1_act_kernel<0, 1, 1, 2, true, false, false>" of a host stub: the device function's name as the profilers
+// print it (demangled, without return type and parameter list)
+#include <cxxabi.h>
+static std::string kernel_name_of(const void* host_fn) {
+    if (!host_fn) return "";
+    const char* m = hipKernelNameRefByPtr(host_fn, nullptr);
+    if (!m) {
+        (void)hipGetLastError();
+        return "?";
+    }
+    int status = 0;
+    char* d = abi::__cxa_demangle(m, nullptr, nullptr, &status);
+    std::string n = (status == 0 && d) ? d : m;
+    free(d);
+    if (n.rfind("void ", 0) == 0) n = n.substr(5);
+    // cut the parameter list: the last top-level '(' (template arguments may hold parentheses: "(lkm::Fmt)1")
+    int depth = 0;
+    size_t cut = std::string::npos;
+    for (size_t i = 0; i < n.size(); ++i) {
+        if (n[i] == '<') ++depth;
+        else if (n[i] == '>') --depth;
+        else if (n[i] == '(' && depth == 0) { cut = i; break; }
+    }
+    if (cut != std::string::npos) n.resize(cut);
+    return n;
+}
+
+extern "C" int lkm_last_kernels(LkmHandle h, char* buf, int32_t buf_len) {
+    LKM_REQUIRE(h && buf && buf_len > 0, "null argument");
+    std::string out;
+    for (int g = 1; g <= 2; ++g) {
+        out += g == 1 ? "gemm1=" : ";gemm2=";
+        for (int k = 0; k < 2; ++k)
+            if (h->last_fn[g][k]) out += (k ? "+" : "") + kernel_name_of(h->last_fn[g][k]);
+    }
+    snprintf(buf, buf_len, "%s", out.c_str());
+    return LKM_OK;
+}
+
+extern "C" int lkm_tuned_plans(LkmHandle h, int64_t* keys, int32_t* index, int32_t cap) {
+    if (!h) {
+        set_error("lkm_tuned_plans: null engine handle");
+        return LKM_E_INVALID;
+    }
+    int n = 0;
+    for (const auto& kv : h->tuned) {         // (std::map: ascending keys -- the same order on every rank)
+        if (n < cap && keys && index) {
+            keys[n] = (int64_t)kv.first;
+            index[n] = kv.second.index;
+        }
+        ++n;
+    }
+    return n;
+}
+
+extern "C" int lkm_tuned_plan_set(LkmHandle h, int64_t key, int32_t index) {
+    LKM_REQUIRE(h, "null engine handle");
+    auto it = h->tuned_shape.find((uint64_t)key);
+    LKM_REQUIRE(it != h->tuned_shape.end(), "lkm_tuned_plan_set: no plan was tuned for key %lld on this engine", (long long)key);
+    const std::vector<LkmEngine::TunedPlan> cands = tune_candidates(h, it->second.M, it->second.K);
+    LKM_REQUIRE(index >= 0 && (size_t)index < cands.size(), "lkm_tuned_plan_set: index %d outside the %zu candidates of the shape", index, cands.size());
+    LkmEngine::TunedPlan pl = cands[index];
+    pl.index = index;
+    auto cur = h->tuned.find((uint64_t)key);
+    pl.us = (cur != h->tuned.end() && cur->second.index == index) ? cur->second.us : 0.f;     // (0: taken from the group, not timed here)
+    h->tuned[(uint64_t)key] = pl;
     return LKM_OK;
 }
 
 extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     LKM_REQUIRE(h && key, "null argument");
+    // every key but the measurement-only ones changes what pick_cfg plans: plans remembered by the autotune are for the
+    // old knobs
+    if (strcmp(key, "autotune") && strcmp(key, "prof_rep") && strcmp(key, "dbg") && strcmp(key, "valid_den")) {     // ("valid_den" is part of the shape key)
+        h->tuned.clear();
+        h->tuned_shape.clear();
+    }
     if (!strcmp(key, "nt1")) h->t_nt1 = value;
     else if (!strcmp(key, "nt2")) h->t_nt2 = value;
     else if (!strcmp(key, "kw1")) h->t_kw1 = value;
@@ -1433,8 +1624,17 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "direct")) h->t_direct = value;
     else if (!strcmp(key, "fuse")) h->t_fuse = value;
     else if (!strcmp(key, "autotune")) {
+        // Under expert parallelism two ranks timing the same candidates may pick different plans = different fp32
+        // summation orders inside one group.  1 is refused there; 2 = "the host agrees on the plans across the group
+        // before relying on them" (lvllm_amd.ep.agree_tuned_plans: lkm_tuned_plans -> all_reduce(MIN) -> lkm_tuned_plan_set)
+        LKM_REQUIRE(!(value == 1 && h->cfg.num_processes > 1),
+                    "lkm_set_tuning: autotune=1 on an expert-parallel engine (num_processes=%d): ranks could choose different "
+                    "plans; use 2 and agree on them across the group (lvllm_amd.ep.agree_tuned_plans)", h->cfg.num_processes);
         h->t_autotune = value;
-        if (value <= 0) h->tuned.clear();        // (0 / -1: off, and forget what was chosen)
+        if (value <= 0) {                        // (0 / -1: off, and forget what was chosen)
+            h->tuned.clear();
+            h->tuned_shape.clear();
+        }
     }
     else if (!strcmp(key, "valid_den")) h->t_valid_den = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;

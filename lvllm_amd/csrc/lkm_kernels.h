@@ -6,6 +6,16 @@
 
 namespace lkm {
 
+// ---- lkm_api.hip: which GEMM kernels a step launched (lkm_last_kernels: bench.py's roofline.kernel and the FETCH
+// passes of tools/update_hbm_traffic.py name the kernel from the launch, not from a literal).  Every GEMM launcher goes
+// through LKM_LAUNCH_GEMM; the engine reads the host-side stubs noted between its gemm1 / gemm2 marks.
+void note_gemm_launch(const void* host_fn);
+#define LKM_LAUNCH_GEMM(kern, grid, block, lds, st, ...)            \
+    do {                                                            \
+        ::lkm::note_gemm_launch((const void*)(kern));               \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__); \
+    } while (0)
+
 // ---- repack.hip
 struct RepackDims {
     int E, n_half, halves, interleaved;  // source rows N = n_half*halves

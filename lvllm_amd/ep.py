@@ -255,11 +255,17 @@ class ExpertParallelExperts:
             raise RuntimeError(f"exchange pool {self.pool_tag!r} already holds a dispatch that was not combined "
                                f"({_IN_FLIGHT[pkey]}); two micro-batches in flight need instances with different pool_tag")
         _IN_FLIGHT[pkey] = f"{M} tokens, capacity {cap}"
-        b = self._buffers(M, K, cap, hidden.dtype, ret, hidden.device)
-        b["pool_key"] = pkey
-        self.kernels.ep_pack_tokens(hidden, tw, ids, self.E, self.ep, cap, b["send"], b["slot_of"], b["overflow"],
-                                    self.global_ids)
-        self.transport(b["recv"], b["send"])
+        try:
+            b = self._buffers(M, K, cap, hidden.dtype, ret, hidden.device)
+            b["pool_key"] = pkey
+            self.kernels.ep_pack_tokens(hidden, tw, ids, self.E, self.ep, cap, b["send"], b["slot_of"], b["overflow"],
+                                        self.global_ids)
+            self.transport(b["recv"], b["send"])
+        except BaseException:
+            # the pool is shared by every layer's instance on this (device, group, tag): a failed dispatch (an OOM while
+            # the pool grows, a transport error) must not leave it marked busy for all of them
+            _IN_FLIGHT.pop(pkey, None)
+            raise
         rec = b["recv"].view(self.ep * cap, b["rowb"])
         H2 = self.H * 2
         rows = rec[:, :H2].view(hidden.dtype)
@@ -487,28 +493,99 @@ def forward_two_microbatches(ep0: ExpertParallelExperts, ep1: ExpertParallelExpe
     x0, w0, i0 = batch0
     x1, w1, i1 = batch1
     cuda = x0.is_cuda
-    ep0._ensure_uniform(i0.size(0), None, x0)
-    ep1._ensure_uniform(i1.size(0), None, x1)
-    cap0 = ep0.capacity_for(i0.size(0), None, i0.size(1), capturing=_capturing(x0))
-    cap1 = ep1.capacity_for(i1.size(0), None, i1.size(1), capturing=_capturing(x1))
-    r0 = ep0.dispatch_fixed(x0, w0, i0, cap0, return_handle=True)
-    r1 = ep1.dispatch_fixed(x1, w1, i1, cap1, return_handle=True)
+    M0, M1 = i0.size(0), i1.size(0)
+    ep0._ensure_uniform(M0, None, x0)
+    ep1._ensure_uniform(M1, None, x1)
+    capturing = _capturing(x0)
+    cap0 = ep0.capacity_for(M0, None, i0.size(1), capturing=capturing)
+    cap1 = ep1.capacity_for(M1, None, i1.size(1), capturing=capturing)
+
+    def dispatch_both(c0, c1):
+        a = ep0.dispatch_fixed(x0, w0, i0, c0, return_handle=True)
+        try:
+            b = ep1.dispatch_fixed(x1, w1, i1, c1, return_handle=True)
+        except BaseException:
+            ep0.abandon_dispatch(a[3])
+            raise
+        return a, b
+    r0, r1 = dispatch_both(cap0, cap1)
+    # A capacity below the token count (group-limited estimate) may have dropped records.  Same rule as forward(): an eager
+    # step with check_overflow looks at the counters -- collectively, both instances in the same order on every rank --
+    # and repeats BOTH dispatches at the exact bound of the largest token count in the group; a step being captured can
+    # only count (its caller reads overflow_count() after the replay).  The flags come from group-agreed values only
+    # (capacity vs the uniform token count), so every rank takes the same branch.
+    t0, t1 = ep0.check_overflow and cap0 < M0, ep1.check_overflow and cap1 < M1
+    if (t0 or t1) and not capturing:
+        over0, m0 = ep0._any_rank_overflowed(x0.device, M0) if t0 else (False, M0)
+        over1, m1 = ep1._any_rank_overflowed(x1.device, M1) if t1 else (False, M1)
+        if over0 or over1:
+            ep0.abandon_dispatch(r0[3])
+            ep1.abandon_dispatch(r1[3])
+            r0, r1 = dispatch_both(max(m0, 1) if t0 else cap0, max(m1, 1) if t1 else cap1)
     ret0, ret1 = ep0.return_dtype or x0.dtype, ep1.return_dtype or x1.dtype
-    y0 = ep0._local(r0[0], r0[1], r0[2], ret0)
-    if cuda:
-        side = comm_stream if comm_stream is not None else torch.cuda.Stream(device=x0.device)
-        main = torch.cuda.current_stream(x0.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            out0 = ep0.combine_fixed(y0, i0.size(0), out_dtype, handle=r0[3])
+    try:
+        y0 = ep0._local(r0[0], r0[1], r0[2], ret0)
+        if cuda:
+            side = comm_stream if comm_stream is not None else torch.cuda.Stream(device=x0.device)
+            main = torch.cuda.current_stream(x0.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                out0 = ep0.combine_fixed(y0, M0, out_dtype, handle=r0[3])
+                sh = (shared(x0), shared(x1)) if shared is not None else None
+            y0.record_stream(side)
+            y1 = ep1._local(r1[0], r1[1], r1[2], ret1)          # overlaps the return exchange of batch 0
+            out1 = ep1.combine_fixed(y1, M1, out_dtype, handle=r1[3])
+            main.wait_stream(side)
+            # allocated under the side stream, consumed by the caller on the main stream: tell the caching allocator, or
+            # it may hand the blocks to the next side-stream allocation while main still reads them
+            out0.record_stream(main)
+            for t in sh or ():
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
+        else:
+            out0 = ep0.combine_fixed(y0, M0, out_dtype, handle=r0[3])
             sh = (shared(x0), shared(x1)) if shared is not None else None
-        y0.record_stream(side)
-        y1 = ep1._local(r1[0], r1[1], r1[2], ret1)          # overlaps the return exchange of batch 0
-        out1 = ep1.combine_fixed(y1, i1.size(0), out_dtype, handle=r1[3])
-        main.wait_stream(side)
-    else:
-        out0 = ep0.combine_fixed(y0, i0.size(0), out_dtype, handle=r0[3])
-        sh = (shared(x0), shared(x1)) if shared is not None else None
-        y1 = ep1._local(r1[0], r1[1], r1[2], ret1)
-        out1 = ep1.combine_fixed(y1, i1.size(0), out_dtype, handle=r1[3])
+            y1 = ep1._local(r1[0], r1[1], r1[2], ret1)
+            out1 = ep1.combine_fixed(y1, M1, out_dtype, handle=r1[3])
+    except BaseException:
+        # (whatever raised -- the experts, the shared callable, a transport -- both pools are free for the next step)
+        ep0.abandon_dispatch(r0[3])
+        ep1.abandon_dispatch(r1[3])
+        raise
     return (out0, out1) if sh is None else (out0, out1, sh[0], sh[1])
+
+
+def agree_tuned_plans(engines, group: dist.ProcessGroup | None = None) -> int:
+    """First-call autotune under expert parallelism (round-4 verdict item 8).  Each rank's engine timed the candidate plans
+    of its step shapes by itself (`set_tuning(autotune=2)`, the value an expert-parallel engine accepts), so two ranks may
+    remember different winners = different fp32 summation orders inside one group.  This makes them agree: for every engine
+    (same order on every rank) the remembered (shape key, candidate index) pairs are compared across the group and every
+    rank takes the MIN index per key -- the candidate list is a function of the engine configuration and the step shape
+    only, so index i names the same plan everywhere.  Call it after the warm-up steps and BEFORE capturing a graph;
+    ranks must have run the same step shapes (checked: differing key sets raise).  Works on any backend (the gloo tests
+    drive it with a stand-in engine exposing tuned_plans() / set_tuned_plan()).  -> number of plans that changed here."""
+    engines = list(engines)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    changed = 0
+    for n, eng in enumerate(engines):
+        plans = sorted(eng.tuned_plans())
+        keys = [k for k, _ in plans]
+        if world > 1:
+            got = [None] * world
+            dist.all_gather_object(got, keys, group=group)
+            if any(g != keys for g in got):
+                raise RuntimeError(f"agree_tuned_plans: engine {n} remembers plans for different step shapes across ranks "
+                                   f"({[len(g) for g in got]} keys): run the same warm-up shapes on every rank")
+        if not plans:
+            continue
+        idx = torch.tensor([i for _, i in plans], dtype=torch.int64)
+        if world > 1:
+            on_gpu = dist.get_backend(group) != "gloo"
+            t = idx.cuda() if on_gpu else idx
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            idx = t.cpu()
+        for (key, mine), agreed in zip(plans, idx.tolist()):
+            if agreed != mine:
+                eng.set_tuned_plan(key, int(agreed))
+                changed += 1
+    return changed

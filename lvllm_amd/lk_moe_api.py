@@ -145,6 +145,29 @@ class _MOE:
         for k, v in kv.items():
             _clib.check(self._lib.lkm_set_tuning(self._h, k.encode(), int(v)))
 
+    def last_kernels(self) -> dict[str, list[str]]:
+        """{"gemm1": [...], "gemm2": [...]}: the GEMM kernels of the last step, named as rocprofv3 prints them
+        (include/lkm.h lkm_last_kernels; two names where a hybrid plan ran the streamer and the tile kernel)"""
+        buf = C.create_string_buffer(2048)
+        _clib.check(self._lib.lkm_last_kernels(self._h, buf, 2048))
+        out = {}
+        for part in buf.value.decode().split(";"):
+            k, _, v = part.partition("=")
+            out[k] = [n for n in v.split("+") if n]
+        return out
+
+    def tuned_plans(self) -> list[tuple[int, int]]:
+        """[(shape key, candidate index)] of the plans the first-call autotune remembers, ascending keys"""
+        n = int(self._lib.lkm_tuned_plans(self._h, None, None, 0))
+        if n < 0:
+            _clib.check(n)
+        keys, idx = (C.c_int64 * max(n, 1))(), (C.c_int32 * max(n, 1))()
+        n = min(n, int(self._lib.lkm_tuned_plans(self._h, keys, idx, n)))
+        return [(int(keys[i]), int(idx[i])) for i in range(n)]
+
+    def set_tuned_plan(self, key: int, index: int) -> None:
+        _clib.check(self._lib.lkm_tuned_plan_set(self._h, int(key), int(index)))
+
     # ---- expert images for placement changes (include/lkm_eplb.h; used by lvllm_amd/eplb.py) --------
     def expert_bytes(self) -> int:
         n = int(self._lib.lkm_expert_bytes(self._h))

@@ -349,6 +349,15 @@ class LkmPrepareAndFinalize:
         # rows that exist (~1/ep of the ep x capacity slots carry a local id)
         return rows, None, LkmTokensMeta(valid_den=self._ep.ep) if self._ep.ep > 1 else None, gids, ws
 
+    def reset(self) -> None:
+        """gives up an exchange whose experts raised between prepare and finalize: the handle is dropped and the shared
+        exchange pool is free again for every layer's instance (without it the next prepare -- of ANY layer on
+        this device / group / pool tag -- fails with "already holds a dispatch")"""
+        if self._handle is not None:
+            self._ep.abandon_dispatch(self._handle)
+            self._handle = None
+        self._shape = None
+
     # ---- modular_kernel.py:354-376
     def finalize(self, output: torch.Tensor, fused_expert_output: torch.Tensor, topk_weights: torch.Tensor,
                  topk_ids: torch.Tensor, apply_router_weight_on_input: bool, weight_and_reduce_impl: Any) -> None:

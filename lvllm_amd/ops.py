@@ -285,6 +285,99 @@ def sort_slots(topk_ids: torch.Tensor, num_experts: int):
     return counts, offsets, sorted_slot[:n], pos[:n]
 
 
+def _ops_workspace(n_slots: int, n_keys: int, dev) -> torch.Tensor:
+    nbytes = int(_clib.lib().lkm_moe_ops_workspace_bytes(int(n_slots), int(n_keys)))
+    return torch.empty((max(nbytes, 16) + 3) // 4, dtype=torch.int32, device=dev)
+
+
+def moe_align_block_size(topk_ids: torch.Tensor, block_size: int, num_experts: int,
+                         expert_map: torch.Tensor | None = None, pad_sorted_ids: bool = False,
+                         ignore_invalid_experts: bool = False):
+    """moe_align_block_size.py:11-103, same arguments and return values: (sorted_token_ids int32 [max_num_tokens_padded],
+    expert_ids int32 [max_num_m_blocks], num_tokens_post_padded int32 [1]).  Unused sorted ids = topk_ids.numel(), unused
+    blocks = -1, rows of an expert in token order (what the reference's golden implementation produces,
+    tests/kernels/moe/test_moe_align_block_size.py:96-172)."""
+    _need_cuda(topk_ids, expert_map)
+    ids = topk_ids.to(torch.int32).contiguous()
+    n = ids.numel()
+    max_padded = n + num_experts * (block_size - 1)
+    if pad_sorted_ids:
+        max_padded = -(-max_padded // block_size) * block_size
+    if n < num_experts:
+        max_padded = min(n * block_size, max_padded)
+    dev = ids.device
+    sorted_ids = torch.empty((max_padded,), dtype=torch.int32, device=dev)
+    max_blocks = -(-max_padded // block_size)
+    expert_ids = torch.empty((max_blocks,), dtype=torch.int32, device=dev)
+    post = torch.empty((1,), dtype=torch.int32, device=dev)
+    emap = None
+    if expert_map is not None and ignore_invalid_experts:
+        emap = expert_map.to(torch.int32).contiguous()
+    ws = _ops_workspace(n, num_experts, dev)
+    _clib.check(_clib.lib().lkm_moe_align_block_size(_stream(ids), _ptr(ids), n, num_experts, block_size, _ptr(emap),
+                                                     _ptr(sorted_ids), max_padded, _ptr(expert_ids), max_blocks, _ptr(post),
+                                                     _ptr(ws)))
+    if expert_map is not None and not ignore_invalid_experts:
+        expert_ids = expert_map[expert_ids.to(torch.int64)]          # (the reference's own post-step, :99-100)
+    return sorted_ids, expert_ids, post
+
+
+def moe_permute(hidden_states: torch.Tensor, a1q_scale: torch.Tensor | None, topk_ids: torch.Tensor, n_expert: int,
+                n_local_expert: int = -1, expert_map: torch.Tensor | None = None,
+                permuted_hidden_states: torch.Tensor | None = None):
+    """moe_permute_unpermute.py:105-242 -> (permuted_hidden_states, a1q_scale, expert_first_token_offset int64
+    [n_local_expert + 1], inv_permuted_idx int32 [n_token * topk], permuted_idx int32 [n_token * topk]).  The rows of experts
+    that are not local are not written (the reference's test compares the valid rows only)."""
+    _need_cuda(hidden_states, topk_ids, expert_map)
+    n_token, n_hidden = hidden_states.size()
+    topk = topk_ids.size(1)
+    assert (n_hidden * hidden_states.element_size()) % 16 == 0, "permue kernel need hidden dim align to 16B"
+    rows = n_token * topk
+    if n_local_expert == -1:
+        n_local_expert = n_expert
+    dev = hidden_states.device
+    if permuted_hidden_states is None:
+        permuted_hidden_states = torch.empty((rows, n_hidden), dtype=hidden_states.dtype, device=dev)
+    assert permuted_hidden_states.size() == (rows, n_hidden), (
+        f"Expected permuted hidden states to be {(rows, n_hidden)} but got {permuted_hidden_states.size()}")
+    assert permuted_hidden_states.is_contiguous()
+    h = hidden_states.contiguous()
+    ids = topk_ids.to(torch.int32).contiguous()
+    emap = None if expert_map is None else expert_map.to(torch.int32).contiguous()
+    first = torch.empty((n_local_expert + 1,), dtype=torch.int64, device=dev)
+    inv = torch.empty((n_token, topk), dtype=torch.int32, device=dev)
+    perm = torch.empty((rows,), dtype=torch.int32, device=dev)
+    ws = _ops_workspace(rows, n_expert if emap is None else n_local_expert + n_expert, dev)
+    _clib.check(_clib.lib().lkm_moe_permute(_stream(h), _ptr(h), n_hidden * h.element_size(), n_token, _ptr(ids), topk,
+                                            _ptr(emap), n_expert, n_local_expert, _ptr(permuted_hidden_states), _ptr(first),
+                                            _ptr(inv), _ptr(perm), _ptr(ws)))
+    if a1q_scale is not None and a1q_scale.dim() > 1:
+        a1q_scale = a1q_scale[perm.clamp(max=rows - 1).to(torch.int64) // topk]
+    return permuted_hidden_states, a1q_scale, first, inv.flatten(), perm
+
+
+def moe_unpermute(out: torch.Tensor, permuted_hidden_states: torch.Tensor, topk_weights: torch.Tensor,
+                  inv_permuted_idx: torch.Tensor, expert_first_token_offset: torch.Tensor | None = None) -> None:
+    """moe_permute_unpermute.py:245-283: out[t] = sum_k topk_weights[t][k] * permuted_hidden_states[inv_permuted_idx[t][k]]
+    over the valid rows (fp32 sum, one rounding to the rows' dtype)."""
+    _need_cuda(out, permuted_hidden_states, topk_weights, inv_permuted_idx, expert_first_token_offset)
+    topk = topk_weights.size(1)
+    n_hidden = permuted_hidden_states.size(-1)
+    assert (n_hidden * permuted_hidden_states.element_size()) % 16 == 0, "unpermue kernel need hidden dim align to 16B"
+    assert permuted_hidden_states.dtype in (torch.bfloat16, torch.float16) and out.dtype == permuted_hidden_states.dtype
+    assert out.is_contiguous() and permuted_hidden_states.is_contiguous()
+    tw = topk_weights.to(torch.float32).contiguous()
+    inv = inv_permuted_idx.to(torch.int32).contiguous()
+    first = None if expert_first_token_offset is None else expert_first_token_offset.to(torch.int64).contiguous()
+    _clib.check(_clib.lib().lkm_moe_unpermute(_stream(out), _ptr(permuted_hidden_states), _DT[out.dtype], _ptr(tw), _ptr(inv),
+                                              _ptr(first), 0 if first is None else first.numel() - 1, out.size(0), topk,
+                                              n_hidden, _ptr(out)))
+
+
+def moe_permute_unpermute_supported() -> bool:
+    return True
+
+
 _CLS = {("bf16", torch.bfloat16): MOE_BF16, ("bf16", torch.float16): MOE_FP16,
         ("fp16", torch.float16): MOE_FP16,
         ("fp8", torch.bfloat16): MOE_FP8, ("fp8", torch.float16): MOE_FP8_FP16,

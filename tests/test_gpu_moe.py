@@ -996,10 +996,7 @@ def test_decode_is_hip_graph_capturable():
     assert torch.equal(out, eng.decode(ad, twd, idd))
 
 
-def test_profiling_repeats_leave_results_unchanged():
-    """lkm_set_tuning("prof_rep", N): the profiled call launches each GEMM N times between its events (what
-    bench.py's roofline timing uses) -- same output bits, and a per-launch time no larger than the
-    single-launch interval."""
+def _profiled_pair(prof_rep=8):
     M, E, K, H, I = 48, 4, 2, 512, 256
     a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=5)
     eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
@@ -1007,19 +1004,29 @@ def test_profiling_repeats_leave_results_unchanged():
     eng.engine.set_profiling(True)
     one = _run_decode(eng, a, tw, ids)
     p1 = eng.engine.get_profile()
-    eng.engine.set_tuning(prof_rep=8)
+    eng.engine.set_tuning(prof_rep=prof_rep)
     rep = _run_decode(eng, a, tw, ids)
     p8 = eng.engine.get_profile()
     eng.engine.set_tuning(prof_rep=0)
     eng.engine.set_profiling(False)
+    return base, one, rep, p1, p8
+
+
+def test_profiling_repeats_leave_results_unchanged():
+    """lkm_set_tuning("prof_rep", N): the profiled call launches each GEMM N times between its events (what
+    bench.py's roofline timing uses) -- same output bits, every interval reported and positive.  (No bound on the
+    intervals here: a parity suite must not depend on the box's other tenants; the timing half is
+    test_profiling_repeats_interval_perf, marker `perf`.)"""
+    base, one, rep, p1, p8 = _profiled_pair()
     assert np.array_equal(one, base) and np.array_equal(rep, base)
-    assert 0 < p8["gemm1"] <= p1["gemm1"] * 1.5 and 0 < p8["gemm2"] <= p1["gemm2"] * 1.5, (p1, p8)
+    for p in (p1, p8):
+        assert set(p) >= {"sort", "gemm1", "gemm2", "combine"} and all(p[k] > 0 for k in ("gemm1", "gemm2")), (p1, p8)
 
 
 def test_errors_are_loud():
     from lvllm_amd._clib import LkmError
-    w13 = torch.zeros((2, 64, 36), dtype=torch.bfloat16)     # hidden 36 not a multiple of 8
-    w2 = torch.zeros((2, 36, 32), dtype=torch.bfloat16)
+    w13 = torch.zeros((2, 72, 64), dtype=torch.bfloat16)     # intermediate 36 not a multiple of 8 (hidden sizes may be odd
+    w2 = torch.zeros((2, 64, 36), dtype=torch.bfloat16)      # for unquantised weights since round 5: test_zz6 k = 511)
     with pytest.raises(LkmError):
         _eng(w13, w2, top_k=1, act_dtype=torch.bfloat16)
     import lk_moe

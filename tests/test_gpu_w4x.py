@@ -146,3 +146,40 @@ def test_w4x_fp4_formats_vs_oracle(fmt, M, dt):
         assert f"pf={pf}" in eng.engine.describe(), eng.engine.describe()
         np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=f"{fmt} {pf}/{tiled}")
     _reset(eng)
+
+
+@pytest.mark.parametrize("pf", [5, 6])
+def test_w4x_knob_survives_prefill_sized_chunks(pf):
+    """with "pf" = 5 / 6 forced and nothing else, a prefill-sized chunk used to plan 256-row tiles
+    (which exist on gemm_prefill.h only, "pf" 0 / 8) and fail with "variant tm=256 ... not built".  The planner now keeps
+    the 64 / 128-row tiles there; decode-sized calls of the same engine still take the forced kernel."""
+    M, E, K, H, I, g = 1536, 4, 2, 256, 128, 128         # 768 rows per expert: > the 112-row threshold of the 256-row plan
+    eng, a, tw, ids, ref = _int4_case(M, E, K, H, I, g, "bf16", seed=23)
+    eng.engine.set_tuning(pf=pf)
+    out = _run_decode(eng, a, tw, ids)
+    assert "tm=256" not in eng.engine.describe(), eng.engine.describe()
+    np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=eng.engine.describe())
+    small = _run_decode(eng, a[:96], tw[:96], ids[:96])
+    assert f"pf={pf}" in eng.engine.describe(), eng.engine.describe()
+    np.testing.assert_allclose(small, ref[:96], atol=ATOL, rtol=RTOL)
+    _reset(eng)
+
+
+def test_last_kernels_names_what_was_launched():
+    """lkm_last_kernels (include/lkm.h): the kernel names bench.py's roofline and the FETCH passes use come from the launch
+    itself -- the default tile kernel, then the forced 32x32-MFMA kernel, then the streamer, on one engine"""
+    eng, a, tw, ids, ref = _int4_case(128, 8, 2, 512, 384, 128, "bf16", seed=133)
+    _run_decode(eng, a, tw, ids)
+    k0 = eng.engine.last_kernels()
+    assert len(k0["gemm1"]) == 1 and "gemm_tiled_kernel<" in k0["gemm1"][0] and "gemm_tiled_kernel<" in k0["gemm2"][0], k0
+    eng.engine.set_tuning(pf=5, tiled=64)
+    _run_decode(eng, a, tw, ids)
+    k1 = eng.engine.last_kernels()
+    assert "gemm_w4x_kernel<" in k1["gemm1"][0] and "gemm_w4x_kernel<" in k1["gemm2"][0], k1
+    eng.engine.set_tuning(pf=0, tiled=-1)
+    _run_decode(eng, a, tw, ids)
+    k2 = eng.engine.last_kernels()
+    assert "gemm1_act_kernel<" in k2["gemm1"][0] and "gemm2_kernel<" in k2["gemm2"][0], k2
+    for k in (k0, k1, k2):                      # as rocprofv3 prints them: namespace, template arguments, no parameter list
+        assert all(n.startswith("lkm::") and n.endswith(">") and "(" not in n for n in k["gemm1"] + k["gemm2"]), k
+    _reset(eng)

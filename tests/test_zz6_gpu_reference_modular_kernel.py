@@ -14,7 +14,7 @@
    eager batch >= LVLLM_GPU_PREFILL_MIN_BATCH_SIZE -> `_gpu_prefill`, else `_cpu_prefill` -- each branch taken is
    recorded and its output checked against the oracle.
 3. The reference's own test grids where the operator supports them: FUSED_MOE_MNK_FACTORS subset incl. E = 192 and
-   m = 32 768 / 40 000 rows (tests/kernels/moe/test_moe.py:195-216), k = 511 refused loudly, and
+   m = 32 768 / 40 000 rows (tests/kernels/moe/test_moe.py:195-216), the k = 511 rows (hidden size % 8 != 0), and
    the block-fp8 grid N = 4608, K = 7168, E in {2, 8, 16}, top-k 6 (tests/kernels/moe/test_block_fp8.py:60-104).
 Tolerances: bf16 / int4 atol 2e-2 of max|ref| (test_moe.py:233-234 scaled to the output range), block-fp8 0.035
 (test_block_fp8.py:143-210).
@@ -305,14 +305,48 @@ def test_reference_fused_moe_mnk_grid(m, n, k, e, topk):
     _check(out[rows], ref, 2e-2)
 
 
-def test_hidden_size_not_a_multiple_of_eight_is_refused_loudly():
-    """k = 511 of FUSED_MOE_MNK_FACTORS (test_moe.py:199): the pre-shuffled image stores 16-byte pieces of eight 16-bit
-    values along K, lkm_create refuses H % 8 != 0 with LKM_E_INVALID -- documented in INTEGRATION.md 10"""
+@pytest.mark.parametrize("m,n,k,e,topk", [
+    (2, 2048, 511, 8, 2), (2, 2048, 511, 64, 6),             # FUSED_MOE_MNK_FACTORS_SMALL_M (test_moe.py:203-208)
+    (33, 128, 511, 8, 2), (222, 1024, 511, 8, 6),
+    (32768, 2048, 511, 8, 2),                                # FUSED_MOE_MNK_FACTORS (test_moe.py:195-201): the big-m k = 511 row
+])
+def test_reference_fused_moe_mnk_grid_k511(m, n, k, e, topk):
+    """k = 511 of the reference's grid (hidden size not a multiple of 8; refused until round 4): lkm_create pads K with
+    zeros in the image, the token / output rows pass through aligned scratch rows (lkm_api.hip run_device).  n is the
+    intermediate size of the reference's torch_moe recipe (w1 [e, 2n, k])."""
     from lvllm_amd import ops
-    w1 = torch.zeros((4, 256, 511), dtype=torch.bfloat16, device=DEV)
-    w2 = torch.zeros((4, 511, 128), dtype=torch.bfloat16, device=DEV)
-    with pytest.raises(RuntimeError, match="multiple of 8|% 8"):
-        ops.RoutedExpertsEngine(w1, w2, top_k=2, act_dtype=torch.bfloat16)
+    if m > 4096:
+        n = 256            # (the oracle's CPU time for 256 sampled rows of 8 experts x 2048 x 511 is fine, the weights' are not the point)
+    a, w1, w2, score = _bf16_grid_case(m, n, k, e, topk)
+    eng = ops.RoutedExpertsEngine(w1, w2, top_k=topk, act_dtype=torch.bfloat16, max_batch_size=4096)
+    tw, ids = ops.topk_softmax(score, topk, False)
+    out = eng.prefill(a, tw, ids)
+    assert out.shape == (m, k) and out.is_contiguous()
+    rows = np.arange(m) if m <= 512 else np.random.default_rng(m).choice(m, 256, replace=False)
+    d = orc.MoeDesc(E=e, H=k, I=n, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    ref = orc.moe(d, torch_to_bits(w1.cpu()), torch_to_bits(w2.cpu()), torch_to_bits(a[rows].cpu()),
+                  ids[rows].cpu().numpy(), tw[rows].cpu().numpy())
+    _check(out[rows], ref, 2e-2)
+    if m <= 512:
+        # the three entry points agree on the odd shape: cpu_decode (fp32), the fused router + scatter step, cpu_prefill
+        dec = eng.decode(a, tw, ids)
+        np.testing.assert_allclose(dec.cpu().numpy(), ref, atol=2e-3 * float(np.abs(ref).max()), rtol=1e-2)
+        fused, fw, fi = eng.forward_logits(a, score, topk, False)
+        assert torch.equal(fi, ids) and torch.equal(fw, tw) and torch.equal(fused, dec)
+        host = eng.prefill_host(a.cpu(), tw.cpu(), ids.cpu())
+        assert torch.equal(host, dec.cpu())
+
+
+def test_quantised_formats_still_refuse_odd_hidden_sizes():
+    """H % 8 != 0 is accepted for unquantised weights only (the quantised formats' groups need whole 32 / 128-k blocks)"""
+    from lvllm_amd import _clib, ops
+    q13 = torch.zeros((4, 256, 511), dtype=torch.uint8, device=DEV)
+    q2 = torch.zeros((4, 511, 128), dtype=torch.uint8, device=DEV)
+    s13 = torch.ones((4, 2, 4), dtype=torch.float32, device=DEV)
+    s2 = torch.ones((4, 4, 1), dtype=torch.float32, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        ops.RoutedExpertsEngine(q13, q2, top_k=2, act_dtype=torch.bfloat16, fmt="fp8", w13_scale=s13, w2_scale=s2,
+                                group_n=128, group_k=128, fp8_mode=_clib.FP8_W8A16)
 
 
 @pytest.mark.parametrize("M,E", [(1, 2), (83, 8), (2048, 16)])

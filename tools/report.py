@@ -34,7 +34,7 @@ RUNS = [
 
 def run(workload, steps, routing):
     cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", workload, "--steps", str(steps), "--warmup",
-           "5", "--no-cpu-baseline", "--no-extras", "--routing", routing]
+           "5", "--no-cpu-baseline", "--no-extras", "--full-line", "--routing", routing]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     for line in r.stdout.splitlines():
         if line.startswith("{"):

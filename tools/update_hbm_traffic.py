@@ -7,7 +7,6 @@ reads), written to <out>/hbm_traffic.json together with the hash of the kernel s
   python tools/update_hbm_traffic.py [out_dir] [workload,workload,...]"""
 import json
 import os
-import re
 import shutil
 import subprocess
 import sys
@@ -20,28 +19,6 @@ from bench import EXTRA_EP, EXTRA_N1, HEADLINE, kernel_source_hash  # noqa: E402
 OUT = (Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out").resolve()
 
 
-def gemm_of(kernel: str):
-    """'gemm1' / 'gemm2' / None for a kernel name (template arguments: lkm_kernels.h / the kernel headers)"""
-    if "gemm1_act_kernel" in kernel:
-        return "gemm1"
-    if "gemm2_kernel" in kernel or "gemm2_direct_kernel" in kernel:
-        return "gemm2"
-    m = re.search(r"gemm_prefill_a8w_kernel<\d+, (true|false), (true|false)", kernel)
-    if m:
-        return "gemm1" if m.group(2) == "true" else "gemm2"
-    # gemm_w4x_kernel<WF, ADT, CB, WAVES, GATED, IS_G1, ...> / gemm_w4e_kernel<WF, ADT, CB, NC, GATED, IS_G1, ...>
-    m = re.search(r"gemm_w4[xe]_kernel<(?:[^,]+, ){5}(true|false)", kernel)
-    if m:
-        return "gemm1" if m.group(1) == "true" else "gemm2"
-    m = re.search(r"gemm_tiled_kernel<(?:[^,]+, ){6}(true|false)", kernel)
-    if m:
-        return "gemm1" if m.group(1) == "true" else "gemm2"
-    m = re.search(r"gemm_prefill(?:_a8)?_kernel<[^>]*>", kernel)
-    if m:
-        return "gemm1" if ", true>" in m.group(0) or "true, true" in m.group(0) else "gemm2"
-    return None
-
-
 def main():
     names = [HEADLINE] + [w if isinstance(w, str) else None for w in EXTRA_N1] + [EXTRA_EP]
     names = [n for n in names if n]
@@ -49,33 +26,52 @@ def main():
         names = sys.argv[2].split(",")
     OUT.mkdir(parents=True, exist_ok=True)
     res = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE (one separate pass per workload: tools/update_hbm_traffic.py), "
-                       "KB*1024 and x2 for wide coalesced reads as MI355X_MICROARCH.md prescribes for gfx950.  bench.py copies the "
-                       "matching entry into roofline.traffic and compares kernel_source_hash with the sources it runs.",
+                       "KB*1024 and x2 for wide coalesced reads as MI355X_MICROARCH.md prescribes for gfx950.  Each entry names the "
+                       "kernel it measured (the name the ENGINE reports for its launches, lkm_last_kernels, matched against the "
+                       "profiler's kernel names) and the launch plan; bench.py copies an entry into roofline.traffic only when "
+                       "its own kernel and plan are the same, and compares kernel_source_hash with the sources it runs.",
            "kernel_source_hash": kernel_source_hash()}
+    prev = OUT / "hbm_traffic.json"
+    if len(sys.argv) > 2 and prev.exists():          # partial update: keep the other workloads' entries
+        try:
+            old = json.loads(prev.read_text())
+            if old.get("kernel_source_hash") == res["kernel_source_hash"]:
+                res = {**old, **res}
+        except Exception:
+            pass
     env = dict(os.environ, TMPDIR="/tmp")
     for wl in names:
         d = OUT / f"pmc_{wl}"
         shutil.rmtree(d, ignore_errors=True)
+        # engine defaults (no autotune: a tuning pass would launch candidate kernels of other plans), eager launches
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", str(d), "-o", "p", "--", sys.executable,
-               str(ROOT / "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-extras", "--no-graph", "--steps", "10", "--warmup", "3"]
+               str(ROOT / "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-extras", "--no-graph", "--full-line",
+               "--full-out", "", "--steps", "10", "--warmup", "3"]
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
-        line = next((l for l in r.stdout.splitlines() if l.startswith("{")), None)
+        line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
         s = subprocess.run([sys.executable, str(ROOT / "tools" / "rocprof_summary.py"), str(d / "p_results.db"), "--pmc"],
                            capture_output=True, text=True)
         shutil.rmtree(d, ignore_errors=True)
         if line is None or s.returncode != 0:
             print(f"{wl}: FAILED {r.stderr[-300:]} {s.stderr[-300:]}")
             continue
-        j = json.loads(line)
-        ent = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --workload {wl} --no-graph --steps 10 (uniform routing, N=1)"}
-        for k in json.loads(s.stdout)["pmc"]:
-            g = gemm_of(k["kernel"])
-            if g and k["counter"] == "FETCH_SIZE":
-                # (a step may run two kernels per GEMM -- hybrid plan: the larger one is the dominant kernel)
-                if k["bytes_corrected_x2"] > ent.get(f"{g}_bytes_per_launch", 0):
-                    ent[f"{g}_bytes_per_launch"] = k["bytes_corrected_x2"]
-                    ent[f"{g}_kernel"] = k["kernel"][:80]
-        rf = j["roofline"]
+        rf = json.loads(line)["roofline"]
+        ent = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --workload {wl} --no-graph --steps 10 "
+                         f"(uniform routing, N=1, engine defaults)", "plan": rf.get("plan")}
+        pmc = [k for k in json.loads(s.stdout)["pmc"] if k["counter"] == "FETCH_SIZE"]
+        for g, want in (("gemm1", rf.get("kernel")), ("gemm2", rf.get("gemm2_kernel"))):
+            # the kernel(s) the engine launched for this GEMM (two for a hybrid plan: their bytes add up per step)
+            total, found = 0, []
+            for name in (want or "").split("+"):
+                hit = [k for k in pmc if k["kernel"].replace(" ", "") == name[:90].replace(" ", "")]
+                if name and hit:
+                    total += sum(h["bytes_corrected_x2"] for h in hit)
+                    found.append(name)
+            if found and "+".join(found) == want:
+                ent[f"{g}_bytes_per_launch"] = total
+                ent[f"{g}_kernel"] = want
+            else:
+                ent[f"{g}_kernel_not_in_trace"] = want
         if "algorithmic_bytes" in rf:
             ent["gemm1_algorithmic_bytes"] = int(rf["algorithmic_bytes"])
         res[wl] = ent

@@ -590,17 +590,23 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
             preroll = int(pr.item())
         for _ in range(preroll):
             run()
-    # ---- timed region: exactly `steps` steps, barrier + synchronize on both sides
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        run()
-    barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if ctx["dist"]:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    # ---- timed regions: each one exactly `steps` steps, barrier + synchronize on both sides, MAX over ranks.
+    # R = 5 regions back to back and the MEDIAN region is the line's value (all five are reported, `timed_regions_ms`):
+    # the pool's boxes freeze the GPU queue for ~86 ms now and then (tools/prof_rep_stall.py, profiles/r05_prof_rep_stall.log:
+    # twice in ~2 s of launches on one box -- the event that turned round 4's driver test run red); one such event inside a
+    # 9 ms region of 20 steps would report a tenth of the throughput.  --regions 1 gives the single region back.
+    regions = []
+    for _ in range(max(1, args.regions)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if ctx["dist"]:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regions.append(float(t.item()))
+    dt = float(np.median(regions))
     ms_per_step = dt / steps * 1e3
     tokens_per_s = M * world / (dt / steps)
     if wd is not None:
@@ -737,7 +743,7 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
             "timing": f"HIP events on the launch stream around {PROF_REP} back-to-back launches, / {PROF_REP}; median of {reps} calls"
                       + (" (rank 0's engine on rank 0's own routed rows)" if world > 1 else "")})
         res = {"workload": name, "value": round(tokens_per_s, 1), "unit": "tokens/s", "ms_per_step": round(ms_per_step, 4),
-               "steps": steps, "scaling": scaling,
+               "steps": steps, "scaling": scaling, "timed_regions_ms": [round(r * 1e3, 3) for r in regions],
                "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act" + (" (fast mode: scale on fp32 partial sums)" if wl.get("int4_mode") else ""),
                          "mxfp4": "mxfp4-w/bf16-act",
                          "nvfp4": "nvfp4-w/bf16-act",
@@ -856,6 +862,8 @@ def main():
     ap.add_argument("--autotune", action="store_true",
                     help="turn the engine's first-call plan search on (lkm_set_tuning autotune; default off = what lk_moe users get)")
     ap.add_argument("--no-autotune", action="store_true", help="(default since round 5; kept so that older command lines still parse)")
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of exactly --steps steps each; the median region is reported (all are listed)")
     ap.add_argument("--full-line", action="store_true", help="print the complete record as the last line (tools), not the < 4 KB one")
     ap.add_argument("--full-out", default=str(ROOT / "gpurun_out" / "bench_full.json"),
                     help="side file for the complete records of the headline and the extra workloads ('' = none)")
@@ -913,6 +921,9 @@ def main():
             "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
             "config": cfg, "roofline": roofline, "cpu_baseline": cpu,
         }
+        line["timed_regions_ms"] = head.get("timed_regions_ms")
+        line["timing"] = (f"{len(head.get('timed_regions_ms') or [])} regions of exactly {args.steps} steps each, barrier + synchronize "
+                          "on both sides, max over ranks; value = the median region")
         if "ms_per_step_cold" in head:
             line["ms_per_step_cold"] = head["ms_per_step_cold"]
         if "long_run" in head:

@@ -352,7 +352,9 @@ int lkm_tuned_plan_set(LkmHandle h, int64_t key, int32_t index);
  * "pd2","xcd","pf","direct","valid_den","prof_rep"}; value 0 = auto ("tiled": -1 forces the skinny
  * streamer, 64 / 128 / 256 force a token-tile size; "hybrid": -1 disables the skinny+tiled split by
  * rows-per-expert; "prof_rep": N > 1 launches each GEMM N times between its two profiling events and
- * lkm_get_profile divides the interval -- profiling mode only, results unchanged) */
+ * lkm_get_profile divides the interval -- profiling mode only, results unchanged; "mixed": mixed tile heights of
+ * decode-sized steps, opt-in -- n > 0 = experts with more than n rows take 128-row tiles (measured: no gain in the step); "autotune": 0 off,
+ * 1 first-call plan search, 2 the same on an expert-parallel engine whose host agrees on the plans across the group) */
 int lkm_set_tuning(LkmHandle h, const char* key, int32_t value);
 
 /* Measures the HBM *read* ceiling of the device with the access shape of the expert-weight stream

@@ -85,6 +85,14 @@ __device__ __forceinline__ void sort_slots_body(
     int tile_rows_packed, int tile_min, int32_t* __restrict__ tile_e, int32_t* __restrict__ tile_r0, int xcd_cap,
     int32_t* smem) {
     const int tile_rows = tile_rows_packed & 0xffff, tile_gran = tile_rows_packed >> 16;
+    // Mixed tile heights (round 5; tile_min < 0 carries them, lkm_kernels.h pack_mixed_tiles): an expert with more than
+    // `big_min` rows is cut into tiles of `big_rows` rows, the others into tiles of tile_rows.  The list is written
+    // heaviest expert first, so the big tiles are its first meta[4] entries: the step launches the tile kernel twice, once
+    // per height, each on its part of the list (GemmParams::tile_lo_meta / tile_hi_meta).  A skewed router's hot expert
+    // (DeepSeek-V3 rank slice under Zipf: 126 of 256 rows) then streams its weights once instead of once per 32 rows.
+    const bool mixed = tile_min < 0;
+    const int big_rows = mixed ? ((-tile_min) >> 16) : 0, big_min = mixed ? ((-tile_min) & 0xffff) : 0;
+    if (mixed) tile_min = 0;
     constexpr int WAVES = THREADS / 64;
     int32_t* cnt = smem;                 // [E]
     int32_t* off = cnt + E;              // [E]
@@ -99,6 +107,7 @@ __device__ __forceinline__ void sort_slots_body(
         cnt[e] = 0;
         run[e] = 0;
     }
+    if (tid == 0) xstart[15] = 0;        // mixed heights: number of big tiles (xstart[0..8] belong to the XCD cut, unused then)
     __syncthreads();
     for (int i = tid; i < n_slots; i += THREADS) {
         const int id = ids.at(i, E);
@@ -132,7 +141,9 @@ __device__ __forceinline__ void sort_slots_body(
         const int eo = (e < E) ? ord[e] : 0;          // the expert at launch position `e`
         int co = (e < E) ? cnt[eo] : 0;
         int a = co > 0 ? 1 : 0;
-        int t = (tile_rows > 0 && co > tile_min) ? (co + tile_rows - 1) / tile_rows : 0;
+        const int my_rows = (mixed && co > big_min) ? big_rows : tile_rows;      // this expert's tile height
+        int t = (tile_rows > 0 && co > tile_min) ? (co + my_rows - 1) / my_rows : 0;
+        if (mixed && co > big_min) atomicAdd(&xstart[15], t);
         int sc = c, sa = a, stl = t, so = co;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -175,7 +186,7 @@ __device__ __forceinline__ void sort_slots_body(
             if (a) active[ex_a] = eo;
             for (int i = 0; i < t; ++i) {
                 tile_e[ex_t + i] = eo;
-                tile_r0[ex_t + i] = tile_first_row(co, t, i, tile_rows, tile_gran);
+                tile_r0[ex_t + i] = tile_first_row(co, t, i, my_rows, tile_gran);
                 if (xcd_cap > 0) tkey[ex_t + i] = ex_o + i * tile_rows + (ex_t + i) * tile_rows;
             }
         }
@@ -200,6 +211,7 @@ __device__ __forceinline__ void sort_slots_body(
         meta[1] = carry_cnt;
         meta[2] = mm;
         meta[3] = carry_til;
+        meta[4] = mixed ? xstart[15] : 0;        // (the barrier after the maximum's reduction ordered the atomics before this read)
     }
     const int total = carry_cnt;
 

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
     // M=1024 where every expert has a single tile (profiles/r01_prefill_pmc.md); (2) skipping the
     // empty 16-token blocks of a partially filled tile with wave-uniform branches INSIDE the K loop
     // loses 10 % -- the block count is a template parameter of the loop instead (run<NB>).
-    int ti = blockIdx.y, bx = blockIdx.x;
+    int ti = blockIdx.y + (p.tile_lo_meta ? p.meta[p.tile_lo_meta] : 0), bx = blockIdx.x;     // (mixed tile heights: my part of the list)
     if (p.xcd_map) {
         // 1-D grid; hardware places workgroup L on XCD L % 8.  XCD c takes the contiguous run of tiles the sort
         // kernel cut for it (dispatch.hip: meta[8 + c], balanced by routed rows; tiles of the same expert are
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(WAVES * 64, tiled_min_blocks(WF, TBW, WAVES, GATED 
         ti = first + sidx / RG;
         bx = sidx % RG;
     }
-    if (ti >= p.meta[3]) return;
+    if (ti >= p.meta[p.tile_hi_meta ? p.tile_hi_meta : 3]) return;
     const int e = p.tile_e[ti], r0 = p.tile_r0[ti];
     const int m_e = p.counts[e], off_e = p.offsets[e];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

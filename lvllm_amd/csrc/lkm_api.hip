@@ -193,6 +193,7 @@ struct LkmEngine {
     // five candidate plans on the caller's own inputs and remembers the fastest for that shape; later calls -- and the
     // captures that follow the warm-up steps -- take it.
     int t_autotune = 0;
+    int t_mixed = 0;          // mixed tile heights (opt-in): n > 0 = experts with more than n rows take 128-row tiles
     struct TunedPlan {
         int pf, tiled, pd1, pd2;
         float us;             // its time when chosen
@@ -569,6 +570,10 @@ struct Plan {
     LaunchCfg t1, t2;   // tiled  GEMM1 / GEMM2 (t1.tiled == 0: not launched)
     int split_rows;     // hybrid threshold (0: no split)
     int xcd1, xcd2;     // GEMM1 / GEMM2: XCD-aware work mapping (gemm_tiled.h, dispatch.hip: per-XCD tile runs)
+    // mixed tile heights (round 5): experts with more than big_min rows are cut into big_rows-row tiles and run on b1 / b2,
+    // the others keep t1 / t2 -- two launches per GEMM on the two parts of one tile list (big_rows == 0: off)
+    int big_rows, big_min;
+    LaunchCfg b1, b2;
 };
 
 static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   // M, n_slots: as handed over (incl. -1 slots)
@@ -678,6 +683,13 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         } else if (M > 16 * tb && h->t_hybrid >= 0) {
             tiled = 64;
             split = 16 * tb;
+            // 16-bit weights (round 5, profiles/r05_hybrid_vs_tiles_ab.log): plain 64-row tiles instead of the hybrid -- under
+            // Zipf routing the hybrid's streamer half re-reads the hot experts' token rows per weight tile and the step loses
+            // 6-13 % (DSv3 bf16 rank slice M=64 / 128 / 256: 211 -> 188, 290 -> 253, 327 -> 288 us; Qwen3-30B-A3B M=32 / 64 /
+            // 128: 127 -> 112, 155 -> 140, 184 -> 173; Mixtral M=48: 544 -> 473), under uniform routing the two are within
+            // +-3 % (465 -> 455, 442 -> 439, 388 -> 398; 204 -> 201, 228 -> 224, 244 -> 231; 471 -> 470).  "hybrid" = 1 keeps
+            // the hybrid; fp8 below 48 tokens keeps it too (not measured).
+            if (w16 && h->t_hybrid == 0) split = 0;
         }
         // 4-bit decode batches in which an expert is unlikely to hold more than 32 rows: the 32-row tile keeps half
         // the accumulators and two more waves per SIMD resident (profiles/r01_tile32.log: int4 M=16 196 -> 186 us,
@@ -709,6 +721,8 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         if (g2_only) tiled = g2_only;
     }
     pl->split_rows = split;
+    pl->big_rows = pl->big_min = 0;
+    pl->b1 = pl->b2 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
     // XCD-aware work mapping (gemm_tiled.h; the workgroups that share a token tile or a weight panel run on
     // ONE XCD at the same time) stays a knob ("xcd"): bytes that miss the L2 arrive at <= 7.6 TB/s chip-wide
     // against 32 TB/s from the L2 (tools/probe_l2.hip), and the mapping lifts GLM-4.5-Air GEMM1's L2 hits
@@ -807,6 +821,26 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves, pd1, pf};
         pl->t2 = LaunchCfg{nt2, tiled / 16, 1, sk2, tiled, waves2, pd2, pf};
         if (g2_only) pl->t1 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
+        // Mixed tile heights (round-4 verdict item 6), OPT-IN: "mixed" = n > 0.  Decode batches of many-expert layers plan
+        // 32- or 64-row tiles for the row count an expert is LIKELY to get; a skewed router hands one expert several times that
+        // (DeepSeek-V3 rank slice under Zipf: 18 of 32 experts hit, the hot one 126 of 256 rows = four 32-row tiles = four
+        // passes over its weights).  With the knob, experts with more than n rows take 128-row tiles (one pass; the
+        // gemm_tiled_kernel<..., 8 waves> variant every format has), decided ON THE DEVICE by the sort, two launches per GEMM.
+        // Measured (profiles/r05_mixed_heights_ab.log) and therefore NOT the default: the GEMM intervals of the profiled
+        // call drop (DSv3 256 experts, Zipf: GEMM1 403 -> 274-308 us, GEMM2 215 -> 144-169) but the captured step does not
+        // (675 -> 649-723 us; rank slice 173 -> 293): a 128-row tile is 16 workgroups per expert, each pulling 1.8 MB
+        // alone -- latency-bound from HBM in the step, cache-resident under the profiler's eight back-to-back launches (one
+        // expert = 29 MB stays in the 256 MB Infinity Cache).  Four 32-row tiles are 128 workgroups that share the panel
+        // through the L2: more bytes from the L2, fewer from a latency-bound stream.  What would pay is the big tiles
+        // running BESIDE the small ones (one launch), not before them.
+        // 16-bit and fp8 weights on gemm_tiled_kernel only, single-workgroup sorts only (<= 4096 slots).
+        if ((tiled == 32 || tiled == 64) && !split && !g2_only && !pf && !wf_is_4bit(h->wf) && n_slots <= 4096 &&
+            h->t_mixed > 0 && h->t_xcd <= 0) {
+            pl->big_rows = 128;
+            pl->big_min = h->t_mixed;
+            pl->b1 = LaunchCfg{1, 8, 1, 1, 128, 8, 2, 0};
+            pl->b2 = LaunchCfg{1, 8, 1, sk2, 128, 8, 2, 0};
+        }
         if (!split && !g2_only) return;
     }
     // ---- skinny geometry (only register-resident variants exist: gated needs nt<=2 and nt*tb<=4;
@@ -922,6 +956,10 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         while (sk_direct * 2 * K <= 16 && waves * sk_direct < 2048 && h->U2 / (sk_direct * 2) >= 2) sk_direct *= 2;
     }
     const bool direct = direct_plan(h, M, K, pl) && il.ids_ld == K && il.tw_ld == K;
+    // hybrid: experts with more than split_rows rows go to the tile list; mixed heights: the packed pair (pack_mixed_tiles)
+    const int tile_min_sort = pl.big_rows ? pack_mixed_tiles(pl.big_rows, pl.big_min) : pl.split_rows;
+    // big tiles of a mixed plan: experts with more than big_min rows, ceil(rows / big_rows) tiles each
+    const int max_big_tiles = pl.big_rows ? (int)(n_slots / (size_t)pl.big_rows + n_slots / (size_t)(pl.big_min + 1)) + 1 : 0;
     const int max_active = (int)((size_t)h->E < n_slots ? (size_t)h->E : n_slots);
     const int max_tiles = tile_rows ? (int)(n_slots / tile_rows) + max_active : 0;
     // XCD-aware mapping: the sort kernel cuts the tile list into 8 runs of equal routed rows, none longer than
@@ -931,11 +969,11 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
     if (!direct && il.route) {
         LKM_REQUIRE(launch_route_sort_ok(M, K, il.route->E, il.route->n_group, h->E), "forward_routed: step planned off both fused paths");
         rc = launch_route_sort(st, *il.route, il.id_off, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
-                               a->active, a->meta, tile_rows_sort, pl.split_rows, a->tile_e, a->tile_r0, xcd_cap);
+                               a->active, a->meta, tile_rows_sort, tile_min_sort, a->tile_e, a->tile_r0, xcd_cap);
         if (rc != LKM_OK) return rc;
     } else if (!direct) {
         rc = launch_sort(st, ids, K, (int)il.ids_ld, il.id_off, (int)n_slots, h->E, a->counts, a->offsets, a->sorted_slot, a->pos_of_slot,
-                         a->active, a->meta, tile_rows_sort, pl.split_rows, a->tile_e, a->tile_r0, a->hist,
+                         a->active, a->meta, tile_rows_sort, tile_min_sort, a->tile_e, a->tile_r0, a->hist,
                          a->hist_cap, xcd_cap);
         if (rc != LKM_OK) return rc;
     }
@@ -1022,6 +1060,13 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
             p1.groups = h->T1_half / pl.s1.nt;
             rc = launch_gemm1(st, h->wfk, h->adt, pl.s1, p1, h->gated, direct ? (int)n_slots : max_active);
             if (rc != LKM_OK) return rc;
+        }
+        if (pl.big_rows) {           // the big tiles first (the longest workgroups), then the rest of the list
+            GemmParams pb = p1;
+            pb.tile_hi_meta = 4;
+            rc = launch_gemm1_tiled(st, h->wfk, h->adt, pl.b1, pb, h->gated, max_big_tiles);
+            if (rc != LKM_OK) return rc;
+            p1.tile_lo_meta = 4;
         }
         if (pl.t1.tiled) {
             rc = launch_gemm1_tiled(st, h->wfk, h->adt, pl.t1, p1, h->gated, max_tiles);
@@ -1120,6 +1165,13 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
             rc = launch_gemm2(st, h->wfk, h->adt, pl.s2, p2, max_active);
             if (rc != LKM_OK) return rc;
         }
+        if (pl.big_rows) {
+            GemmParams pb = p2;
+            pb.tile_hi_meta = 4;
+            rc = launch_gemm2_tiled(st, h->wfk, h->adt, pl.b2, pb, max_big_tiles);
+            if (rc != LKM_OK) return rc;
+            p2.tile_lo_meta = 4;
+        }
         if (pl.t2.tiled) {
             rc = launch_gemm2_tiled(st, h->wfk, h->adt, pl.t2, p2, max_tiles);
             if (rc != LKM_OK) return rc;
@@ -1136,10 +1188,10 @@ static int run_chunk(LkmEngine* h, hipStream_t st, int M, int K, const void* x, 
         h->prof_valid = true;
     }
     snprintf(h->last_desc, sizeof(h->last_desc),
-             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2 nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d pd=%d/%d split=%d pf=%d xcd=%d/%d | nt_loads=%d",
+             "M=%d K=%d | %s%s | skinny g1 nt=%d tb=%d kw=%d, g2 nt=%d tb=%d sk=%d | tiled g1 nt=%d, g2 nt=%d, tm=%d waves=%d pd=%d/%d split=%d pf=%d xcd=%d/%d mixed=%d>%d | nt_loads=%d",
              M, K, pl.s1.tb ? "skinny" : "", pl.t1.tiled ? (pl.s1.tb ? "+tiled" : "tiled") : "", pl.s1.nt,
              pl.s1.tb, pl.s1.kw, pl.s2.nt, pl.s2.tb, pl.s2.sk, pl.t1.nt, pl.t2.nt, tile_rows, pl.t1.waves,
-             pl.t1.pd, pl.t2.pd, pl.split_rows, pl.t1.pf, p1.xcd_map ? 1 : 0, p2.xcd_map ? 1 : 0, stream_nt);
+             pl.t1.pd, pl.t2.pd, pl.split_rows, pl.t1.pf, p1.xcd_map ? 1 : 0, p2.xcd_map ? 1 : 0, pl.big_rows, pl.big_min, stream_nt);
     return LKM_OK;
 }
 
@@ -1638,6 +1690,7 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     }
     else if (!strcmp(key, "valid_den")) h->t_valid_den = value;
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
+    else if (!strcmp(key, "mixed")) h->t_mixed = value;
     else if (!strcmp(key, "prof_rep")) h->t_prof_rep = value;
     else if (!strcmp(key, "dbg")) h->t_dbg = value;
     else {
@@ -1714,7 +1767,7 @@ static int copy_expert(LkmHandle h, void* stream, int32_t expert, char* image, b
         const size_t pad = (16 - s.bytes[i] % 16) % 16;   // images are deterministic: padding is written as zeros
         if (to_image && pad) LKM_HIP_CHECK(hipMemsetAsync(img + s.bytes[i], 0, pad, (hipStream_t)stream));
         LKM_HIP_CHECK(hipMemcpyAsync(to_image ? (void*)img : (void*)s.ptr[i], to_image ? (const void*)s.ptr[i] : (const void*)img,
-                                     s.bytes[i], hipMemcpyDeviceToDevice, (hipStream_t)stream));
+                                     s.bytes[i], hipMemcpyDefault, (hipStream_t)stream));      // (the image may be pinned host memory: lvllm_amd/spill.py)
     }
     return LKM_OK;
 }

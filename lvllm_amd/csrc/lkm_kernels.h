@@ -55,6 +55,9 @@ int launch_route_sort(hipStream_t st, const RouteArgs& ra, int id_offset, int E,
 // tile_rows of the two sort launchers may carry a granule in its high half: pack_tile_rows(256, 32) = 256-row tiles,
 // an expert's rows dealt to its tiles as evenly as 32-row granules allow (dispatch.hip tile_first_row)
 inline int pack_tile_rows(int rows, int gran) { return rows | (gran << 16); }
+// tile_min of the two single-workgroup sort launchers may instead carry MIXED tile heights (negative): experts with more than
+// big_min rows get tiles of big_rows rows, the others tiles of tile_rows; the big tiles are the first meta[4] list entries
+inline int pack_mixed_tiles(int big_rows, int big_min) { return -((big_rows << 16) | (big_min & 0xffff)); }
 constexpr int kMetaInts = 32;   // meta[0..3]: see dispatch.hip; meta[8..16]: per-XCD runs of the tile list
 int launch_quant_fp8_rows(hipStream_t st, const void* src, int ld_src, int adt, int R, int K, void* dst,
                           float* scales);
@@ -131,6 +134,8 @@ struct GemmParams {
     int route_on;
     RouteArgs route;
     long long x_rows;  // rows of the activation matrix behind `x` (bounds of the LDS-DMA buffer window)
+    int tile_lo_meta, tile_hi_meta;   // gemm_tiled_kernel on a PART of the tile list (mixed tile heights): item = blockIdx.y +
+                       // meta[tile_lo_meta] (0: the list's start), valid below meta[tile_hi_meta] (0: meta[3], the whole list)
     int xcd_map;       // tiled kernels: != 0 -> XCD-aware 1-D work mapping.  Host side: the longest run of tiles one
                        // XCD may get (launch_sort's xcd_cap); the launcher replaces it by the row-group count
     int y_dt;          // GEMM2: dtype of the per-row partials `out` (LKM_DT_F32, or the activation dtype where the

@@ -313,6 +313,10 @@ def moe_align_block_size(topk_ids: torch.Tensor, block_size: int, num_experts: i
     emap = None
     if expert_map is not None and ignore_invalid_experts:
         emap = expert_map.to(torch.int32).contiguous()
+    if n == 0:                      # (no slots: no blocks; the output tensors are empty, there is nothing to launch)
+        expert_ids.fill_(-1)
+        sorted_ids.fill_(0)
+        return sorted_ids, expert_ids, post.zero_()
     ws = _ops_workspace(n, num_experts, dev)
     _clib.check(_clib.lib().lkm_moe_align_block_size(_stream(ids), _ptr(ids), n, num_experts, block_size, _ptr(emap),
                                                      _ptr(sorted_ids), max_padded, _ptr(expert_ids), max_blocks, _ptr(post),
@@ -347,6 +351,8 @@ def moe_permute(hidden_states: torch.Tensor, a1q_scale: torch.Tensor | None, top
     first = torch.empty((n_local_expert + 1,), dtype=torch.int64, device=dev)
     inv = torch.empty((n_token, topk), dtype=torch.int32, device=dev)
     perm = torch.empty((rows,), dtype=torch.int32, device=dev)
+    if rows == 0:
+        return permuted_hidden_states, a1q_scale, first.zero_(), inv.flatten(), perm
     ws = _ops_workspace(rows, n_expert if emap is None else n_local_expert + n_expert, dev)
     _clib.check(_clib.lib().lkm_moe_permute(_stream(h), _ptr(h), n_hidden * h.element_size(), n_token, _ptr(ids), topk,
                                             _ptr(emap), n_expert, n_local_expert, _ptr(permuted_hidden_states), _ptr(first),

@@ -31,8 +31,8 @@ def _has_gpu() -> bool:
 _GPU_ORDER = [
     "test_gpu_routing.py", "test_gpu_fused_step.py", "test_gpu_fullsize.py", "<reference_cpu_kernel>",
     "test_zz4_gpu_reference_glue.py", "test_zz6_gpu_reference_modular_kernel.py", "test_zz2_gpu_layer.py",
-    "test_gpu_moe.py", "test_gpu_quant.py", "test_gpu_w4x.py", "test_gpu_odd_hidden.py", "test_gpu_router.py",
-    "test_zz1_gpu_shared_experts.py", "test_ingest.py", "test_residency.py", "test_zz3_gpu_eplb.py", "test_gpu_ep.py",
+    "test_gpu_moe.py", "test_gpu_moe_ops.py", "test_gpu_quant.py", "test_gpu_w4x.py", "test_gpu_odd_hidden.py", "test_gpu_router.py",
+    "test_zz1_gpu_shared_experts.py", "test_ingest.py", "test_residency.py", "test_gpu_spill.py", "test_zz3_gpu_eplb.py", "test_gpu_ep.py",
     "test_gpu_ep_rank_shapes.py", "test_gpu_create_streaming.py", "test_zz5_gpu_create_near_capacity.py",
     "test_gpu_autotune.py",
 ]

@@ -327,6 +327,9 @@ def test_hybrid_dispatch_skewed_routing(M, E, K, H, I, skew):
     a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=M + 3, skew=skew)
     counts = np.bincount(ids[ids >= 0].ravel(), minlength=E)
     eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+    # (round 5: for 16-bit weights the planner's default at these sizes is plain 64-row tiles -- measured faster under
+    #  skew, profiles/r05_hybrid_vs_tiles_ab.log; "hybrid" = 1 asks for the hybrid, which stays a parity-tested plan)
+    eng.engine.set_tuning(hybrid=1)
     out = _run_decode(eng, a, tw, ids)
     desc = eng.engine.describe()
     assert "skinny+tiled" in desc, desc
@@ -337,6 +340,10 @@ def test_hybrid_dispatch_skewed_routing(M, E, K, H, I, skew):
     np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL)
     eng.engine.set_tuning(hybrid=-1)
     np.testing.assert_allclose(_run_decode(eng, a, tw, ids), out, atol=1e-4, rtol=1e-4)
+    eng.engine.set_tuning(hybrid=0)              # the default plan: tiles only
+    dflt = _run_decode(eng, a, tw, ids)
+    assert "| tiled |" in eng.engine.describe() and "split=0" in eng.engine.describe(), eng.engine.describe()
+    np.testing.assert_allclose(dflt, ref, atol=ATOL, rtol=RTOL)
 
 
 @pytest.mark.parametrize("fmt,M,E,K,H,I,skew", [("bf16", 32, 8, 2, 512, 1024, 2.0), ("bf16", 32, 16, 4, 256, 384, 0.0),
@@ -1256,3 +1263,77 @@ def test_modular_experts_top1_preweighted_and_fp8_quant_config():
     want = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=ATOL, rtol=RTOL)
     assert LkmQuant.from_vllm(QC(), torch.bfloat16).fp8_mode == _clib.FP8_W8A16
+
+
+# ----------------------------------------------------------------------------------------- mixed tile heights (round 5)
+def _mixed_case(fmt, M, E, K, H, I, seed, skew):
+    a, w13, w2, tw, ids = _rand_case(M, E, K, H, I, torch.bfloat16, seed=seed, skew=skew, drop=0.05)
+    if fmt == "bf16":
+        eng = _eng(w13, w2, top_k=K, act_dtype=torch.bfloat16)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+        ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
+        tol = (ATOL, RTOL)
+    else:
+        from lvllm_amd import _clib
+        a8 = fmt == "fp8_w8a8"
+        q13, s13 = orc.quant_fp8_block(w13.float().numpy(), 128, 128)
+        q2, s2 = orc.quant_fp8_block(w2.float().numpy(), 128, 128)
+        eng = _eng(torch.from_numpy(q13), torch.from_numpy(q2), top_k=K, act_dtype=torch.bfloat16, fmt="fp8",
+                   w13_scale=torch.from_numpy(s13), w2_scale=torch.from_numpy(s2), group_n=128, group_k=128,
+                   fp8_mode=_clib.FP8_W8A8 if a8 else _clib.FP8_W8A16)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128, round_gemm1=a8, w8a8=a8)
+        ref = orc.moe(d, q13, q2, torch_to_bits(a), ids, tw, s13=s13, s2=s2)
+        tol = (ATOL, RTOL) if not a8 else (0.035 * float(np.abs(ref).max()), 0.035)
+    return eng, a, tw, ids, ref, tol
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "fp8_w8a16", "fp8_w8a8"])
+@pytest.mark.parametrize("M,E,K,skew", [
+    (256, 32, 1, 2.5),        # the DeepSeek-V3 rank-slice shape in small: 32 experts, one of them far above the mean
+    (160, 24, 2, 1.5),        # top-2, several experts above the threshold, ragged
+    (96, 16, 2, 0.0),         # uniform: the big-tile part of the list is empty (its workgroups exit at once)
+])
+def test_mixed_tile_heights_vs_oracle(fmt, M, E, K, skew):
+    """round-4 verdict item 6: experts with many more rows than the plan's small tiles take 128-row tiles, decided on the
+    device by the sort (dispatch.hip sort_slots_body, meta[4]); two launches per GEMM on the two parts of one tile list.
+    Against the oracle with the plan forced on and off, through the plain sort and the fused router + sort, eager and
+    replayed from a hipGraph on new routing."""
+    H, I = 512, 256
+    eng, a, tw, ids, ref, (atol, rtol) = _mixed_case(fmt, M, E, K, H, I, seed=31 + M, skew=skew)
+    counts = np.bincount(ids[ids >= 0], minlength=E)
+    outs = {}
+    for mixed, tiled in ((40, 32), (40, 64), (-1, 32), (0, 0)):
+        eng.engine.set_tuning(mixed=mixed, tiled=tiled)
+        outs[(mixed, tiled)] = _run_decode(eng, a, tw, ids)
+        desc = eng.engine.describe()
+        assert ("mixed=128>40" in desc) == (mixed > 0), desc
+        np.testing.assert_allclose(outs[(mixed, tiled)], ref, atol=atol, rtol=rtol, err_msg=f"{fmt} mixed={mixed} tiled={tiled} {desc}")
+        if mixed > 0 and skew > 0:
+            assert counts.max() > 40                     # the case really has a big-tile expert
+    eng.engine.set_tuning(mixed=0, tiled=0)
+    # fused router + sort (lkm_forward_routed) on logits that reproduce a skewed routing, captured and replayed
+    g = torch.Generator().manual_seed(5 + M)
+    logits = torch.randn((M, E), generator=g)
+    if skew > 0:
+        logits = logits + skew * torch.log(1.0 / torch.arange(1, E + 1, dtype=torch.float32))[None, :]
+    eng.engine.set_tuning(mixed=40, tiled=32)
+    xd, ld = a.to(DEV), logits.to(DEV)
+    out = torch.zeros((M, H), dtype=torch.float32, device=DEV)
+    fused, fw, fi = eng.forward_logits(xd, ld, K, True, out=out)
+    plain = eng.decode(xd, fw, fi)
+    assert torch.equal(fused, plain)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        eng.forward_logits(xd, ld, K, True, out=out)
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=st):
+        eng.forward_logits(xd, ld, K, True, out=out)
+    ld.copy_(torch.flip(ld, dims=[1]))                  # the hot expert moves: the device re-decides the tile heights
+    gr.replay()
+    torch.cuda.synchronize()
+    want, _, _ = eng.forward_logits(xd, ld, K, True)
+    assert torch.equal(out, want)
+    eng.engine.set_tuning(mixed=0, tiled=0)

@@ -1,0 +1,140 @@
+"""SURVEY 8 a9 as stand-alone operators (round-4 verdict, "missing" 4): lvllm_amd.ops.moe_align_block_size / moe_permute /
+moe_unpermute against vectors produced by the REFERENCE's own golden implementations (tests/golden/make_golden_moe_ops.py
+executes torch_moe_align_block_size, torch_permute and torch_unpermute of the reference's test files; tests/golden/moe_ops.npz).
+Index outputs are compared exactly -- stricter than the reference's own test, which accepts any order inside an expert
+(test_moe_align_block_size.py:49-93): the counting sort here is stable, like the golden implementation.  moe_unpermute:
+the reference's tolerance (atol 2e-2, test_moe_permute_unpermute.py:216) and, tighter, one bf16 ulp of the fp32 sum."""
+import numpy as np
+import pytest
+import torch
+
+from pathlib import Path
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = None
+
+
+def _g():
+    global G
+    if G is None:
+        G = np.load(Path(__file__).resolve().parent / "golden" / "moe_ops.npz")
+    return G
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.view(dtype)
+
+
+@pytest.mark.parametrize("i", range(9))
+def test_moe_align_block_size_matches_the_reference_golden(i):
+    from lvllm_amd import ops
+    g = _g()
+    assert i < int(g["n_align"])
+    bs, E, pad = (int(v) for v in g[f"align{i}_args"])
+    ids = _t(g[f"align{i}_ids"])
+    s, e, p = ops.moe_align_block_size(ids, bs, E, pad_sorted_ids=bool(pad))
+    gs, ge, gp = g[f"align{i}_sorted"], g[f"align{i}_experts"], g[f"align{i}_post"]
+    assert p.cpu().numpy().tolist() == gp.tolist()
+    # (numel < num_experts: the operator sizes its outputs min(numel * block, ...) (moe_align_block_size.py:76-79), the
+    #  golden numel * block (:112-113) -- compare the common prefix, the rest must be padding)
+    n, nb = min(s.numel(), gs.size), min(e.numel(), ge.size)
+    np.testing.assert_array_equal(s.cpu().numpy()[:n], gs[:n])
+    np.testing.assert_array_equal(e.cpu().numpy()[:nb], ge[:nb])
+    assert (s.cpu().numpy()[n:] == ids.numel()).all() and (e.cpu().numpy()[nb:] == -1).all()
+    total = int(gp[0])
+    assert total % bs == 0 and total >= ids.numel() and (s[:total] < ids.numel()).sum().item() == ids.numel()
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_moe_align_block_size_with_expert_map_matches_the_reference_golden(i):
+    """test_moe_align_block_size.py:243-300 (ignore_invalid_experts=True): ids of experts that are not local -- and ids -1 --
+    take no part, expert_ids hold local ids"""
+    from lvllm_amd import ops
+    g = _g()
+    ids, emap = _t(g[f"alignm{i}_ids"]), _t(g[f"alignm{i}_map"])
+    s, e, p = ops.moe_align_block_size(ids, 64, emap.numel(), expert_map=emap, ignore_invalid_experts=True)
+    assert p.cpu().numpy().tolist() == g[f"alignm{i}_post"].tolist()
+    n, nb = min(s.numel(), g[f"alignm{i}_sorted"].size), min(e.numel(), g[f"alignm{i}_experts"].size)
+    np.testing.assert_array_equal(s.cpu().numpy()[:n], g[f"alignm{i}_sorted"][:n])
+    np.testing.assert_array_equal(e.cpu().numpy()[:nb], g[f"alignm{i}_experts"][:nb])
+    # ... and the reference's other mode (ignore_invalid_experts=False, :99-100): every expert takes part, the block's expert
+    # id is mapped afterwards (-1 = a block of an expert that is not local)
+    ids2 = ids.clamp(min=0)
+    s2, e2, p2 = ops.moe_align_block_size(ids2, 64, emap.numel(), expert_map=emap)
+    s0, e0, p0 = ops.moe_align_block_size(ids2, 64, emap.numel())
+    assert torch.equal(s2, s0) and torch.equal(p2, p0) and torch.equal(e2, emap[e0.long()])
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_moe_permute_unpermute_match_the_reference_golden(i):
+    from lvllm_amd import ops
+    g = _g()
+    assert i < int(g["n_perm"])
+    E, n_local, ep, rank = (int(v) for v in g[f"perm{i}_args"])
+    hidden = _t(g[f"perm{i}_hidden"], torch.bfloat16)
+    ids, tw = _t(g[f"perm{i}_ids"]), _t(g[f"perm{i}_tw"])
+    emap = _t(g[f"perm{i}_map"]) if ep != 1 else None
+    rows, _, first, inv, perm = ops.moe_permute(hidden, None, ids, E, n_local, emap)
+    nvalid = int(g[f"perm{i}_nvalid"])
+    np.testing.assert_array_equal(first.cpu().numpy(), g[f"perm{i}_first"])                 # :181-183, atol 0
+    np.testing.assert_array_equal(inv.cpu().numpy(), g[f"perm{i}_inv"].reshape(-1))        # :185-187, atol 0
+    np.testing.assert_array_equal(perm.cpu().numpy(), g[f"perm{i}_perm"])
+    assert int(first[-1]) == nvalid
+    assert torch.equal(rows[:nvalid].view(torch.int16).cpu(), torch.from_numpy(g[f"perm{i}_rows"][:nvalid]))   # :190-195: valid rows
+    res0 = _t(g[f"perm{i}_res0"], torch.bfloat16)
+    out = torch.empty_like(hidden)
+    ops.moe_unpermute(out, res0, tw, inv, first)
+    gold = _t(g[f"perm{i}_gold4"], torch.bfloat16)
+    torch.testing.assert_close(out, gold, atol=2e-2, rtol=0)                                # :216
+    ulp = (gold.float().abs() * 2.0 ** -7).clamp(min=2.0 ** -20)
+    assert bool(((out.float() - gold.float()).abs() <= ulp).all())
+    # the operator pair is the engine's scatter + combine: permute -> identity "experts" -> unpermute = sum_k w[t,k] * x[t]
+    # over the local experts' slots
+    out2 = torch.empty_like(hidden)
+    ops.moe_unpermute(out2, rows, tw, inv, first)
+    local = torch.ones_like(ids, dtype=torch.bool) if emap is None else (emap[ids.long()] >= 0)
+    want = ((tw * local).sum(1, keepdim=True) * hidden.float())
+    torch.testing.assert_close(out2.float(), want, atol=2e-2, rtol=2e-2)
+
+
+def test_moe_ops_are_graph_capturable_and_take_ragged_inputs():
+    """no allocation or host synchronisation inside the C entry points (workspace from the caller): captured + replayed on
+    new ids; zero tokens; ids -1 without a map are skipped"""
+    from lvllm_amd import _clib, ops
+    import ctypes as C
+    E, bs, M, K = 64, 32, 100, 4
+    ids = torch.randint(0, E, (M, K), dtype=torch.int32, device=DEV)
+    lib = _clib.lib()
+    n = ids.numel()
+    cap = n + E * (bs - 1)
+    s = torch.empty(cap, dtype=torch.int32, device=DEV)
+    e = torch.empty(-(-cap // bs), dtype=torch.int32, device=DEV)
+    p = torch.empty(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(int(lib.lkm_moe_ops_workspace_bytes(n, E)) // 4 + 4, dtype=torch.int32, device=DEV)
+    st = torch.cuda.Stream()
+
+    def call():
+        _clib.check(lib.lkm_moe_align_block_size(C.c_void_p(st.cuda_stream), C.c_void_p(ids.data_ptr()), n, E, bs, None,
+                                                 C.c_void_p(s.data_ptr()), cap, C.c_void_p(e.data_ptr()), e.numel(),
+                                                 C.c_void_p(p.data_ptr()), C.c_void_p(ws.data_ptr())))
+    with torch.cuda.stream(st):
+        call()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=st):
+        call()
+    ids.copy_(torch.randint(0, E, (M, K), dtype=torch.int32, device=DEV))
+    ids[3, 1] = -1
+    gr.replay()
+    torch.cuda.synchronize()
+    s2, e2, p2 = ops.moe_align_block_size(ids, bs, E)
+    assert torch.equal(s, s2) and torch.equal(e, e2) and torch.equal(p, p2)
+    assert (s2 < n).sum().item() == n - 1                                  # the -1 slot is nowhere
+    z = torch.zeros((0, K), dtype=torch.int32, device=DEV)
+    sz, ez, pz = ops.moe_align_block_size(z, bs, E)
+    assert int(pz) == 0 and sz.numel() == 0
+    hz = torch.zeros((0, 64), dtype=torch.bfloat16, device=DEV)
+    rows, _, first, inv, perm = ops.moe_permute(hz, None, z, E)
+    assert rows.shape == (0, 64) and first.tolist() == [0] * (E + 1) and inv.numel() == 0

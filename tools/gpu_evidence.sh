@@ -21,16 +21,18 @@ smoke) echo "== smoke"; timeout 600 python __graft_entry__.py smoke 2>&1 | tail 
 tests) echo "== pytest gpu"; timeout 3000 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -3 | tee gpurun_out/${TAG}_pytest_gpu.log ;;
 traffic) echo "== FETCH_SIZE passes"; timeout 1500 python tools/update_hbm_traffic.py gpurun_out 2>&1 | grep -v amdgpu.ids | cut -c1-120
          cp gpurun_out/hbm_traffic.json profiles/hbm_traffic.json ;;
-bench) echo "== bench (driver flags)"; timeout 1200 python bench.py --steps 20 --warmup 5 2>gpurun_out/${TAG}_bench_stderr.log | grep '^{' > gpurun_out/${TAG}_bench_n1.json
+bench) echo "== bench (driver flags)"; timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 --full-out gpurun_out/${TAG}_bench_full.json 2>gpurun_out/${TAG}_bench_stderr.log > gpurun_out/${TAG}_bench_stdout.log
+  tail -1 gpurun_out/${TAG}_bench_stdout.log > gpurun_out/${TAG}_bench_n1.json
   python - <<PY
 import json
-j = json.load(open("gpurun_out/${TAG}_bench_n1.json"))
+lines = [json.loads(l) for l in open("gpurun_out/${TAG}_bench_stdout.log") if l.startswith("{")]
+j = lines[-1]
 r = j["roofline"]
-print("step us", round(j["ms_per_step"] * 1e3, 1), "tok/s", j["value"], r["kernel_ms"], "frac", r["frac"], "stale", r.get("traffic_stale"), "long_run", j.get("long_run", {}).get("ms_per_step"))
+print("last line bytes", len(json.dumps(j)), "step us", round(j["ms_per_step"] * 1e3, 1), "tok/s", j["value"], "regions", j.get("timed_regions_ms"), r["kernel"], r["kernel_ms"], "frac", r["frac"], "traffic", r.get("traffic"), "stale", r.get("traffic_stale"))
 c = j.get("cpu_baseline") or {}; print({k: v for k, v in c.items() if k not in ("port", "sample", "host")})
-for e in j.get("extra", []):
+for e in lines[:-1]:
     r = e["roofline"]
-    print(" extra", e["workload"], e["config"]["routing"], "step us", round(e["ms_per_step"]*1e3,1), r["kernel_ms"], "frac", r["frac"], r.get("gemm2"), r.get("traffic_stale"))
+    print(" extra", e["extra_workload"], e["routing"], "step us", round(e["ms_per_step"]*1e3,1), r["kernel"], r["kernel_ms"], "frac", r["frac"], "traffic", r.get("traffic"))
 PY
   ;;
 trace) echo "== rocprof kernel-trace"; cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt -o bench -- python $R/bench.py --no-cpu-baseline --steps 100 > $R/gpurun_out/${TAG}_rocprof_kt.log 2>&1; cd $R

@@ -442,6 +442,8 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
         M, scaling = wl["M_global"] // world, "strong"
     else:
         M, scaling = wl["M"], "weak"
+    if args.batch_per_gpu and name == args.workload:      # (development: the same experts at another batch size)
+        M = args.batch_per_gpu
     if E % world:
         return None
     use_ep = world > 1 or force_ep
@@ -862,6 +864,7 @@ def main():
     ap.add_argument("--autotune", action="store_true",
                     help="turn the engine's first-call plan search on (lkm_set_tuning autotune; default off = what lk_moe users get)")
     ap.add_argument("--no-autotune", action="store_true", help="(default since round 5; kept so that older command lines still parse)")
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="override the workload's tokens per GPU (plan A/Bs; not for the headline)")
     ap.add_argument("--regions", type=int, default=5,
                     help="timed regions of exactly --steps steps each; the median region is reported (all are listed)")
     ap.add_argument("--full-line", action="store_true", help="print the complete record as the last line (tools), not the < 4 KB one")

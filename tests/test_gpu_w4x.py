@@ -170,6 +170,10 @@ def test_last_kernels_names_what_was_launched():
     itself -- the default tile kernel, then the forced 32x32-MFMA kernel, then the streamer, on one engine"""
     eng, a, tw, ids, ref = _int4_case(128, 8, 2, 512, 384, 128, "bf16", seed=133)
     _run_decode(eng, a, tw, ids)
+    kd = eng.engine.last_kernels()                # round 5: uint4b8 on 64-row tiles defaults to the loader-wave kernel
+    assert len(kd["gemm1"]) == 1 and "gemm_w4e_kernel<" in kd["gemm1"][0] and "gemm_w4e_kernel<" in kd["gemm2"][0], kd
+    eng.engine.set_tuning(pf=-1)
+    _run_decode(eng, a, tw, ids)
     k0 = eng.engine.last_kernels()
     assert len(k0["gemm1"]) == 1 and "gemm_tiled_kernel<" in k0["gemm1"][0] and "gemm_tiled_kernel<" in k0["gemm2"][0], k0
     eng.engine.set_tuning(pf=5, tiled=64)
@@ -180,6 +184,6 @@ def test_last_kernels_names_what_was_launched():
     _run_decode(eng, a, tw, ids)
     k2 = eng.engine.last_kernels()
     assert "gemm1_act_kernel<" in k2["gemm1"][0] and "gemm2_kernel<" in k2["gemm2"][0], k2
-    for k in (k0, k1, k2):                      # as rocprofv3 prints them: namespace, template arguments, no parameter list
+    for k in (kd, k0, k1, k2):                  # as rocprofv3 prints them: namespace, template arguments, no parameter list
         assert all(n.startswith("lkm::") and n.endswith(">") and "(" not in n for n in k["gemm1"] + k["gemm2"]), k
     _reset(eng)

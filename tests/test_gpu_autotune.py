@@ -69,3 +69,44 @@ def test_autotune_picks_a_tested_plan_and_graphs_replay_it(fmt, M):
     eng.engine.set_tuning(tiled=0, autotune=0)
     again = eng.decode(a, tw, ids)
     assert "autotuned" not in eng.engine.describe() and torch.equal(again, base)
+
+
+def test_autotune_robustness_and_the_plan_agreement_calls():
+    """ADVICE r4 + verdict item 8: an in-place caller is never tuned (the candidates would run repeatedly on its own
+    buffers), changing a planning knob forgets the remembered plans, the remembered plans can be read and replaced by
+    candidate index (what ep.agree_tuned_plans does across a group), and an expert-parallel engine refuses autotune = 1."""
+    from lvllm_amd._clib import LkmError
+    from lvllm_amd.ops import RoutedExpertsEngine
+    M, E, K, H, I = 128, 8, 2, 512, 384
+    eng, a, tw, ids, ref = _case("int4", M, E, K, H, I, seed=77)
+    eng.engine.set_tuning(autotune=1)
+    inplace = a.clone()
+    eng.forward_rows(inplace, tw, ids, out=inplace, out_dtype=torch.bfloat16)          # out aliases the token rows
+    assert eng.engine.tuned_plans() == [] and "autotuned" not in eng.engine.describe()
+    np.testing.assert_allclose(inplace.float().cpu().numpy(), ref, atol=2e-2 * float(np.abs(ref).max()), rtol=2e-2)
+    out = eng.decode(a, tw, ids).clone()
+    plans = eng.engine.tuned_plans()
+    assert len(plans) == 1 and plans[0][1] >= 0, plans
+    key, idx = plans[0]
+    # replace the choice by candidate 0 (= the default plan), as a group agreement would: the next call runs it
+    eng.engine.set_tuned_plan(key, 0)
+    assert eng.engine.tuned_plans() == [(key, 0)]
+    dflt = eng.decode(a, tw, ids).clone()
+    assert "autotuned: default" in eng.engine.describe(), eng.engine.describe()
+    np.testing.assert_allclose(dflt.cpu().numpy(), ref, atol=2e-3, rtol=1e-2)
+    with pytest.raises(LkmError):
+        eng.engine.set_tuned_plan(key, 99)                     # outside the shape's candidate list
+    with pytest.raises(LkmError):
+        eng.engine.set_tuned_plan(key + 1, 0)                  # a shape that was never tuned here
+    eng.engine.set_tuning(nt2=1)                               # a planning knob: remembered plans are for the old knobs
+    assert eng.engine.tuned_plans() == []
+    eng.engine.set_tuning(nt2=0, autotune=0)
+    # expert-parallel engine (num_processes > 1): 1 is refused loudly, 2 = "the host agrees on the plans" is accepted
+    g = torch.Generator().manual_seed(5)
+    w13 = (torch.randn((4, 2 * 128, 256), generator=g) / 10).to(torch.bfloat16)
+    w2 = (torch.randn((4, 256, 128), generator=g) / 10).to(torch.bfloat16)
+    ep_eng = RoutedExpertsEngine(w13, w2, top_k=2, act_dtype=torch.bfloat16, num_processes=2, process_id=0)
+    with pytest.raises(LkmError, match="agree"):
+        ep_eng.engine.set_tuning(autotune=1)
+    ep_eng.engine.set_tuning(autotune=2)
+    ep_eng.engine.set_tuning(autotune=0)

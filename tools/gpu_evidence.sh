@@ -18,7 +18,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for s in $STEPS; do case $s in
 smoke) echo "== smoke"; timeout 600 python __graft_entry__.py smoke 2>&1 | tail -1 | cut -c1-200 ;;
-tests) echo "== pytest gpu"; timeout 3000 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -3 | tee gpurun_out/${TAG}_pytest_gpu.log ;;
+tests) echo "== pytest gpu"; timeout 3000 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3 | tee gpurun_out/${TAG}_pytest_gpu.log ;;
 traffic) echo "== FETCH_SIZE passes"; timeout 1500 python tools/update_hbm_traffic.py gpurun_out 2>&1 | grep -v amdgpu.ids | cut -c1-120
          cp gpurun_out/hbm_traffic.json profiles/hbm_traffic.json ;;
 bench) echo "== bench (driver flags)"; timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 --full-out gpurun_out/${TAG}_bench_full.json 2>gpurun_out/${TAG}_bench_stderr.log > gpurun_out/${TAG}_bench_stdout.log

@@ -302,3 +302,74 @@ def eplb_map_record(topk_ids: np.ndarray, log2phy: np.ndarray, logcnt: np.ndarra
             sel &= np.arange(flat.size) < int(num_unpadded) * K
         np.add.at(out_load, phys[sel], 1)
     return phys.reshape(M, K).astype(np.int32), out_load
+
+
+# ------------------------------------------------------------------ the scatter / gather step as operators (numpy)
+# CPU restatements of the reference's operator forms of SURVEY 8 a9, pinned against vectors produced by the reference's own
+# golden functions (tests/golden/moe_ops.npz, tests/test_oracle_golden.py); the GPU tests compare lvllm_amd.ops with these at
+# sizes the goldens do not hold (tests/test_gpu_moe_ops.py).
+def moe_align_block_size(topk_ids: np.ndarray, block_size: int, num_experts: int, expert_map: np.ndarray | None = None,
+                         pad_sorted_ids: bool = False):
+    """moe_align_block_size (vllm/model_executor/layers/fused_moe/moe_align_block_size.py:11-103; golden
+    tests/kernels/moe/test_moe_align_block_size.py:96-172): slots sorted by expert (stable), every expert padded to a multiple
+    of block_size with the value numel; expert_map (the ignore_invalid_experts form): ids mapped to -1 -- and ids < 0 -- take
+    no part, expert_ids hold the mapped ids.  -> (sorted_ids int32 [max_padded], expert_ids int32 [blocks], total int)."""
+    ids = np.asarray(topk_ids, np.int64).reshape(-1)
+    n = ids.size
+    max_padded = n + num_experts * (block_size - 1)
+    if pad_sorted_ids:
+        max_padded = -(-max_padded // block_size) * block_size
+    if n < num_experts:
+        max_padded = min(n * block_size, max_padded)
+    sorted_ids = np.full(max_padded, n, np.int32)
+    expert_ids = np.full(-(-max_padded // block_size) if max_padded else 0, -1, np.int32)
+    pos = blk = 0
+    for e in range(num_experts):
+        if expert_map is not None and expert_map[e] < 0:
+            continue
+        rows = np.nonzero(ids == e)[0]
+        if rows.size == 0:
+            continue
+        padded = -(-rows.size // block_size) * block_size
+        sorted_ids[pos:pos + rows.size] = rows
+        expert_ids[blk:blk + padded // block_size] = e if expert_map is None else expert_map[e]
+        pos += padded
+        blk += padded // block_size
+    return sorted_ids, expert_ids, pos
+
+
+def moe_permute(topk_ids: np.ndarray, n_expert: int, n_local_expert: int | None = None, expert_map: np.ndarray | None = None):
+    """moe_permute's index outputs (moe_permute_unpermute.py:105-242; golden tests/kernels/moe/test_moe_permute_unpermute.py:
+    37-89): slots sorted (stable) by local expert id, slots of experts that are not local behind them by global id.
+    -> (expert_first_token_offset int64 [n_local + 1], inv_permuted_idx int32 [n] slot -> row, permuted_idx int32 [n] row ->
+    slot with n for the rows of non-local experts)."""
+    ids = np.asarray(topk_ids, np.int64).reshape(-1)
+    n = ids.size
+    n_local = n_expert if n_local_expert is None else n_local_expert
+    if expert_map is None:
+        key = ids.copy()
+    else:
+        loc = np.asarray(expert_map, np.int64)[ids]
+        key = np.where(loc >= 0, loc, ids + n_expert)
+    order = np.argsort(key, kind="stable")
+    first = np.zeros(n_local + 1, np.int64)
+    first[1:] = np.cumsum(np.bincount(key[key < n_local], minlength=n_local)[:n_local])
+    inv = np.empty(n, np.int32)
+    inv[order] = np.arange(n, dtype=np.int32)
+    perm = order.astype(np.int32)
+    perm[first[-1]:] = n
+    return first, inv, perm
+
+
+def moe_unpermute(rows_bits: np.ndarray, dt: int, topk_weights: np.ndarray, inv_permuted_idx: np.ndarray, n_valid: int) -> np.ndarray:
+    """moe_unpermute (moe_permute_unpermute.py:245-283): out[t] = T(sum_k w[t, k] * rows[inv[t, k]]) over the valid rows, fp32
+    sum in slot order, one rounding to the rows' dtype.  rows as bit patterns [R, H]; -> bit patterns [M, H]."""
+    rows = bits_to_f32(rows_bits, dt)
+    tw = np.asarray(topk_weights, np.float32)
+    M, K = tw.shape
+    inv = np.asarray(inv_permuted_idx, np.int64).reshape(M, K)
+    acc = np.zeros((M, rows.shape[1]), np.float32)
+    for k in range(K):
+        ok = (inv[:, k] >= 0) & (inv[:, k] < n_valid)
+        acc[ok] += tw[ok, k:k + 1] * rows[inv[ok, k]]
+    return f32_to_bits(acc, dt)

@@ -138,3 +138,65 @@ def test_moe_ops_are_graph_capturable_and_take_ragged_inputs():
     hz = torch.zeros((0, 64), dtype=torch.bfloat16, device=DEV)
     rows, _, first, inv, perm = ops.moe_permute(hz, None, z, E)
     assert rows.shape == (0, 64) and first.tolist() == [0] * (E + 1) and inv.numel() == 0
+
+
+@pytest.mark.parametrize("M,E,K,H,bs,ep", [
+    (8192, 128, 8, 4096, 128, 1),      # GLM-4.5-Air prefill (BASELINE configs[4]): 65 536 slots, the multi-workgroup sort
+    (256, 256, 8, 7168, 32, 8),        # DeepSeek-V3 decode batch (configs[3]) on one of eight ranks' expert maps
+    (128, 8, 2, 4096, 64, 1),          # Mixtral decode (configs[2])
+    (1, 128, 8, 2048, 16, 1),          # Qwen3-30B-A3B single token (configs[0])
+])
+def test_operator_forms_at_baseline_sizes_vs_oracle(M, E, K, H, bs, ep):
+    """the operators at BASELINE.json's shapes against the CPU restatements (oracle.moe_align_block_size / moe_permute /
+    moe_unpermute, themselves pinned to the reference's goldens in tests/test_oracle_golden.py): index outputs bit-exact,
+    permuted rows bit-exact, the weighted sum within one bf16 ulp; plus the size-independent properties -- every slot
+    appears exactly once, blocks are expert-pure, permute then unpermute with unit weights returns K x the token."""
+    from lvllm_amd import ops
+    from oracle import oracle as orc
+    g = torch.Generator(device=DEV).manual_seed(M + E)
+    logits = torch.randn((M, E), generator=g, device=DEV)
+    tw, ids = ops.topk_softmax(logits, K, True)
+    ids_np = ids.cpu().numpy()
+    emap = emap_np = None
+    n_local = E
+    if ep > 1:
+        n_local, emap = ops.determine_expert_map(ep, 3, E)
+        emap = emap.to(DEV).to(torch.int32)
+        emap_np = emap.cpu().numpy()
+    # ---- align
+    s, e, post = ops.moe_align_block_size(ids, bs, E, expert_map=emap, ignore_invalid_experts=emap is not None)
+    os_, oe, ototal = orc.moe_align_block_size(ids_np, bs, E, emap_np)
+    assert int(post) == ototal
+    np.testing.assert_array_equal(s.cpu().numpy(), os_)
+    np.testing.assert_array_equal(e.cpu().numpy(), oe)
+    real = s[:ototal][s[:ototal] < ids.numel()]
+    want_n = ids.numel() if emap is None else int((emap_np[ids_np] >= 0).sum())
+    assert real.numel() == want_n and torch.unique(real).numel() == want_n
+    blocks = s[:ototal].view(-1, bs)
+    eb = e[:ototal // bs]
+    flat = ids.reshape(-1)
+    for b in (0, blocks.size(0) // 2, blocks.size(0) - 1):                      # sampled blocks are expert-pure
+        rows = blocks[b][blocks[b] < ids.numel()]
+        got = flat[rows.long()]
+        assert bool((got == (eb[b] if emap is None else torch.nonzero(emap == eb[b])[0, 0])).all())
+    # ---- permute / unpermute
+    x = (torch.randn((M, H), generator=g, device=DEV) / 4).to(torch.bfloat16)
+    rows, _, first, inv, perm = ops.moe_permute(x, None, ids, E, n_local, emap)
+    of, oi, op_ = orc.moe_permute(ids_np, E, n_local, emap_np)
+    np.testing.assert_array_equal(first.cpu().numpy(), of)
+    np.testing.assert_array_equal(inv.cpu().numpy(), oi)
+    np.testing.assert_array_equal(perm.cpu().numpy(), op_)
+    nv = int(of[-1])
+    assert torch.equal(rows[:nv], x[(perm[:nv] // K).long()])
+    ones = torch.ones_like(tw)
+    back = torch.empty_like(x)
+    ops.moe_unpermute(back, rows, ones, inv, first)
+    local_cnt = torch.full((M, 1), float(K), device=DEV) if emap is None else (emap[ids.long()] >= 0).sum(1, keepdim=True).float()
+    torch.testing.assert_close(back.float(), (x.float() * local_cnt), atol=0, rtol=2.0 ** -7)
+    sub = slice(0, min(M, 64))                                                   # weighted sum vs the oracle on a row sample
+    out = torch.empty_like(x)
+    ops.moe_unpermute(out, rows, tw, inv, first)
+    want = orc.bits_to_f32(orc.moe_unpermute(rows.view(torch.int16).cpu().numpy().view(np.uint16), orc.BF16, tw.cpu().numpy()[sub],
+                                             oi.reshape(M, K)[sub].reshape(-1), nv), orc.BF16)
+    got = out[sub].float().cpu().numpy()
+    assert (np.abs(got - want) <= np.maximum(np.abs(want) * 2.0 ** -7, 2.0 ** -20)).all()

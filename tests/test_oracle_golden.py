@@ -235,3 +235,36 @@ def test_router_logits_vs_f_linear_fp32():
         bb, wd = (b.numpy(), orc.F32) if wdt == torch.float32 else (b.view(torch.int16).numpy().view(np.uint16), xd)
         out = orc.router_logits(ab, xd, bb, wd)
         np.testing.assert_allclose(out, ref, atol=2e-4, rtol=0)
+
+
+def test_operator_forms_of_the_scatter_step_match_the_reference_goldens():
+    """oracle.moe_align_block_size / moe_permute / moe_unpermute against the vectors the reference's own golden functions
+    produced (tests/golden/make_golden_moe_ops.py): index outputs exact, the weighted sum within one bf16 ulp of the
+    reference's torch sum (its fp32 accumulation order is torch's, ours slot order)."""
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "moe_ops.npz")
+    for i in range(int(g["n_align"])):
+        bs, E, pad = (int(v) for v in g[f"align{i}_args"])
+        s, e, total = orc.moe_align_block_size(g[f"align{i}_ids"], bs, E, None, bool(pad))
+        gs, ge = g[f"align{i}_sorted"], g[f"align{i}_experts"]
+        n, nb = min(s.size, gs.size), min(e.size, ge.size)
+        assert total == int(g[f"align{i}_post"][0])
+        np.testing.assert_array_equal(s[:n], gs[:n])
+        np.testing.assert_array_equal(e[:nb], ge[:nb])
+    for i in range(int(g["n_alignm"])):
+        emap = g[f"alignm{i}_map"]
+        s, e, total = orc.moe_align_block_size(g[f"alignm{i}_ids"], 64, emap.size, emap)
+        assert total == int(g[f"alignm{i}_post"][0])
+        n, nb = min(s.size, g[f"alignm{i}_sorted"].size), min(e.size, g[f"alignm{i}_experts"].size)
+        np.testing.assert_array_equal(s[:n], g[f"alignm{i}_sorted"][:n])
+        np.testing.assert_array_equal(e[:nb], g[f"alignm{i}_experts"][:nb])
+    for i in range(int(g["n_perm"])):
+        E, n_local, ep, rank = (int(v) for v in g[f"perm{i}_args"])
+        emap = g[f"perm{i}_map"] if ep != 1 else None
+        first, inv, perm = orc.moe_permute(g[f"perm{i}_ids"], E, n_local, emap)
+        np.testing.assert_array_equal(first, g[f"perm{i}_first"])
+        np.testing.assert_array_equal(inv, g[f"perm{i}_inv"].reshape(-1))
+        np.testing.assert_array_equal(perm, g[f"perm{i}_perm"])
+        out = orc.moe_unpermute(g[f"perm{i}_res0"].view(np.uint16), orc.BF16, g[f"perm{i}_tw"], inv, int(g[f"perm{i}_nvalid"]))
+        a, b = orc.bits_to_f32(out, orc.BF16), orc.bits_to_f32(g[f"perm{i}_gold4"].view(np.uint16), orc.BF16)
+        assert (np.abs(a - b) <= np.maximum(np.abs(b) * 2.0 ** -7, 2.0 ** -20)).all()

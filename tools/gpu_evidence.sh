@@ -7,6 +7,7 @@
 #     traffic   one --pmc FETCH_SIZE pass per bench workload -> gpurun_out/hbm_traffic.json (copy to profiles/)
 #     bench     bench.py with the driver's flags -> gpurun_out/<tag>_bench_n1.json
 #     trace     rocprofv3 --kernel-trace --stats of the bench command -> gpurun_out/<tag>_bench_kernel_trace_stats.json
+#     trace_headline   the same for the headline workload alone (--no-extras): the kernel averages that must agree with roofline.kernel_ms
 #     report    every BASELINE configuration, uniform + Zipf -> gpurun_out/<tag>_report_all_configs.{md,jsonl}
 #     ep1       one-rank RCCL step, captured
 # --pmc passes are separate rocprofv3 runs and never combined with the sys/hip/hsa trace domains.
@@ -41,6 +42,12 @@ trace) echo "== rocprof kernel-trace"; cd /tmp && timeout 900 rocprofv3 --kernel
 import json; d=json.load(open('gpurun_out/${TAG}_bench_kernel_trace_stats.json'))
 for k in d['kernels'][:10]: print(k)"
   rm -rf gpurun_out/prof_kt ;;
+trace_headline) echo "== rocprof kernel-trace, headline workload alone"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt_h -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $R/gpurun_out/${TAG}_rocprof_kt_headline.log 2>&1; cd $R
+  python tools/rocprof_summary.py gpurun_out/prof_kt_h/bench_results.db > gpurun_out/${TAG}_bench_headline_kernel_trace_stats.json
+  python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_headline_kernel_trace_stats.json'))
+for k in d['kernels'][:4]: print(k)"
+  rm -rf gpurun_out/prof_kt_h ;;
 report) echo "== report"; timeout 2400 python tools/report.py gpurun_out 2>&1 | grep -v amdgpu.ids | grep "^| [1-5]" | cut -d'|' -f2-7
   for x in md jsonl; do [ -f gpurun_out/report.$x ] && cp gpurun_out/report.$x gpurun_out/${TAG}_report_all_configs.$x; done ;;
 ep1) echo "== one-rank EP (captured)"; timeout 300 python bench.py --gpus 1 --steps 100 --warmup 10 --force-ep --no-cpu-baseline --no-extras 2>/dev/null | grep '^{' | python -c "

@@ -184,10 +184,10 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
     auto run_c = [&](auto CBC, auto HC) __attribute__((always_inline)) {
         constexpr int CBR = decltype(CBC)::v;
         constexpr bool HOIST = decltype(HC)::v != 0;            // int4, one scale group per unit: multipliers once per unit
-        for (int u = 0; u < U; ++u) {
-            __builtin_amdgcn_s_barrier();
-            if (!wave_on) continue;
-            const char* sb = lds + (u % S) * STAGE;
+        // (round 5: the unit loop is unrolled by the ring depth, so a unit's stage is a compile-time constant and the LDS
+        //  reads of the body take it as an immediate offset: 167 -> 159 vector instructions per unit in the general loop
+        //  (tools/isa_loop_stats.py), GEMM1 at Mixtral int4 M=128 146 -> 138 us, profiles/r05_int4_unrolled_ab.log)
+        auto unit = [&](const char* sb) __attribute__((always_inline)) {
             u32x4 w[2][1];
             w[0][0] = *(const u32x4*)(sb + wlds);
             w[1][0] = *(const u32x4*)(sb + wlds + 256);
@@ -221,6 +221,15 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
                 for (int c = 0; c < CBR; ++c) acc[c] = Mfma32<ADT>::run(a, bf[s_ & 1][q_][c], acc[c]);
                 a = an;
             }
+        };
+        for (int u0 = 0; u0 < U; u0 += S) {
+            static_for<S>([&](auto SC) __attribute__((always_inline)) {
+                constexpr int st = decltype(SC)::v;
+                if (u0 + st < U) {                               // (wave-uniform; every wave of the workgroup counts the same barriers)
+                    __builtin_amdgcn_s_barrier();
+                    if (wave_on) unit(lds + st * STAGE);
+                }
+            });
         }
     };
     auto run = [&](auto CBC) __attribute__((always_inline)) {

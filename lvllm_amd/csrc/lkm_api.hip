@@ -784,15 +784,17 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         const bool w4x = wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && !split && (h->t_pf == 5 || h->t_pf == 6) &&
                          h->H % 128 == 0 && h->I % 128 == 0;
         if (w4x) pf = h->t_pf;                  // (6: with a loader wave per workgroup, gemm_w4e.h; "pd" = ring depth 3 / 4)
-        // round 5: uint4b8 (exact mode) on 64-row tiles runs GEMM2 on the loader-wave kernel (gemm_w4e.h) BY DEFAULT, GEMM1
-        // stays on gemm_tiled_kernel.  Round 4 left the choice to the first-call autotune; with the autotune off (the engine's
-        // default, and bench.py's since round 5) the better plan must be the planner's.  Same box, captured step, alternating
-        // (profiles/r05_int4_default_ab.log, Mixtral int4-g128 M=128): GEMM2 78.9-79.8 -> 74.9-75.2 us uniform, 87.7-88.7 ->
-        // 82.2-82.7 Zipf; GEMM1 144.0-145.5 vs 145.7-146.0 uniform, 147.0 vs 152.8-154.1 Zipf (the tile kernel keeps it).
-        // (Eager per-kernel sweeps had shown 5-8 % for the whole step, profiles/r05_plan_robustness_sweep.log -- the captured
-        // step does not: plans are judged through the graph.)  "pf" = -1 gives the tile kernel back for both.
-        const bool w4e_g2 = h->wf == LKM_W_INT4_B8 && !h->ps && tiled == 64 && !split && !g2_only && h->t_pf == 0 &&
-                            h->H % 128 == 0 && h->I % 128 == 0;
+        // round 5: uint4b8 (exact mode) on 64-row tiles takes the loader-wave kernel (gemm_w4e.h) BY DEFAULT for both GEMMs.
+        // Round 4 left the choice to the first-call autotune; with the autotune off (the engine's default, and bench.py's since
+        // round 5) the better plan must be the planner's.  Same box, captured step, alternating, after the consumer loop was
+        // unrolled by the ring depth (profiles/r05_int4_unrolled_ab.log, Mixtral int4-g128 M=128, tile kernel -> gemm_w4e.h):
+        // uniform step 243.0 -> 232.1 us (GEMM1 144.4 -> 137.3-139.7, GEMM2 79.4 -> 72.3-72.8), Zipf 253.2 -> 247.0-249.6 (GEMM1
+        // 147.7 -> 147.0-148.7, GEMM2 88.3 -> 79.4-80.2).  Before the unroll GEMM1 was behind (profiles/r05_int4_default_ab.log).
+        // (Eager per-kernel sweeps over-state such differences, profiles/r05_plan_robustness_sweep.log: plans are judged through
+        // the graph.)  "pf" = -1 gives the tile kernel back.
+        const bool w4e_dflt = h->wf == LKM_W_INT4_B8 && !h->ps && tiled == 64 && !split && !g2_only && h->t_pf == 0 &&
+                              h->H % 128 == 0 && h->I % 128 == 0;
+        if (w4e_dflt) pf = 6;
         if (tiled == 256 && h->a8) {          // the fp8 x fp8 prefill kernels are the only 256-row variants of the format
             // 9 = gemm_prefill_a8w.h (weights straight to registers, tokens through a 4-stage LDS ring, equal token tiles);
             // round 2's kernel ("pf" = 8: both operands through two LDS buffers) was removed in round 4 -- K loops outside
@@ -836,7 +838,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         int waves2 = waves;
         if (h->wf == LKM_W_FP8_E4M3 && !h->a8 && tiled == 64 && avg_rows >= 192 && h->t_waves == 0 && nt2 == 1) waves2 = 8;
         pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves, pd1, pf};
-        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, sk2, tiled, waves2, pd2, w4e_g2 ? 6 : pf};
+        pl->t2 = LaunchCfg{nt2, tiled / 16, 1, sk2, tiled, waves2, pd2, pf};
         if (g2_only) pl->t1 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
         // Mixed tile heights (round-4 verdict item 6), OPT-IN: "mixed" = n > 0.  Decode batches of many-expert layers plan
         // 32- or 64-row tiles for the row count an expert is LIKELY to get; a skewed router hands one expert several times that

@@ -170,8 +170,8 @@ def test_last_kernels_names_what_was_launched():
     itself -- the default tile kernel, then the forced 32x32-MFMA kernel, then the streamer, on one engine"""
     eng, a, tw, ids, ref = _int4_case(128, 8, 2, 512, 384, 128, "bf16", seed=133)
     _run_decode(eng, a, tw, ids)
-    kd = eng.engine.last_kernels()                # round 5 default for uint4b8 on 64-row tiles: GEMM2 on the loader-wave kernel
-    assert len(kd["gemm1"]) == 1 and "gemm_tiled_kernel<" in kd["gemm1"][0] and "gemm_w4e_kernel<" in kd["gemm2"][0], kd
+    kd = eng.engine.last_kernels()                # round 5 default for uint4b8 on 64-row tiles: the loader-wave kernel
+    assert len(kd["gemm1"]) == 1 and "gemm_w4e_kernel<" in kd["gemm1"][0] and "gemm_w4e_kernel<" in kd["gemm2"][0], kd
     eng.engine.set_tuning(pf=-1)
     _run_decode(eng, a, tw, ids)
     k0 = eng.engine.last_kernels()

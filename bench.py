@@ -96,10 +96,15 @@ EXTRA_N1 = [# the headline workload under Zipf routing first, in the thermal sta
             # benchmarks/kernels/benchmark_moe.py:96-333
             ("mixtral8x7b_bf16_decode_m32", "zipf"),
             "mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128", "mixtral8x7b_int4g128_fast_decode_m128",
-            # BASELINE.json configs[4] (the MFMA-bound grouped GEMM)
-            "glm45air_fp8w8a8_prefill_m8192",
+            # BASELINE.json configs[4] (the MFMA-bound grouped GEMM): with the synthetic score-correction bias of rounds 1-4
+            # (a heavily skewed routing) and with a zero bias (uniform-ish routing: SURVEY 8d)
+            "glm45air_fp8w8a8_prefill_m8192", ("glm45air_fp8w8a8_prefill_m8192", "nobias"),
             # ... and the path the reference's gpu_prefill actually takes (MOE_BF16 / MOE_FP8 = W8A16: routed_experts.py:1884-1899)
-            "glm45air_bf16_prefill_m8192", "glm45air_fp8w8a16_prefill_m8192", "mixtral8x7b_int4g128_prefill_m4096"]
+            "glm45air_bf16_prefill_m8192", ("glm45air_bf16_prefill_m8192", "nobias"), "glm45air_fp8w8a16_prefill_m8192",
+            "mixtral8x7b_int4g128_prefill_m4096",
+            # configs[3]'s layer on one GPU with a zero score-correction bias (all 256 experts hit; the biased default runs below as
+            # EXTRA_EP at every N)
+            ("dsv3_fp8w8a8_ep_decode_b256", "nobias")]
 EXTRA_EP = "dsv3_fp8w8a8_ep_decode_b256"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp8": 5000.0}   # dense, MI355X_MICROARCH.md
@@ -469,6 +474,13 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
     bias = None
     if rt.get("bias"):
         bias = torch.randn((E,), generator=torch.Generator(device=dev).manual_seed(99), device=dev) * 0.1
+        if routing == "nobias":
+            # The sigmoid + score-correction-bias routers (GLM-4.5-Air, DeepSeek-V3): a model's bias is LEARNED to balance the
+            # load; the synthetic N(0, 0.1) one above does the opposite on randn logits (GLM workload: 3 of 128 experts get no
+            # row, the busiest 4469 of 65 536 = 8.7 x the mean -- profiles/r05_a8w_uniform_items_probe.log).  "nobias" runs the
+            # same router code with a zero bias: the uniform-ish routing SURVEY 8d asks for.  The biased variant stays the
+            # default of these workloads for continuity with rounds 1-4.
+            bias = torch.zeros_like(bias)
 
     def route():
         if rt["kind"] == "grouped":
@@ -685,6 +697,7 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
         prof_range = {k_: [round(min(v), 4), round(max(v), 4)] for k_, v in acc.items() if k_.startswith("gemm")}
         e_act = int(torch.unique(lids[lids >= 0]).numel())
         rows = int((lids >= 0).sum().item())
+        per_e = torch.bincount(lids[lids >= 0].flatten().long(), minlength=E_local)
         g1_bytes = e_act * 2 * I * H * bpe                           # algorithmic weight bytes of GEMM1 (bpe incl. scales)
         layer_flops = 6.0 * rows * H * I
         layer_bytes = e_act * 3 * I * H * bpe
@@ -737,7 +750,8 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
             "step": {"mfma_frac": step_fl["mfma_frac"], "hbm_frac": step_fl["hbm_frac"], "frac_of_roof": step_fl["frac_of_roof"],
                      "roof_bound": step_fl["roof_bound"],
                      "what": "the whole layer step (router, scatter, GEMM1, GEMM2, combine) against the same two peaks"},
-            "layer": {"routed_rows": rows, "experts_hit": e_act, "weight_bytes": layer_bytes, "flops": layer_flops,
+            "layer": {"routed_rows": rows, "experts_hit": e_act, "rows_per_expert_min_max": [int(per_e.min()), int(per_e.max())],
+                      "weight_bytes": layer_bytes, "flops": layer_flops,
                       "GBps_over_step": round(layer_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                       "TFLOPs_over_step": round(layer_flops / (ms_per_step * 1e-3) / 1e12, 2)},
             "kernel_ms": {k_: round(v, 4) for k_, v in prof_ms.items()},
@@ -859,8 +873,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="time the headline workload only")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget (s) for each CPU baseline sample (reference kernel, port)")
-    ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf"],
-                    help="router logits: randn (uniform-ish) or randn + Zipf(s=1) expert popularity bias (SURVEY 8d)")
+    ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf", "nobias"],
+                    help="router logits: randn (uniform-ish) or randn + Zipf(s=1) expert popularity bias (SURVEY 8d); nobias = "
+                         "randn logits and a ZERO score-correction bias for the sigmoid + bias routers (their default synthetic "
+                         "bias skews the routing)")
     ap.add_argument("--autotune", action="store_true",
                     help="turn the engine's first-call plan search on (lkm_set_tuning autotune; default off = what lk_moe users get)")
     ap.add_argument("--no-autotune", action="store_true", help="(default since round 5; kept so that older command lines still parse)")
@@ -944,6 +960,7 @@ def main():
                 "parallelism": r["config"].get("parallelism"), "launch": r["config"].get("launch"),
                 "roofline": {k_: rf.get(k_) for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                        "algorithmic_bytes", "kernel_ms", "gemm2_kernel")},
+                "rows_per_expert_min_max": (rf.get("layer") or {}).get("rows_per_expert_min_max"),
                 "plan": rf.get("plan"), "exchange": r["config"].get("exchange")}
 
     extras = []

@@ -20,7 +20,8 @@ OUT = (Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out").resolve(
 
 
 def main():
-    names = [HEADLINE] + [w if isinstance(w, str) else None for w in EXTRA_N1] + [EXTRA_EP]
+    # (workload, routing) pairs; an entry of another routing is stored as "workload@routing", the key bench.py looks up
+    names = [HEADLINE] + [w if isinstance(w, str) else (f"{w[0]}@{w[1]}" if w[1] != "zipf" else None) for w in EXTRA_N1] + [EXTRA_EP]
     names = [n for n in names if n]
     if len(sys.argv) > 2:
         names = sys.argv[2].split(",")
@@ -40,24 +41,26 @@ def main():
         except Exception:
             pass
     env = dict(os.environ, TMPDIR="/tmp")
-    for wl in names:
-        d = OUT / f"pmc_{wl}"
+    for key in names:
+        wl, _, routing = key.partition("@")
+        routing = routing or "uniform"
+        d = OUT / f"pmc_{wl}_{routing}"
         shutil.rmtree(d, ignore_errors=True)
         # engine defaults (no autotune: a tuning pass would launch candidate kernels of other plans), eager launches
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", "FETCH_SIZE", "-d", str(d), "-o", "p", "--", sys.executable,
-               str(ROOT / "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-extras", "--no-graph", "--full-line",
-               "--full-out", "", "--steps", "10", "--warmup", "3"]
+               str(ROOT / "bench.py"), "--workload", wl, "--routing", routing, "--no-cpu-baseline", "--no-extras", "--no-graph",
+               "--full-line", "--full-out", "", "--steps", "10", "--warmup", "3"]
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
         line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
         s = subprocess.run([sys.executable, str(ROOT / "tools" / "rocprof_summary.py"), str(d / "p_results.db"), "--pmc"],
                            capture_output=True, text=True)
         shutil.rmtree(d, ignore_errors=True)
         if line is None or s.returncode != 0:
-            print(f"{wl}: FAILED {r.stderr[-300:]} {s.stderr[-300:]}")
+            print(f"{key}: FAILED {r.stderr[-300:]} {s.stderr[-300:]}")
             continue
         rf = json.loads(line)["roofline"]
         ent = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --workload {wl} --no-graph --steps 10 "
-                         f"(uniform routing, N=1, engine defaults)", "plan": rf.get("plan")}
+                         f"--routing {routing} (N=1, engine defaults)", "plan": rf.get("plan")}
         pmc = [k for k in json.loads(s.stdout)["pmc"] if k["counter"] == "FETCH_SIZE"]
         for g, want in (("gemm1", rf.get("kernel")), ("gemm2", rf.get("gemm2_kernel"))):
             # the kernel(s) the engine launched for this GEMM (two for a hybrid plan: their bytes add up per step)
@@ -74,8 +77,8 @@ def main():
                 ent[f"{g}_kernel_not_in_trace"] = want
         if "algorithmic_bytes" in rf:
             ent["gemm1_algorithmic_bytes"] = int(rf["algorithmic_bytes"])
-        res[wl] = ent
-        print(wl, ent, flush=True)
+        res[key] = ent
+        print(key, ent, flush=True)
     (OUT / "hbm_traffic.json").write_text(json.dumps(res, indent=1) + "\n")
 
 

@@ -17,7 +17,8 @@ from bench import WORKLOADS, build_engine  # noqa: E402
 from lvllm_amd import ops  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "both"
-wl = WORKLOADS["glm45air_fp8w8a8_prefill_m8192"]
+wl_name = sys.argv[2] if len(sys.argv) > 2 else "glm45air_fp8w8a8_prefill_m8192"     # (any GLM-4.5-Air prefill workload of bench.py)
+wl = WORKLOADS[wl_name]
 E, K, H, I, M = wl["E"], wl["K"], wl["H"], wl["I"], wl["M"]
 dev = torch.device("cuda", 0)
 eng = build_engine(ops, wl, E, 0, dev, max_num_seqs=8192, max_batch_size=8192)[0]
@@ -46,6 +47,7 @@ for name, tw, ids in (("router", tw_r, ids_r), ("balanced", tw_b, ids_b)):
     med = {kk: sorted(v)[len(v) // 2] for kk, v in acc.items()}
     flops1 = 4.0 * M * K * H * I
     tf = flops1 / med["gemm1"] / 1e6
-    print(f"{name:9s} rows/expert min {int(cnt.min())} max {int(cnt.max())} | gemm1 {med['gemm1']:.1f} us ({tf:.0f} TFLOP/s = "
-          f"{tf / 5000:.3f} of 5 PF) gemm2 {med['gemm2']:.1f} sort {med['sort']:.1f} combine {med['combine']:.1f} | "
+    peak = 5000 if (wl["fmt"] == "fp8" and wl.get("fp8_mode")) else 2500
+    print(f"{wl_name} {name:9s} rows/expert min {int(cnt.min())} max {int(cnt.max())} | gemm1 {med['gemm1']:.1f} us ({tf:.0f} TFLOP/s = "
+          f"{tf / peak:.3f} of {peak / 1000} PF) gemm2 {med['gemm2']:.1f} sort {med['sort']:.1f} combine {med['combine']:.1f} | "
           f"{eng.engine.last_kernels()['gemm1'][0]}", flush=True)

@@ -96,15 +96,15 @@ EXTRA_N1 = [# the headline workload under Zipf routing first, in the thermal sta
             # benchmarks/kernels/benchmark_moe.py:96-333
             ("mixtral8x7b_bf16_decode_m32", "zipf"),
             "mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128", "mixtral8x7b_int4g128_fast_decode_m128",
-            # BASELINE.json configs[4] (the MFMA-bound grouped GEMM): with the synthetic score-correction bias of rounds 1-4
-            # (a heavily skewed routing) and with a zero bias (uniform-ish routing: SURVEY 8d)
-            "glm45air_fp8w8a8_prefill_m8192", ("glm45air_fp8w8a8_prefill_m8192", "nobias"),
+            # BASELINE.json configs[4] (the MFMA-bound grouped GEMM) on the uniform-ish routing SURVEY 8d specifies (zero
+            # score-correction bias), and on the skewed synthetic bias of rounds 1-5, labelled as such
+            "glm45air_fp8w8a8_prefill_m8192", ("glm45air_fp8w8a8_prefill_m8192", "biased"),
             # ... and the path the reference's gpu_prefill actually takes (MOE_BF16 / MOE_FP8 = W8A16: routed_experts.py:1884-1899)
-            "glm45air_bf16_prefill_m8192", ("glm45air_bf16_prefill_m8192", "nobias"), "glm45air_fp8w8a16_prefill_m8192",
+            "glm45air_bf16_prefill_m8192", ("glm45air_bf16_prefill_m8192", "biased"), "glm45air_fp8w8a16_prefill_m8192",
             "mixtral8x7b_int4g128_prefill_m4096",
-            # configs[3]'s layer on one GPU with a zero score-correction bias (all 256 experts hit; the biased default runs below as
-            # EXTRA_EP at every N)
-            ("dsv3_fp8w8a8_ep_decode_b256", "nobias")]
+            # configs[3]'s layer on one GPU under the skewed synthetic bias (174 of 256 experts hit; the uniform default runs
+            # below as EXTRA_EP at every N)
+            ("dsv3_fp8w8a8_ep_decode_b256", "biased")]
 EXTRA_EP = "dsv3_fp8w8a8_ep_decode_b256"
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp8": 5000.0}   # dense, MI355X_MICROARCH.md
@@ -468,19 +468,21 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
     x = (torch.randn((M, H), generator=gen, device=dev) / 10).to(torch.bfloat16)
     logits = torch.randn((M, E), generator=gen, device=dev, dtype=torch.float32)
     routing = routing or args.routing
+    if routing == "nobias":    # round-5 name of what is now the default of the bias routers
+        routing = "uniform"
     if routing == "zipf":      # log-popularity bias: p(e) ~ 1/(e+1)
         logits = logits + torch.log(1.0 / torch.arange(1, E + 1, device=dev, dtype=torch.float32))[None, :]
     rt = wl.get("router", dict(kind="softmax"))
     bias = None
     if rt.get("bias"):
-        bias = torch.randn((E,), generator=torch.Generator(device=dev).manual_seed(99), device=dev) * 0.1
-        if routing == "nobias":
-            # The sigmoid + score-correction-bias routers (GLM-4.5-Air, DeepSeek-V3): a model's bias is LEARNED to balance the
-            # load; the synthetic N(0, 0.1) one above does the opposite on randn logits (GLM workload: 3 of 128 experts get no
-            # row, the busiest 4469 of 65 536 = 8.7 x the mean -- profiles/r05_a8w_uniform_items_probe.log).  "nobias" runs the
-            # same router code with a zero bias: the uniform-ish routing SURVEY 8d asks for.  The biased variant stays the
-            # default of these workloads for continuity with rounds 1-4.
-            bias = torch.zeros_like(bias)
+        # The sigmoid + score-correction-bias routers (GLM-4.5-Air, DeepSeek-V3).  A model's bias is LEARNED to balance the
+        # load, so "uniform" (randn logits, uniform-ish routing) and "zipf" run these routers with a ZERO bias.
+        # "biased" adds the synthetic N(0, 0.1) bias rounds 1-5 used by default and mislabelled "uniform": on randn logits it
+        # SKEWS the routing (GLM workload: 3 of 128 experts get no row, the busiest 4469 of 65 536 = 8.7 x the mean; DSv3:
+        # 174 of 256 experts hit -- profiles/r05_a8w_uniform_items_probe.log); it stays as a separately labelled skewed variant.
+        bias = torch.zeros((E,), device=dev)
+        if routing == "biased":
+            bias = torch.randn((E,), generator=torch.Generator(device=dev).manual_seed(99), device=dev) * 0.1
 
     def route():
         if rt["kind"] == "grouped":
@@ -873,10 +875,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="time the headline workload only")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget (s) for each CPU baseline sample (reference kernel, port)")
-    ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf", "nobias"],
-                    help="router logits: randn (uniform-ish) or randn + Zipf(s=1) expert popularity bias (SURVEY 8d); nobias = "
-                         "randn logits and a ZERO score-correction bias for the sigmoid + bias routers (their default synthetic "
-                         "bias skews the routing)")
+    ap.add_argument("--routing", default="uniform", choices=["uniform", "zipf", "biased", "nobias"],
+                    help="router logits: randn (uniform-ish; the sigmoid + bias routers run a ZERO score-correction bias) or "
+                         "randn + Zipf(s=1) expert popularity (SURVEY 8d); biased = randn logits + the synthetic N(0, 0.1) "
+                         "score-correction bias of rounds 1-5, which skews the routing; nobias = old name of uniform")
     ap.add_argument("--autotune", action="store_true",
                     help="turn the engine's first-call plan search on (lkm_set_tuning autotune; default off = what lk_moe users get)")
     ap.add_argument("--no-autotune", action="store_true", help="(default since round 5; kept so that older command lines still parse)")

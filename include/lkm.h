@@ -279,6 +279,20 @@ int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots, int32_t E,
 int lkm_per_token_group_quant_fp8(void* stream, const void* x, int32_t x_dtype, int64_t ld_x, int32_t rows, int32_t cols,
                                   void* q, float* scales);
 
+/*
+ * Weight-only integer experts of the in-tree operator surface (secondary boundary): int4_w4a16 / int8_w8a16 with or
+ * without zero points (vllm/model_executor/layers/fused_moe/fused_moe.py:207-276; config.py int4_w4a16_moe_quant_config /
+ * int8_w8a16_moe_quant_config; grid tests/kernels/moe/test_moe.py:565-693) expanded ONCE, at weight hand-off, to the
+ * 16-bit weights that kernel feeds its dot product: out[r][k] = T((q[r][k] - zp[r][k / group]) * scale[r][k / group]),
+ * one rounding, zp = 8 / 128 when `zeros` is null.  rows = E*N; qweight [rows][K/2] (low nibble = even k) or
+ * [rows][K]; scales [rows][K/group] in out_dtype; zeros 4-bit [rows/2][K/group] (low nibble = even row) or 8-bit
+ * [rows][K/group]; out [rows][K] 16-bit.  The engine then runs its 16-bit kernels on the image (288 GB of HBM pay
+ * for exact zero-point arithmetic with no extra decoder; the symmetric 4-bit case keeps its native packed format).
+ * The primary boundary does not take this path: lk_moe refuses AWQ / zero points (routed_experts.py:1539-1547).
+ */
+int lkm_wna16_expand(void* stream, const void* qweight, const void* scales, const void* zeros, void* out, int64_t rows,
+                     int32_t K, int32_t group, int32_t weight_bits, int32_t out_dtype);
+
 /* -------------------------------------------------------------------------------------------
  * The scatter / gather step as stand-alone operators.  The engine never materialises these forms (its GEMMs
  * gather through the sort's index lists); they exist for callers that want the reference operators' outputs.  All device
@@ -298,7 +312,8 @@ int lkm_per_token_group_quant_fp8(void* stream, const void* x, int32_t x_dtype, 
  * int64 [n_local_expert + 1]; inv_permuted_idx int32 [n_token * topk]: slot -> permuted row; permuted_idx int32
  * [n_token * topk]: permuted row -> slot, n_token * topk for the rows of non-local experts; permuted_hidden
  * [n_token * topk][row_bytes]: the rows of the LOCAL experts (the others are not written).  n_keys for the workspace:
- * n_expert without an expert_map, n_local_expert + n_expert with one (<= 512).
+ * n_expert without an expert_map, min(n_local_expert + n_expert, 512) with one.  n_expert <= 512 (the engine's limit,
+ * lkm_create); a 512-expert model under expert parallelism is accepted (non-local experts are ranked into n_expert keys).
  *
  * lkm_moe_unpermute -- moe_unpermute (moe_permute_unpermute.py:245-283): out[t] = T(sum_k w[t][k] * rows[inv[t][k]]) over
  * the rows below expert_first_token_offset[n_local_expert] (NULL: all), fp32 sum in slot order, one rounding.  rows / out

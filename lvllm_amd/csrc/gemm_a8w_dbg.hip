@@ -1,7 +1,16 @@
 // gemm_a8w_dbg.hip -- ablation builds of the round-3 fp8 x fp8 prefill kernel (gemm_prefill_a8w.h), gated GEMM1 with
 // bf16 activations only: tuning key "dbg" selects one; results are wrong by construction, only the time is read.
+// MEASUREMENT SCAFFOLDING: compiled only into a development library (python -m lvllm_amd.build --flag=-DLKM_ABLATIONS
+// -> liblkm_<tag>.so).  The default liblkm.so -- the one `lk_moe` loads -- carries no kernel that can return wrong numbers:
+// there this unit is the stub below and lkm_set_tuning refuses the "dbg" key.
 #include "gemm_prefill_a8w.h"
 namespace lkm {
+#ifndef LKM_ABLATIONS
+int launch_prefill_a8w_dbg(hipStream_t, const GemmParams&, int, int dbg, bool) {
+    set_error("fp8 W8A8 prefill kernel: ablation dbg=%d needs a library built with -DLKM_ABLATIONS", dbg);
+    return LKM_E_UNSUPPORTED;
+}
+#else
 int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, int dbg, bool gemm2) {
     if (gemm2) {
         switch (dbg) {
@@ -47,4 +56,5 @@ int launch_prefill_a8w_dbg(hipStream_t st, const GemmParams& p, int max_tiles, i
         return LKM_E_INVALID;
     }
 }
+#endif  // LKM_ABLATIONS
 }  // namespace lkm

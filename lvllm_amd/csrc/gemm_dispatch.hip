@@ -22,14 +22,15 @@ int launch_gemm2_tiled_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParam
 int launch_gemm1_tiled_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
 int launch_gemm2_tiled_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 
-// round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h: cfg.pf == 5; gemm_w4e.h, loader wave: cfg.pf == 6);
+// round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h: cfg.pf == 5; gemm_w4e.h, loader wave: cfg.pf == 6;
+// round 6: gemm_w4s.h, token loader wave + register-streamed weights: cfg.pf == 7);
 // false = not taken (shape / variant)
 #define LKM_DECL_W4X(SUFFIX) bool launch_w4x_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, bool, bool, int, int*);
 LKM_DECL_W4X(int4_bf16) LKM_DECL_W4X(int4_f16) LKM_DECL_W4X(mxfp4_bf16) LKM_DECL_W4X(mxfp4_f16) LKM_DECL_W4X(nvfp4_bf16) LKM_DECL_W4X(nvfp4_f16)
 #undef LKM_DECL_W4X
 static bool launch_w4x(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
                        int max_tiles, int* rc) {
-    if (cfg.pf != 5 && cfg.pf != 6) return false;
+    if (cfg.pf != 5 && cfg.pf != 6 && cfg.pf != 7) return false;     // (7: gemm_w4s.h, uint4b8 only)
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_BF16) return launch_w4x_int4_bf16(st, cfg, p, gated, is_g1, max_tiles, rc);
     if (wf == LKM_W_INT4_B8 && adt == LKM_DT_F16) return launch_w4x_int4_f16(st, cfg, p, gated, is_g1, max_tiles, rc);
     if (wf == LKM_W_MXFP4 && adt == LKM_DT_BF16) return launch_w4x_mxfp4_bf16(st, cfg, p, gated, is_g1, max_tiles, rc);

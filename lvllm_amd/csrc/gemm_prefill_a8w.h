@@ -1015,12 +1015,14 @@ static bool launch_prefill_a8w_if(hipStream_t st, const LaunchCfg& cfg, const Ge
         *rc = LKM_E_INVALID;
         return true;
     }
+#ifdef LKM_ABLATIONS
     if constexpr (ADT == LKM_DT_BF16) {     // ablation builds: bf16 activations only; bit 1024 = of GEMM2 instead of the gated GEMM1
         if ((p.dbg & 0x3fb) && ((p.dbg & 0x400) ? !is_g1 : (is_g1 && gated))) {
             *rc = launch_prefill_a8w_dbg(st, p, max_tiles, p.dbg & 0x3fb, !is_g1);
             return true;
         }
     }
+#endif
     if (is_g1) *rc = gated ? launch_prefill_a8w_t<ADT, true, true>(st, p, max_tiles) : launch_prefill_a8w_t<ADT, false, true>(st, p, max_tiles);
     else *rc = launch_prefill_a8w_t<ADT, false, false>(st, p, max_tiles);
     return true;

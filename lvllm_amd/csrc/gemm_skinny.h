@@ -496,7 +496,16 @@ struct Streamer {
     }
 };
 
-__device__ __forceinline__ float act_silu(float g) { return g / (1.0f + lkm_expf(-g)); }
+// SiLU with the sigmoid on the transcendental unit (v_exp_f32 + v_rcp_f32: ~6 VALU per element).  Until round 6 the decode /
+// tile kernels shared the CPU restatement's polynomial exp and an IEEE division here -- ~70 instructions per element behind
+// per-lane branches, 1200 of the ~5700 vector instructions a wave of the int4 decode kernel executes (profiles/
+// r06_int4_pmc_raw.log: 179 VALU per wave and K unit against 141 in the loop), on kernels whose bound IS the vector port.
+// Same rounding points; the fp32 sigmoid differs from the restatement in its last bits (<= 2 ulp of fp32), i.e. one ulp of
+// the activation dtype on ~1e-4 of the intermediate elements -- what gemm_prefill.h / gemm_prefill_a8w.h have done since
+// rounds 3-4, far inside the operator's tolerance (bf16 atol 2e-2, test_moe.py:233).  Routing keeps lkm_expf: its ids and
+// weights are bit-exact against the CPU restatement.
+__device__ __forceinline__ float act_sigmoid_fast(float g) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896341f)); }
+__device__ __forceinline__ float act_silu(float g) { return g * act_sigmoid_fast(g); }
 
 // ------------------------------------------------------------------ epilogues shared by all GEMM kernels
 // One D fragment = 4 consecutive output features n..n+3 of one routed row.
@@ -514,7 +523,7 @@ __device__ __forceinline__ void gemm1_act4(const GemmParams& p, const f32x4& gat
             if (p.act_type == LKM_ACT_SWIGLUOAI) {
                 const float gg = fminf(a, p.limit);
                 const float uu = fmaxf(fminf(up, p.limit), -p.limit);
-                v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
+                v[r] = (uu + 1.0f) * gg * act_sigmoid_fast(gg * p.alpha);
             } else if (p.round_gemm1) {
                 // T(silu_f32(g)) * u  (activation_kernels.cu:57-75,157-160)
                 v[r] = ActT<ADT>::to_f32(ActT<ADT>::from_f32(act_silu(a))) * up;

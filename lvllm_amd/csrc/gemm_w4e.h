@@ -16,7 +16,13 @@
 // The loader's waits are counted (vector memory retires in order): every slot is exactly IPU DMA instructions, so IPU is a
 // template parameter of the K loop and no other vector-memory instruction exists in the loader's loop.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include "gemm_w4x.h"
+
+#ifndef LKM_W4E_VAR
+#define LKM_W4E_VAR 0      // development variants (python -m lvllm_amd.build --flag=-DLKM_W4E_VAR=n --only=gemm_w4x_int4): see the #if sites
+#endif
 
 namespace lkm {
 
@@ -57,6 +63,9 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
 
     if (wave == 0) {
         // ================================================================== loader
+#if LKM_W4E_VAR & 2
+        __builtin_amdgcn_s_setprio(3);      // (round-6 experiment: the loader never waits for an issue slot behind the consumers)
+#endif
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
             (void*)((const char*)p.w + (size_t)e * p.w_estride * 16), 0, (int)0xffffffffu, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
@@ -106,15 +115,25 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
             static_assert((S - 2) * IPU < 64, "vmcnt range");      // (launch_w4e_if refuses the variants that would not fit)
             auto dma = [&](int u) __attribute__((always_inline)) {
                 char* base = lds + (u % S) * STAGE;
-#pragma unroll
-                for (int d = 0; d < XIR; ++d)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LdsPtr)(base + d * 1024), 16, xv[d], u * ROWB, 0, 0);
+#if LKM_W4E_VAR & 1     // (round-6 experiment: the HBM stream first, the L2-resident token rows behind it)
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + WOFF + (c * 2 + t2) * 1024), 16, lane * 16,
                                                                  woff[c][t2] + u * wstep, 0, 2);
+#endif
+#pragma unroll
+                for (int d = 0; d < XIR; ++d)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (LdsPtr)(base + d * 1024), 16, xv[d], u * ROWB, 0, 0);
+#if !(LKM_W4E_VAR & 1)
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + WOFF + (c * 2 + t2) * 1024), 16, lane * 16,
+                                                                 woff[c][t2] + u * wstep, 0, 2);
+#endif
 #pragma unroll
                 for (int k = 0; k < AIR; ++k)
                     if (k * 64 + lane < n_adw)      // (partial exec on the last instruction; every instruction has >= 1 lane)
@@ -283,6 +302,11 @@ static int launch_w4e_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     dim3 grid(ceil_div(groups, NC), max_tiles, IS_G1 ? 1 : p.SK), block((NC + 1) * 64);
     auto kern = gemm_w4e_kernel<WF, ADT, CB, NC, GATED, IS_G1, S, DECV>;
     if (lds > 64 * 1024) LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (getenv("LKM_DEBUG_OCC")) {
+        int nb = -1;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, (NC + 1) * 64, lds);
+        fprintf(stderr, "[w4e] CB=%d NC=%d S=%d lds=%zu: occupancy API -> %d workgroups per CU (%s)\n", CB, NC, S, lds, nb, hipGetErrorString(e));
+    }
     LKM_LAUNCH_GEMM(kern, grid, block, lds, st, p);
     LKM_HIP_CHECK(hipGetLastError());
     return LKM_OK;
@@ -323,6 +347,14 @@ static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
 #define LKM_DEFINE_W4X_LAUNCHER(SUFFIX, WF, ADT)                                                              \
     bool launch_w4x_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1, \
                              int max_tiles, int* rc) {                                                        \
+        if (launch_w4e_if<WF, ADT>(st, cfg, p, gated, is_g1, max_tiles, rc)) return true;                     \
+        return launch_w4x_if<WF, ADT>(st, cfg, p, gated, is_g1, max_tiles, rc);                               \
+    }
+// ... and with "pf" = 7 the two-queue kernel (gemm_w4s.h) first: the translation units that include gemm_w4s.h use this one
+#define LKM_DEFINE_W4S_LAUNCHER(SUFFIX, WF, ADT)                                                              \
+    bool launch_w4x_##SUFFIX(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1, \
+                             int max_tiles, int* rc) {                                                        \
+        if (launch_w4s_if<WF, ADT>(st, cfg, p, gated, is_g1, max_tiles, rc)) return true;                     \
         if (launch_w4e_if<WF, ADT>(st, cfg, p, gated, is_g1, max_tiles, rc)) return true;                     \
         return launch_w4x_if<WF, ADT>(st, cfg, p, gated, is_g1, max_tiles, rc);                               \
     }

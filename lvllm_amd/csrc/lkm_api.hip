@@ -688,7 +688,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             // 6-13 % (DSv3 bf16 rank slice M=64 / 128 / 256: 211 -> 188, 290 -> 253, 327 -> 288 us; Qwen3-30B-A3B M=32 / 64 /
             // 128: 127 -> 112, 155 -> 140, 184 -> 173; Mixtral M=48: 544 -> 473), under uniform routing the two are within
             // +-3 % (465 -> 455, 442 -> 439, 388 -> 398; 204 -> 201, 228 -> 224, 244 -> 231; 471 -> 470).  "hybrid" = 1 keeps
-            // the hybrid; fp8 below 48 tokens keeps it too (not measured).
+            // the hybrid.
             if (w16 && h->t_hybrid == 0) split = 0;
             // fp8 (both modes) below 48 tokens (profiles/r05_plan_robustness_sweep.log, r05_plan_sweep_followup.log): 32-row
             // tiles -- Mixtral W8A8 M=40: 261 -> 256 us uniform, 296 -> 263 Zipf; DSv3 rank slice (32 experts) W8A8 M=32:
@@ -781,9 +781,11 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // (round 2's LDS-DMA ring kernel for the 4-bit formats, "pf" = 4, was removed in round 4: three to four times the
         // bytes in flight per CU and no faster, profiles/r02_w4dma_sweep.log)
         // round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h), "pf" = 5
-        const bool w4x = wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && !split && (h->t_pf == 5 || h->t_pf == 6) &&
+        const bool w4x = wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && !split &&
+                         (h->t_pf == 5 || h->t_pf == 6 || (h->t_pf == 7 && h->wf == LKM_W_INT4_B8 && !h->ps)) &&
                          h->H % 128 == 0 && h->I % 128 == 0;
-        if (w4x) pf = h->t_pf;                  // (6: with a loader wave per workgroup, gemm_w4e.h; "pd" = ring depth 3 / 4)
+        if (w4x) pf = h->t_pf;                  // (6: with a loader wave per workgroup, gemm_w4e.h; "pd" = ring depth 3 / 4;
+                                                //  7: two memory queues, gemm_w4s.h; "pd" = depth of the weight register ring)
         // round 5: uint4b8 (exact mode) on 64-row tiles takes the loader-wave kernel (gemm_w4e.h) BY DEFAULT for both GEMMs.
         // Round 4 left the choice to the first-call autotune; with the autotune off (the engine's default, and bench.py's since
         // round 5) the better plan must be the planner's.  Same box, captured step, alternating, after the consumer loop was
@@ -820,7 +822,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // tile -- Mixtral EP=8: 64 of them; slabs are summed by combine_kernel.  Not with the hybrid plan
         // (the skinny GEMM2 shares the slab layout and runs sk = 1 there) nor with the prefill kernel.
         int sk2 = 1;
-        if (!split && (!pf || pf == 5 || pf == 6)) {
+        if (!split && (!pf || pf == 5 || pf == 6 || pf == 7)) {
             const int tpw = pf >= 5 ? 2 : nt2;     // weight tiles per wave
             const long long wg = (long long)n_act * ((avg_rows + tiled - 1) / tiled) * ((h->T2 + waves * tpw - 1) / (waves * tpw));
             // 4-bit weights: a workgroup's K loop is latency-bound, so more and shorter ones pay up to 4 slabs
@@ -1383,6 +1385,7 @@ static int run_device(LkmHandle h, hipStream_t st, int M, int K, const void* x, 
     const size_t xrow = (size_t)il.x_ld * 2, orow = (size_t)h->Hu * osz;
     const int64_t x_ld_user = il.x_ld;
     if (odd) il.x_ld = h->H;
+    LKM_REQUIRE(!il.route || chunk >= (size_t)M, "forward_routed: a fused router needs the batch in one chunk (M=%d, chunk=%zu)", M, chunk);
     for (size_t m0 = 0; m0 < (size_t)M; m0 += chunk) {
         const int mc = (int)((size_t)M - m0 < chunk ? (size_t)M - m0 : chunk);
         const void* xc = (const char*)x + m0 * xrow;
@@ -1443,9 +1446,13 @@ extern "C" int lkm_forward_routed(LkmHandle h, void* stream, int32_t num_tokens,
     if (M == 0) return LKM_OK;
     LKM_REQUIRE(router_logits && topk_weights_out && topk_ids_out, "forward_routed: null device pointer");
     // one chunk, batched path: the router rides in the sort launch; otherwise the two calls it stands for
-    bool fused = M > 1 && launch_route_sort_ok(M, K, E, n_group, h->E) && h->t_fuse >= 0 &&
-                 chunk_tokens(h, K) >= (size_t)M;
-    if (M <= direct_max_tokens(h) && h->t_fuse >= 0 && chunk_tokens(h, K) >= (size_t)M) {
+    // (the chunk size run_device will really use: an engine whose rows pass through aligned scratch rows, hidden_size % 8
+    // != 0, chunks at pad_tokens even when the shared arena would hold more -- a fused router on a split batch would
+    // route all M rows against one chunk's scratch)
+    size_t eff_chunk = chunk_tokens(h, K);
+    if (h->Hu != h->H && h->pad_tokens < eff_chunk) eff_chunk = h->pad_tokens;
+    bool fused = M > 1 && launch_route_sort_ok(M, K, E, n_group, h->E) && h->t_fuse >= 0 && eff_chunk >= (size_t)M;
+    if (M <= direct_max_tokens(h) && h->t_fuse >= 0 && eff_chunk >= (size_t)M) {
         // one to four tokens: the direct path (two launches) routes inside GEMM1 -- when the plan takes that path
         Plan pl;
         pick_cfg(h, M, (size_t)M * K, &pl);
@@ -1526,6 +1533,17 @@ extern "C" int lkm_per_token_group_quant_fp8(void* stream, const void* x, int32_
     LKM_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && ld_x >= cols && ld_x % 8 == 0 && ld_x <= 0x7fffffffLL,
                 "lkm_per_token_group_quant_fp8: rows=%d cols=%d ld=%lld (cols and ld multiples of 8)", rows, cols, (long long)ld_x);
     return launch_quant_fp8_rows((hipStream_t)stream, x, (int)ld_x, x_dtype, rows, cols, q, scales);
+}
+
+extern "C" int lkm_wna16_expand(void* stream, const void* qweight, const void* scales, const void* zeros, void* out,
+                                int64_t rows, int32_t K, int32_t group, int32_t weight_bits, int32_t out_dtype) {
+    LKM_REQUIRE(qweight && scales && out, "lkm_wna16_expand: null pointer");
+    LKM_REQUIRE(out_dtype == LKM_DT_BF16 || out_dtype == LKM_DT_F16, "lkm_wna16_expand: 16-bit output only");
+    LKM_REQUIRE(weight_bits == 4 || weight_bits == 8, "lkm_wna16_expand: weight_bits=%d (4 or 8)", weight_bits);
+    LKM_REQUIRE(rows >= 0 && K > 0 && K % 8 == 0 && group > 0 && group % 8 == 0 && K % group == 0,
+                "lkm_wna16_expand: rows=%lld K=%d group=%d (K a multiple of the group, the group of 8)", (long long)rows, K, group);
+    LKM_REQUIRE(!(zeros && weight_bits == 4 && (rows & 1)), "lkm_wna16_expand: packed 4-bit zero points need an even row count");
+    return launch_wna16_expand((hipStream_t)stream, qweight, scales, zeros, out, rows, K, group, weight_bits, out_dtype);
 }
 
 extern "C" int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots, int32_t E,
@@ -1711,7 +1729,17 @@ extern "C" int lkm_set_tuning(LkmHandle h, const char* key, int32_t value) {
     else if (!strcmp(key, "hybrid")) h->t_hybrid = value;
     else if (!strcmp(key, "mixed")) h->t_mixed = value;
     else if (!strcmp(key, "prof_rep")) h->t_prof_rep = value;
-    else if (!strcmp(key, "dbg")) h->t_dbg = value;
+    else if (!strcmp(key, "dbg")) {
+#ifndef LKM_ABLATIONS
+        // Bits 1 (4-bit kernels: the packed-fp32-free decoder), 4 (fp8 x fp8 prefill: serialised units), 8 (16-bit prefill:
+        // plain run order inside an XCD) and 256 (streamer: per-unit scales) select result-preserving variants, each covered
+        // by a parity test.  Every other bit is a TIMING ABLATION that returns wrong numbers by construction: development
+        // libraries only (python -m lvllm_amd.build --flag=-DLKM_ABLATIONS), never the liblkm.so that `lk_moe` loads.
+        LKM_REQUIRE((value & ~(1 | 4 | 8 | 256)) == 0,
+                    "lkm_set_tuning: 'dbg' = %d selects a timing ablation; this library ships none (build with -DLKM_ABLATIONS)", value);
+#endif
+        h->t_dbg = value;
+    }
     else {
         set_error("lkm_set_tuning: unknown key '%s'", key);
         return LKM_E_INVALID;

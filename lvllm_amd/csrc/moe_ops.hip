@@ -38,13 +38,34 @@ static OpsWs ops_ws_carve(void* ws, int n_slots, int E) {
     return w;
 }
 
-// key of a slot for the sort.  No expert_map: the id itself.  With one, align (compact == 0): the id, ids whose map entry
-// is -1 dropped; permute (compact > 0 = n_local): local experts by their local id first, then the others by n_local +
+// key of a slot for the sort.  No expert_map: the id itself.  With one, align (compact == 0): the MAPPED (local) id, ids
+// whose map entry is -1 dropped -- the reference counts and ranks by get_local_expert_id (moe_align_sum_kernels.cu:86-100),
+// so its blocks come in local-id order for ANY map (permuted / EPLB-style placements too), and expert_ids holds the local
+// id; permute (compact > 0 = n_local): local experts by their local id first, then the others by n_local +
 // global id (test_moe_permute_unpermute.py:49-55: "topk_ids + n_expert" -- any order-preserving offset sorts the same).
 __global__ __launch_bounds__(256) void ops_keys_kernel(const int32_t* __restrict__ ids, int n, int n_expert,
-                                                       const int32_t* __restrict__ expert_map, int n_local,
+                                                       const int32_t* __restrict__ expert_map, int n_local, int n_keys,
                                                        int32_t* __restrict__ keys) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // permute with a map: the non-local experts sort behind the local ones BY GLOBAL ID.  Their keys are n_local + (rank
+    // among the non-local global ids), not n_local + id: the key range stays n_expert (<= 512, the sort's range) for a
+    // 512-expert model under expert parallelism too.  Every block rebuilds the <= 512-entry rank table in LDS.
+    __shared__ int s_rank[kOpsMaxKeys];
+    const int tid = threadIdx.x;
+    if (expert_map && n_local > 0) {
+        for (int j = tid; j < kOpsMaxKeys; j += 256) s_rank[j] = (j < n_expert && expert_map[j] < 0) ? 1 : 0;
+        __syncthreads();
+        for (int d = 1; d < kOpsMaxKeys; d <<= 1) {          // inclusive scan (Hillis-Steele), two entries per thread
+            int v[2];
+            for (int q = 0; q < 2; ++q) {
+                const int j = tid + q * 256;
+                v[q] = s_rank[j] + (j >= d ? s_rank[j - d] : 0);
+            }
+            __syncthreads();
+            for (int q = 0; q < 2; ++q) s_rank[tid + q * 256] = v[q];
+            __syncthreads();
+        }
+    }
+    const int i = blockIdx.x * 256 + tid;
     if (i >= n) return;
     const int id = ids[i];
     int key = -1;
@@ -52,7 +73,12 @@ __global__ __launch_bounds__(256) void ops_keys_kernel(const int32_t* __restrict
         if (!expert_map) key = id;
         else {
             const int l = expert_map[id];
-            key = n_local > 0 ? (l >= 0 ? l : n_local + id) : (l >= 0 ? id : -1);
+            if (n_local > 0) {
+                key = (l >= 0 && l < n_local) ? l : n_local + s_rank[id] - 1;     // (inclusive rank of a non-local id >= 1)
+                if (key >= n_keys) key = n_keys - 1;                              // malformed map: stay inside the sort's range
+            } else {
+                key = (l >= 0 && l < n_expert) ? l : -1;
+            }
         }
     }
     keys[i] = key;
@@ -87,7 +113,7 @@ __global__ __launch_bounds__(256) void align_place_kernel(const int32_t* __restr
     const int padded = (cnt + block_size - 1) / block_size * block_size;
     for (int i = tid; i < padded; i += 256)
         if (poff + i < sorted_cap) sorted_ids[poff + i] = i < cnt ? sorted_slot[off + i] : n_slots;
-    const int eid = expert_map ? expert_map[e] : e;
+    const int eid = e;      // keys are local ids when an expert_map is given (ops_keys_kernel)
     for (int b = tid; b < padded / block_size; b += 256)
         if (poff / block_size + b < blocks_cap) expert_ids[poff / block_size + b] = eid;
 }
@@ -184,7 +210,7 @@ extern "C" int lkm_moe_align_block_size(void* stream, const int32_t* topk_ids, i
     const OpsWs w = ops_ws_carve(workspace, n_slots, num_experts);
     if (n_slots > 0) {
         hipLaunchKernelGGL(ops_keys_kernel, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, st, topk_ids, n_slots, num_experts,
-                           expert_map, 0, w.keys);
+                           expert_map, 0, num_experts, w.keys);
         int rc = ops_sort(st, w, n_slots, num_experts);
         if (rc != LKM_OK) return rc;
     } else {
@@ -204,8 +230,10 @@ extern "C" int lkm_moe_permute(void* stream, const void* hidden, int32_t row_byt
     LKM_REQUIRE(row_bytes > 0 && row_bytes % 16 == 0, "moe_permute: hidden rows must be a multiple of 16 bytes (got %d)", row_bytes);   // (the reference's assert, :136-138)
     LKM_REQUIRE(expert_first_token_offset && inv_permuted_idx && permuted_idx && permuted_hidden && workspace, "moe_permute: null output");
     LKM_REQUIRE(expert_map || n_local_expert == n_expert, "moe_permute: n_local_expert < n_expert needs an expert_map");
-    const int n_keys = expert_map ? n_local_expert + n_expert : n_expert;
-    LKM_REQUIRE(n_keys <= kOpsMaxKeys, "moe_permute: %d local + %d global experts exceed the sort's %d keys", expert_map ? n_local_expert : 0, n_expert, kOpsMaxKeys);
+    // keys: local ids, then the non-local experts ranked by global id -- n_expert keys for a well-formed map (n_local of its
+    // entries >= 0); the workspace contract stays n_local_expert + n_expert (lkm.h), capped at the sort's range
+    LKM_REQUIRE(n_expert <= kOpsMaxKeys, "moe_permute: n_expert=%d exceeds the sort's %d keys", n_expert, kOpsMaxKeys);
+    const int n_keys = expert_map ? (n_local_expert + n_expert <= kOpsMaxKeys ? n_local_expert + n_expert : kOpsMaxKeys) : n_expert;
     LKM_REQUIRE(((uintptr_t)hidden & 15) == 0 && ((uintptr_t)permuted_hidden & 15) == 0, "moe_permute: rows must be 16-byte aligned");
     const long long n = (long long)n_token * topk;
     LKM_REQUIRE(n < (1LL << 31), "moe_permute: %lld slots", n);
@@ -217,7 +245,7 @@ extern "C" int lkm_moe_permute(void* stream, const void* hidden, int32_t row_byt
     }
     LKM_REQUIRE(hidden && topk_ids, "moe_permute: null input");
     hipLaunchKernelGGL(ops_keys_kernel, dim3((unsigned)ceil_div((int)n, 256)), dim3(256), 0, st, topk_ids, (int)n, n_expert, expert_map,
-                       expert_map ? n_local_expert : 0, w.keys);
+                       expert_map ? n_local_expert : 0, n_keys, w.keys);
     int rc = ops_sort(st, w, (int)n, n_keys);
     if (rc != LKM_OK) return rc;
     const int cover = (int)n > n_local_expert + 1 ? (int)n : n_local_expert + 1;

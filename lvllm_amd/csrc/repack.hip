@@ -270,4 +270,59 @@ int launch_repack_s_fp8(hipStream_t st, const void* src, void* dst, const Repack
     return LKM_OK;
 }
 
+// ---- weight-only integer experts with zero points / 8 bits (the in-tree operator's int4_w4a16 / int8_w8a16 schemes,
+// fused_moe.py:207-276) -> 16-bit weights, T((q - zp) * s) with ONE rounding: exactly what that kernel feeds tl.dot.
+// One thread produces 8 consecutive k of one row (16 bytes out); q: [R][K/2] nibbles (low = even k) or [R][K] bytes;
+// scales [R][K/group] act dtype; zp: 4-bit [R/2][K/group] (low nibble = even row, rows within an expert: N even) or
+// 8-bit [R][K/group]; null = symmetric (8 / 128).  R = E*N rows.
+template <int ADT, int BITS>
+__global__ __launch_bounds__(256) void wna16_expand_kernel(const uint8_t* __restrict__ q, const unsigned short* __restrict__ sc,
+                                                           const uint8_t* __restrict__ zp, u32x4* __restrict__ out,
+                                                           int64_t R, int K, int group) {
+    typedef ActT<ADT> A;
+    const int K8 = K >> 3, KG = K / group;
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= R * K8) return;
+    const int64_t r = v / K8;
+    const int k0 = (int)(v - r * K8) * 8;
+    const int g = k0 / group;                       // group is a multiple of 8: the 8 weights share scale and zp
+    const float s = A::to_f32(sc[r * KG + g]);
+    float z = BITS == 4 ? 8.0f : 128.0f;
+    if (zp) z = BITS == 4 ? (float)((zp[(r >> 1) * KG + g] >> ((r & 1) * 4)) & 0xF) : (float)zp[r * KG + g];
+    float w[8];
+    if (BITS == 4) {
+        const unsigned b = *(const unsigned*)(q + r * (K >> 1) + (k0 >> 1));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (float)((b >> (4 * j)) & 0xF);
+    } else {
+        const uint2 b = *(const uint2*)(q + r * K + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w[j] = (float)((b.x >> (8 * j)) & 0xFF);
+            w[4 + j] = (float)((b.y >> (8 * j)) & 0xFF);
+        }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = A::pack2((w[2 * j] - z) * s, (w[2 * j + 1] - z) * s);
+    out[v] = o;
+}
+
+int launch_wna16_expand(hipStream_t st, const void* q, const void* scales, const void* zp, void* out, int64_t rows,
+                        int K, int group, int bits, int adt) {
+    const int64_t nvec = rows * (K >> 3);
+    if (nvec == 0) return LKM_OK;
+    const dim3 grid((unsigned)ceil_div64(nvec, 256)), block(256);
+#define LKM_WNA16_CASE(ADT_, BITS_)                                                                                     \
+    hipLaunchKernelGGL((wna16_expand_kernel<ADT_, BITS_>), grid, block, 0, st, (const uint8_t*)q,                       \
+                       (const unsigned short*)scales, (const uint8_t*)zp, (u32x4*)out, rows, K, group)
+    if (adt == LKM_DT_BF16 && bits == 4) LKM_WNA16_CASE(LKM_DT_BF16, 4);
+    else if (adt == LKM_DT_BF16) LKM_WNA16_CASE(LKM_DT_BF16, 8);
+    else if (bits == 4) LKM_WNA16_CASE(LKM_DT_F16, 4);
+    else LKM_WNA16_CASE(LKM_DT_F16, 8);
+#undef LKM_WNA16_CASE
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
 }  // namespace lkm

@@ -41,7 +41,7 @@ def _act_name(activation: Any) -> str:
 class LkmQuant:
     """What the engine needs of a FusedMoEQuantConfig (fused_moe/config.py): the weight format, its scales and
     group / block shape.  `from_vllm` reads the same facts off the reference's object."""
-    fmt: str = "bf16"                    # bf16 | fp16 | int4 | fp8 | mxfp4 | nvfp4
+    fmt: str = "bf16"                    # bf16 | fp16 | int4 | fp8 | mxfp4 | nvfp4 | wna16 (expanded at hand-off)
     w1_scale: torch.Tensor | None = None
     w2_scale: torch.Tensor | None = None
     group_n: int = 0
@@ -49,6 +49,11 @@ class LkmQuant:
     w1_global_scale: torch.Tensor | None = None
     w2_global_scale: torch.Tensor | None = None
     fp8_mode: int = _clib.FP8_W8A16      # FP8_W8A8: activations quantised 1x128 on the fly (in-tree block-fp8)
+    # fmt "wna16": weight-only integers the packed uint4b8 format cannot hold -- zero points and / or 8 bits
+    # (fused_moe.py:207-276).  Expanded once to T((q - zp) * s) by lkm_wna16_expand; the 16-bit engine runs on them.
+    weight_bits: int = 4
+    w1_zp: torch.Tensor | None = None
+    w2_zp: torch.Tensor | None = None
 
     @staticmethod
     def from_vllm(qc: Any, act_dtype: torch.dtype) -> "LkmQuant":
@@ -60,8 +65,23 @@ class LkmQuant:
                 raise ValueError(f"fp8 experts: only 128x128 block scales are supported, got {block}")
             return LkmQuant("fp8", qc.w1_scale, qc.w2_scale, 128, 128,
                             fp8_mode=_clib.FP8_W8A8 if getattr(qc, "use_fp8_w8a8", False) else _clib.FP8_W8A16)
-        if getattr(qc, "use_int4_w4a16", False):
-            return LkmQuant("int4", qc.w1_scale, qc.w2_scale, 1, int(block[1]) if block else 128)
+        int4, int8 = getattr(qc, "use_int4_w4a16", False), getattr(qc, "use_int8_w8a16", False)
+        if int4 or int8:
+            for name in ("w1_bias", "w2_bias"):
+                if getattr(qc, name, None) is not None:
+                    raise ValueError(f"weight-only integer experts with {name} are not supported by the MI355X engine")
+            z1, z2 = getattr(qc, "w1_zp", None), getattr(qc, "w2_zp", None)
+            if (z1 is None) != (z2 is None):
+                raise ValueError("zero points must be given for both w1 and w2 or for neither")
+            if not block or int(block[1]) <= 0:
+                raise ValueError(f"weight-only integer experts need block_shape [0, group], got {block}")
+            group = int(block[1])
+            if int4 and z1 is None:      # symmetric 4-bit (uint4b8): the engine's native packed format
+                return LkmQuant("int4", qc.w1_scale, qc.w2_scale, 1, group)
+            # zero points (uint4 / uint8) or symmetric 8-bit (uint8b128): NEVER the uint4b8 decoder -- (q - 8) * s
+            # is not (q - zp) * s
+            return LkmQuant("wna16", qc.w1_scale, qc.w2_scale, 1, group, weight_bits=4 if int4 else 8,
+                            w1_zp=z1, w2_zp=z2)
         if getattr(qc, "use_mxfp4_w4a16", False):
             return LkmQuant("mxfp4", qc.w1_scale, qc.w2_scale, 1, 32)
         raise ValueError("quantisation scheme of this FusedMoEQuantConfig is not supported by the MI355X engine")
@@ -136,8 +156,12 @@ class LkmExperts:
             return a == "none"
         if "fp8" in w and "128" in w:                       # kFp8Static128BlockSym x (None | kFp8Dynamic128Sym)
             return a == "none" or ("fp8" in a and "128" in a)
-        if "mxfp4" in w or "nvfp4" in w or "int4" in w or "uint4" in w:
+        if "mxfp4" in w or "nvfp4" in w:
             return a == "none"                              # W4A16
+        if "int4" in w or "uint4" in w or "int8" in w or "uint8" in w:
+            # uint4b8 natively; zero-point uint4 and 8-bit weight-only (uint8b128 / uint8 + zp) expanded to 16 bits at
+            # hand-off (LkmQuant fmt "wna16").  Integer ACTIVATIONS (w8a8 int8) are not supported.
+            return a == "none"
         return False
 
     @staticmethod
@@ -191,9 +215,17 @@ class LkmExperts:
             fmt = q.fmt if q.fmt not in ("bf16", "fp16") else ("bf16" if act_dtype == torch.bfloat16 else "fp16")
             w1u = w1.view(torch.uint8) if w1.dtype == torch.float8_e4m3fn else w1
             w2u = w2.view(torch.uint8) if w2.dtype == torch.float8_e4m3fn else w2
+            s1, s2, group_n, group_k = q.w1_scale, q.w2_scale, q.group_n, q.group_k
+            if fmt == "wna16":
+                if q.w1_scale.dtype != act_dtype or q.w2_scale.dtype != act_dtype:
+                    raise ValueError(f"wna16 scales are {q.w1_scale.dtype}, activations {act_dtype}: the in-tree "
+                                     "operator dequantises to the activation dtype (fused_moe.py:270-276)")
+                w1u = ops.wna16_expand(w1u.view(torch.uint8), q.w1_scale, q.w1_zp, q.weight_bits, q.group_k)
+                w2u = ops.wna16_expand(w2u.view(torch.uint8), q.w2_scale, q.w2_zp, q.weight_bits, q.group_k)
+                fmt, s1, s2, group_n, group_k = ("bf16" if act_dtype == torch.bfloat16 else "fp16"), None, None, 0, 0
             self._engine = ops.RoutedExpertsEngine(
-                w1u, w2u, top_k=topk, act_dtype=act_dtype, fmt=fmt, w13_scale=q.w1_scale, w2_scale=q.w2_scale,
-                group_n=q.group_n, group_k=q.group_k, has_gate_proj=gated, activation_type=act_type,
+                w1u, w2u, top_k=topk, act_dtype=act_dtype, fmt=fmt, w13_scale=s1, w2_scale=s2,
+                group_n=group_n, group_k=group_k, has_gate_proj=gated, activation_type=act_type,
                 max_num_seqs=self._max_num_seqs, max_batch_size=self._max_num_tokens, fp8_mode=q.fp8_mode,
                 w13_global_scale=q.w1_global_scale, w2_global_scale=q.w2_global_scale)
             self._engine_key = key

@@ -269,6 +269,31 @@ def per_token_group_quant_fp8(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tens
     return q, sc
 
 
+def wna16_expand(qweight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor | None, weight_bits: int,
+                 group: int) -> torch.Tensor:
+    """Weight-only integer experts -> 16-bit weights T((q - zp) * s), the in-tree operator's dequantisation
+    (fused_moe.py:207-276; layouts of tests/kernels/moe/test_moe.py:565-693): qweight uint8 [E, N, K/2] (4-bit) or
+    [E, N, K]; scales [E, N, K/group] bf16 / fp16; zeros uint8 [E, N/2, K/group] (4-bit) / [E, N, K/group] (8-bit) or
+    None (symmetric: 8 / 128).  -> [E, N, K] in the scales' dtype."""
+    _need_cuda(qweight)
+    assert qweight.dtype == torch.uint8 and qweight.dim() == 3 and qweight.is_contiguous()
+    assert scales.dtype in (torch.bfloat16, torch.float16) and scales.is_contiguous() and scales.is_cuda
+    E, N = qweight.shape[:2]
+    K = qweight.size(2) * (2 if weight_bits == 4 else 1)
+    if tuple(scales.shape) != (E, N, K // group):
+        raise ValueError(f"wna16 scales {tuple(scales.shape)}: expected {(E, N, K // group)} for group {group}")
+    if zeros is not None:
+        want = (E, N // 2, K // group) if weight_bits == 4 else (E, N, K // group)
+        if zeros.dtype != torch.uint8 or tuple(zeros.shape) != want or not zeros.is_cuda:
+            raise ValueError(f"wna16 zero points {tuple(zeros.shape)} {zeros.dtype}: expected uint8 {want} on the GPU")
+        zeros = zeros.contiguous()
+    out = torch.empty((E, N, K), dtype=scales.dtype, device=qweight.device)
+    _clib.check(_clib.lib().lkm_wna16_expand(_stream(qweight), _ptr(qweight), _ptr(scales),
+                                             _ptr(zeros) if zeros is not None else None, _ptr(out), E * N, K, group,
+                                             weight_bits, _DT[scales.dtype]))
+    return out
+
+
 def sort_slots(topk_ids: torch.Tensor, num_experts: int):
     """Stable counting sort of the M*K slots by expert.
     -> counts [E], offsets [E+1], sorted_slot [M*K] (tail -1), pos_of_slot [M*K] (-1 = skipped)."""

@@ -249,6 +249,41 @@ def dequant_rows(wfmt: int, act_dtype: int, w: np.ndarray, scale: np.ndarray, K:
     return out
 
 
+def dequant_wna16(q: np.ndarray, scale_bits: np.ndarray, zp: np.ndarray | None, weight_bits: int, group: int,
+                  act_dtype: int) -> np.ndarray:
+    """Weight-only integer experts with or without zero points -> act-dtype bits [E, N, K]: the dequantisation of
+    the in-tree operator, `((b - zp) * scale).to(compute_type)` with zp = 8 / 128 when symmetric
+    (vllm/model_executor/layers/fused_moe/fused_moe.py:207-276), layouts as the reference's test packs them
+    (tests/kernels/moe/test_moe.py:634-641): q uint8 [E, N, K/2] (4-bit, low nibble = even k) or [E, N, K];
+    scales [E, N, K/group] act-dtype bits; zp uint8 [E, N/2, K/group] (4-bit, low nibble = even n) or
+    [E, N, K/group] (8-bit), None = symmetric.  The product of a small integer and a 16-bit scale is exact in
+    fp32, so one rounding to the act dtype reproduces quantize_weights' w_ref (quant_utils.py:703-710) bit for
+    bit -- pinned by tests/golden/moe_wna16.npz."""
+    q = _c(q, np.uint8)
+    E, N = q.shape[0], q.shape[1]
+    if weight_bits == 4:
+        v = np.empty((E, N, q.shape[2] * 2), np.float32)
+        v[..., 0::2] = q & 0xF
+        v[..., 1::2] = q >> 4
+    else:
+        assert weight_bits == 8
+        v = q.astype(np.float32)
+    K = v.shape[2]
+    if zp is None:
+        z = np.float32(8.0 if weight_bits == 4 else 128.0)
+    else:
+        zp = _c(zp, np.uint8)
+        if weight_bits == 4:
+            zf = np.empty((E, N, zp.shape[2]), np.float32)
+            zf[:, 0::2] = zp & 0xF
+            zf[:, 1::2] = zp >> 4
+        else:
+            zf = zp.astype(np.float32)
+        z = np.repeat(zf, group, axis=2)[..., :K]
+    s = np.repeat(bits_to_f32(scale_bits, act_dtype), group, axis=2)[..., :K]
+    return f32_to_bits(((v - z) * s).astype(np.float32), act_dtype)
+
+
 def router_logits(x: np.ndarray, x_dt: int, w: np.ndarray, w_dt: int, bias=None, round_dt: int = F32) -> np.ndarray:
     """x [M,H] (uint16 bits of x_dt), w [E,H] (uint16 bits or float32) -> fp32 logits [M,E]"""
     x, w = _c(x), _c(w)
@@ -324,7 +359,14 @@ def moe_align_block_size(topk_ids: np.ndarray, block_size: int, num_experts: int
     sorted_ids = np.full(max_padded, n, np.int32)
     expert_ids = np.full(-(-max_padded // block_size) if max_padded else 0, -1, np.int32)
     pos = blk = 0
-    for e in range(num_experts):
+    order = range(num_experts)
+    if expert_map is not None:
+        # the KERNEL counts and ranks by the mapped id (get_local_expert_id, csrc/.../moe_align_sum_kernels.cu:86-100,144-185):
+        # blocks come in LOCAL-id order.  The reference's golden walks global ids (test_moe_align_block_size.py:150-172);
+        # the two agree for the monotone maps its test uses (:250-262), and only there.
+        em = np.asarray(expert_map, np.int64)
+        order = [int(e) for e in np.argsort(np.where(em >= 0, em, np.iinfo(np.int64).max), kind="stable") if em[e] >= 0]
+    for e in order:
         if expert_map is not None and expert_map[e] < 0:
             continue
         rows = np.nonzero(ids == e)[0]

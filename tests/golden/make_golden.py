@@ -16,7 +16,7 @@ Functions executed (paths relative to /root/reference):
   SiluAndMul.forward_native         vllm/model_executor/layers/activation.py:140-143
   torch_experts / torch_moe         tests/kernels/utils.py:855-1021
   quantize_weights                  vllm/model_executor/layers/quantization/utils/quant_utils.py:642-738
-  scalar_types.uint4b8              vllm/scalar_type.py
+  scalar_types.uint4b8 / uint4 / uint8b128 / uint8   vllm/scalar_type.py
   native_per_token_group_quant_fp8  tests/kernels/quant_utils.py:157-180
   native_w8a8_block_matmul          tests/kernels/quant_utils.py:91-154
   torch_w8a8_block_fp8_moe          tests/kernels/moe/test_block_fp8.py:107-137
@@ -323,6 +323,85 @@ def gen_moe_int4(ns):
     print("moe_int4.npz:", idx, "cases")
 
 
+def gen_moe_wna16(ns):
+    """the has_zp x weight_bits grid of tests/kernels/moe/test_moe.py:565-693 (test_fused_moe_wn16): quantize_weights
+    with uint4 / uint4b8 / uint8 / uint8b128, packed as the test packs them; expected = torch_moe on w_ref"""
+    spec = importlib.util.spec_from_file_location("ref_scalar_type", REF / "vllm/scalar_type.py")
+    st = importlib.util.module_from_spec(spec)
+    sys.modules["ref_scalar_type"] = st
+    spec.loader.exec_module(st)
+    ns2 = dict(ns, ScalarType=st.ScalarType, scalar_types=st.scalar_types,
+               moe_kernel_quantize_input=lambda a, s, qd, pt, bs=None: (a, None), native_w8a8_block_matmul=None)
+    extract("vllm/model_executor/layers/quantization/utils/quant_utils.py", ["quantize_weights"], ns2)
+    extract("tests/kernels/utils.py", ["torch_experts"], ns2)
+    quantize_weights, torch_experts = ns2["quantize_weights"], ns2["torch_experts"]
+    cases = {}
+    idx = 0
+    dtype = torch.bfloat16
+    for (m, n, k, e, topk) in ((1, 128, 128, 4, 2), (33, 128, 256, 4, 2)):
+        for g in ((64, 128) if m == 1 else (128,)):
+            for has_zp in (True, False):
+                for weight_bits in (4, 8):
+                    torch.manual_seed(7)
+                    a = torch.randn((m, k), dtype=dtype) / 10
+                    w1 = torch.randn((e, 2 * n, k), dtype=dtype) / 10
+                    w2 = torch.randn((e, k, n), dtype=dtype) / 10
+                    score = torch.randn((m, e), dtype=dtype)
+                    # test_moe.py:590-596
+                    if weight_bits == 4:
+                        quant_type = st.scalar_types.uint4 if has_zp else st.scalar_types.uint4b8
+                    else:
+                        quant_type = st.scalar_types.uint8 if has_zp else st.scalar_types.uint8b128
+                    packs, scales, zeros, refs = [], [], [], []
+                    for w in (w1, w2):
+                        qw, sc, zz, rf = [], [], [], []
+                        for i in range(e):
+                            # test_moe.py:632-651
+                            weight, qweight, s_, qzeros = quantize_weights(w[i].T, quant_type, g, has_zp, False)
+                            weight = weight.T
+                            qweight = qweight.T.contiguous().to(torch.uint8)
+                            s_ = s_.T
+                            if has_zp:
+                                qzeros = qzeros.T.contiguous().to(torch.uint8)
+                            if weight_bits == 4:
+                                qweight = qweight[:, 1::2] * 16 + qweight[:, ::2]
+                                if has_zp:
+                                    qzeros = qzeros[1::2, :] * 16 + qzeros[::2, :]
+                            qw.append(qweight)
+                            sc.append(s_.contiguous())
+                            rf.append(weight.contiguous())
+                            if has_zp:
+                                zz.append(qzeros)
+                        packs.append(torch.stack(qw))
+                        scales.append(torch.stack(sc))
+                        refs.append(torch.stack(rf))
+                        zeros.append(torch.stack(zz) if has_zp else None)
+                    # fused_moe(renormalize=False) vs torch_moe: softmax scores, top-k, no renormalisation
+                    p_ = torch.softmax(score.float(), dim=-1)
+                    tw, ids = torch.topk(p_, topk)
+                    out = torch_experts(a, refs[0], refs[1], tw.float(), ids.long())
+                    key = f"c{idx}"
+                    cases[key + "_meta"] = np.array([m, n, k, e, topk, g, int(has_zp), weight_bits], np.int32)
+                    cases[key + "_a"] = bits(a)
+                    cases[key + "_q1"] = packs[0].numpy()
+                    cases[key + "_q2"] = packs[1].numpy()
+                    cases[key + "_s1"] = bits(scales[0])
+                    cases[key + "_s2"] = bits(scales[1])
+                    if has_zp:
+                        cases[key + "_z1"] = zeros[0].numpy()
+                        cases[key + "_z2"] = zeros[1].numpy()
+                    if m == 1 and g == 64:   # dequantised reference weights: one case per (has_zp, bits) pins the dequant
+                        cases[key + "_ref1"] = bits(refs[0])
+                        cases[key + "_ref2"] = bits(refs[1])
+                    cases[key + "_tw"] = tw.float().numpy()
+                    cases[key + "_ids"] = ids.to(torch.int32).numpy()
+                    cases[key + "_out"] = bits(out)
+                    idx += 1
+    cases["n"] = np.array(idx, np.int32)
+    np.savez_compressed(OUT / "moe_wna16.npz", **cases)
+    print("moe_wna16.npz:", idx, "cases")
+
+
 def gen_moe_fp8(ns):
     ns2 = dict(ns, is_deep_gemm_e8m0_used=lambda: False, _ceil_to_ue8m0=None,
                FP8_DTYPE=torch.float8_e4m3fn)
@@ -594,7 +673,7 @@ def main():
     torch.set_num_threads(8)
     ns = base_ns()
     gens = {"topk": gen_topk, "grouped": gen_grouped, "expert_map": gen_expert_map, "bf16": gen_moe_bf16,
-            "int4": gen_moe_int4, "fp8": gen_moe_fp8, "fp4": gen_moe_fp4, "ingest": gen_ingest, "residency": gen_residency}
+            "int4": gen_moe_int4, "wna16": gen_moe_wna16, "fp8": gen_moe_fp8, "fp4": gen_moe_fp4, "ingest": gen_ingest, "residency": gen_residency}
     for name in (sys.argv[1:] or list(gens)):    # `make_golden.py fp4` regenerates one file only
         gens[name](dict(ns))
 

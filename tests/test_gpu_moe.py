@@ -27,6 +27,18 @@ def _run_decode(eng, a, tw, ids):
     return eng.decode(a.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)).cpu().numpy()
 
 
+def _assert_same_math(got, want, msg=""):
+    """Two launch plans of ONE engine on the same inputs: the same arithmetic in another fp32 summation order.  The sums of
+    GEMM1 may differ in their last bits, so now and then ONE element of the activation-dtype intermediate lands on the other
+    side of a rounding boundary (one ulp of bf16 on ~1e-5 of the elements: seen once in 65 536 in
+    test_hybrid_dispatch_skewed_routing, 1.6e-4 on outputs of scale 0.21); everything else agrees to ~1e-5.  Hence: <= 1e-3
+    of the output scale everywhere, and <= 1e-4 on all but a handful of elements."""
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(got, want, atol=1e-3 * scale, rtol=1e-3, err_msg=msg)
+    loose = np.abs(got - want) > 1e-4 + 1e-4 * np.abs(want)
+    assert int(loose.sum()) <= max(32, got.size // 2000), (int(loose.sum()), got.size, msg)
+
+
 def test_library_loaded_and_device():
     from lvllm_amd import _clib
     n, arch = _clib.device_info()
@@ -316,7 +328,7 @@ def test_dense_tiled_path_multi_tile_ragged(M, E, K, H, I, tiled):
         eng.engine.set_tuning(tiled=tiled, ydt=-1)
         out = _run_decode(eng, a, tw, ids)
     eng.engine.set_tuning(tiled=-1, ydt=0)     # skinny streamer on the same inputs
-    np.testing.assert_allclose(_run_decode(eng, a, tw, ids), out, atol=1e-4, rtol=1e-4)
+    _assert_same_math(_run_decode(eng, a, tw, ids), out)
 
 
 @pytest.mark.parametrize("M,E,K,H,I,skew", [(100, 16, 2, 256, 128, 3.0), (256, 32, 1, 512, 256, 2.0),
@@ -339,7 +351,7 @@ def test_hybrid_dispatch_skewed_routing(M, E, K, H, I, skew):
     ref = orc.moe(d, torch_to_bits(w13), torch_to_bits(w2), torch_to_bits(a), ids, tw)
     np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL)
     eng.engine.set_tuning(hybrid=-1)
-    np.testing.assert_allclose(_run_decode(eng, a, tw, ids), out, atol=1e-4, rtol=1e-4)
+    _assert_same_math(_run_decode(eng, a, tw, ids), out)
     eng.engine.set_tuning(hybrid=0)              # the default plan: tiles only
     dflt = _run_decode(eng, a, tw, ids)
     assert "| tiled |" in eng.engine.describe() and "split=0" in eng.engine.describe(), eng.engine.describe()
@@ -940,27 +952,27 @@ def test_all_launch_geometries_agree():
                 continue
             eng.engine.set_tuning(tiled=-1, nt1=nt1, tbmax=tb, kw1=kw, nt2=nt2, sk2=sk)
             out = _run_decode(eng, a, tw, ids)
-            np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())
+            _assert_same_math(out, base, eng.engine.describe())
     # tiled GEMM2 with split-K slabs (few experts per EP rank)
     for tiled, waves, sk in ((64, 4, 2), (64, 4, 4), (128, 8, 8), (128, 4, 2), (256, 8, 2)):
         eng.engine.set_tuning(tiled=tiled, waves=waves, nt1=1, nt2=1, tbmax=0, kw1=0, sk2=sk, pf=-1)
         out = _run_decode(eng, a, tw, ids)
         assert f"sk={sk}" in eng.engine.describe() or True
-        np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=f"tiled sk={sk} " + eng.engine.describe())
+        _assert_same_math(out, base, f"tiled sk={sk} " + eng.engine.describe())
     eng.engine.set_tuning(sk2=0)
     # LDS-DMA prefill kernels (gemm_prefill.h): 256-row tiles
     for pf in (8,):
         eng.engine.set_tuning(tiled=256, waves=8, nt1=1, nt2=1, pf=pf, tbmax=0, kw1=0, sk2=0, ydt=-1)
         out = _run_decode(eng, a, tw, ids)
         assert f"pf={pf}" in eng.engine.describe(), eng.engine.describe()
-        np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=f"pf={pf} " + eng.engine.describe())
+        _assert_same_math(out, base, f"pf={pf} " + eng.engine.describe())
     eng.engine.set_tuning(pf=-1, ydt=0)
     # LDS-staged tiled kernels (gemm_tiled.h)
     for tiled, waves, nt1, nt2 in ((32, 4, 1, 1), (64, 4, 1, 1), (64, 8, 1, 1), (64, 4, 1, 2), (128, 8, 1, 1), (128, 8, 1, 2),
                                    (256, 8, 1, 1), (256, 8, 1, 2)):
         eng.engine.set_tuning(tiled=tiled, waves=waves, nt1=nt1, nt2=nt2, tbmax=0, kw1=0, sk2=0, pf=-1)
         out = _run_decode(eng, a, tw, ids)
-        np.testing.assert_allclose(out, base, atol=1e-4, rtol=1e-4, err_msg=eng.engine.describe())
+        _assert_same_math(out, base, eng.engine.describe())
 
 
 def test_prefill_host_and_chunking():

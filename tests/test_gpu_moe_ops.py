@@ -200,3 +200,30 @@ def test_operator_forms_at_baseline_sizes_vs_oracle(M, E, K, H, bs, ep):
                                              oi.reshape(M, K)[sub].reshape(-1), nv), orc.BF16)
     got = out[sub].float().cpu().numpy()
     assert (np.abs(got - want) <= np.maximum(np.abs(want) * 2.0 ** -7, 2.0 ** -20)).all()
+
+
+def test_moe_align_block_size_with_a_permuted_expert_map_follows_the_kernel_order():
+    """an EPLB-style (non-monotone) map.  The reference KERNEL ranks by the mapped id (get_local_expert_id,
+    moe_align_sum_kernels.cu:86-100), so blocks come in local-id order and expert_ids holds local ids; checked against the
+    oracle (same rule) and through the order-free properties."""
+    from lvllm_amd import ops
+    from oracle import oracle as orc
+    E, M, K, bs = 16, 300, 4, 16
+    g = torch.Generator().manual_seed(11)
+    ids = torch.stack([torch.randperm(E, generator=g)[:K] for _ in range(M)]).to(torch.int32)
+    emap_np = np.full(E, -1, np.int32)
+    local = [9, 2, 14, 5, 0, 11]                      # local id j lives at global id local[j]: not monotone
+    for j, ge in enumerate(local):
+        emap_np[ge] = j
+    s, e, post = ops.moe_align_block_size(ids.to(DEV), bs, E, expert_map=torch.from_numpy(emap_np).to(DEV), ignore_invalid_experts=True)
+    os_, oe, ototal = orc.moe_align_block_size(ids.numpy(), bs, E, emap_np)
+    assert int(post) == ototal
+    np.testing.assert_array_equal(s.cpu().numpy(), os_)
+    np.testing.assert_array_equal(e.cpu().numpy(), oe)
+    eb = e.cpu().numpy()[:ototal // bs]
+    assert (np.diff(eb) >= 0).all() and eb.min() >= 0 and eb.max() < len(local)      # local-id order
+    flat = ids.reshape(-1).numpy()
+    blocks = s.cpu().numpy()[:ototal].reshape(-1, bs)
+    for b in range(blocks.shape[0]):
+        rows = blocks[b][blocks[b] < flat.size]
+        assert (flat[rows] == local[eb[b]]).all()

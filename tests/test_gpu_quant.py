@@ -53,3 +53,33 @@ def test_per_token_group_quant_is_bit_exact(rows, cols, kind, dtype):
     got = q.cpu().numpy()
     bad = np.flatnonzero(got.ravel() != q_ref.ravel())
     assert bad.size == 0, (bad.size, got.ravel()[bad[:5]], q_ref.ravel()[bad[:5]], x.float().numpy().ravel()[bad[:5]])
+
+
+def test_wna16_expand_is_bit_exact_vs_oracle_and_reference_w_ref():
+    """lkm_wna16_expand = T((q - zp) * s) (fused_moe.py:207-276) on the reference test's packings: equal to the oracle bit
+    for bit on every golden case, and to quantize_weights' w_ref where the golden file carries it."""
+    from lvllm_amd import ops
+    from tests.helpers import bits_to_torch, load_golden
+    n_ref = 0
+    for i, c in load_golden("moe_wna16.npz"):
+        m, n, k, e, topk, g, has_zp, bits = [int(v) for v in c["meta"]]
+        for w in ("1", "2"):
+            q, s_ = torch.from_numpy(c["q" + w]).to(DEV), bits_to_torch(c["s" + w], orc.BF16).to(DEV)
+            z = torch.from_numpy(c["z" + w]).to(DEV) if has_zp else None
+            got = ops.wna16_expand(q, s_, z, bits, g).cpu().view(torch.int16).numpy().view(np.uint16)
+            np.testing.assert_array_equal(got, orc.dequant_wna16(c["q" + w], c["s" + w], c["z" + w] if has_zp else None,
+                                                                 bits, g, orc.BF16), err_msg=f"case {i} w{w}")
+            if "ref" + w in c:
+                np.testing.assert_array_equal(got, c["ref" + w], err_msg=f"case {i} w{w} vs w_ref")
+                n_ref += 1
+    assert n_ref == 8
+    # fp16 scales, group 32, odd sizes of the expert count
+    g_ = torch.Generator().manual_seed(9)
+    for bits in (4, 8):
+        E, N, K, grp = 3, 64, 96, 32
+        q = torch.randint(0, 256, (E, N, K // 2 if bits == 4 else K), generator=g_, dtype=torch.uint8)
+        s_ = (torch.rand((E, N, K // grp), generator=g_) * 0.02 + 1e-3).to(torch.float16)
+        z = torch.randint(0, 256, (E, N // 2 if bits == 4 else N, K // grp), generator=g_, dtype=torch.uint8)
+        got = ops.wna16_expand(q.to(DEV), s_.to(DEV), z.to(DEV), bits, grp).cpu().view(torch.int16).numpy().view(np.uint16)
+        want = orc.dequant_wna16(q.numpy(), s_.view(torch.int16).numpy().view(np.uint16), z.numpy(), bits, grp, orc.F16)
+        np.testing.assert_array_equal(got, want)

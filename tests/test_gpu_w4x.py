@@ -21,6 +21,9 @@ ATOL, RTOL = 2e-3, 1e-2
 # (pf, tile rows, waves, ring depth, decoder)
 VARIANTS = [(5, tiled, 4, 2, dbg) for tiled in (32, 64) for dbg in (0, 1)] + \
            [(6, tiled, 0, 3, dbg) for tiled in (32, 64) for dbg in (0, 1)]
+# round 6, gemm_w4s.h (uint4b8): weight register ring 6 (token ring 3) / 3 / 4 / 8 (token ring 4), 4 or 8 consumer waves
+VARIANTS_INT4 = VARIANTS + [(7, 32, 0, 6, 0), (7, 64, 0, 6, 0), (7, 64, 0, 3, 0), (7, 64, 0, 4, 0), (7, 64, 0, 8, 0),
+                            (7, 32, 0, 8, 0), (7, 64, 8, 6, 0), (7, 64, 8, 4, 0)]
 
 
 def _eng(*a, **k):
@@ -62,7 +65,7 @@ def test_w4x_int4_dequant_is_bit_exact(g, dt):
     for e in range(E):
         ids = np.full((H, 1), e, np.int32)
         tw = np.ones((H, 1), np.float32)
-        for (pf, tiled, waves, pd, dbg) in VARIANTS:
+        for (pf, tiled, waves, pd, dbg) in VARIANTS_INT4:
             _set(eng, pf, tiled, waves, pd, dbg)
             for sign in (1.0, -1.0):
                 out = _run_decode(eng, x * sign, tw, ids)[:, :I]                       # out[j, i] = T(relu(+-W[e,i,j])^2)
@@ -101,7 +104,7 @@ def _int4_case(M, E, K, H, I, g, dt, seed, gated=True, drop=0.0, skew=0.0):
 def test_w4x_layers_vs_oracle(M, E, K, H, I, g, dt, gated, drop, skew):
     eng, a, tw, ids, ref = _int4_case(M, E, K, H, I, g, dt, seed=5 + M, gated=gated, drop=drop, skew=skew)
     assert np.abs(ref).max() > 0
-    for (pf, tiled, waves, pd, dbg) in VARIANTS:
+    for (pf, tiled, waves, pd, dbg) in VARIANTS_INT4:
         for sk2 in ((0, 2) if I >= 512 else (0,)):
             _set(eng, pf, tiled, waves, pd, dbg, sk2)
             out = _run_decode(eng, a, tw, ids)

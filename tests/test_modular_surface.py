@@ -95,6 +95,38 @@ def test_quant_from_reference_style_config():
     assert LkmQuant.from_vllm(None, torch.float16).fmt == "fp16"
 
 
+def test_weight_only_integer_configs_never_fall_into_the_symmetric_4bit_decoder():
+    """a config with zero points (or 8-bit weights) must not be mapped to uint4b8 -- it takes the
+    expanded format (exact (q - zp) * s), or raises; test grid of tests/kernels/moe/test_moe.py:565-693."""
+    class QC:
+        w1_scale = torch.ones(2, 4, 1)
+        w2_scale = torch.ones(2, 2, 2)
+        w1_zp = w2_zp = w1_bias = w2_bias = None
+        block_shape = [0, 128]
+        use_int4_w4a16 = True
+        use_int8_w8a16 = False
+    q = LkmQuant.from_vllm(QC(), torch.bfloat16)
+    assert (q.fmt, q.group_k, q.weight_bits) == ("int4", 128, 4)          # uint4b8: native
+    QC.w1_zp, QC.w2_zp = torch.zeros(2, 2, 1, dtype=torch.uint8), torch.zeros(2, 1, 2, dtype=torch.uint8)
+    q = LkmQuant.from_vllm(QC(), torch.bfloat16)
+    assert q.fmt == "wna16" and q.weight_bits == 4 and q.w1_zp is QC.w1_zp and q.w2_zp is QC.w2_zp
+    QC.w2_zp = None
+    with pytest.raises(ValueError):                                        # half a zero-point pair
+        LkmQuant.from_vllm(QC(), torch.bfloat16)
+    QC.w1_zp = None
+    QC.use_int4_w4a16, QC.use_int8_w8a16 = False, True
+    q = LkmQuant.from_vllm(QC(), torch.bfloat16)
+    assert q.fmt == "wna16" and q.weight_bits == 8 and q.w1_zp is None      # uint8b128
+    QC.w1_bias = torch.zeros(2, 4)
+    with pytest.raises(ValueError):
+        LkmQuant.from_vllm(QC(), torch.bfloat16)
+    QC.w1_bias, QC.block_shape = None, None
+    with pytest.raises(ValueError):
+        LkmQuant.from_vllm(QC(), torch.bfloat16)
+    assert LkmExperts._supports_quant_scheme("uint4b8", None) and LkmExperts._supports_quant_scheme("uint4", None)
+    assert LkmExperts._supports_quant_scheme("uint8b128", None) and not LkmExperts._supports_quant_scheme("int8", "int8")
+
+
 def test_errors_are_loud_on_the_host_side():
     ex = LkmExperts()
     x = torch.zeros(4, 64, dtype=torch.bfloat16)

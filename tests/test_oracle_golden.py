@@ -165,6 +165,26 @@ def test_int4_quantiser_and_moe_vs_reference():
             np.testing.assert_array_equal(out2, out)
 
 
+def test_wna16_zero_point_and_8bit_dequant_vs_reference():
+    """The has_zp x weight_bits grid of test_fused_moe_wn16 (tests/kernels/moe/test_moe.py:565-693): the oracle's
+    dequantisation ((q - zp) * s, fused_moe.py:207-276) equals quantize_weights' w_ref BIT FOR BIT for uint4 + zp,
+    uint4b8, uint8 + zp and uint8b128, and the MoE on those weights is inside the test's atol 2e-2 of torch_moe."""
+    seen = set()
+    for i, c in load_golden("moe_wna16.npz"):
+        m, n, k, e, topk, g, has_zp, bits = [int(v) for v in c["meta"]]
+        d1 = orc.dequant_wna16(c["q1"], c["s1"], c["z1"] if has_zp else None, bits, g, orc.BF16)
+        d2 = orc.dequant_wna16(c["q2"], c["s2"], c["z2"] if has_zp else None, bits, g, orc.BF16)
+        if "ref1" in c:
+            np.testing.assert_array_equal(d1, c["ref1"], err_msg=f"case {i}")
+            np.testing.assert_array_equal(d2, c["ref2"], err_msg=f"case {i}")
+            seen.add((has_zp, bits))
+        if not has_zp and bits == 4:      # the symmetric 4-bit case is also the native packed format's dequantisation
+            np.testing.assert_array_equal(d1, orc.dequant_rows(orc.W_INT4, orc.BF16, c["q1"], c["s1"], k, g))
+        out = orc.moe(orc.MoeDesc(E=e, H=k, I=n, act_dtype=orc.BF16), d1, d2, c["a"], c["ids"], c["tw"])
+        np.testing.assert_allclose(out, orc.bits_to_f32(c["out"], orc.BF16), atol=2e-2, rtol=0, err_msg=f"case {i}")
+    assert seen == {(0, 4), (1, 4), (0, 8), (1, 8)}
+
+
 def test_int4_scale_on_partial_sums_stays_inside_the_reference_tolerance():
     """Checker for a candidate kernel mode (DESIGN_history.md 6): group scale applied to fp32 partial sums = the weight (q-8)*s
     kept unrounded.  Not the reference's semantics, but inside its int4 tolerance (atol 2e-2, test_moe.py:565-693)

@@ -56,7 +56,7 @@ class _QC:
     a1_scale = a2_scale = a1_gscale = a2_gscale = w1_zp = w2_zp = w1_bias = w2_bias = g1_alphas = g2_alphas = None
     quant_dtype = weight_quant_dtype = None
     per_act_token_quant = per_out_ch_quant = False
-    use_fp8_w8a8 = use_fp8_w8a16 = use_int4_w4a16 = use_mxfp4_w4a16 = False
+    use_fp8_w8a8 = use_fp8_w8a16 = use_int4_w4a16 = use_int8_w8a16 = use_mxfp4_w4a16 = False
     w1_scale = w2_scale = block_shape = None
 
     def __init__(self, **kw):
@@ -136,6 +136,34 @@ def test_reference_fused_moe_kernel_drives_the_bound_classes(fmt):
     # twice through the same kernel object (the engine is cached, the exchange pool is free again after finalize)
     out2 = k.apply(a.to(DEV), w1d, w2d, twd, idd, mk.MoEActivation.SILU, E, None, False)
     assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
+
+
+def test_reference_wn16_grid_zero_points_and_8bit_through_the_reference_driver():
+    """test_fused_moe_wn16's has_zp x weight_bits x group grid (tests/kernels/moe/test_moe.py:565-693) through the
+    reference's FusedMoEKernel over the bound classes: expected = torch_moe on quantize_weights' w_ref (golden, produced
+    by the reference's own functions), the test's own tolerance atol 2e-2, rtol 0; and against the oracle on the
+    oracle-dequantised weights.  Symmetric 4-bit runs the native packed format, the other three the expanded one."""
+    mk = _load("modular_kernel_glue")
+    from tests.helpers import bits_to_torch, load_golden
+    seen = set()
+    for i, c in load_golden("moe_wna16.npz"):
+        m, n, k, e, topk, g, has_zp, bits = [int(v) for v in c["meta"]]
+        qc = _QC(w1_scale=bits_to_torch(c["s1"], orc.BF16).to(DEV), w2_scale=bits_to_torch(c["s2"], orc.BF16).to(DEV),
+                 block_shape=[0, g], use_int4_w4a16=bits == 4, use_int8_w8a16=bits == 8,
+                 w1_zp=torch.from_numpy(c["z1"]).to(DEV) if has_zp else None,
+                 w2_zp=torch.from_numpy(c["z2"]).to(DEV) if has_zp else None)
+        kern = _kernel(mk, e, k, qc, transport=_copy)
+        out = kern.apply(bits_to_torch(c["a"], orc.BF16).to(DEV), torch.from_numpy(c["q1"]).to(DEV), torch.from_numpy(c["q2"]).to(DEV),
+                         torch.from_numpy(c["tw"]).to(DEV), torch.from_numpy(c["ids"]).to(DEV), mk.MoEActivation.SILU, e, None, False)
+        ex = kern.impl.fused_experts
+        desc = ex._engine.engine.describe()      # "wf=3" = the native packed uint4b8 image, "wf=0" = 16-bit (expanded)
+        assert ("wf=3" if (bits == 4 and not has_zp) else "wf=0") in desc, desc
+        np.testing.assert_allclose(out.float().cpu().numpy(), orc.bits_to_f32(c["out"], orc.BF16), atol=2e-2, rtol=0, err_msg=f"case {i}")
+        d1 = orc.dequant_wna16(c["q1"], c["s1"], c["z1"] if has_zp else None, bits, g, orc.BF16)
+        d2 = orc.dequant_wna16(c["q2"], c["s2"], c["z2"] if has_zp else None, bits, g, orc.BF16)
+        _check(out, orc.moe(orc.MoeDesc(E=e, H=k, I=n, act_dtype=orc.BF16), d1, d2, c["a"], c["ids"], c["tw"]), 2e-2)
+        seen.add((has_zp, bits, g))
+    assert len(seen) == 8
 
 
 def test_reference_fused_moe_kernel_expert_map_and_router_weight_on_input():

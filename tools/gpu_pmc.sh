@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 PMC passes over one workload's kernels (development): per-kernel mean counter values.
-#   bash tools/gpu_pmc.sh <workload> [sweep cfg, e.g. "xcd=1"] [counter set: sq | mem | all]
+#   bash tools/gpu_pmc.sh <workload> [sweep cfg, e.g. "xcd=1"] [counter set: sq | mem | all | occ (wave residency only)]
 # Counter passes run separately (SQ has 8 slots, TCC 4; FETCH_SIZE alone takes 3); --pmc is never
 # combined with the sys/hip/hsa trace domains.
 set -u
@@ -19,6 +19,9 @@ for k in d['pmc']:
 PY
   rm -rf gpurun_out/pmc_$1
 }
+if [ "$SET" = occ ]; then
+run a "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+fi
 if [ "$SET" = sq ] || [ "$SET" = all ]; then
 run a "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 run b "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC"

@@ -48,9 +48,10 @@ def main():
     for name, wl, steps, mfma_peak, _ in RUNS:
         if ONLY is not None and wl not in ONLY:
             continue
-        # (the sigmoid + bias routers also with a zero score-correction bias: their default synthetic bias skews the routing)
+        # (the sigmoid + bias routers also under the synthetic N(0, 0.1) score-correction bias of rounds 1-5: a skewed routing,
+        # labelled "biased"; their "uniform" and "zipf" rows run a zero bias)
         biased = wl.startswith("glm45air") or wl == "dsv3_fp8w8a8_ep_decode_b256"
-        for routing in ("uniform", "zipf") + (("nobias",) if biased else ()):
+        for routing in ("uniform", "zipf") + (("biased",) if biased else ()):
             try:
                 j = run(wl, steps, routing)
             except Exception as e:  # keep going: one failing config must not hide the others

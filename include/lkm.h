@@ -334,6 +334,11 @@ int lkm_moe_unpermute(void* stream, const void* permuted_hidden, int32_t dtype, 
 /* -------------------------------------------------------------------------------------------
  * Introspection / measurement.
  */
+/* 1 when `p` is device (or managed) memory of a HIP device, 0 for host memory -- the rule lkm_create applies to its six
+ * weight pointers.  The host-side `lk_moe` classes use it to decide whether an engine that does not fit HBM can fall back to the
+ * spill tier (host-resident weights streamed through a window of device slots: routed_experts.py:1344-1357, 1884-1899). */
+int lkm_pointer_is_device(const void* p);
+
 const char* lkm_last_error(void);
 int lkm_abi_version(void);
 /* number of visible HIP devices and the gfx arch name of device 0 (buf >= 32 bytes) */

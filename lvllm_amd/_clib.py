@@ -82,6 +82,7 @@ _SIGS = {
                                               C.c_void_p, C.c_void_p]),
     "lkm_wna16_expand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_int32]),
+    "lkm_pointer_is_device": (C.c_int, [C.c_void_p]),
     "lkm_moe_ops_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "lkm_moe_align_block_size": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -38,7 +38,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
     typedef Dec<WF, ADT> D;
     typedef __attribute__((address_space(3))) void* LdsPtr;
     static_assert(D::LOADS == 1 && D::UNITK == 128 && !D::A8 && !D::XS && !D::UNIT_SCALE, "4-bit formats decoded per row");
-    static_assert(S >= 3, "ring: the slot being read, the slot in flight, the slot being refilled");
+    static_assert(S >= 2, "ring: the slot being read and the slot in flight (S = 2: a slot is refilled right after its barrier; experiment)");
     constexpr int TM = 32 * CB, ROWB = 256;
     constexpr int XBYTES = TM * ROWB, WBYTES = NC * 2048;
     constexpr int AUXMAX = 128;                                  // scale bytes per (tile, unit): int4 32*spu, MXFP4 64, NVFP4 128
@@ -319,7 +319,7 @@ static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
     if (cfg.pf != 6 || (cfg.tiled != 32 && cfg.tiled != 64) || !w4x_ok(p)) return false;
     // built: four consumer waves, ring depth 3 (7 / 8 / 14 consumers and depth 4 measured and dropped:
     // profiles/r04_w4e_schedule_ab.log, r04_w4x_batch_sweep.log)
-    const int cb = cfg.tiled / 32, s = 3, nc = 4;
+    const int cb = cfg.tiled / 32, s = cfg.pd == 2 ? 2 : 3, nc = 4;     // ("pd" = 2: two-slot ring, three workgroups per CU -- round-6 experiment)
     const int decv = (WF == LKM_W_INT4_B8 && (p.dbg & 1)) ? 1 : 0;
     // the loader's counted waits need (S - 2) x (DMA instructions per slot) < 64
     const int aux_b = WF == LKM_W_INT4_B8 ? 32 * p.spu : (WF == LKM_W_MXFP4 ? 64 : 128);      // = Dec<>::aux_step (device side)
@@ -333,7 +333,7 @@ static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
 #define LKM_W4E_DV(CB_, G_, IS1_, S_)                                                               \
     LKM_W4E_1(CB_, 4, G_, IS1_, S_, 0)                                                               \
     if constexpr (WF == LKM_W_INT4_B8) { LKM_W4E_1(CB_, 4, G_, IS1_, S_, 1) }
-#define LKM_W4E_ALL(G_, IS1_) LKM_W4E_DV(1, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 3)
+#define LKM_W4E_ALL(G_, IS1_) LKM_W4E_DV(1, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 2)
     if (is_g1 && gated) { LKM_W4E_ALL(true, true) }
     else if (is_g1) { LKM_W4E_ALL(false, true) }
     else { LKM_W4E_ALL(false, false) }

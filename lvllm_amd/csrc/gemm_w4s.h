@@ -314,22 +314,23 @@ static int launch_w4s_t(hipStream_t st, const GemmParams& p, int max_tiles) {
 }
 
 // cfg.pf == 7 selects the kernel; cfg.tiled 32 / 64 -> one / two token column blocks; cfg.pd = depth R of the weight
-// register ring (6 default; 3, 4, 8 built), the token ring has 3 slots when 3 divides R, else 4; cfg.waves = consumer waves
-// per workgroup (4 default, 8)
+// register ring (6 default, 4), the token ring has 3 slots when 3 divides R, else 4; cfg.waves = consumer waves per
+// workgroup (4 default, 7 at 64-row tiles)
 template <int WF, int ADT>
 static bool launch_w4s_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1, int max_tiles, int* rc) {
     if (cfg.pf != 7 || (cfg.tiled != 32 && cfg.tiled != 64) || !w4x_ok(p)) return false;
     const int cb = cfg.tiled / 32;
-    const int r = (cfg.pd == 3 || cfg.pd == 4 || cfg.pd == 8) ? cfg.pd : 6;
-    const int nc = cfg.waves == 8 ? 8 : 4;
+    const int r = cfg.pd == 4 ? 4 : 6;
+    const int nc = cfg.waves == 7 ? 7 : 4;
 #define LKM_W4S_1(CB_, NC_, G_, IS1_, R_, S_)                                                       \
     if (cb == CB_ && nc == NC_ && r == R_) {                                                         \
         *rc = launch_w4s_t<WF, ADT, CB_, NC_, G_, IS1_, R_, S_>(st, p, max_tiles);                   \
         return true;                                                                                 \
     }
-#define LKM_W4S_R(CB_, NC_, G_, IS1_) LKM_W4S_1(CB_, NC_, G_, IS1_, 6, 3) LKM_W4S_1(CB_, NC_, G_, IS1_, 3, 3) \
-    LKM_W4S_1(CB_, NC_, G_, IS1_, 4, 4) LKM_W4S_1(CB_, NC_, G_, IS1_, 8, 4)
-#define LKM_W4S_ALL(G_, IS1_) LKM_W4S_R(1, 4, G_, IS1_) LKM_W4S_R(2, 4, G_, IS1_) LKM_W4S_R(2, 8, G_, IS1_)
+    // built: ring depths 6 / 4, four or seven consumers (3 / 8 deep and eight consumers measured and dropped:
+    // profiles/r06_int4_w4s_ab.log, r06_w4s_nc7.log)
+#define LKM_W4S_R(CB_, NC_, G_, IS1_) LKM_W4S_1(CB_, NC_, G_, IS1_, 6, 3) LKM_W4S_1(CB_, NC_, G_, IS1_, 4, 4)
+#define LKM_W4S_ALL(G_, IS1_) LKM_W4S_R(1, 4, G_, IS1_) LKM_W4S_R(2, 4, G_, IS1_) LKM_W4S_R(2, 7, G_, IS1_)
     if (is_g1 && gated) { LKM_W4S_ALL(true, true) }
     else if (is_g1) { LKM_W4S_ALL(false, true) }
     else { LKM_W4S_ALL(false, false) }

@@ -816,6 +816,14 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // (profiles/r04_prefill_plan_sweep.log).  Few large experts (Mixtral) lose with it and keep the plain grid.
         if (tiled == 256 && (w16 || w8a16 || w4pf) && n_act >= 32 && h->t_xcd >= 0 && (!pf || pf == 8))
             pl->xcd1 = pl->xcd2 = 1;
+        // gemm_w4e.h reads "pd" as its LDS ring depth: 3 slots (two workgroups per CU), or 2 -- round 6: a slot is refilled right
+        // behind its barrier, 51 KiB instead of 77 per workgroup, three workgroups per CU.  Same box, captured step, Mixtral
+        // int4 M=128 (profiles/r06_w4e_s2.log): GEMM1 132.4 -> 130.4 us with two slots, GEMM2 70.1 -> 77.8 (its K loop of 28 units
+        // per slab is all start-up: the deeper ring matters) -- so GEMM1 takes two, GEMM2 three
+        if (pf == 6) {
+            pd1 = tiled == 64 ? 2 : 3;
+            pd2 = 3;
+        }
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;
         // tiled GEMM2 split-K: few experts per rank (expert parallel) leave T2/waves workgroups per token
@@ -1544,6 +1552,11 @@ extern "C" int lkm_wna16_expand(void* stream, const void* qweight, const void* s
                 "lkm_wna16_expand: rows=%lld K=%d group=%d (K a multiple of the group, the group of 8)", (long long)rows, K, group);
     LKM_REQUIRE(!(zeros && weight_bits == 4 && (rows & 1)), "lkm_wna16_expand: packed 4-bit zero points need an even row count");
     return launch_wna16_expand((hipStream_t)stream, qweight, scales, zeros, out, rows, K, group, weight_bits, out_dtype);
+}
+
+extern "C" int lkm_pointer_is_device(const void* p) {
+    if (!p) return 0;
+    return is_device_ptr(p) ? 1 : 0;
 }
 
 extern "C" int lkm_sort_slots(void* stream, const int32_t* ids, int32_t n_slots, int32_t E,

@@ -26,6 +26,7 @@ import os
 import torch
 
 from . import ops
+from .lk_moe_api import spill_disabled
 
 
 def prefetch_window_from_env(env=None) -> int:
@@ -80,8 +81,9 @@ class HostResidentExperts:
             st = torch.cuda.current_stream(self.dev).cuda_stream
             for lo in range(0, self.E, self.slots):
                 c13, c2, s13, s2, g13, g2 = chunk(lo, self.slots)
-                eng = ops.RoutedExpertsEngine(c13, c2, top_k=top_k, act_dtype=act_dtype, fmt=fmt, w13_scale=s13, w2_scale=s2,
-                                              w13_global_scale=g13, w2_global_scale=g2, gpu_id=self.dev.index, **engine_kw)
+                with spill_disabled():                     # (a window that does not fit HBM is an error, not another tier)
+                    eng = ops.RoutedExpertsEngine(c13, c2, top_k=top_k, act_dtype=act_dtype, fmt=fmt, w13_scale=s13, w2_scale=s2,
+                                                  w13_global_scale=g13, w2_global_scale=g2, gpu_id=self.dev.index, **engine_kw)
                 nbytes = eng.engine.expert_bytes()
                 stage = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
                 for i in range(min(self.slots, self.E - lo)):

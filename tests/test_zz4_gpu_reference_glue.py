@@ -153,6 +153,44 @@ def test_reference_glue_bf6_fp16(dtype):
     _drive(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a13, a2, x, ids, tw), 3e-3, 1.5e-2)
 
 
+def test_reference_glue_layer_that_does_not_fit_takes_the_spill_tier(monkeypatch):
+    """the spill tier behind the SAME three calls.  With an HBM budget smaller than the layer
+    (LKM_HBM_CAP_BYTES; on hardware: lkm_create -> LKM_E_NOMEM) the reference's own glue -- _process_bf6_fp16 with host
+    pointers, then _cpu_decode / _cpu_prefill / _gpu_prefill -- ends in lvllm_amd.spill.HostResidentExperts (pinned host
+    images, 2 x LVLLM_GPU_PREFETCH_WINDOW device slots): routed_experts.py:1344-1357, 1884-1899; vllm/envs.py:265,1942-1943.
+    Eager only, like the reference's gpu_prefill (HostResidentExperts.forward refuses a capturing stream)."""
+    glue = _load_glue()
+    from lvllm_amd.residency import expert_layer_bytes
+    E, K, H, I = 10, 2, 256, 128
+    dtype = torch.bfloat16
+    w13, w2 = _masters(E, H, I, 7, dtype)
+    a13, a2 = torch_to_bits(w13), torch_to_bits(w2)
+    monkeypatch.setenv("LKM_HBM_CAP_BYTES", str(expert_layer_bytes(E, H, I, "bf16") // 2))     # half the layer fits
+    monkeypatch.setenv("LVLLM_GPU_PREFETCH_WINDOW", "2")
+    s = _stand_in(glue, E, K, H, I, dtype, w13_weight=w13, w2_weight=w2)
+    s._process_bf6_fp16()
+    eng = s.lk_moe
+    assert type(eng).__name__ == "MOE_BF16" and type(eng._spill).__name__ == "HostResidentExperts"
+    assert eng._spill.slots == 4 and len(eng._spill.images) == E and "spill tier" in eng.describe()
+    assert eng.weight_bytes() < expert_layer_bytes(E, H, I, "bf16")           # HBM holds the window, not the layer
+    s._initialize_cuda_graph_buffers()
+    s.clean_weights_after_loading()
+    del w13, w2
+    d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_BF16)
+    gen = torch.Generator().manual_seed(5)
+    for M, seed in ((24, 1), (300, 2)):
+        x = (torch.randn((M, H), generator=gen) / 8).to(dtype)
+        tw, ids = make_routing(M, E, K, seed=seed, drop=0.1)
+        ref = orc.moe(d, a13, a2, torch_to_bits(x), ids, tw)
+        scale = float(np.abs(ref).max())
+        xd, twd, idd = x.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)
+        for name in (("_cpu_decode",) if M <= s.max_num_seqs else ()) + ("_cpu_prefill", "_gpu_prefill"):
+            out = getattr(s, name)(xd, twd, idd)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=3e-3 * scale, rtol=1.5e-2, err_msg=f"{name} M={M}")
+    eng.close()
+
+
 def test_reference_glue_wna16():
     """MOE_WNA16 through RoutedExperts._process_wna16 (:1456-1533): the checkpoint's transposed int32 / scale tensors,
     `.cpu().transpose(1, 2).contiguous().view(torch.uint8)` pointers, group size from _get_quant_params"""

@@ -319,8 +319,15 @@ static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
     if (cfg.pf != 6 || (cfg.tiled != 32 && cfg.tiled != 64) || !w4x_ok(p)) return false;
     // built: four consumer waves, ring depth 3 (7 / 8 / 14 consumers and depth 4 measured and dropped:
     // profiles/r04_w4e_schedule_ab.log, r04_w4x_batch_sweep.log)
-    const int cb = cfg.tiled / 32, s = cfg.pd == 2 ? 2 : 3, nc = 4;     // ("pd" = 2: two-slot ring, three workgroups per CU -- round-6 experiment)
+    const int cb = cfg.tiled / 32, s = cfg.pd == 2 ? 2 : 3, nc_ask = cfg.waves == 7 ? 7 : 4;
+    // round 6 (profiles/r06_w4e_nc7.log, r06_w4e_nc7_b.log): "pd" = 2 -> a two-slot ring (a slot is refilled right behind its
+    // barrier; 51 KiB per four-consumer workgroup instead of 77); "waves" = 7 -> SEVEN consumers per workgroup on the two-slot
+    // ring (65 KiB, two workgroups = 14 consumers per CU): Mixtral's 896 row groups per expert are 128 workgroups of 7, eight
+    // experts = 1024 workgroups = exactly two rounds of the chip's 512 slots, where 224 workgroups of 4 leave the fourth round
+    // half empty -- GEMM1 132.5 -> 124.3 us uniform, 145.4 -> 139 Zipf (same box, captured step, alternating).  Built for the
+    // default decoder at 64-row tiles; eight and fourteen consumers, and seven on the three-slot ring, measured and dropped.
     const int decv = (WF == LKM_W_INT4_B8 && (p.dbg & 1)) ? 1 : 0;
+    const int nc = (nc_ask == 7 && cb == 2 && s == 2 && decv == 0) ? 7 : 4;
     // the loader's counted waits need (S - 2) x (DMA instructions per slot) < 64
     const int aux_b = WF == LKM_W_INT4_B8 ? 32 * p.spu : (WF == LKM_W_MXFP4 ? 64 : 128);      // = Dec<>::aux_step (device side)
     const int air = (nc * 2 * aux_b / 4 + 63) / 64;
@@ -333,7 +340,7 @@ static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
 #define LKM_W4E_DV(CB_, G_, IS1_, S_)                                                               \
     LKM_W4E_1(CB_, 4, G_, IS1_, S_, 0)                                                               \
     if constexpr (WF == LKM_W_INT4_B8) { LKM_W4E_1(CB_, 4, G_, IS1_, S_, 1) }
-#define LKM_W4E_ALL(G_, IS1_) LKM_W4E_DV(1, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 2)
+#define LKM_W4E_ALL(G_, IS1_) LKM_W4E_DV(1, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 2) LKM_W4E_1(2, 7, G_, IS1_, 2, 0)
     if (is_g1 && gated) { LKM_W4E_ALL(true, true) }
     else if (is_g1) { LKM_W4E_ALL(false, true) }
     else { LKM_W4E_ALL(false, false) }

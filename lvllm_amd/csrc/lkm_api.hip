@@ -824,6 +824,12 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
             pd1 = tiled == 64 ? 2 : 3;
             pd2 = 3;
         }
+        // ... and seven consumers per workgroup where the expert's row groups come in sevens (gemm_w4e.h launch_w4e_if: Mixtral's
+        // 896 gate / up tile pairs = 128 x 7 -> 1024 workgroups = two exact rounds of the chip; GEMM1 132.5 -> 124.3 us).  GEMM2
+        // keeps four (its 128 groups x 4 slabs are 1024 workgroups already; seven measured 91 vs 71 us)
+        int waves1 = waves;
+        if (pf == 6 && tiled == 64 && h->wf == LKM_W_INT4_B8 && h->t_waves == 0 && (h->gated ? h->T1_half : h->T1_half / 2) % 7 == 0)
+            waves1 = 7;
         if (h->t_pd1 > 0) pd1 = h->t_pd1;
         if (h->t_pd2 > 0) pd2 = h->t_pd2;
         // tiled GEMM2 split-K: few experts per rank (expert parallel) leave T2/waves workgroups per token
@@ -847,7 +853,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // GEMM2 1474 -> 1156 us uniform, 1491 -> 1200 Zipf (GEMM1 unchanged by it): profiles/r04_prefill_plan_sweep.log
         int waves2 = waves;
         if (h->wf == LKM_W_FP8_E4M3 && !h->a8 && tiled == 64 && avg_rows >= 192 && h->t_waves == 0 && nt2 == 1) waves2 = 8;
-        pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves, pd1, pf};
+        pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves1, pd1, pf};
         pl->t2 = LaunchCfg{nt2, tiled / 16, 1, sk2, tiled, waves2, pd2, pf};
         if (g2_only) pl->t1 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
         // Mixed tile heights (round-4 verdict item 6), OPT-IN: "mixed" = n > 0.  Decode batches of many-expert layers plan

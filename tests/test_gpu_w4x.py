@@ -21,9 +21,10 @@ ATOL, RTOL = 2e-3, 1e-2
 # (pf, tile rows, waves, ring depth, decoder)
 VARIANTS = [(5, tiled, 4, 2, dbg) for tiled in (32, 64) for dbg in (0, 1)] + \
            [(6, tiled, 0, 3, dbg) for tiled in (32, 64) for dbg in (0, 1)]
-# round 6: gemm_w4e.h with a two-slot ring ("pd" = 2; the default of GEMM1 at 64-row tiles) and gemm_w4s.h (uint4b8, "pf" = 7:
+# round 6: gemm_w4e.h with a two-slot ring ("pd" = 2; the default of GEMM1 at 64-row tiles), with seven consumers per workgroup
+# ("waves" = 7: GEMM1's default where the row groups come in sevens; here also on group counts that do not) and gemm_w4s.h (uint4b8, "pf" = 7:
 # weight register ring 6 (token ring 3) / 4 (token ring 4), 4 or 7 consumer waves)
-VARIANTS_INT4 = VARIANTS + [(6, 64, 0, 2, 0), (6, 64, 0, 2, 1), (7, 32, 0, 6, 0), (7, 64, 0, 6, 0), (7, 64, 0, 4, 0), (7, 32, 0, 4, 0),
+VARIANTS_INT4 = VARIANTS + [(6, 64, 0, 2, 0), (6, 64, 0, 2, 1), (6, 64, 7, 2, 0), (7, 32, 0, 6, 0), (7, 64, 0, 6, 0), (7, 64, 0, 4, 0), (7, 32, 0, 4, 0),
                             (7, 64, 7, 6, 0), (7, 64, 7, 4, 0)]
 
 

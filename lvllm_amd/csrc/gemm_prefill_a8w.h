@@ -911,7 +911,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                         if constexpr (GATED) {
                             const int n = (done.tbase + wave) * 16 + gg * 4;
                             if (done.tbase + wave < T_half && n < p.n_real) {
-                                if (p.act_type == LKM_ACT_SWIGLUOAI) store_gemm1_frag<ADT, true>(p, c0, c1, orow, n);
+                                if (p.act_type == LKM_ACT_SWIGLUOAI) store_gemm1_frag<ADT, true, true>(p, c0, c1, orow, n);   // (LEGACY: gemm_skinny.h act_silu_poly)
                                 else a8w_store_silu_mul<ADT>(p, c0, c1, orow, n);
                             }
                         } else {
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(a8w::kNumVgpr))
                                 const int n = tl * 16 + gg * 4;
                                 const f32x4 v = t ? c1 : c0;
                                 if (tl < T_half && n < p.n_real) {
-                                    if constexpr (IS_G1) store_gemm1_frag<ADT, false>(p, v, v, orow, n);
+                                    if constexpr (IS_G1) store_gemm1_frag<ADT, false, true>(p, v, v, orow, n);
                                     else if (p.y_dt == LKM_DT_F32) store_gemm2_frag(p, v, 0, orow, n);
                                     else {      // the reference's block-fp8 GEMM rounds its output to the activation dtype
                                         unsigned short* o = (unsigned short*)p.out + orow * p.ldo + n;

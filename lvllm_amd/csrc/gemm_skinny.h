@@ -506,12 +506,16 @@ struct Streamer {
 // weights are bit-exact against the CPU restatement.
 __device__ __forceinline__ float act_sigmoid_fast(float g) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896341f)); }
 __device__ __forceinline__ float act_silu(float g) { return g * act_sigmoid_fast(g); }
+// (the polynomial form, kept for ONE call site: the swigluoai fallback inside gemm_prefill_a8w.h's epilogue.  That kernel runs on
+//  a fixed register map with 40 registers left to the compiler; the shorter sigmoid there moved its allocation and put a spill + a
+//  vmcnt(0) into the K loop -- tests/test_a8w_codegen.py caught it.  LEGACY = true compiles that call site as it was.)
+__device__ __forceinline__ float act_silu_poly(float g) { return g / (1.0f + lkm_expf(-g)); }
 
 // ------------------------------------------------------------------ epilogues shared by all GEMM kernels
 // One D fragment = 4 consecutive output features n..n+3 of one routed row.
 // GEMM1: activation (SiLU-mul / swigluoai / relu2; rounding points per GemmParams::round_gemm1) and ONE
 // rounding to the activation dtype; the row is `out_row` of the expert-sorted intermediate.
-template <int ADT, bool GATED>
+template <int ADT, bool GATED, bool LEGACY = false>
 __device__ __forceinline__ void gemm1_act4(const GemmParams& p, const f32x4& gate, const f32x4& upv, float (&v)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -523,12 +527,13 @@ __device__ __forceinline__ void gemm1_act4(const GemmParams& p, const f32x4& gat
             if (p.act_type == LKM_ACT_SWIGLUOAI) {
                 const float gg = fminf(a, p.limit);
                 const float uu = fmaxf(fminf(up, p.limit), -p.limit);
-                v[r] = (uu + 1.0f) * gg * act_sigmoid_fast(gg * p.alpha);
+                if constexpr (LEGACY) v[r] = (uu + 1.0f) * gg / (1.0f + lkm_expf(-gg * p.alpha));
+                else v[r] = (uu + 1.0f) * gg * act_sigmoid_fast(gg * p.alpha);
             } else if (p.round_gemm1) {
                 // T(silu_f32(g)) * u  (activation_kernels.cu:57-75,157-160)
-                v[r] = ActT<ADT>::to_f32(ActT<ADT>::from_f32(act_silu(a))) * up;
+                v[r] = ActT<ADT>::to_f32(ActT<ADT>::from_f32(LEGACY ? act_silu_poly(a) : act_silu(a))) * up;
             } else {
-                v[r] = act_silu(a) * up;
+                v[r] = (LEGACY ? act_silu_poly(a) : act_silu(a)) * up;
             }
         } else {
             const float tt = a > 0.0f ? a : 0.0f;
@@ -536,11 +541,11 @@ __device__ __forceinline__ void gemm1_act4(const GemmParams& p, const f32x4& gat
         }
     }
 }
-template <int ADT, bool GATED>
+template <int ADT, bool GATED, bool LEGACY = false>
 __device__ __forceinline__ void store_gemm1_frag(const GemmParams& p, const f32x4& gate, const f32x4& upv,
                                                  size_t out_row, int n) {
     float v[4];
-    gemm1_act4<ADT, GATED>(p, gate, upv, v);
+    gemm1_act4<ADT, GATED, LEGACY>(p, gate, upv, v);
     unsigned short* o = (unsigned short*)p.out + out_row * p.ldo + n;
     if (n + 4 <= p.n_real) {
         u32x2 pk;

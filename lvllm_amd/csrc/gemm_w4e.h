@@ -32,7 +32,11 @@ __device__ __forceinline__ void w4e_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WF, int ADT, int CB, int NC, bool GATED, bool IS_G1, int S, int DECV>
+// G (round 6): row-group SETS per workgroup.  A workgroup of G > 1 walks G consecutive sets of NC row groups of ITS token tile
+// as ONE stream of G x U units: the loader's ring never drains between sets (the first units of set g + 1 are in flight while the
+// consumers finish set g and run its epilogue), the tile's metadata and token-row offsets are fetched once, and Mixtral's GEMM1
+// is 512 workgroups -- every one resident at once.  Needs U % S == 0 and groups % (NC x G) == 0 (launch_w4e_if checks both).
+template <int WF, int ADT, int CB, int NC, bool GATED, bool IS_G1, int S, int DECV, int G = 1>
 __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef Dec<WF, ADT> D;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
             (void*)((const char*)p.x + (size_t)k_base * 2), 0, (int)0xffffffffu, 0x00020000);
         auto tile_of = [&](int c, int t2) __attribute__((always_inline)) {
-            const int grp = bx * NC + c;
+            const int grp = bx * G * NC + c;                      // (set 0; set g is NC groups further: wset / aset below)
             const bool on = (pairs ? grp : 2 * grp) < p.T_half;   // a consumer past the padded tile count streams tile 0
             return on ? (pairs ? (t2 ? p.T_half + grp : grp) : 2 * grp + t2) : 0;
         };
@@ -85,6 +89,8 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
             for (int t2 = 0; t2 < 2; ++t2)
                 woff[c][t2] = __builtin_amdgcn_readfirstlane((int)((tile_of(c, t2) * p.w_tstride + (long long)u0 * p.w_ustride) * 16));
         const int wstep = (int)(p.w_ustride * 16);
+        const int wset = (int)((long long)NC * (pairs ? 1 : 2) * p.w_tstride * 16);      // byte offset of the next set's tiles
+        const int aset = NC * (pairs ? 1 : 2) * p.U * auxB;
         // scales: dword dw = (c*2 + t2) * adw + w of the slot's dense aux area; instruction k moves dwords k*64 .. k*64+63,
         // the lanes past the last dword of the last instruction are masked off
         constexpr int AIMAX = (NC * 2 * AUXMAX / 4 + 63) / 64;
@@ -113,15 +119,21 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
             constexpr int XIR = CBR * 8;
             constexpr int IPU = XIR + 2 * NC + AIR;              // DMA instructions per slot: the counted waits rely on it
             static_assert((S - 2) * IPU < 64, "vmcnt range");      // (launch_w4e_if refuses the variants that would not fit)
-            auto dma = [&](int u) __attribute__((always_inline)) {
-                char* base = lds + (u % S) * STAGE;
+            auto dma = [&](int ug) __attribute__((always_inline)) {
+                char* base = lds + (ug % S) * STAGE;
+                int set = 0, u = ug;
+                if constexpr (G > 1) {
+                    set = ug / U;
+                    u = ug - set * U;
+                }
+                const int wso = set * wset, aso = set * aset;
 #if LKM_W4E_VAR & 1     // (round-6 experiment: the HBM stream first, the L2-resident token rows behind it)
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + WOFF + (c * 2 + t2) * 1024), 16, lane * 16,
-                                                                 woff[c][t2] + u * wstep, 0, 2);
+                                                                 woff[c][t2] + wso + u * wstep, 0, 2);
 #endif
 #pragma unroll
                 for (int d = 0; d < XIR; ++d)
@@ -132,24 +144,25 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (LdsPtr)(base + WOFF + (c * 2 + t2) * 1024), 16, lane * 16,
-                                                                 woff[c][t2] + u * wstep, 0, 2);
+                                                                 woff[c][t2] + wso + u * wstep, 0, 2);
 #endif
 #pragma unroll
                 for (int k = 0; k < AIR; ++k)
                     if (k * 64 + lane < n_adw)      // (partial exec on the last instruction; every instruction has >= 1 lane)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (LdsPtr)(base + AOFF + k * 256), 4, av[k], u * auxB, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (LdsPtr)(base + AOFF + k * 256), 4, av[k], aso + u * auxB, 0, 0);
             };
+            const int UT = G * U;                                 // units of the whole stream
 #pragma unroll
             for (int s = 0; s < S - 1; ++s)
-                if (s < U) dma(s);
-            for (int u = 0; u < U; ++u) {
-                const int younger = U - 1 - u;                    // slots issued after slot u
+                if (s < UT) dma(s);
+            for (int u = 0; u < UT; ++u) {
+                const int younger = UT - 1 - u;                   // slots issued after slot u
                 if (younger >= S - 2) w4e_wait_vmcnt<(S - 2) * IPU>();
                 else if (S > 3 && younger == 1) w4e_wait_vmcnt<IPU>();
                 else w4e_wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (u + S - 1 < U) dma(u + S - 1);
+                if (u + S - 1 < UT) dma(u + S - 1);
             }
             w4e_wait_vmcnt<0>();
         };
@@ -181,8 +194,8 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
     // ====================================================================== consumers
     const int cw = wave - 1;                                     // consumer index = 32-row group inside the workgroup
     const int j = lane & 31, h = lane >> 5, i16 = lane & 15, sel = (lane >> 4) & 1;
-    const int grp = bx * NC + cw;
-    const bool wave_on = (pairs ? grp : 2 * grp) < p.T_half;
+    int grp = bx * G * NC + cw;                                  // (set 0; the set loop below advances it by NC)
+    bool wave_on = (pairs ? grp : 2 * grp) < p.T_half;
     const int dparam = WF == LKM_W_NVFP4 ? __builtin_bit_cast(int, p.gs ? p.gs[e] : 1.0f) : p.spu;
     // weight pieces of lane (tile sel, row i16, half h): old lanes (2h + q, i16) of the tile's 1-KiB block
     const int wlds = WOFF + (cw * 2 + sel) * 1024 + ((2 * h) * 16 + i16) * 16;
@@ -195,10 +208,6 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
         for (int q = 0; q < 2; ++q) baddr[s][q] = j * ROWB + (((s * 4 + 2 * h + q) ^ (j & 15)) * 16);
 
     f32x16 acc[CB];
-#pragma unroll
-    for (int c = 0; c < CB; ++c)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
     auto run_c = [&](auto CBC, auto HC) __attribute__((always_inline)) {
         constexpr int CBR = decltype(CBC)::v;
@@ -257,6 +266,15 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
         }
         run_c(CBC, IC<0>{});
     };
+    for (int set = 0; set < G; ++set) {
+    if (set) {
+        grp += NC;
+        wave_on = (pairs ? grp : 2 * grp) < p.T_half;
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
     if constexpr (CB == 2) {
         if (two_blocks) run(IC<2>{});
         else run(IC<1>{});
@@ -265,7 +283,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
     }
 
     // epilogue: as gemm_w4x_kernel (D layout of the 32x32 MFMA)
-    if (!wave_on) return;
+    if (wave_on)
     static_for<CB>([&](auto CC) __attribute__((always_inline)) {
         constexpr int c = decltype(CC)::v;
         const int r_tok = r0 + c * 32 + j;
@@ -290,19 +308,21 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
             });
         }
     });
+    }   // set
 #else
     (void)p;
 #endif
 }
 
-template <int WF, int ADT, int CB, int NC, bool GATED, bool IS_G1, int S, int DECV>
+template <int WF, int ADT, int CB, int NC, bool GATED, bool IS_G1, int S, int DECV, int G = 1>
 static int launch_w4e_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     constexpr size_t lds = (size_t)S * (CB * 32 * 256 + NC * 2048 + NC * 2 * 128);
     const int groups = (IS_G1 && GATED) ? p.T_half : p.T_half / 2;
-    dim3 grid(ceil_div(groups, NC), max_tiles, IS_G1 ? 1 : p.SK), block((NC + 1) * 64);
-    auto kern = gemm_w4e_kernel<WF, ADT, CB, NC, GATED, IS_G1, S, DECV>;
+    dim3 grid(ceil_div(groups, NC * G), max_tiles, IS_G1 ? 1 : p.SK), block((NC + 1) * 64);
+    auto kern = gemm_w4e_kernel<WF, ADT, CB, NC, GATED, IS_G1, S, DECV, G>;
     if (lds > 64 * 1024) LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (getenv("LKM_DEBUG_OCC")) {
+    static const bool dbg_occ = getenv("LKM_DEBUG_OCC") != nullptr;      // (development: what the occupancy API says about this variant)
+    if (dbg_occ) {
         int nb = -1;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, (NC + 1) * 64, lds);
         fprintf(stderr, "[w4e] CB=%d NC=%d S=%d lds=%zu: occupancy API -> %d workgroups per CU (%s)\n", CB, NC, S, lds, nb, hipGetErrorString(e));
@@ -328,6 +348,9 @@ static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
     // default decoder at 64-row tiles; eight and fourteen consumers, and seven on the three-slot ring, measured and dropped.
     const int decv = (WF == LKM_W_INT4_B8 && (p.dbg & 1)) ? 1 : 0;
     const int nc = (nc_ask == 7 && cb == 2 && s == 2 && decv == 0) ? 7 : 4;
+    // "kw" = 2 (round 6): TWO sets of seven row groups per workgroup, one uninterrupted stream of 2 U units (gemm_w4e_kernel: G)
+    const int groups_all = (is_g1 && gated) ? p.T_half : p.T_half / 2;
+    const int sets = (cfg.kw == 2 && nc == 7 && is_g1 && p.U % 2 == 0 && groups_all % 14 == 0) ? 2 : 1;
     // the loader's counted waits need (S - 2) x (DMA instructions per slot) < 64
     const int aux_b = WF == LKM_W_INT4_B8 ? 32 * p.spu : (WF == LKM_W_MXFP4 ? 64 : 128);      // = Dec<>::aux_step (device side)
     const int air = (nc * 2 * aux_b / 4 + 63) / 64;
@@ -341,6 +364,11 @@ static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
     LKM_W4E_1(CB_, 4, G_, IS1_, S_, 0)                                                               \
     if constexpr (WF == LKM_W_INT4_B8) { LKM_W4E_1(CB_, 4, G_, IS1_, S_, 1) }
 #define LKM_W4E_ALL(G_, IS1_) LKM_W4E_DV(1, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 2) LKM_W4E_1(2, 7, G_, IS1_, 2, 0)
+    if (sets == 2) {
+        if (gated) *rc = launch_w4e_t<WF, ADT, 2, 7, true, true, 2, 0, 2>(st, p, max_tiles);
+        else *rc = launch_w4e_t<WF, ADT, 2, 7, false, true, 2, 0, 2>(st, p, max_tiles);
+        return true;
+    }
     if (is_g1 && gated) { LKM_W4E_ALL(true, true) }
     else if (is_g1) { LKM_W4E_ALL(false, true) }
     else { LKM_W4E_ALL(false, false) }

@@ -303,7 +303,8 @@ static int launch_w4s_t(hipStream_t st, const GemmParams& p, int max_tiles) {
     dim3 grid(ceil_div(groups, NC), max_tiles, IS_G1 ? 1 : p.SK), block((NC + 1) * 64);
     auto kern = gemm_w4s_kernel<WF, ADT, CB, NC, GATED, IS_G1, R, S>;
     if (lds > 64 * 1024) LKM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (getenv("LKM_DEBUG_OCC")) {
+    static const bool dbg_occ = getenv("LKM_DEBUG_OCC") != nullptr;      // (development: what the occupancy API says about this variant)
+    if (dbg_occ) {
         int nb = -1;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, (NC + 1) * 64, lds);
         fprintf(stderr, "[w4s] CB=%d NC=%d R=%d S=%d lds=%zu: occupancy API -> %d workgroups per CU (%s)\n", CB, NC, R, S, lds, nb, hipGetErrorString(e));

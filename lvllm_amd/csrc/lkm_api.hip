@@ -853,7 +853,11 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // GEMM2 1474 -> 1156 us uniform, 1491 -> 1200 Zipf (GEMM1 unchanged by it): profiles/r04_prefill_plan_sweep.log
         int waves2 = waves;
         if (h->wf == LKM_W_FP8_E4M3 && !h->a8 && tiled == 64 && avg_rows >= 192 && h->t_waves == 0 && nt2 == 1) waves2 = 8;
-        pl->t1 = LaunchCfg{nt1, tiled / 16, 1, 1, tiled, waves1, pd1, pf};
+        // gemm_w4e.h with seven consumers: "kw1" = 2 -> two sets of seven row groups per workgroup, one stream (LaunchCfg::kw)
+        // (measured, profiles/r06_w4e_two_sets_ab.log: 512 workgroups, all resident at once -- GEMM1 126.8 -> 128.9 us uniform,
+        // 142.7 -> 161.7 under Zipf: the bigger static items cost more under skew than the spared start-ups give back; opt-in)
+        const int sets1 = (pf == 6 && waves1 == 7 && h->t_kw1 == 2) ? 2 : 1;
+        pl->t1 = LaunchCfg{nt1, tiled / 16, sets1, 1, tiled, waves1, pd1, pf};
         pl->t2 = LaunchCfg{nt2, tiled / 16, 1, sk2, tiled, waves2, pd2, pf};
         if (g2_only) pl->t1 = LaunchCfg{0, 0, 0, 0, 0, 0, 0, 0};
         // Mixed tile heights (round-4 verdict item 6), OPT-IN: "mixed" = n > 0.  Decode batches of many-expert layers plan

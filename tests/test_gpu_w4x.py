@@ -117,6 +117,25 @@ def test_w4x_layers_vs_oracle(M, E, K, H, I, g, dt, gated, drop, skew):
     np.testing.assert_allclose(base, ref, atol=ATOL, rtol=RTOL)
 
 
+@pytest.mark.parametrize("M,gated,dt", [(128, True, "bf16"), (70, False, "f16"), (300, True, "bf16")])
+def test_w4e_two_sets_per_workgroup_vs_oracle(M, gated, dt):
+    """round 6: gemm_w4e.h walking TWO sets of seven row groups per workgroup as one stream ("kw1" = 2 with seven consumers):
+    row-group counts that are multiples of 14 (I = 896: 56 pairs gated, 28 non-gated), ~32 rows per expert and skewed
+    multi-tile experts, against the oracle and against the one-set plan"""
+    E, K, H, I = 4, 2, 512, 896
+    eng, a, tw, ids, ref = _int4_case(M, E, K, H, I, 128, dt, seed=21 + M, gated=gated, skew=0.0 if M < 200 else 1.0)
+    eng.engine.set_tuning(pf=6, tiled=64, waves=7, pd1=2, pd2=3, kw1=2)
+    out = _run_decode(eng, a, tw, ids)
+    assert "pf=6" in eng.engine.describe() and "waves=7" in eng.engine.describe(), eng.engine.describe()
+    k1 = eng.engine.last_kernels()["gemm1"]
+    assert any("gemm_w4e_kernel" in k and k.rstrip(">").endswith(", 2") for k in k1), k1      # (..., S = 2, DECV = 0, G = 2)
+    np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=eng.engine.describe())
+    eng.engine.set_tuning(pf=6, tiled=64, waves=7, pd1=2, pd2=3, kw1=0)
+    one = _run_decode(eng, a, tw, ids)
+    np.testing.assert_array_equal(out, one)        # the same arithmetic in the same order, only the workgroup boundaries moved
+    eng.engine.set_tuning(pf=0, tiled=0, waves=0, pd1=0, pd2=0, kw1=0)
+
+
 @pytest.mark.parametrize("fmt", ["mxfp4", "nvfp4"])
 @pytest.mark.parametrize("M,dt", [(128, "bf16"), (45, "f16")])
 def test_w4x_fp4_formats_vs_oracle(fmt, M, dt):

@@ -25,7 +25,10 @@ VARIANTS = [(5, tiled, 4, 2, dbg) for tiled in (32, 64) for dbg in (0, 1)] + \
 # ("waves" = 7: GEMM1's default where the row groups come in sevens; here also on group counts that do not) and gemm_w4s.h (uint4b8, "pf" = 7:
 # weight register ring 6 (token ring 3) / 4 (token ring 4), 4 or 7 consumer waves)
 VARIANTS_INT4 = VARIANTS + [(6, 64, 0, 2, 0), (6, 64, 0, 2, 1), (6, 64, 7, 2, 0), (7, 32, 0, 6, 0), (7, 64, 0, 6, 0), (7, 64, 0, 4, 0), (7, 32, 0, 4, 0),
-                            (7, 64, 7, 6, 0), (7, 64, 7, 4, 0)]
+                            (7, 64, 7, 6, 0), (7, 64, 7, 4, 0),
+                            (6, 64, 7, 32, 0),      # split rings: three weight slots, two token slots (gemm_w4e_kernel: SX)
+                            (6, 64, 7, 34, 0),      # the consumers fetch the next unit's weights into registers (gemm_w4e_kernel: PW)
+                            (6, 64, 7, 36, 0), (6, 64, 7, 37, 0)]   # two row groups per consumer against one set of token fragments (R), ring 2 / 3
 
 
 def _eng(*a, **k):
@@ -128,7 +131,8 @@ def test_w4e_two_sets_per_workgroup_vs_oracle(M, gated, dt):
     out = _run_decode(eng, a, tw, ids)
     assert "pf=6" in eng.engine.describe() and "waves=7" in eng.engine.describe(), eng.engine.describe()
     k1 = eng.engine.last_kernels()["gemm1"]
-    assert any("gemm_w4e_kernel" in k and k.rstrip(">").endswith(", 2") for k in k1), k1      # (..., S = 2, DECV = 0, G = 2)
+    # template arguments: WF, ADT, CB, NC, GATED, IS_G1, S, DECV, G, SX, PW -> G = 2
+    assert any("gemm_w4e_kernel" in k and [t.strip() for t in k[k.index("<") + 1:k.rindex(">")].split(",")][8] == "2" for k in k1), k1
     np.testing.assert_allclose(out, ref, atol=ATOL, rtol=RTOL, err_msg=eng.engine.describe())
     eng.engine.set_tuning(pf=6, tiled=64, waves=7, pd1=2, pd2=3, kw1=0)
     one = _run_decode(eng, a, tw, ids)

@@ -24,7 +24,14 @@ using namespace lkm;
         }                                                         \
     } while (0)
 
-// MODE bit 0: decode, bit 1: MFMA; DECV: 0 packed-fp32 decoder, 1 plain
+// accumulators in the AGPR half of the register file (round 6, second probe: does the C / D traffic of a 32 x 32 MFMA -- 16
+// registers read and written per instruction -- stop competing with the decoder's VALU operand reads when it is there?)
+__device__ __forceinline__ void mfma_agpr(f32x16& acc, u32x4 a, u32x4 b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+// MODE bit 0: decode, bit 1: MFMA, bit 2: accumulators in AGPRs, bit 3: the column blocks' MFMAs spread between the next
+// fragment's decode (sched_group_barrier) instead of back to back; DECV: 0 packed-fp32 decoder, 1 plain
 template <int CB, int MODE, int DECV, int THREADS>
 __global__ __launch_bounds__(THREADS) void probe(const u32x4* __restrict__ w, const u32x4* __restrict__ x, float* __restrict__ out, int iters) {
     typedef Dec<LKM_W_INT4_B8, LKM_DT_BF16> D;
@@ -63,9 +70,18 @@ __global__ __launch_bounds__(THREADS) void probe(const u32x4* __restrict__ w, co
             const int s_ = t >> 1, q_ = t & 1;
             u32x4 an = a;
             if (t + 1 < 8) an = dec((t + 1) >> 1, (t + 1) & 1);
-            if constexpr (MODE & 2) {
+            if constexpr ((MODE & 6) == 6) {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) mfma_agpr(acc[c], a, bf[s_][q_][c]);
+            } else if constexpr (MODE & 2) {
 #pragma unroll
                 for (int c = 0; c < CB; ++c) acc[c] = Mfma32<LKM_DT_BF16>::run(a, bf[s_][q_][c], acc[c]);
+                if constexpr ((MODE & 8) != 0 && CB == 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < CB; ++c) acc[c][0] += __builtin_bit_cast(float, a.x ^ a.y ^ a.z ^ a.w);
@@ -73,6 +89,7 @@ __global__ __launch_bounds__(THREADS) void probe(const u32x4* __restrict__ w, co
             a = an;
         }
     }
+    if constexpr ((MODE & 6) == 6) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < CB; ++c)
@@ -112,6 +129,10 @@ static int sweep(const u32x4* w, const u32x4* x, float* out) {
     run<2, 3, 0, WPS>("decode (packed fp32) + MFMA", w, x, out);
     run<1, 3, 1, WPS>("decode (plain) + MFMA", w, x, out);
     run<2, 3, 1, WPS>("decode (plain) + MFMA", w, x, out);
+    run<1, 7, 0, WPS>("decode (packed fp32) + MFMA, AGPR acc", w, x, out);
+    run<2, 7, 0, WPS>("decode (packed fp32) + MFMA, AGPR acc", w, x, out);
+    run<2, 6, 0, WPS>("MFMA only, AGPR acc", w, x, out);
+    run<2, 11, 0, WPS>("decode (packed fp32) + MFMA, spread", w, x, out);
     return 0;
 }
 

@@ -191,6 +191,93 @@ def test_reference_glue_layer_that_does_not_fit_takes_the_spill_tier(monkeypatch
     eng.close()
 
 
+def _drive_spill(s, E, K, H, I, ref_fn, atol, rtol, cls):
+    """the three entry points on a layer that took the spill tier (eager: no capture), against the oracle"""
+    eng = s.lk_moe
+    assert type(eng).__name__ == cls and type(eng._spill).__name__ == "HostResidentExperts", (type(eng).__name__, eng.describe())
+    assert len(eng._spill.images) == E and eng._spill.slots < E and "spill tier" in eng.describe()
+    s._initialize_cuda_graph_buffers()
+    s.clean_weights_after_loading()
+    dt = s.params_dtype
+    gen = torch.Generator().manual_seed(11)
+    for M, seed in ((24, 1), (300, 2)):
+        x = (torch.randn((M, H), generator=gen) / 8).to(dt)
+        tw, ids = make_routing(M, E, K, seed=seed, drop=0.1)
+        ref = ref_fn(torch_to_bits(x), ids, tw)
+        scale = float(np.abs(ref).max())
+        xd, twd, idd = x.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)
+        for name in (("_cpu_decode",) if M <= s.max_num_seqs else ()) + ("_cpu_prefill", "_gpu_prefill"):
+            out = getattr(s, name)(xd, twd, idd)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=atol * scale, rtol=rtol, err_msg=f"{name} M={M}")
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["wna16", "fp8_block", "mxfp4", "nvfp4"])
+def test_reference_glue_quantised_layers_take_the_spill_tier(monkeypatch, kind):
+    """the spill tier behind lk_moe.MOE_WNA16 / MOE_FP8 / MOE_MXFP4 (the formats the reference's GPU-prefill tier exists for:
+    a quantised layer too big for HBM): the same glue calls as the resident tests above with half the layer as the HBM budget;
+    the per-format host views of lk_moe_api._build_spill (shapes of SURVEY 8 a5) against the oracle"""
+    glue = _load_glue()
+    from lvllm_amd.residency import expert_layer_bytes
+    E, K, H, I = 6, 2, 512, 256
+    monkeypatch.setenv("LVLLM_GPU_PREFETCH_WINDOW", "2")
+    if kind == "wna16":
+        g = 64
+        w13, w2 = _masters(E, H, I, 12)
+        q13, s13 = bench.quantize_int4(w13.to(DEV), g)
+        q2, s2 = bench.quantize_int4(w2.to(DEV), g)
+        q13, s13, q2, s2 = q13.cpu(), s13.cpu(), q2.cpu(), s2.cpu()
+        pk = lambda q: q.contiguous().view(torch.int32).transpose(1, 2).contiguous()       # noqa: E731
+        monkeypatch.setenv("LKM_HBM_CAP_BYTES", str(expert_layer_bytes(E, H, I, "int4", group_k=g) // 2))
+        s = _stand_in(glue, E, K, H, I, torch.bfloat16, w13_weight_packed=pk(q13), w2_weight_packed=pk(q2),
+                      w13_weight_scale=s13.transpose(1, 2).contiguous(), w2_weight_scale=s2.transpose(1, 2).contiguous(),
+                      quant_method=_QuantMethod(g))
+        s._process_wna16("group")
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_INT4, groupN=1, groupK=g)
+        a = (q13.numpy(), q2.numpy(), torch_to_bits(s13), torch_to_bits(s2))
+        _drive_spill(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3]), 3e-3, 1.5e-2, "MOE_WNA16")
+    elif kind == "fp8_block":
+        w13, w2 = _masters(E, H, I, 13)
+        q13, s13 = bench.quantize_fp8_block(w13.to(DEV))
+        q2, s2 = bench.quantize_fp8_block(w2.to(DEV))
+        q13, s13, q2, s2 = q13.cpu(), s13.cpu(), q2.cpu(), s2.cpu()
+        monkeypatch.setenv("LKM_HBM_CAP_BYTES", str(expert_layer_bytes(E, H, I, "fp8") // 2))
+        s = _stand_in(glue, E, K, H, I, torch.bfloat16, w13_weight=q13.view(torch.float8_e4m3fn),
+                      w2_weight=q2.view(torch.float8_e4m3fn), w13_weight_scale_inv=s13, w2_weight_scale_inv=s2)
+        s._process_fp8(True)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_FP8, groupN=128, groupK=128)
+        a = (q13.numpy(), q2.numpy(), s13.numpy(), s2.numpy())
+        _drive_spill(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3]), 3e-3, 1.5e-2, "MOE_FP8")
+    elif kind == "nvfp4":
+        w13, w2 = _masters(E, H, I, 15)
+        q13, s13, m13 = bench.quantize_nvfp4(w13.to(DEV))
+        q2, s2, m2 = bench.quantize_nvfp4(w2.to(DEV))
+        q13, s13, m13, q2, s2, m2 = q13.cpu(), s13.cpu(), m13.cpu(), q2.cpu(), s2.cpu(), m2.cpu()
+        monkeypatch.setenv("LKM_HBM_CAP_BYTES", str(expert_layer_bytes(E, H, I, "nvfp4") // 2))
+        s = _stand_in(glue, E, K, H, I, torch.bfloat16, w13_weight_packed=q13, w2_weight_packed=q2,
+                      w13_weight_scale=s13.view(torch.float8_e4m3fn), w2_weight_scale=s2.view(torch.float8_e4m3fn),
+                      w13_weight_global_scale=1.0 / m13, w2_weight_global_scale=1.0 / m2)
+        s._process_nvfp4(need_reciprocal_global_scale=True)
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_NVFP4, groupN=1, groupK=16)
+        g13, g2 = (1.0 / (1.0 / m13)).numpy(), (1.0 / (1.0 / m2)).numpy()
+        a = (q13.numpy(), q2.numpy(), s13.numpy(), s2.numpy())
+        _drive_spill(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3], gs13=g13, gs2=g2),
+                     3e-3, 1.5e-2, "MOE_NVFP4")
+    else:
+        w13, w2 = _masters(E, H, I, 14)
+        q13, s13 = bench.quantize_mxfp4(w13.to(DEV))
+        q2, s2 = bench.quantize_mxfp4(w2.to(DEV))
+        q13, s13, q2, s2 = q13.cpu(), s13.cpu(), q2.cpu(), s2.cpu()
+        monkeypatch.setenv("LKM_HBM_CAP_BYTES", str(expert_layer_bytes(E, H, I, "mxfp4") // 2))
+        s = _stand_in(glue, E, K, H, I, torch.bfloat16, w13_weight_packed=q13, w2_weight_packed=q2, w13_weight_scale=s13,
+                      w2_weight_scale=s2)
+        s._process_mxfp4()
+        d = orc.MoeDesc(E=E, H=H, I=I, act_dtype=orc.BF16, wfmt=orc.W_MXFP4, groupN=1, groupK=32)
+        a = (q13.numpy(), q2.numpy(), s13.numpy(), s2.numpy())
+        _drive_spill(s, E, K, H, I, lambda x, ids, tw: orc.moe(d, a[0], a[1], x, ids, tw, s13=a[2], s2=a[3]), 3e-3, 1.5e-2, "MOE_MXFP4")
+
+
 def test_reference_glue_wna16():
     """MOE_WNA16 through RoutedExperts._process_wna16 (:1456-1533): the checkpoint's transposed int32 / scale tensors,
     `.cpu().transpose(1, 2).contiguous().view(torch.uint8)` pointers, group size from _get_quant_params"""

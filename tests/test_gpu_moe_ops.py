@@ -145,6 +145,8 @@ def test_moe_ops_are_graph_capturable_and_take_ragged_inputs():
     (256, 256, 8, 7168, 32, 8),        # DeepSeek-V3 decode batch (configs[3]) on one of eight ranks' expert maps
     (128, 8, 2, 4096, 64, 1),          # Mixtral decode (configs[2])
     (1, 128, 8, 2048, 16, 1),          # Qwen3-30B-A3B single token (configs[0])
+    (96, 512, 8, 1024, 16, 8),         # a 512-expert model under expert parallelism: the sort keys of the non-local experts stay inside
+                                       # the 512-key range (moe_ops.hip ops_keys_kernel ranks them)
 ])
 def test_operator_forms_at_baseline_sizes_vs_oracle(M, E, K, H, bs, ep):
     """the operators at BASELINE.json's shapes against the CPU restatements (oracle.moe_align_block_size / moe_permute /

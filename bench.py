@@ -63,6 +63,9 @@ WORKLOADS = {
     "mixtral8x7b_int4g128_prefill_m4096": dict(E=8, K=2, H=4096, I=14336, M=4096, fmt="int4", g=128, prefill=True),
     # the same checkpoint in the engine's opt-in fast int4 mode (LkmConfig.int4_mode: group scale on fp32 partial sums)
     "mixtral8x7b_int4g128_fast_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="int4", g=128, int4_mode=1),
+    # ... and with ZERO POINTS (AWQ-style asymmetric uint4; LkmConfig.int4_mode = LKM_INT4_ZP: T((q - zp) s) decoded in registers
+    # from the packed image).  The synthetic zero points are all 8, so the layer is the symmetric one above, number for number.
+    "mixtral8x7b_int4g128_zp_decode_m128": dict(E=8, K=2, H=4096, I=14336, M=128, fmt="int4", g=128, int4_mode=2),
     "qwen3_30b_a3b_bf16_decode_m1": dict(E=128, K=8, H=2048, I=768, M=1, fmt="bf16"),
     # BASELINE.json configs[3]: DeepSeek-V3-style layer -- 256 fp8 (128x128 block) experts, group-limited sigmoid
     # router with score-correction bias, GLOBAL decode batch 256 split over the ranks (M_global), experts sharded
@@ -218,11 +221,16 @@ def build_engine(ops, wl, E_local, first, dev, **kw):
     if fmt == "int4":
         q13, s13, q2, s2 = cat
         g = wl["g"]
-        fast = int(wl.get("int4_mode", 0))
+        mode = int(wl.get("int4_mode", 0))
+        fast = mode == 1
+        zkw = {}
+        if mode == 2:
+            zkw = dict(w13_zp=torch.full(s13.shape, 8, dtype=torch.uint8, device=s13.device),
+                       w2_zp=torch.full(s2.shape, 8, dtype=torch.uint8, device=s2.device))
         eng = ops.RoutedExpertsEngine(q13, q2, top_k=K, act_dtype=torch.bfloat16, fmt="int4", w13_scale=s13,
-                                      w2_scale=s2, group_n=1, group_k=g, int4_mode=fast, **kw)
-        # the fast mode keeps its group scales as fp32 (4 bytes per row and 128-k block)
-        return eng, 0.5 + (4.0 if fast else 2.0) / g, dict(wfmt="W_INT4", groupN=1, groupK=g, int4_unrounded=bool(fast),
+                                      w2_scale=s2, group_n=1, group_k=g, int4_mode=mode, **zkw, **kw)
+        # the fast mode keeps its group scales as fp32 (4 bytes per row and 128-k block); the zero-point mode (scale, zp) pairs
+        return eng, 0.5 + (4.0 if mode else 2.0) / g, dict(wfmt="W_INT4", groupN=1, groupK=g, int4_unrounded=bool(fast),
                                                            w13=q13, w2=q2, s13=s13, s2=s2), None
     if fmt == "mxfp4":
         q13, s13, q2, s2 = cat

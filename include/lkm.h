@@ -62,6 +62,10 @@ extern "C" {
                           * the weights -- (q-8) exact, no per-weight rounding; 2.5x fewer VALU instructions per  *
                           * weight, inside the reference's int4 tolerance (atol 2e-2) but not bit-identical to it; *
                           * groupK must be a multiple of 128                                                        */
+#define LKM_INT4_ZP 2    /* asymmetric uint4 (AWQ / GPTQ with zero points, the in-tree operator's has_zp grid:     *
+                          * fused_moe.py:207-208,237-238,272-276): weights dequantised to T((q - zp) * s).  The     *
+                          * zero points ride in the two global-scale pointer slots of lkm_create: uint8            *
+                          * [E, rows, K / group], one byte (0..15) per weight row and scale group                   */
 
 /*
  * Mirrors lk_moe.MOEConfigV2 field for field (routed_experts.py:1490-1511), plus the three

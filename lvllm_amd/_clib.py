@@ -20,7 +20,7 @@ DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 W_BF16, W_F16, W_FP8_E4M3, W_INT4_B8, W_NVFP4, W_MXFP4 = 0, 1, 2, 3, 4, 5
 ACT_SILU, ACT_SWIGLUOAI, ACT_RELU2 = 0, 1, 2
 FP8_W8A16, FP8_W8A8 = 0, 1
-INT4_EXACT, INT4_FAST = 0, 1
+INT4_EXACT, INT4_FAST, INT4_ZP = 0, 1, 2
 PROF_SORT, PROF_GEMM1, PROF_GEMM2, PROF_COMBINE, PROF_N = 0, 1, 2, 3, 4
 
 

@@ -9,7 +9,7 @@ namespace lkm {
     int launch_gemm2_tiled_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, int);
 LKM_DECL(bf16) LKM_DECL(f16) LKM_DECL(int4_bf16) LKM_DECL(int4_f16) LKM_DECL(fp8_bf16) LKM_DECL(fp8_f16)
 LKM_DECL(mxfp4_bf16) LKM_DECL(mxfp4_f16) LKM_DECL(nvfp4_bf16) LKM_DECL(nvfp4_f16)
-LKM_DECL(int4ps_bf16) LKM_DECL(int4ps_f16)
+LKM_DECL(int4ps_bf16) LKM_DECL(int4ps_f16) LKM_DECL(int4zp_bf16) LKM_DECL(int4zp_f16)
 #undef LKM_DECL
 int launch_gemm1_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, bool, int);
 int launch_gemm2_fp8a8_bf16(hipStream_t, const LaunchCfg&, const GemmParams&, int);
@@ -55,6 +55,8 @@ int launch_gemm1(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const Ge
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm1_fp8_f16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_INT4_PS && adt == LKM_DT_BF16) return launch_gemm1_int4ps_bf16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_INT4_PS && adt == LKM_DT_F16) return launch_gemm1_int4ps_f16(st, cfg, p, gated, max_active);
+    if (wf == LKM_W_INT4_ZP && adt == LKM_DT_BF16) return launch_gemm1_int4zp_bf16(st, cfg, p, gated, max_active);
+    if (wf == LKM_W_INT4_ZP && adt == LKM_DT_F16) return launch_gemm1_int4zp_f16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm1_fp8a8_bf16(st, cfg, p, gated, max_active);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm1_fp8a8_f16(st, cfg, p, gated, max_active);
     set_error("gemm1: unsupported weight format %d with activation dtype %d", wf, adt);
@@ -76,6 +78,8 @@ int launch_gemm2(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const Ge
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm2_fp8_f16(st, cfg, p, max_active);
     if (wf == LKM_W_INT4_PS && adt == LKM_DT_BF16) return launch_gemm2_int4ps_bf16(st, cfg, p, max_active);
     if (wf == LKM_W_INT4_PS && adt == LKM_DT_F16) return launch_gemm2_int4ps_f16(st, cfg, p, max_active);
+    if (wf == LKM_W_INT4_ZP && adt == LKM_DT_BF16) return launch_gemm2_int4zp_bf16(st, cfg, p, max_active);
+    if (wf == LKM_W_INT4_ZP && adt == LKM_DT_F16) return launch_gemm2_int4zp_f16(st, cfg, p, max_active);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm2_fp8a8_bf16(st, cfg, p, max_active);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm2_fp8a8_f16(st, cfg, p, max_active);
     set_error("gemm2: unsupported weight format %d with activation dtype %d", wf, adt);
@@ -96,6 +100,8 @@ int launch_gemm2_direct(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, c
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm2_direct_fp8_f16(st, cfg, p, K);
     if (wf == LKM_W_INT4_PS && adt == LKM_DT_BF16) return launch_gemm2_direct_int4ps_bf16(st, cfg, p, K);
     if (wf == LKM_W_INT4_PS && adt == LKM_DT_F16) return launch_gemm2_direct_int4ps_f16(st, cfg, p, K);
+    if (wf == LKM_W_INT4_ZP && adt == LKM_DT_BF16) return launch_gemm2_direct_int4zp_bf16(st, cfg, p, K);
+    if (wf == LKM_W_INT4_ZP && adt == LKM_DT_F16) return launch_gemm2_direct_int4zp_f16(st, cfg, p, K);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm2_direct_fp8a8_bf16(st, cfg, p, K);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm2_direct_fp8a8_f16(st, cfg, p, K);
     set_error("gemm2 direct: unsupported weight format %d with activation dtype %d", wf, adt);
@@ -121,6 +127,8 @@ int launch_gemm1_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, co
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm1_tiled_fp8_f16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_INT4_PS && adt == LKM_DT_BF16) return launch_gemm1_tiled_int4ps_bf16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_INT4_PS && adt == LKM_DT_F16) return launch_gemm1_tiled_int4ps_f16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_INT4_ZP && adt == LKM_DT_BF16) return launch_gemm1_tiled_int4zp_bf16(st, cfg, p, gated, max_tiles);
+    if (wf == LKM_W_INT4_ZP && adt == LKM_DT_F16) return launch_gemm1_tiled_int4zp_f16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm1_tiled_fp8a8_bf16(st, cfg, p, gated, max_tiles);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm1_tiled_fp8a8_f16(st, cfg, p, gated, max_tiles);
     set_error("gemm1 tiled: unsupported weight format %d with activation dtype %d", wf, adt);
@@ -146,6 +154,8 @@ int launch_gemm2_tiled(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, co
     if (wf == LKM_W_FP8_E4M3 && adt == LKM_DT_F16) return launch_gemm2_tiled_fp8_f16(st, cfg, p, max_tiles);
     if (wf == LKM_W_INT4_PS && adt == LKM_DT_BF16) return launch_gemm2_tiled_int4ps_bf16(st, cfg, p, max_tiles);
     if (wf == LKM_W_INT4_PS && adt == LKM_DT_F16) return launch_gemm2_tiled_int4ps_f16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_INT4_ZP && adt == LKM_DT_BF16) return launch_gemm2_tiled_int4zp_bf16(st, cfg, p, max_tiles);
+    if (wf == LKM_W_INT4_ZP && adt == LKM_DT_F16) return launch_gemm2_tiled_int4zp_f16(st, cfg, p, max_tiles);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_BF16) return launch_gemm2_tiled_fp8a8_bf16(st, cfg, p, max_tiles);
     if (wf == LKM_W_FP8_A8 && adt == LKM_DT_F16) return launch_gemm2_tiled_fp8a8_f16(st, cfg, p, max_tiles);
     set_error("gemm2 tiled: unsupported weight format %d with activation dtype %d", wf, adt);

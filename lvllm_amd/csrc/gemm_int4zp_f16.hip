@@ -1,0 +1,5 @@
+// gemm_int4zp_f16.hip -- skinny grouped-GEMM kernels for uint4 weights with zero points (LkmConfig.int4_mode = LKM_INT4_ZP).
+#include "gemm_skinny.h"
+namespace lkm {
+LKM_DEFINE_GEMM_LAUNCHERS(int4zp_f16, LKM_W_INT4_ZP, LKM_DT_F16)
+}  // namespace lkm

@@ -162,6 +162,49 @@ struct Dec<LKM_W_FP8_E4M3, ADT> {
     }
 };
 
+// uint4 with zero points (LKM_W_INT4_ZP, lkm_common.h): the decoder above with the addend -zp * s.  The scale image holds
+// (scale, zero point) pairs in the activation dtype; a lane fetches the (up to four) pairs of its row for the 128-k unit with
+// one 16-byte load.  fma(v * 2^-9, 512 s, -zp s) = (v - zp) s exactly, one RNE to the act dtype: the reference's
+// T((q - zp) * s) (fused_moe.py:272-276), bit for bit.
+template <int ADT>
+struct Dec<LKM_W_INT4_ZP, ADT> {
+    static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
+    static constexpr bool UNIT_SCALE = false, A8 = false, XS = false;
+    typedef Dec<LKM_W_INT4_B8, ADT> B8;
+    typedef typename B8::Mult Mult;
+    struct Aux {
+        u32x4 raw;   // up to four (scale, zero point) pairs of this lane's weight row for the 128-k unit
+    };
+    typedef u32x4 __attribute__((aligned(4))) u32x4_unaligned;
+    // pairs: [tile][unit][16 rows][spu][2] act dtype; 4 spu bytes per row.  Branch-free as in the symmetric decoder: always
+    // fetch 16 bytes (the buffer is padded) and pick pair (kstep * spu) / 4 when the fragment is decoded.
+    static __device__ __forceinline__ void load_aux(Aux& a, const void* sbase, size_t tu, int lane, int spu) {
+        a.raw = *(const u32x4_unaligned*)((const unsigned*)sbase + (tu * 16 + (lane & 15)) * spu);
+    }
+    static __device__ __forceinline__ const char* aux_ptr(const void* sbase, size_t tu, int lane, int spu) {
+        return (const char*)((const unsigned*)sbase + (tu * 16 + (lane & 15)) * spu);
+    }
+    static __device__ __forceinline__ int aux_step(int spu) { return 64 * spu; }
+    static __device__ __forceinline__ void load_aux_at(Aux& a, const char* p) { a.raw = *(const u32x4_unaligned*)p; }
+    static __device__ __forceinline__ Mult mult(const Aux& a, int ks, int spu) {
+        const int idx = (ks * spu) >> 2;   // 0 for g>=128, ks/2 for g=64, ks for g=32 (wave-uniform)
+        const unsigned pair = idx == 0 ? a.raw.x : (idx == 1 ? a.raw.y : (idx == 2 ? a.raw.z : a.raw.w));
+        const float s = ActT<ADT>::to_f32((unsigned short)(pair & 0xffffu));
+        const float z = ActT<ADT>::to_f32((unsigned short)(pair >> 16));
+        f32x2 sv = {s, s};
+        asm("" : "+v"(sv));
+        Mult m;
+        m.s512 = sv * f32x2{512.0f, 512.0f};
+        m.m8 = sv * f32x2{-z, -z};
+        asm("" : "+v"(m.s512));
+        asm("" : "+v"(m.m8));
+        return m;
+    }
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&raw)[LOADS], const Aux& a, int ks, int spu) {
+        return B8::frag_m(raw, ks, mult(a, ks, spu));
+    }
+};
+
 // uint4b8, fast mode (LKM_W_INT4_PS, lkm_common.h): 7 VALU per 16 x 32 fragment (three shifts, four v_and_or_b32)
 // where the bit-exact decoder above needs 16-19.  A nibble v in the low bits of the mantissa of BIAS = 2^7 (bf16)
 // / 2^10 (fp16) IS the value BIAS + v; the pair order of the re-packed dword (repack.hip) makes dword p of the

@@ -168,6 +168,7 @@ struct LkmEngine {
     int wf, adt;
     int wfk;                   // kernel format: wf, LKM_W_FP8_A8 for fp8 W8A8, LKM_W_INT4_PS for the fast int4 mode
     bool a8;
+    bool zp;                   // uint4 with zero points (int4_mode ZP): (scale, zero point) pairs in the scale image, kernel format LKM_W_INT4_ZP
     bool ps;                   // int4 fast mode: per-(row, 128-k) activation sums feed the GEMMs (arena xqs / aqs)
     // geometry
     int unitk;
@@ -382,7 +383,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
         }
         LKM_REQUIRE((gk13 >= 128) == (gk2 >= 128) && (gk13 >= 128 || gk13 == gk2), "lkm_create: int4 groups of the two GEMMs (%d, %d) need the same scales per 128-k unit", gk13, gk2);
         const int g = gk13 < gk2 ? gk13 : gk2;
-        LKM_REQUIRE(cfg->int4_mode == LKM_INT4_EXACT || cfg->int4_mode == LKM_INT4_FAST, "lkm_create: bad int4_mode %d", cfg->int4_mode);
+        LKM_REQUIRE(cfg->int4_mode == LKM_INT4_EXACT || cfg->int4_mode == LKM_INT4_FAST || cfg->int4_mode == LKM_INT4_ZP, "lkm_create: bad int4_mode %d", cfg->int4_mode);
+        LKM_REQUIRE(cfg->int4_mode != LKM_INT4_ZP || (w13_gs && w2_gs), "lkm_create: int4_mode ZP takes the zero points (uint8 [E, rows, K / group]) in the two global-scale pointer slots");
         LKM_REQUIRE(cfg->int4_mode != LKM_INT4_FAST || g % 128 == 0, "lkm_create: int4_mode FAST applies the group scale per 128-k block; groupK must be a multiple of 128 (got %d)", g);
     }
     int ndev = 0;
@@ -409,7 +411,8 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
     h->adt = adt;
     h->a8 = wf == LKM_W_FP8_E4M3 && cfg->fp8_mode == LKM_FP8_W8A8;
     h->ps = wf == LKM_W_INT4_B8 && cfg->int4_mode == LKM_INT4_FAST;
-    h->wfk = h->a8 ? LKM_W_FP8_A8 : (h->ps ? LKM_W_INT4_PS : wf);
+    h->zp = wf == LKM_W_INT4_B8 && cfg->int4_mode == LKM_INT4_ZP;
+    h->wfk = h->a8 ? LKM_W_FP8_A8 : (h->ps ? LKM_W_INT4_PS : (h->zp ? LKM_W_INT4_ZP : wf));
     h->unitk = wf_unitk(wf);
     h->T1_half = round_up(ceil_div(h->I, 16), 4);
     h->U1 = ceil_div(h->H, h->unitk);
@@ -490,6 +493,18 @@ extern "C" int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2,
         auto rs2 = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4ps(nullptr, sp, dp, dd, gk2, adt); };
         LKM_TRY(hand_off(w13_scale, (size_t)halves * h->I * (h->H / gk13) * 2, h->s13, n13 * 4, d13, rs13));
         LKM_TRY(hand_off(w2_scale, (size_t)h->H * (h->I / gk2) * 2, h->s2, n2 * 4, d2, rs2));
+    } else if (h->zp) {     // (scale, zero point) pairs: two passes over one image, the zero points from the global-scale slots
+        const size_t n13 = (size_t)halves * h->T1_half * h->U1 * 16 * h->spu, n2 = (size_t)h->T2 * h->U2 * 16 * h->spu;
+        LKM_TRY_HIP(hipMalloc(&h->s13, h->E * n13 * 4 + 16));   // +16: the kernels fetch 16 bytes per lane
+        LKM_TRY_HIP(hipMalloc(&h->s2, h->E * n2 * 4 + 16));
+        h->weight_bytes += (int64_t)h->E * (n13 + n2) * 4;
+        for (int which = 0; which < 2; ++which) {
+            auto rs13 = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4zp(nullptr, sp, dp, dd, gk13, h->spu, which, adt); };
+            auto rs2 = [&](const void* sp, void* dp, const RepackDims& dd) { return launch_repack_s_int4zp(nullptr, sp, dp, dd, gk2, h->spu, which, adt); };
+            const size_t eb = which ? 1 : 2;       // source bytes per entry: act-dtype scale / uint8 zero point
+            LKM_TRY(hand_off(which ? w13_gs : w13_scale, (size_t)halves * h->I * (h->H / gk13) * eb, h->s13, n13 * 4, d13, rs13));
+            LKM_TRY(hand_off(which ? w2_gs : w2_scale, (size_t)h->H * (h->I / gk2) * eb, h->s2, n2 * 4, d2, rs2));
+        }
     } else if (wf == LKM_W_INT4_B8) {
         const size_t n13 = (size_t)halves * h->T1_half * h->U1 * 16 * h->spu, n2 = (size_t)h->T2 * h->U2 * 16 * h->spu;
         LKM_TRY_HIP(hipMalloc(&h->s13, h->E * n13 * 2 + 16));   // +16: the kernels fetch 8 bytes per lane
@@ -605,7 +620,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
     // tile and 128-k unit
     const bool w8a16 = h->wf == LKM_W_FP8_E4M3 && !h->a8;
     // ... and the 4-bit formats (decoded once per workgroup into the 16-bit image): uint4b8, MXFP4, NVFP4
-    const bool w4pf = (h->wf == LKM_W_INT4_B8 && !h->ps) || h->wf == LKM_W_MXFP4 || h->wf == LKM_W_NVFP4;   // (not the fast int4 mode: its own image)
+    const bool w4pf = (h->wf == LKM_W_INT4_B8 && !h->ps && !h->zp) || h->wf == LKM_W_MXFP4 || h->wf == LKM_W_NVFP4;   // (not the fast int4 mode: its own image)
     const size_t pf_ub = w4pf ? 1024 : 2048;     // bytes of a (tile, unit) of the image
     const bool pf8_ok = (w16 || w8a16 || w4pf) && h->H % 128 == 0 && h->I % 128 == 0 && (size_t)M * (size_t)h->H * 2 < (size_t)0x7fffffff &&
                         n_slots * (size_t)h->ld_act * 2 < (size_t)0x7fffffff &&
@@ -782,7 +797,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // bytes in flight per CU and no faster, profiles/r02_w4dma_sweep.log)
         // round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h), "pf" = 5
         const bool w4x = wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && !split &&
-                         (h->t_pf == 5 || h->t_pf == 6 || (h->t_pf == 7 && h->wf == LKM_W_INT4_B8 && !h->ps)) &&
+                         (h->t_pf == 5 || h->t_pf == 6 || (h->t_pf == 7 && h->wf == LKM_W_INT4_B8 && !h->ps)) && !h->zp &&
                          h->H % 128 == 0 && h->I % 128 == 0;
         if (w4x) pf = h->t_pf;                  // (6: with a loader wave per workgroup, gemm_w4e.h; "pd" = ring depth 3 / 4;
                                                 //  7: two memory queues, gemm_w4s.h; "pd" = depth of the weight register ring)
@@ -794,7 +809,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // 147.7 -> 147.0-148.7, GEMM2 88.3 -> 79.4-80.2).  Before the unroll GEMM1 was behind (profiles/r05_int4_default_ab.log).
         // (Eager per-kernel sweeps over-state such differences, profiles/r05_plan_robustness_sweep.log: plans are judged through
         // the graph.)  "pf" = -1 gives the tile kernel back.
-        const bool w4e_dflt = h->wf == LKM_W_INT4_B8 && !h->ps && tiled == 64 && !split && !g2_only && h->t_pf == 0 &&
+        const bool w4e_dflt = h->wf == LKM_W_INT4_B8 && !h->ps && !h->zp && tiled == 64 && !split && !g2_only && h->t_pf == 0 &&
                               h->H % 128 == 0 && h->I % 128 == 0;
         if (w4e_dflt) pf = 6;
         if (tiled == 256 && h->a8) {          // the fp8 x fp8 prefill kernels are the only 256-row variants of the format
@@ -1290,7 +1305,7 @@ static std::vector<LkmEngine::TunedPlan> tune_candidates(const LkmEngine* h, int
     if (def_tiled != 64 && !(pl.t1.tiled > 64)) cands.push_back({0, 64, 0, 0, 0.f, "64-row tiles"});
     if (def_tiled != 32 && wf_is_4bit(h->wf) && M * K <= 64 * h->E) cands.push_back({0, 32, 0, 0, 0.f, "32-row tiles"});
     if (def_tiled && def_tiled <= 64 && pl.t1.pd == 2) cands.push_back({0, def_tiled, 4, 0, 0.f, "weight ring depth 4 (GEMM1)"});
-    if (wf_is_4bit(h->wf) && !h->ps && h->H % 128 == 0 && h->I % 128 == 0 && M >= 32) {
+    if (wf_is_4bit(h->wf) && !h->ps && !h->zp && h->H % 128 == 0 && h->I % 128 == 0 && M >= 32) {
         cands.push_back({6, def_tiled == 32 ? 32 : 64, 0, 0, 0.f, "32x32-MFMA + loader wave (gemm_w4e.h)"});
         cands.push_back({5, def_tiled == 32 ? 32 : 64, 0, 0, 0.f, "32x32-MFMA (gemm_w4x.h)"});
     }
@@ -1636,8 +1651,8 @@ extern "C" int64_t lkm_weight_bytes(LkmHandle h) { return h ? h->weight_bytes : 
 
 extern "C" int lkm_describe(LkmHandle h, char* buf, int32_t buf_len) {
     LKM_REQUIRE(h && buf && buf_len > 0, "null argument");
-    snprintf(buf, buf_len, "E=%d H=%d I=%d wf=%d adt=%d gated=%d T1_half=%d U1=%d T2=%d U2=%d | %s",
-             h->E, h->Hu, h->I, h->wf, h->adt, (int)h->gated, h->T1_half, h->U1, h->T2, h->U2,
+    snprintf(buf, buf_len, "E=%d H=%d I=%d wf=%d%s adt=%d gated=%d T1_half=%d U1=%d T2=%d U2=%d | %s",
+             h->E, h->Hu, h->I, h->wf, h->zp ? " zp=1" : "", h->adt, (int)h->gated, h->T1_half, h->U1, h->T2, h->U2,
              h->last_desc);
     return LKM_OK;
 }
@@ -1791,6 +1806,9 @@ static void expert_slabs(const LkmEngine* h, int expert, ExpertSlabs* s) {
     if (h->ps) {
         sb13 = t13 * 16 * 4;
         sb2 = t2 * 16 * 4;
+    } else if (h->zp) {
+        sb13 = t13 * 16 * h->spu * 4;
+        sb2 = t2 * 16 * h->spu * 4;
     } else if (h->wf == LKM_W_INT4_B8) {
         sb13 = t13 * 16 * h->spu * 2;
         sb2 = t2 * 16 * h->spu * 2;

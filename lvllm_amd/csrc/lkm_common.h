@@ -224,6 +224,10 @@ __device__ __forceinline__ void store1<f16_out>(f16_out* p, float v) {
 // Same bytes as LKM_W_INT4_B8 with the nibbles of a dword re-ordered (k -> position k/2 + 4 (k & 1)), fp32 scales in
 // the fp8 unit layout.  NOT the reference's rounding (it rounds (q-8) s to the activation dtype first): opt-in.
 #define LKM_W_INT4_PS 101
+// internal kernel-format code: uint4 weights with ZERO POINTS (LkmConfig.int4_mode = LKM_INT4_ZP): the LKM_W_INT4_B8 weight
+// image; the scale image holds (scale, zero point) PAIRS in the activation dtype -- [tile][unit][16 rows][spu][2] -- and the
+// decoder's addend is -zp * s instead of -8 * s (exact: zp <= 15 times a 16-bit scale has <= 15 significant bits).
+#define LKM_W_INT4_ZP 102
 
 template <int WF>
 struct WGeom;
@@ -246,6 +250,11 @@ struct WGeom<LKM_W_INT4_B8> {
 
 template <>
 struct WGeom<LKM_W_INT4_PS> {
+    static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
+};
+
+template <>
+struct WGeom<LKM_W_INT4_ZP> {
     static constexpr int UNITK = 128, LOADS = 1, KSTEPS = 4;
 };
 

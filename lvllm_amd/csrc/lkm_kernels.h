@@ -27,6 +27,7 @@ int launch_repack_w(hipStream_t st, int wf, const void* src, void* dst, const Re
 int launch_repack_s_int4(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group,
                          int spu);
 int launch_repack_s_int4ps(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group, int adt);
+int launch_repack_s_int4zp(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group, int spu, int which, int adt);
 int launch_wna16_expand(hipStream_t st, const void* q, const void* scales, const void* zp, void* out, int64_t rows,
                         int K, int group, int bits, int adt);
 int launch_repack_s_fp8(hipStream_t st, const void* src, void* dst, const RepackDims& d, int gN,

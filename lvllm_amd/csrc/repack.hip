@@ -122,6 +122,49 @@ __global__ __launch_bounds__(256) void repack_s_int4_kernel(const unsigned short
     dst[v] = s;
 }
 
+// uint4 with zero points: the scale image holds (scale, zero point) PAIRS -- dst [E][tile][unit][16 rows][SPU][2] act dtype.
+// Two passes over one destination (the hand-off stages one source at a time): which = 0 copies the act-dtype scales
+// src [E][N][K/g] into the even half-words, which = 1 converts the zero points src uint8 [E][N][K/g] (0..15) to the act dtype
+// (exact) into the odd ones.  Padding rows / units: scale 0 (their weights decode to (8 - zp) * 0 = 0).
+template <int ADT>
+__global__ __launch_bounds__(256) void repack_s_int4zp_kernel(const void* __restrict__ src, unsigned short* __restrict__ dst,
+                                                              RepackDims d, int group, int spu, int which) {
+    const size_t n_out = (size_t)d.E * d.halves * d.T_half * d.U * 16 * spu;
+    size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_out) return;
+    const int j = (int)(v % spu);
+    size_t t = v / spu;
+    const int i = (int)(t & 15);
+    t >>= 4;
+    const int u = (int)(t % d.U);
+    t /= d.U;
+    const int tile = (int)(t % (d.halves * d.T_half));
+    const int e = (int)(t / (d.halves * d.T_half));
+    const int half = tile / d.T_half;
+    const int idx = (tile % d.T_half) * 16 + i;
+    const int N = d.n_half * d.halves;
+    const int n = d.interleaved ? idx * d.halves + half : half * d.n_half + idx;
+    const int k = u * 128 + j * (128 / spu);
+    unsigned short s = 0;
+    if (idx < d.n_half && k < d.K) {
+        const size_t at = ((size_t)e * N + n) * (d.K / group) + k / group;
+        if (which == 0) s = ((const unsigned short*)src)[at];
+        else s = ActT<ADT>::from_f32((float)(((const uint8_t*)src)[at] & 15));
+    }
+    dst[2 * v + which] = s;
+}
+
+int launch_repack_s_int4zp(hipStream_t st, const void* src, void* dst, const RepackDims& d, int group, int spu, int which, int adt) {
+    const size_t n_out = (size_t)d.E * d.halves * d.T_half * d.U * 16 * spu;
+    dim3 grid((unsigned)ceil_div64((int64_t)n_out, 256)), block(256);
+    if (adt == LKM_DT_BF16)
+        hipLaunchKernelGGL(repack_s_int4zp_kernel<LKM_DT_BF16>, grid, block, 0, st, src, (unsigned short*)dst, d, group, spu, which);
+    else
+        hipLaunchKernelGGL(repack_s_int4zp_kernel<LKM_DT_F16>, grid, block, 0, st, src, (unsigned short*)dst, d, group, spu, which);
+    LKM_HIP_CHECK(hipGetLastError());
+    return LKM_OK;
+}
+
 // int4 fast mode: src act-dtype group scales [E][N][K/g] (g a multiple of 128) -> dst fp32 [E][tile][unit][16 rows]
 template <int ADT>
 __global__ __launch_bounds__(256) void repack_s_int4ps_kernel(const unsigned short* __restrict__ src,

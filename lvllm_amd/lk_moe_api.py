@@ -82,7 +82,8 @@ class MOEConfigV2:
         self.use_gpu_prefill = False
         # extension (not in the reference): fp8 compute mode, 0 = W8A16 (lk_moe semantics)
         self.fp8_mode = _clib.FP8_W8A16
-        # extension: uint4b8 compute mode, 0 = the reference's rounding T((q-8) s), 1 = scale on fp32 partial sums
+        # extension: uint4 compute mode, 0 = the reference's rounding T((q-8) s), 1 = scale on fp32 partial sums,
+        # 2 = zero points (uint8 [E, rows, K / group] in the two global-scale pointer slots): T((q - zp) s)
         self.int4_mode = _clib.INT4_EXACT
 
     def _to_c(self, weight_format: int, act_dtype: int) -> _clib.LkmConfig:
@@ -118,7 +119,8 @@ class _MOE:
         self._spill = None
         ccfg = cfg._to_c(self._WEIGHT_FORMAT, self._ACT_DTYPE)
         ptrs = (w13_ptr, w2_ptr, w13_scale_ptr, w2_scale_ptr, w13_global_scale_ptr, w2_global_scale_ptr)
-        may_spill = not getattr(_tls, "no_spill", False)
+        # (zero-point experts -- LkmConfig.int4_mode ZP, an extension the reference's lk_moe surface does not have -- stay resident)
+        may_spill = not getattr(_tls, "no_spill", False) and int(getattr(cfg, "int4_mode", 0)) != _clib.INT4_ZP
         cap = hbm_cap_bytes() if may_spill else 0
         too_big = False
         if cap:

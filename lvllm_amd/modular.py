@@ -20,6 +20,7 @@ No CPU path: CPU tensors raise, a missing liblkm.so raises at import of `lvllm_a
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Any
 
@@ -85,6 +86,16 @@ class LkmQuant:
         if getattr(qc, "use_mxfp4_w4a16", False):
             return LkmQuant("mxfp4", qc.w1_scale, qc.w2_scale, 1, 32)
         raise ValueError("quantisation scheme of this FusedMoEQuantConfig is not supported by the MI355X engine")
+
+
+def _unpack_zp4(zp: torch.Tensor) -> torch.Tensor:
+    """packed 4-bit zero points [E, R / 2, K / g] (low nibble = even row: tests/kernels/moe/test_moe.py:634-641) -> uint8
+    [E, R, K / g], what lkm_create takes in the zero-point mode"""
+    z = zp.view(torch.uint8)
+    out = torch.empty((z.shape[0], z.shape[1] * 2, z.shape[2]), dtype=torch.uint8, device=z.device)
+    out[:, 0::2] = z & 0xF
+    out[:, 1::2] = z >> 4
+    return out
 
 
 class _NoOpReduce:
@@ -216,10 +227,17 @@ class LkmExperts:
             w1u = w1.view(torch.uint8) if w1.dtype == torch.float8_e4m3fn else w1
             w2u = w2.view(torch.uint8) if w2.dtype == torch.float8_e4m3fn else w2
             s1, s2, group_n, group_k = q.w1_scale, q.w2_scale, q.group_n, q.group_k
+            zp1 = zp2 = None
             if fmt == "wna16":
                 if q.w1_scale.dtype != act_dtype or q.w2_scale.dtype != act_dtype:
                     raise ValueError(f"wna16 scales are {q.w1_scale.dtype}, activations {act_dtype}: the in-tree "
                                      "operator dequantises to the activation dtype (fused_moe.py:270-276)")
+                if q.weight_bits == 4 and q.w1_zp is not None and self._native_zp_ok(w1u, w2u, q):
+                    # asymmetric uint4: the engine streams the packed 4-bit image and decodes T((q - zp) * s) in registers
+                    # (LkmConfig.int4_mode = LKM_INT4_ZP); zero points unpacked to one byte per (row, group)
+                    fmt, zp1, zp2 = "int4", _unpack_zp4(q.w1_zp), _unpack_zp4(q.w2_zp)
+                    w1u, w2u = w1u.view(torch.uint8), w2u.view(torch.uint8)
+            if fmt == "wna16":
                 w1u = ops.wna16_expand(w1u.view(torch.uint8), q.w1_scale, q.w1_zp, q.weight_bits, q.group_k)
                 w2u = ops.wna16_expand(w2u.view(torch.uint8), q.w2_scale, q.w2_zp, q.weight_bits, q.group_k)
                 fmt, s1, s2, group_n, group_k = ("bf16" if act_dtype == torch.bfloat16 else "fp16"), None, None, 0, 0
@@ -227,9 +245,19 @@ class LkmExperts:
                 w1u, w2u, top_k=topk, act_dtype=act_dtype, fmt=fmt, w13_scale=s1, w2_scale=s2,
                 group_n=group_n, group_k=group_k, has_gate_proj=gated, activation_type=act_type,
                 max_num_seqs=self._max_num_seqs, max_batch_size=self._max_num_tokens, fp8_mode=q.fp8_mode,
-                w13_global_scale=q.w1_global_scale, w2_global_scale=q.w2_global_scale)
+                w13_global_scale=q.w1_global_scale, w2_global_scale=q.w2_global_scale, w13_zp=zp1, w2_zp=zp2)
             self._engine_key = key
         return self._engine
+
+    @staticmethod
+    def _native_zp_ok(w1u: torch.Tensor, w2u: torch.Tensor, q: LkmQuant) -> bool:
+        """the shapes lkm_create takes in the zero-point mode (include/lkm.h: LkmConfig.groupK for int4); anything else is
+        expanded to 16 bits at hand-off"""
+        g = int(q.group_k)
+        k1, k2 = w1u.shape[-1] * 2, w2u.shape[-1] * 2
+        if not (g in (32, 64, 128) or (g > 128 and g % 128 == 0)):
+            return False
+        return k1 % g == 0 and k2 % g == 0 and k1 % 128 == 0 and k2 % 128 == 0 and os.environ.get("LKM_WNA16_EXPAND", "0") != "1"
 
     def invalidate(self) -> None:
         """Drop the cached engine: the next apply() copies and pre-shuffles w1 / w2 again.  lkm_create COPIES the

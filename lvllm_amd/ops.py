@@ -430,7 +430,11 @@ class RoutedExpertsEngine:
                  group_max_len: int = 0, num_processes: int = 1, process_id: int = 0,
                  gpu_id: int | None = None, fp8_mode: int = _clib.FP8_W8A16, int4_mode: int = _clib.INT4_EXACT,
                  w13_global_scale: torch.Tensor | None = None,
-                 w2_global_scale: torch.Tensor | None = None):
+                 w2_global_scale: torch.Tensor | None = None,
+                 w13_zp: torch.Tensor | None = None, w2_zp: torch.Tensor | None = None):
+        """w13_zp / w2_zp (fmt "int4" only): the zero points of asymmetric uint4 experts, uint8 [E, rows, K / group_k], one byte
+        (0..15) per weight row and scale group -> LkmConfig.int4_mode = LKM_INT4_ZP, weights dequantised to T((q - zp) * s)
+        (fused_moe.py:272-276); they travel in the global-scale pointer slots of lkm_create (include/lkm.h)."""
         E = w13.shape[0]
         H = w2.shape[1]
         inter = w13.shape[1] // (2 if has_gate_proj else 1)
@@ -446,6 +450,17 @@ class RoutedExpertsEngine:
         cfg.activation_type = activation_type
         cfg.swiglu_alpha, cfg.swiglu_limit = swiglu_alpha, swiglu_limit
         cfg.fp8_mode = fp8_mode
+        if (w13_zp is None) != (w2_zp is None):
+            raise ValueError("zero points: w13_zp and w2_zp come together")
+        if w13_zp is not None:
+            if fmt != "int4" or int4_mode not in (_clib.INT4_EXACT, _clib.INT4_ZP):
+                raise ValueError("zero points belong to fmt='int4' in the exact mode")
+            if w13_zp.dtype != torch.uint8 or w2_zp.dtype != torch.uint8 or tuple(w13_zp.shape) != tuple(w13_scale.shape) \
+                    or tuple(w2_zp.shape) != tuple(w2_scale.shape):
+                raise ValueError("zero points: uint8 tensors shaped like the scales ([E, rows, K / group])")
+            int4_mode = _clib.INT4_ZP
+        elif int4_mode == _clib.INT4_ZP:
+            raise ValueError("int4_mode ZP without zero points")
         cfg.int4_mode = int4_mode
         self.cfg = cfg
         self.H, self.K, self.act_dtype = H, top_k, act_dtype
@@ -455,6 +470,8 @@ class RoutedExpertsEngine:
         s2 = None if w2_scale is None else w2_scale.contiguous()
         g13 = None if w13_global_scale is None else w13_global_scale.to(torch.float32).contiguous()
         g2 = None if w2_global_scale is None else w2_global_scale.to(torch.float32).contiguous()
+        if w13_zp is not None:
+            g13, g2 = w13_zp.contiguous(), w2_zp.contiguous()
         self.engine = cls(cfg, w13c.data_ptr(), w2c.data_ptr(), 0 if s13 is None else s13.data_ptr(),
                           0 if s2 is None else s2.data_ptr(), 0 if g13 is None else g13.data_ptr(),
                           0 if g2 is None else g2.data_ptr())

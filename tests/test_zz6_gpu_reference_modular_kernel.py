@@ -142,7 +142,8 @@ def test_reference_wn16_grid_zero_points_and_8bit_through_the_reference_driver()
     """test_fused_moe_wn16's has_zp x weight_bits x group grid (tests/kernels/moe/test_moe.py:565-693) through the
     reference's FusedMoEKernel over the bound classes: expected = torch_moe on quantize_weights' w_ref (golden, produced
     by the reference's own functions), the test's own tolerance atol 2e-2, rtol 0; and against the oracle on the
-    oracle-dequantised weights.  Symmetric 4-bit runs the native packed format, the other three the expanded one."""
+    oracle-dequantised weights.  4-bit runs the native packed format -- symmetric as uint4b8, with zero points in the engine's
+    zero-point mode (LkmConfig.int4_mode = LKM_INT4_ZP: T((q - zp) * s) decoded in registers) -- 8-bit the expanded one."""
     mk = _load("modular_kernel_glue")
     from tests.helpers import bits_to_torch, load_golden
     seen = set()
@@ -156,8 +157,9 @@ def test_reference_wn16_grid_zero_points_and_8bit_through_the_reference_driver()
         out = kern.apply(bits_to_torch(c["a"], orc.BF16).to(DEV), torch.from_numpy(c["q1"]).to(DEV), torch.from_numpy(c["q2"]).to(DEV),
                          torch.from_numpy(c["tw"]).to(DEV), torch.from_numpy(c["ids"]).to(DEV), mk.MoEActivation.SILU, e, None, False)
         ex = kern.impl.fused_experts
-        desc = ex._engine.engine.describe()      # "wf=3" = the native packed uint4b8 image, "wf=0" = 16-bit (expanded)
-        assert ("wf=3" if (bits == 4 and not has_zp) else "wf=0") in desc, desc
+        desc = ex._engine.engine.describe()      # "wf=3" = the native packed 4-bit image (" zp=1": zero-point mode), "wf=0" = 16-bit (expanded)
+        native_zp = bits == 4 and has_zp and k % 128 == 0 and n % 128 == 0
+        assert ("wf=3 zp=1" if native_zp else ("wf=3 adt" if (bits == 4 and not has_zp) else "wf=0")) in desc, (desc, m, n, k, g)
         np.testing.assert_allclose(out.float().cpu().numpy(), orc.bits_to_f32(c["out"], orc.BF16), atol=2e-2, rtol=0, err_msg=f"case {i}")
         d1 = orc.dequant_wna16(c["q1"], c["s1"], c["z1"] if has_zp else None, bits, g, orc.BF16)
         d2 = orc.dequant_wna16(c["q2"], c["s2"], c["z2"] if has_zp else None, bits, g, orc.BF16)

@@ -27,6 +27,7 @@ int launch_gemm2_tiled_fp8a8_f16(hipStream_t, const LaunchCfg&, const GemmParams
 // false = not taken (shape / variant)
 #define LKM_DECL_W4X(SUFFIX) bool launch_w4x_##SUFFIX(hipStream_t, const LaunchCfg&, const GemmParams&, bool, bool, int, int*);
 LKM_DECL_W4X(int4_bf16) LKM_DECL_W4X(int4_f16) LKM_DECL_W4X(mxfp4_bf16) LKM_DECL_W4X(mxfp4_f16) LKM_DECL_W4X(nvfp4_bf16) LKM_DECL_W4X(nvfp4_f16)
+LKM_DECL_W4X(int4zp_bf16) LKM_DECL_W4X(int4zp_f16)
 #undef LKM_DECL_W4X
 static bool launch_w4x(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, const GemmParams& p, bool gated, bool is_g1,
                        int max_tiles, int* rc) {
@@ -37,6 +38,8 @@ static bool launch_w4x(hipStream_t st, int wf, int adt, const LaunchCfg& cfg, co
     if (wf == LKM_W_MXFP4 && adt == LKM_DT_F16) return launch_w4x_mxfp4_f16(st, cfg, p, gated, is_g1, max_tiles, rc);
     if (wf == LKM_W_NVFP4 && adt == LKM_DT_BF16) return launch_w4x_nvfp4_bf16(st, cfg, p, gated, is_g1, max_tiles, rc);
     if (wf == LKM_W_NVFP4 && adt == LKM_DT_F16) return launch_w4x_nvfp4_f16(st, cfg, p, gated, is_g1, max_tiles, rc);
+    if (cfg.pf != 7 && wf == LKM_W_INT4_ZP && adt == LKM_DT_BF16) return launch_w4x_int4zp_bf16(st, cfg, p, gated, is_g1, max_tiles, rc);
+    if (cfg.pf != 7 && wf == LKM_W_INT4_ZP && adt == LKM_DT_F16) return launch_w4x_int4zp_f16(st, cfg, p, gated, is_g1, max_tiles, rc);
     return false;
 }
 

@@ -370,7 +370,7 @@ __global__ __launch_bounds__((NC + 1) * 64) void gemm_w4e_kernel(GemmParams p) {
         }
     };
     auto run = [&](auto CBC) __attribute__((always_inline)) {
-        if constexpr (WF == LKM_W_INT4_B8) {
+        if constexpr (WF == LKM_W_INT4_B8 || WF == LKM_W_INT4_ZP) {
             if (p.spu <= 1) return run_c(CBC, IC<1>{});
         }
         run_c(CBC, IC<0>{});
@@ -492,7 +492,8 @@ static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
     const int groups_all = (is_g1 && gated) ? p.T_half : p.T_half / 2;
     const int sets = (cfg.kw == 2 && nc == 7 && is_g1 && p.U % 2 == 0 && groups_all % 14 == 0) ? 2 : 1;
     // the loader's counted waits need (S - 2) x (DMA instructions per slot) < 64
-    const int aux_b = WF == LKM_W_INT4_B8 ? 32 * p.spu : (WF == LKM_W_MXFP4 ? 64 : 128);      // = Dec<>::aux_step (device side)
+    const int aux_b = WF == LKM_W_INT4_B8 ? 32 * p.spu : (WF == LKM_W_INT4_ZP ? 64 * p.spu : (WF == LKM_W_MXFP4 ? 64 : 128));      // = Dec<>::aux_step (device side)
+    if (aux_b > 128) return false;                      // (zero points at 32-k groups: 256 bytes of pairs per (tile, unit) -- the tile kernel's)
     const int air = (nc * 2 * aux_b / 4 + 63) / 64;
     if ((s - 2) * (cb * 8 + 2 * nc + air) >= 64) return false;
 #define LKM_W4E_1(CB_, NC_, G_, IS1_, S_, DV_)                                                      \
@@ -504,6 +505,7 @@ static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
     LKM_W4E_1(CB_, 4, G_, IS1_, S_, 0)                                                               \
     if constexpr (WF == LKM_W_INT4_B8) { LKM_W4E_1(CB_, 4, G_, IS1_, S_, 1) }
 #define LKM_W4E_ALL(G_, IS1_) LKM_W4E_DV(1, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 3) LKM_W4E_DV(2, G_, IS1_, 2) LKM_W4E_1(2, 7, G_, IS1_, 2, 0)
+    if constexpr (WF == LKM_W_INT4_B8) {               // (the round-6 experiments are built for uint4b8 only)
     if (cfg.pd == 34 && is_g1 && nc == 7 && sets == 1) {       // "pd" = 34 (experiment): the two-slot ring with the consumers' weight prefetch
         if (gated) *rc = launch_w4e_t<WF, ADT, 2, 7, true, true, 2, 0, 1, 2, 1>(st, p, max_tiles);
         else *rc = launch_w4e_t<WF, ADT, 2, 7, false, true, 2, 0, 1, 2, 1>(st, p, max_tiles);
@@ -529,6 +531,7 @@ static bool launch_w4e_if(hipStream_t st, const LaunchCfg& cfg, const GemmParams
         if (gated) *rc = launch_w4e_t<WF, ADT, 2, 7, true, true, 2, 0, 2>(st, p, max_tiles);
         else *rc = launch_w4e_t<WF, ADT, 2, 7, false, true, 2, 0, 2>(st, p, max_tiles);
         return true;
+    }
     }
     if (is_g1 && gated) { LKM_W4E_ALL(true, true) }
     else if (is_g1) { LKM_W4E_ALL(false, true) }

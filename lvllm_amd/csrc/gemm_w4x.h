@@ -73,6 +73,25 @@ struct W4Int4<LKM_W_INT4_B8, ADT> {
     }
 };
 
+// uint4 with zero points (LKM_W_INT4_ZP): the same, the multipliers from a (scale, zero point) pair
+template <int ADT>
+struct W4Int4<LKM_W_INT4_ZP, ADT> {
+    typedef Dec<LKM_W_INT4_ZP, ADT> D;
+    typedef typename D::Mult M;
+    typedef typename D::Aux Aux;
+    static __device__ __forceinline__ M mult(const Aux& a) { return D::mult(a, 0, 0); }
+    template <int DECV>
+    static __device__ __forceinline__ u32x4 frag(const u32x4 (&w)[1], int s, const M& m) {
+        return Dec<LKM_W_INT4_B8, ADT>::frag_m(w, s, m);
+    }
+    // aligned reads of the 1 / 2 / 4 pairs of a unit (4 bytes each)
+    static __device__ __forceinline__ void load_aux_lds(Aux& a, const char* p, int spu, bool hoist) {
+        if (hoist) a.raw = u32x4{*(const unsigned*)p, 0u, 0u, 0u};
+        else if (spu == 2) a.raw = u32x4{((const unsigned*)p)[0], ((const unsigned*)p)[1], 0u, 0u};
+        else a.raw = *(const u32x4*)p;
+    }
+};
+
 // resident workgroups per CU the register allocation must allow
 constexpr int w4x_min_blocks(int cb, int waves) { return waves == 8 ? (cb == 1 ? 2 : 1) : (cb == 1 ? 4 : 3); }
 
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(WAVES * 64, w4x_min_blocks(CB, WAVES)) void gemm_w4
         }
     };
     auto run = [&](auto CBC) __attribute__((always_inline)) {
-        if constexpr (WF == LKM_W_INT4_B8) {
+        if constexpr (WF == LKM_W_INT4_B8 || WF == LKM_W_INT4_ZP) {
             if (p.spu <= 1) return run_h(CBC, IC<1>{});
         }
         run_h(CBC, IC<0>{});

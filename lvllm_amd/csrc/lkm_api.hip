@@ -797,7 +797,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // bytes in flight per CU and no faster, profiles/r02_w4dma_sweep.log)
         // round 4: the 32x32-MFMA kernels of the 4-bit formats (gemm_w4x.h), "pf" = 5
         const bool w4x = wf_is_4bit(h->wf) && (tiled == 32 || tiled == 64) && !split &&
-                         (h->t_pf == 5 || h->t_pf == 6 || (h->t_pf == 7 && h->wf == LKM_W_INT4_B8 && !h->ps)) && !h->zp &&
+                         (h->t_pf == 5 || h->t_pf == 6 || (h->t_pf == 7 && h->wf == LKM_W_INT4_B8 && !h->ps && !h->zp)) && (!h->zp || h->spu <= 2) &&
                          h->H % 128 == 0 && h->I % 128 == 0;
         if (w4x) pf = h->t_pf;                  // (6: with a loader wave per workgroup, gemm_w4e.h; "pd" = ring depth 3 / 4;
                                                 //  7: two memory queues, gemm_w4s.h; "pd" = depth of the weight register ring)
@@ -809,7 +809,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
         // 147.7 -> 147.0-148.7, GEMM2 88.3 -> 79.4-80.2).  Before the unroll GEMM1 was behind (profiles/r05_int4_default_ab.log).
         // (Eager per-kernel sweeps over-state such differences, profiles/r05_plan_robustness_sweep.log: plans are judged through
         // the graph.)  "pf" = -1 gives the tile kernel back.
-        const bool w4e_dflt = h->wf == LKM_W_INT4_B8 && !h->ps && !h->zp && tiled == 64 && !split && !g2_only && h->t_pf == 0 &&
+        const bool w4e_dflt = h->wf == LKM_W_INT4_B8 && !h->ps && (!h->zp || h->spu <= 2) && tiled == 64 && !split && !g2_only && h->t_pf == 0 &&
                               h->H % 128 == 0 && h->I % 128 == 0;
         if (w4e_dflt) pf = 6;
         if (tiled == 256 && h->a8) {          // the fp8 x fp8 prefill kernels are the only 256-row variants of the format

@@ -61,15 +61,18 @@ def test_zero_point_dequant_is_bit_exact(g, dt):
     for e in range(E):
         ids = np.full((H, 1), e, np.int32)
         tw = np.ones((H, 1), np.float32)
-        for tiled in (0, 32, 64, 128):                      # the planner's own choice, then every tile height of the tile kernel
-            eng.engine.set_tuning(tiled=tiled)
+        # the planner's own choice, every tile height of the tile kernel ("pf" = -1), the 32 x 32 MFMA kernels (gemm_w4x.h 5,
+        # gemm_w4e.h 6 with four and seven consumers; not at 32-k groups: their scale area holds two pairs per unit)
+        plans = [(0, 0, 0), (-1, 32, 0), (-1, 64, 0), (-1, 128, 0)] + ([(5, 32, 0), (5, 64, 0), (6, 32, 0), (6, 64, 0), (6, 64, 7)] if g >= 64 else [])
+        for pf, tiled, waves in plans:
+            eng.engine.set_tuning(pf=pf, tiled=tiled, waves=waves, pd1=2 if waves == 7 else 0)
             for sign in (1.0, -1.0):
                 out = eng.decode((x * sign).to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)).cpu().numpy()[:, :I]
                 want = np.maximum(sign * wd[e].T, 0.0) ** 2                                   # out[j, i] = T(relu(+-W[e, i, j])^2)
                 want = orc.bits_to_f32(orc.f32_to_bits(want.astype(np.float32), odt), odt)
-                np.testing.assert_array_equal(out, want, err_msg=f"g={g} e={e} tiled={tiled} sign={sign} {eng.engine.describe()}")
+                np.testing.assert_array_equal(out, want, err_msg=f"g={g} e={e} pf={pf} tiled={tiled} waves={waves} sign={sign} {eng.engine.describe()}")
         # few rows per expert: the streamer
-        eng.engine.set_tuning(tiled=0)
+        eng.engine.set_tuning(pf=0, tiled=0, waves=0, pd1=0)
         rows = np.array([0, 1, 7, H - 1])
         out = eng.decode(x[rows].to(DEV), torch.ones((4, 1), dtype=torch.float32, device=DEV),
                          torch.full((4, 1), e, dtype=torch.int32, device=DEV)).cpu().numpy()[:, :I]

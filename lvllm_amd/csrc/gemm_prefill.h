@@ -70,6 +70,13 @@ struct PfAux<LKM_W_INT4_B8> {
     }
 };
 template <>
+struct PfAux<LKM_W_INT4_ZP> {
+    template <typename A>
+    static __device__ __forceinline__ void set(A& a, unsigned a1, u32x2 a2, int spu) {                         // 1 / 2 (scale, zero point) pairs
+        a.raw = spu == 1 ? u32x4{a1, 0u, 0u, 0u} : u32x4{a2.x, a2.y, 0u, 0u};
+    }
+};
+template <>
 struct PfAux<LKM_W_MXFP4> {
     template <typename A>
     static __device__ __forceinline__ void set(A& a, unsigned a1, u32x2, int) { a.raw = a1; }                   // four E8M0
@@ -133,7 +140,7 @@ template <int WF, int ADT, bool GATED, bool IS_G1>
 __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
     static_assert(!GATED || IS_G1, "only GEMM1 is gated");
     constexpr bool W8 = WF == LKM_W_FP8_E4M3;
-    constexpr bool W4 = WF == LKM_W_INT4_B8 || WF == LKM_W_MXFP4 || WF == LKM_W_NVFP4;
+    constexpr bool W4 = WF == LKM_W_INT4_B8 || WF == LKM_W_INT4_ZP || WF == LKM_W_MXFP4 || WF == LKM_W_NVFP4;
     constexpr int AG = W8 ? 1 : 2, BG = 2;                    // LDS-DMA instructions per wave and weight / token quarter (W4: two hand-issued loads)
     constexpr int UB = W4 ? 1024 : 2048;                      // bytes of a (16-row tile, K unit) in the weight image
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer resources / LDS-DMA builtins exist in the device pass only
@@ -277,6 +284,10 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
                 if (p.spu == 1) asm volatile("buffer_load_ushort %0, %1, %2, %3 offen" : "=v"(a1) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
                 else if (p.spu == 2) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a1) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
                 else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a2) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
+            } else if constexpr (wf == LKM_W_INT4_ZP) {
+                // 1 / 2 (scale, zero point) pairs per row and unit (groups of >= 128 / 64 k; 32-k groups keep the tile kernels)
+                if (p.spu == 1) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a1) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
+                else asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(a2) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
             } else if constexpr (wf == LKM_W_MXFP4)
                 asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(a1) : "v"(av), "s"(rs_ar), "s"(ao) : "memory");
             else
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm_prefill_kernel(GemmParams p) {
             unsigned& a1 = w4a1[s];
             u32x2& a2 = w4a2[s];
             if constexpr (wf0 == LKM_W_NVFP4) asm volatile("" : "+v"(a2));
-            else if constexpr (wf0 == LKM_W_INT4_B8) asm volatile("" : "+v"(a1), "+v"(a2));
+            else if constexpr (wf0 == LKM_W_INT4_B8 || wf0 == LKM_W_INT4_ZP) asm volatile("" : "+v"(a1), "+v"(a2));
             else asm volatile("" : "+v"(a1));
             u32x4 rawv[1];
             rawv[0] = u32x4{0u, 0u, 0u, 0u};

@@ -540,7 +540,7 @@ struct W16Only {
 template <int WF>
 struct PfFormat {
     static constexpr bool value = WF == LKM_W_BF16 || WF == LKM_W_F16 || WF == LKM_W_FP8_E4M3 || WF == LKM_W_INT4_B8 ||
-                                  WF == LKM_W_MXFP4 || WF == LKM_W_NVFP4;
+                                  WF == LKM_W_INT4_ZP || WF == LKM_W_MXFP4 || WF == LKM_W_NVFP4;
 };
 template <int WF>
 struct W4Only {

@@ -620,7 +620,7 @@ static void pick_cfg(const LkmEngine* h, int M, size_t n_slots, Plan* pl) {   //
     // tile and 128-k unit
     const bool w8a16 = h->wf == LKM_W_FP8_E4M3 && !h->a8;
     // ... and the 4-bit formats (decoded once per workgroup into the 16-bit image): uint4b8, MXFP4, NVFP4
-    const bool w4pf = (h->wf == LKM_W_INT4_B8 && !h->ps && !h->zp) || h->wf == LKM_W_MXFP4 || h->wf == LKM_W_NVFP4;   // (not the fast int4 mode: its own image)
+    const bool w4pf = (h->wf == LKM_W_INT4_B8 && !h->ps && (!h->zp || h->spu <= 2)) || h->wf == LKM_W_MXFP4 || h->wf == LKM_W_NVFP4;   // (not the fast int4 mode: its own image)
     const size_t pf_ub = w4pf ? 1024 : 2048;     // bytes of a (tile, unit) of the image
     const bool pf8_ok = (w16 || w8a16 || w4pf) && h->H % 128 == 0 && h->I % 128 == 0 && (size_t)M * (size_t)h->H * 2 < (size_t)0x7fffffff &&
                         n_slots * (size_t)h->ld_act * 2 < (size_t)0x7fffffff &&

@@ -287,7 +287,7 @@ __device__ __forceinline__ float div_by(float x, const DivBy& d) {
 }
 
 
-inline bool wf_is_4bit(int wf) { return wf == LKM_W_INT4_B8 || wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4; }
+inline bool wf_is_4bit(int wf) { return wf == LKM_W_INT4_B8 || wf == LKM_W_INT4_ZP || wf == LKM_W_MXFP4 || wf == LKM_W_NVFP4; }
 inline int wf_unitk(int wf) { return (wf == LKM_W_BF16 || wf == LKM_W_F16) ? 64 : 128; }
 inline int wf_loads(int wf) { return wf_is_4bit(wf) ? 1 : 2; }
 

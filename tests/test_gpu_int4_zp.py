@@ -115,6 +115,14 @@ def test_zero_point_layers_vs_oracle(M, E, K, H, I, g, dt, gated, prefill):
     if prefill:
         out = eng.prefill(a.to(DEV), twd, idd).float().cpu().numpy()
         np.testing.assert_allclose(out, ref, atol=4e-3 * scale, rtol=1.5e-2, err_msg=eng.engine.describe())
+        if H % 128 == 0 and I % 128 == 0 and g >= 64:
+            # ... and on the 256-row prefill kernel (gemm_prefill.h: the weights decoded ONCE per workgroup into a 16-bit image,
+            # with the same decoder), whatever the planner chose above
+            eng.engine.set_tuning(tiled=256, waves=8, pf=8)
+            o8 = eng.prefill(a.to(DEV), twd, idd).float().cpu().numpy()
+            assert "pf=8" in eng.engine.describe() and "tm=256" in eng.engine.describe(), eng.engine.describe()
+            np.testing.assert_allclose(o8, ref, atol=4e-3 * scale, rtol=1.5e-2, err_msg=eng.engine.describe())
+            eng.engine.set_tuning(tiled=0, waves=0, pf=0)
     else:
         out = eng.decode(a.to(DEV), twd, idd).cpu().numpy()
         np.testing.assert_allclose(out, ref, atol=ATOL * scale, rtol=RTOL, err_msg=eng.engine.describe())

@@ -99,6 +99,8 @@ EXTRA_N1 = [# the headline workload under Zipf routing first, in the thermal sta
             # benchmarks/kernels/benchmark_moe.py:96-333
             ("mixtral8x7b_bf16_decode_m32", "zipf"),
             "mixtral8x7b_fp8w8a8_decode_m32", "mixtral8x7b_int4g128_decode_m128", "mixtral8x7b_int4g128_fast_decode_m128",
+            # BASELINE.json configs[2] says "AWQ-int4": the same layer with ZERO POINTS (asymmetric uint4, LKM_INT4_ZP)
+            "mixtral8x7b_int4g128_zp_decode_m128",
             # BASELINE.json configs[4] (the MFMA-bound grouped GEMM) on the uniform-ish routing SURVEY 8d specifies (zero
             # score-correction bias), and on the skewed synthetic bias of rounds 1-5, labelled as such
             "glm45air_fp8w8a8_prefill_m8192", ("glm45air_fp8w8a8_prefill_m8192", "biased"),
@@ -770,7 +772,7 @@ def run_workload(name, args, ctx, *, steps, warmup, with_cpu, force_ep=False, ro
                       + (" (rank 0's engine on rank 0's own routed rows)" if world > 1 else "")})
         res = {"workload": name, "value": round(tokens_per_s, 1), "unit": "tokens/s", "ms_per_step": round(ms_per_step, 4),
                "steps": steps, "scaling": scaling, "timed_regions_ms": [round(r * 1e3, 3) for r in regions],
-               "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act" + (" (fast mode: scale on fp32 partial sums)" if wl.get("int4_mode") else ""),
+               "dtype": {"bf16": "bf16", "int4": "int4-w/bf16-act" + {0: "", 1: " (fast mode: scale on fp32 partial sums)", 2: " (zero points: T((q - zp) s))"}[int(wl.get("int4_mode", 0))],
                          "mxfp4": "mxfp4-w/bf16-act",
                          "nvfp4": "nvfp4-w/bf16-act",
                          "fp8": "fp8-w/" + ("fp8-act" if wl.get("fp8_mode") else "bf16-act")}[fmt],

@@ -19,6 +19,7 @@ RUNS = [
     ("2b Mixtral-8x7B fp8-W8A8 M=32", "mixtral8x7b_fp8w8a8_decode_m32", 200, 2.5e3, 1.0),
     ("3 Mixtral-8x7B int4-g128 M=128", "mixtral8x7b_int4g128_decode_m128", 200, 2.5e3, 0.5),
     ("3' same, int4 fast mode (opt-in)", "mixtral8x7b_int4g128_fast_decode_m128", 200, 2.5e3, 0.5),
+    ("3'' same, uint4 with zero points (AWQ-style, LKM_INT4_ZP)", "mixtral8x7b_int4g128_zp_decode_m128", 200, 2.5e3, 0.5),
     ("3b Mixtral-8x7B MXFP4 M=128", "mixtral8x7b_mxfp4_decode_m128", 200, 2.5e3, 0.5),
     ("3c Mixtral-8x7B NVFP4 M=128", "mixtral8x7b_nvfp4_decode_m128", 200, 2.5e3, 0.5),
     ("3d Mixtral-8x7B MXFP4 M=32", "mixtral8x7b_mxfp4_decode_m32", 200, 2.5e3, 0.5),

@@ -127,6 +127,34 @@ def test_weight_only_integer_configs_never_fall_into_the_symmetric_4bit_decoder(
     assert LkmExperts._supports_quant_scheme("uint8b128", None) and not LkmExperts._supports_quant_scheme("int8", "int8")
 
 
+def test_zero_point_layers_choose_the_native_mode_by_shape_and_unpack_the_reference_layout():
+    """4-bit experts with zero points run the engine's zero-point mode (LkmConfig.int4_mode = LKM_INT4_ZP) when lkm_create takes
+    their shape -- group 32 / 64 / 128 / a multiple of 128, both K multiples of 128 and of the group -- and are expanded to 16 bits
+    otherwise (LKM_WNA16_EXPAND=1 forces that); the packed zero points [E, R / 2, K / g] (low nibble = even row,
+    tests/kernels/moe/test_moe.py:634-641) become one byte per (row, group)."""
+    import numpy as np
+    from lvllm_amd.modular import _unpack_zp4
+    rng = np.random.default_rng(0)
+    z = rng.integers(0, 16, (3, 8, 5), dtype=np.uint8)
+    packed = torch.from_numpy((z[:, 0::2] | (z[:, 1::2] << 4)).astype(np.uint8))
+    assert np.array_equal(_unpack_zp4(packed).numpy(), z) and _unpack_zp4(packed).dtype == torch.uint8
+    w1, w2 = torch.zeros(2, 64, 128, dtype=torch.uint8), torch.zeros(2, 256, 64, dtype=torch.uint8)      # K = 256 / 128
+
+    def ok(group, a=w1, b=w2):
+        return LkmExperts._native_zp_ok(a, b, LkmQuant("wna16", None, None, 1, group, weight_bits=4))
+    assert ok(32) and ok(64) and ok(128)
+    assert not ok(256)                                     # does not divide GEMM2's K = 128
+    assert ok(256, b=torch.zeros(2, 256, 128, dtype=torch.uint8))
+    assert not ok(48) and not ok(16)
+    assert not ok(64, a=torch.zeros(2, 64, 96, dtype=torch.uint8))       # K = 192: not a multiple of 128
+    import os
+    os.environ["LKM_WNA16_EXPAND"] = "1"
+    try:
+        assert not ok(128)
+    finally:
+        del os.environ["LKM_WNA16_EXPAND"]
+
+
 def test_errors_are_loud_on_the_host_side():
     ex = LkmExperts()
     x = torch.zeros(4, 64, dtype=torch.bfloat16)

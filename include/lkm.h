@@ -116,7 +116,8 @@ typedef struct LkmEngine* LkmHandle;
  * (routed_experts.py:1514-1533, 1596-1616, 1648-1668).  Pointers may be host OR device
  * memory (detected); contiguous, layouts of SURVEY 8(a5).  The engine COPIES the weights
  * (pre-shuffled into its MFMA-native HBM layout) -- the caller frees its tensors right
- * after (routed_experts.py:1420-1432).  NULL = absent.
+ * after (routed_experts.py:1420-1432).  NULL = absent.  The two global-scale slots carry the NVFP4 per-expert multipliers
+ * (fp32 [E]) or, with weight_format LKM_W_INT4_B8 and int4_mode LKM_INT4_ZP, the zero points (uint8 [E, rows, K / group]).
  */
 int lkm_create(const LkmConfig* cfg, const void* w13, const void* w2, const void* w13_scale,
                const void* w2_scale, const void* w13_global_scale, const void* w2_global_scale,

@@ -24,7 +24,7 @@ DEV = "cuda:0"
 FORMATS = ["bf16", "f16", "int4", "int4zp", "fp8", "fp8a8", "mxfp4", "nvfp4"]
 
 
-def build(fmt, rng, E, K, H, I, gated, seed):
+def build(fmt, rng, E, K, H, I, gated, seed, oai=False):
     """-> (engine, oracle closure(x_bits, ids, tw, prefill) -> fp32 reference, torch activation dtype, tolerances)"""
     dt = torch.float16 if fmt == "f16" or (fmt in ("int4", "int4zp") and rng.integers(0, 3) == 0) else torch.bfloat16
     odt = orc.F16 if dt == torch.float16 else orc.BF16
@@ -32,8 +32,8 @@ def build(fmt, rng, E, K, H, I, gated, seed):
     halves = 2 if gated else 1
     w13 = (torch.randn((E, halves * I, H), generator=g) / 10).to(dt)
     w2 = (torch.randn((E, H, I), generator=g) / 10).to(dt)
-    kw = dict(has_gate_proj=False, activation_type=2) if not gated else {}
-    dk = dict(E=E, H=H, I=I, has_gate=gated, activation=orc.ACT_SILU if gated else orc.ACT_RELU2, act_dtype=odt)
+    kw = dict(has_gate_proj=False, activation_type=2) if not gated else (dict(activation_type=1) if oai else {})
+    dk = dict(E=E, H=H, I=I, has_gate=gated, activation=(orc.ACT_SWIGLUOAI if oai else orc.ACT_SILU) if gated else orc.ACT_RELU2, act_dtype=odt)
     tol = (2e-3, 1e-2)
     if fmt in ("bf16", "f16"):
         eng = RoutedExpertsEngine(w13, w2, top_k=K, act_dtype=dt, max_num_seqs=256, **kw)
@@ -110,8 +110,11 @@ def main():
         K = int(rng.integers(1, min(E, 8) + 1))
         H = int(rng.integers(1, 9)) * 128
         I = int(rng.integers(1, 7)) * 128
+        if fmt in ("bf16", "f16") and rng.integers(0, 2):           # 16-bit weights: any multiple of 8 / 16 (models off the 128 grid)
+            H, I = int(rng.integers(2, 130)) * 8, int(rng.integers(1, 50)) * 16
+        oai = gated and bool(rng.integers(0, 4) == 0)               # gpt-oss' clamped, interleaved swiglu
         try:
-            eng, ref, dt, (atol, rtol) = build(fmt, rng, E, K, H, I, gated, seed * 100000 + n)
+            eng, ref, dt, (atol, rtol) = build(fmt, rng, E, K, H, I, gated, seed * 100000 + n, oai)
         except Exception as ex:                                     # a refused configuration is a finding too
             bad.append(f"case {n}: {fmt} E={E} K={K} H={H} I={I} gated={gated}: constructor raised {type(ex).__name__}: {ex}")
             print(bad[-1], flush=True)
@@ -133,7 +136,7 @@ def main():
             for name, (out, a_, r_) in outs.items():
                 err = np.abs(out - want)
                 ok = bool((err <= a_ * scale + r_ * np.abs(want)).all()) and np.isfinite(out).all()
-                line = (f"case {n}: {fmt} {str(dt)[6:]} E={E} K={K} H={H} I={I} gated={gated} M={M} {name}: "
+                line = (f"case {n}: {fmt} {str(dt)[6:]} E={E} K={K} H={H} I={I} gated={gated}{' oai' if oai else ''} M={M} {name}: "
                         f"max err {float(err.max()) if M else 0.0:.3e} (scale {scale:.2e}) {'ok' if ok else 'MISMATCH'} | {eng.engine.describe()[-90:]}")
                 print(line, flush=True)
                 if not ok:

@@ -2,10 +2,10 @@
 """GPU: seeded random sweep of whole layers against the CPU oracle, for a time budget -- every weight format (16-bit, uint4b8 at
 three group sizes, uint4 with zero points, fp8 W8A16 / W8A8, MXFP4, NVFP4), gated / relu2, batch sizes from 0 to a few thousand
 (decode, fp32 output, up to the engine's max_num_seqs; prefill, activation-dtype output, above it and as a second look at the
-decode sizes), skewed routing and dropped slots, whatever launch plan the planner picks.  The -m gpu suite holds a 28-case
+decode sizes), skewed routing and dropped slots, whatever launch plan the planner picks.  (It lives under tests/: only tests/, smoke() and the bench cpu_baseline leg may import the oracle.)  The -m gpu suite holds a 28-case
 version of this (tests/test_gpu_moe.py::test_randomised_shapes_and_formats_vs_oracle); this is the long run.
 
-    python tools/fuzz_vs_oracle.py [seconds=240] [seed=1]        # prints one line per case, a summary, exit code 1 on a mismatch
+    python tests/fuzz_vs_oracle.py [seconds=240] [seed=1]        # prints one line per case, a summary, exit code 1 on a mismatch
 """
 import sys
 import time

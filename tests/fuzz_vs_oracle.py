@@ -5,8 +5,9 @@ three group sizes, uint4 with zero points, fp8 W8A16 / W8A8, MXFP4, NVFP4), gate
 decode sizes), skewed routing and dropped slots, whatever launch plan the planner picks.  (It lives under tests/: only tests/, smoke() and the bench cpu_baseline leg may import the oracle.)  The -m gpu suite holds a 28-case
 version of this (tests/test_gpu_moe.py::test_randomised_shapes_and_formats_vs_oracle); this is the long run.
 
-    python tests/fuzz_vs_oracle.py [seconds=240] [seed=1]        # prints one line per case, a summary, exit code 1 on a mismatch
+    [FUZZ_EMAX=256] python tests/fuzz_vs_oracle.py [seconds=240] [seed=1]        # prints one line per case, a summary, exit code 1 on a mismatch
 """
+import os
 import sys
 import time
 
@@ -106,7 +107,7 @@ def main():
     while time.time() - t0 < budget:
         fmt = FORMATS[n % len(FORMATS)]
         gated = bool(rng.integers(0, 4))
-        E = int(rng.integers(1, 41))
+        E = int(rng.integers(1, int(os.environ.get("FUZZ_EMAX", "40")) + 1))      # (FUZZ_EMAX=256: many small experts, expert-parallel-like sparsity)
         K = int(rng.integers(1, min(E, 8) + 1))
         H = int(rng.integers(1, 9)) * 128
         I = int(rng.integers(1, 7)) * 128
@@ -125,7 +126,7 @@ def main():
                 M = max(1, 3_000_000 // H)
             g = torch.Generator().manual_seed(n * 7 + M)
             x = (torch.randn((M, H), generator=g) / 10).to(dt)
-            tw, ids = make_routing(M, E, K, seed=n + M, skew=float(rng.choice([0.0, 1.5, 3.0])), drop=float(rng.choice([0.0, 0.2])))
+            tw, ids = make_routing(M, E, K, seed=n + M, skew=float(rng.choice([0.0, 1.5, 3.0])), drop=float(rng.choice([0.0, 0.2, 0.9] if E > 40 else [0.0, 0.2])))
             want = ref(torch_to_bits(x), ids, tw) if M else np.zeros((0, H), np.float32)
             scale = max(1.0, float(np.abs(want).max())) if M else 1.0
             xd, twd, idd = x.to(DEV), torch.from_numpy(tw).to(DEV), torch.from_numpy(ids).to(DEV)
